@@ -1,0 +1,260 @@
+/*
+ * mi355x_rec.h — C ABI of libmi355x_rec.so, the MI355X (gfx950 / CDNA4) DeepFM / Wide&Deep
+ * training hot path.
+ *
+ * The reference (leotimus/recommender-tensorflow) has no FFI of its own: every FLOP on the path
+ * is executed by TensorFlow 1.12 ops that trainers/deep_fm.py:36-125 strings together.  Each entry
+ * point below therefore names the reference *call site* whose arithmetic it replaces (file:line
+ * relative to the reference root) and, where TensorFlow supplies the semantics implicitly, the
+ * SURVEY.md appendix paragraph that restates them.
+ *
+ * Conventions
+ *   - plain C, no exceptions; every entry returns 0 on success or a negative mi_status; the text
+ *     of the last failure on the calling thread is mi_last_error().
+ *   - the caller owns every buffer.  Device entries take device pointers (allocated by whoever
+ *     owns the HIP context — PyTorch in the shipped host) and a hipStream_t passed as void*;
+ *     they only enqueue work on that stream and never synchronise, allocate or free.
+ *   - scratch space is an explicit caller-sized workspace: ask mi_*_workspace_bytes() first.
+ *   - shapes are validated on the host before any launch (a bad shape returns
+ *     MI_ERR_INVALID instead of faulting the GPU).
+ *   - all floating point is IEEE fp32 ("f32" in bench.py); index work is int32/int64, bit exact.
+ */
+#ifndef MI355X_REC_H
+#define MI355X_REC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* mi_stream_t; /* hipStream_t */
+
+enum mi_status {
+  MI_OK = 0,
+  MI_ERR_INVALID = -1,     /* bad argument / shape / alignment */
+  MI_ERR_UNSUPPORTED = -2, /* legal but not built (e.g. embedding size not a multiple of 4 > 256) */
+  MI_ERR_LAUNCH = -3,      /* HIP reported an error at launch */
+  MI_ERR_WORKSPACE = -4    /* workspace too small */
+};
+
+/* ---- library ---------------------------------------------------------------------------- */
+int32_t mi_abi_version(void);       /* bumps when a signature changes */
+const char* mi_last_error(void);    /* thread-local, never NULL */
+const char* mi_build_info(void);    /* "gfx950 hipcc <ver>" */
+
+/* ---- (a1) categorical id transforms, host side --------------------------------------------
+ * replaces the column constructors of trainers/ml_100k.py:19-35.
+ * All integer work; results are bit exact against oracle/fingerprint.py. */
+
+/* FarmHash Fingerprint64 (farmhashna::Hash64) of len bytes — what
+ * tf.feature_column.categorical_column_with_hash_bucket applies (ml_100k.py:19,20,29,30). */
+uint64_t mi_fingerprint64(const void* data, size_t len);
+
+/* id = Fingerprint64(decimal ASCII of v) mod num_buckets — hash_bucket column with an integer
+ * dtype (user_id, item_id: ml_100k.py:19-20). */
+int32_t mi_hash_bucket_i64(const int64_t* values, int64_t n, int64_t num_buckets, int32_t* out_ids);
+
+/* id = Fingerprint64(bytes[offsets[i]:offsets[i+1]]) mod num_buckets — string hash_bucket column
+ * (occupation, zipcode: ml_100k.py:29-30).  offsets has n+1 entries. */
+int32_t mi_hash_bucket_bytes(const uint8_t* bytes, const int64_t* offsets, int64_t n,
+                             int64_t num_buckets, int32_t* out_ids);
+
+/* id = number of boundaries <= x (upper_bound) — bucketized_column (ml_100k.py:23-24,33-34). */
+int32_t mi_bucketize_f32(const float* values, int64_t n, const float* boundaries,
+                         int32_t num_boundaries, int32_t* out_ids);
+
+/* ---- (a2,a3,a5) embedding gather + wide linear reduce + FM second order, forward ------------
+ * replaces tf.feature_column.linear_model (deep_fm.py:39), embedding_column + input_layer
+ * (deep_fm.py:52-54) and the mf block (deep_fm.py:79-87) with ONE kernel.
+ *
+ *   row(b,f)      = field_off[f] + ids[b*F+f]                 (fused row-major table, all fields)
+ *   concat[b,f,:] = table[row(b,f), :]                        (deep_fm.py:54; mean of one id = row)
+ *   sumv[b,:]     = sum_f concat[b,f,:]                       (saved for the backward)
+ *   fm[b]         = 0.5 * sum_e( sumv[b,e]^2 - sum_f concat[b,f,e]^2 )   (deep_fm.py:81-87)
+ *   lin[b]        = sum_f lin_w[row(b,f)]                     (deep_fm.py:39; bias is added by the head)
+ *
+ * table [R,E] f32, lin_w [R] f32 (may be NULL: lin not produced), field_off [F] int64 (device),
+ * ids [B,F] int32 (device).  Outputs: concat [B,F*E] with leading dimension ld_concat (floats,
+ * >= F*E: numeric-embedding columns may follow, deep_fm.py:73), sumv [B,E], fm [B], lin [B]
+ * (fm / lin / sumv may be NULL).  E must be a multiple of 4 and <= 256.  Fields must already be
+ * in the reference's sorted-by-column-name order. */
+int32_t mi_embed_fm_linear_fwd(const float* table, const float* lin_w, const int64_t* field_off,
+                               const int32_t* ids, int64_t B, int32_t F, int32_t E,
+                               float* concat, int64_t ld_concat, float* sumv, float* fm, float* lin,
+                               mi_stream_t stream);
+
+/* Owner-side half of the row-sharded path (multi-GPU): out_rows[i,:] = table[rows[i],:],
+ * out_lin[i] = lin_w[rows[i]].  rows [n] int32 local row ids. */
+int32_t mi_gather_rows(const float* table, const float* lin_w, const int32_t* rows, int64_t n,
+                       int32_t E, float* out_rows, float* out_lin, mi_stream_t stream);
+
+/* (a4) numeric embedding, deep_fm.py:62-70: out[b, j*E+e] = x[b,j] * V[j,e], written at
+ * concat[b, col0 + j*E + e]; also accumulates into sumv / fm so the FM term sees the numeric
+ * fields (deep_fm.py:79 reshapes the concatenated layer), and lin[b] += sum_j x[b,j]*w_num[j]. */
+int32_t mi_numeric_embed_fwd(const float* x, const float* V, const float* w_num, int64_t B,
+                             int32_t n_d, int32_t E, float* concat, int64_t ld_concat, int64_t col0,
+                             float* sumv, float* fm, float* lin, mi_stream_t stream);
+
+/* ---- (a2,a3,a5) backward: per-entry row gradients -------------------------------------------
+ * d_rows[p(b,f), :] = d_concat[b,f,:] + d_logit_fm[b] * (sumv[b,:] - concat[b,f,:])
+ * d_lin [p(b,f)]    = d_logit_lin[b]
+ * (gradient of deep_fm.py:54,81-87,39 w.r.t. the gathered rows; TF: IndexedSlices values).
+ * pos [B*F] int32 gives the destination slot p(b,f) (NULL = identity b*F+f); the sharded path
+ * uses it to write straight into all-to-all send order.  d_concat may be NULL (no DNN),
+ * d_logit_fm may be NULL (no FM), d_lin/d_logit_lin may be NULL (no linear part). */
+int32_t mi_embed_fm_linear_bwd(const float* d_concat, int64_t ld_dconcat, const float* concat,
+                               int64_t ld_concat, const float* sumv, const float* d_logit_fm,
+                               const float* d_logit_lin, const int32_t* pos, int64_t B, int32_t F,
+                               int32_t E, float* d_rows, float* d_lin, mi_stream_t stream);
+
+/* (a4) backward of the numeric embedding: dV[j,e] = sum_b x[b,j]*g[b,j,e] with
+ * g = d_concat + d_logit_fm*(sumv - concat);  dw_num[j] = sum_b d_logit_lin[b]*x[b,j].
+ * Deterministic two-stage reduction; workspace from mi_numeric_embed_bwd_workspace_bytes. */
+size_t mi_numeric_embed_bwd_workspace_bytes(int64_t B, int32_t n_d, int32_t E);
+int32_t mi_numeric_embed_bwd(const float* x, const float* d_concat, int64_t ld_dconcat,
+                             const float* concat, int64_t ld_concat, int64_t col0, const float* sumv,
+                             const float* d_logit_fm, const float* d_logit_lin, int64_t B,
+                             int32_t n_d, int32_t E, float* dV, float* dw_num, void* workspace,
+                             size_t workspace_bytes, mi_stream_t stream);
+
+/* ---- row bookkeeping for sparse updates -----------------------------------------------------
+ * Sorts the n requested rows (stable LSD radix sort, key = row, payload = entry index) and
+ * compacts duplicates — the device analogue of TF's unique + unsorted_segment_sum that
+ * precedes every sparse optimizer apply.  Outputs (all device):
+ *   sorted_entry [n]   entry index (into rows / d_rows) in ascending (row, entry) order
+ *   uniq_rows    [n]   first U slots hold the distinct rows in ascending order
+ *   seg_start    [n+1] segment u covers sorted_entry[seg_start[u] .. seg_start[u+1])
+ *   num_uniq     [1]   U (int32) — stays on the device; later kernels read it there
+ * num_rows_total bounds the key range (picks the number of radix passes). */
+size_t mi_sort_unique_workspace_bytes(int64_t n);
+int32_t mi_sort_unique_rows(const int32_t* rows, int64_t n, int64_t num_rows_total,
+                            int32_t* sorted_entry, int32_t* uniq_rows, int32_t* seg_start,
+                            int32_t* num_uniq, void* workspace, size_t workspace_bytes,
+                            mi_stream_t stream);
+
+/* rows[b*F+f] = field_off[f] + ids[b*F+f]  (int32 global row per entry) */
+int32_t mi_global_rows(const int32_t* ids, const int64_t* field_off, int64_t B, int32_t F,
+                       int32_t* rows, mi_stream_t stream);
+
+/* ---- (a9) optimizers ------------------------------------------------------------------------
+ * get_optimizer (model_utils.py:57-66) -> tf.train.{Adam,Adagrad,Ftrl,RMSProp,GradientDescent}
+ * Optimizer(learning_rate), applied by head.create_estimator_spec (deep_fm.py:119-125).
+ * SURVEY Appendix A.6/A.7 restate the TF-1.12 update rules the kernels follow op for op
+ * (compiled with -ffp-contract=off so the fp32 sequence equals the oracle's). */
+
+enum mi_optimizer {
+  MI_OPT_ADAM = 0,     /* tf.train.AdamOptimizer: beta1 .9 beta2 .999 eps 1e-8 */
+  MI_OPT_ADAGRAD = 1,  /* tf.train.AdagradOptimizer: initial_accumulator_value .1 */
+  MI_OPT_FTRL = 2,     /* tf.train.FtrlOptimizer: lr_power -.5, init accum .1, l1=l2=0 */
+  MI_OPT_RMSPROP = 3,  /* tf.train.RMSPropOptimizer: decay .9 momentum 0 eps 1e-10 */
+  MI_OPT_SGD = 4       /* tf.train.GradientDescentOptimizer */
+};
+
+typedef struct mi_opt_hparams {
+  int32_t kind;      /* enum mi_optimizer */
+  float lr;          /* learning_rate as given to the TF constructor */
+  float beta1, beta2, epsilon;          /* Adam */
+  float lr_t;        /* Adam: lr*sqrt(1-beta2^t)/(1-beta1^t) for THIS step, computed by the host in fp32 */
+  float decay, momentum;                /* RMSProp */
+  float lr_power, l1, l2;               /* Ftrl */
+} mi_opt_hparams;
+
+/* Dense apply over a flat parameter buffer (all MLP kernels/biases, numeric embeddings, linear
+ * bias live in one buffer).  slot0/slot1: Adam m,v | Adagrad accum,- | Ftrl accum,linear |
+ * RMSProp ms,mom | SGD -,-.  Fused ApplyAdam / ApplyAdagrad / ApplyFtrl / ApplyRMSProp /
+ * ApplyGradientDescent semantics. */
+int32_t mi_dense_apply(float* param, float* slot0, float* slot1, const float* grad, int64_t n,
+                       const mi_opt_hparams* hp, mi_stream_t stream);
+
+/* Sparse apply on the U distinct rows found by mi_sort_unique_rows: segment-sums the entry
+ * gradients in ascending entry order (== TF's unsorted_segment_sum order on CPU), then applies
+ * the optimizer's sparse rule to table row r (width E) and, when lin_w != NULL, to lin_w[r]
+ * (width 1) with d_lin.  For Adam the rule is TF's dense-equivalent one: see mi_sparse_catchup.
+ * last_step[r] is set to step.  slot arrays mirror the parameter arrays' shapes. */
+int32_t mi_sparse_apply(float* table, float* t_slot0, float* t_slot1, float* lin_w, float* l_slot0,
+                        float* l_slot1, int32_t* last_step, const int32_t* uniq_rows,
+                        const int32_t* seg_start, const int32_t* sorted_entry,
+                        const int32_t* num_uniq, int64_t n_max, const float* d_rows,
+                        const float* d_lin, int32_t E, int32_t step, const mi_opt_hparams* hp,
+                        mi_stream_t stream);
+
+/* TF-1.12 AdamOptimizer._apply_sparse decays m and v of EVERY row and moves EVERY row each step
+ * (SURVEY Appendix A.6).  Instead of sweeping the table, rows carry last_step[r] and are brought
+ * up to date lazily: for s in (last_step[r], step_to]: m*=b1; v*=b2; w -= lr_t[s]*m/(sqrt(v)+eps)
+ * — the same fp32 op sequence as the sweep, hence the same bits.  lr_table[s] (device, f32) holds
+ * lr_t of step s.  Runs on the U distinct rows about to be gathered (step_to = step-1), or on all
+ * rows (uniq_rows == NULL, n_max = R) before evaluation / checkpoint. */
+int32_t mi_sparse_catchup(float* table, float* t_m, float* t_v, float* lin_w, float* l_m, float* l_v,
+                          int32_t* last_step, const int32_t* uniq_rows, const int32_t* num_uniq,
+                          int64_t n_max, int32_t E, int32_t step_to, const float* lr_table,
+                          float beta1, float beta2, float epsilon, mi_stream_t stream);
+
+/* ---- (a6) the [hidden_units] MLP: fp32-input MFMA GEMMs with fused epilogues ------------------
+ * replaces tf.layers.dense / tf.layers.dropout (deep_fm.py:98-108).  Row-major everywhere.
+ * v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate (needed for the 1e-5 logit bar). */
+
+/* Y[M,N] = act( X[M,K] * W[K,N] + bias[N] ), act = relu if relu != 0.  If keep_prob < 1 the
+ * TRAIN-mode dropout of deep_fm.py:102-103 is applied after the activation with a counter-based
+ * mask (seed, layer, element index): survivors scaled by 1/keep_prob. */
+int32_t mi_dense_fwd(const float* X, int64_t ldx, const float* W, const float* bias, float* Y,
+                     int64_t ldy, int64_t M, int32_t N, int32_t K, int32_t relu, float keep_prob,
+                     uint64_t seed, mi_stream_t stream);
+
+/* dX[M,K] = (dY[M,N] * W[K,N]^T) .* mask.  When Xact != NULL (the previous layer's stored
+ * post-relu, post-dropout output) mask = (Xact > 0) / keep_prob — a unit with Xact > 0 was both
+ * relu-active and kept, every other unit gets gradient 0 — so dX is the gradient w.r.t. the
+ * previous layer's PRE-activation, ready to be that layer's dY. */
+int32_t mi_dense_bwd_data(const float* dY, int64_t lddy, const float* W, const float* Xact,
+                          int64_t ldxa, float* dX, int64_t lddx, int64_t M, int32_t N, int32_t K,
+                          float keep_prob, mi_stream_t stream);
+
+/* dW[K,N] = X[M,K]^T * dY[M,N], db[N] = column sums of dY.  Split-K over M with a
+ * fixed-order slab reduction (bitwise reproducible). */
+size_t mi_dense_bwd_weight_workspace_bytes(int64_t M, int32_t N, int32_t K);
+int32_t mi_dense_bwd_weight(const float* X, int64_t ldx, const float* dY, int64_t lddy, float* dW,
+                            float* db, int64_t M, int32_t N, int32_t K, void* workspace,
+                            size_t workspace_bytes, mi_stream_t stream);
+
+/* ---- (a7,a8) logits sum + sigmoid cross-entropy head -----------------------------------------
+ * replaces `logits += ...` (deep_fm.py:36,44,90,111) and
+ * tf.contrib.estimator.binary_classification_head (deep_fm.py:118-125).
+ *   logits[b] = ((lin[b] + lin_bias) + fm[b]) + dnn[b]        (NULL terms skipped, same order)
+ *   loss_b    = max(x,0) - x*y + log1p(exp(-|x|))
+ *   loss_out[0] = sum_b loss_b * loss_scale   (loss_scale = 1/B_global for the contrib head's
+ *                 SUM_OVER_BATCH_SIZE, 1 for the canned estimators' SUM)
+ *   d_logit[b]  = (sigmoid(x) - y) * loss_scale
+ * labels: uint8 0/1 (ml_100k.py:48 rating >= cutoff).  d_logit / loss_out may be NULL (eval /
+ * predict).  workspace: mi_head_workspace_bytes(B). */
+size_t mi_head_workspace_bytes(int64_t B);
+int32_t mi_sigmoid_ce_head(const float* lin, const float* lin_bias, const float* fm,
+                           const float* dnn, const uint8_t* labels, int64_t B, float loss_scale,
+                           float* logits, float* loss_out, float* d_logit, void* workspace,
+                           size_t workspace_bytes, mi_stream_t stream);
+
+/* column sums: out[j] = sum_b X[b,j] (used for bias-style gradients), deterministic. */
+size_t mi_colsum_workspace_bytes(int64_t M, int32_t N);
+int32_t mi_colsum(const float* X, int64_t ldx, int64_t M, int32_t N, float* out, void* workspace,
+                  size_t workspace_bytes, mi_stream_t stream);
+
+/* ---- (a10) layer_summary statistics (model_utils.py:4-6) ------------------------------------
+ * out[0] = fraction of zeros, out[1] = min, out[2] = max, out[3] = mean. */
+size_t mi_layer_stats_workspace_bytes(int64_t n);
+int32_t mi_layer_stats(const float* x, int64_t n, float* out4, void* workspace,
+                       size_t workspace_bytes, mi_stream_t stream);
+
+/* ---- (f3) streaming eval metrics: tf.metrics.auc confusion counts --------
+ * Accumulates (integer atomics, order independent) into device arrays the caller zeroed:
+ *   hist   [2*201] int64: hist[y*201+k] = examples with label y whose sigmoid exceeds exactly k of
+ *          tf.metrics.auc's 200 ascending thresholds; tp[j] = sum_{k>j} hist[1][k] etc. on the host
+ *   counts [8] int64: n, n_pos, n_pred_pos, n_correct, tp@.5, fp@.5, fn@.5, (unused)
+ *   sums   [4] f64 : sum(loss_b), sum(sigmoid), sum(label), (unused) */
+int32_t mi_eval_accumulate(const float* logits, const uint8_t* labels, int64_t B,
+                           int64_t* hist /*[2*201]*/, int64_t* counts /*[8]*/,
+                           double* sums /*[4]*/, mi_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355X_REC_H */

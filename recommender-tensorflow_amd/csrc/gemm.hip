@@ -1,0 +1,410 @@
+// fp32 MFMA GEMMs of the [hidden_units] MLP with fused epilogues.
+//
+// Replaces tf.layers.dense / tf.layers.dropout (trainers/deep_fm.py:98-108) and their gradients.
+// The 1e-5 logit bar forbids bf16 operands, so the matrix pipe runs v_mfma_f32_32x32x2_f32
+// (exact fp32 products, fp32 accumulate: 64 FLOP/clk/SIMD, 157 TF/s chip peak).
+//
+// One kernel template, three operand layouts:
+//   NN  Y  = X  * W      forward          A k-contiguous,  B n-contiguous
+//   NT  dX = dY * W^T    data gradient    A k-contiguous,  B k-contiguous
+//   TN  dW = X^T * dY    weight gradient  A m-contiguous,  B n-contiguous   (split-K over the batch)
+// Tile 128x128x32, 256 threads = 4 waves in 2x2, each wave 64x64 = 2x2 MFMA tiles (64 accumulator
+// VGPRs).  Operands are staged HBM -> registers -> LDS with the next tile's global loads in flight
+// under the current tile's 64 MFMAs; two LDS buffers, one barrier per k-tile, two blocks per CU.
+// k-contiguous operands sit in LDS as [mn][32+4] (ds_read_b128 conflict-free at the 36-float
+// stride), mn-contiguous ones as [k][128] (ds_read_b32, one bank per lane).  A lane's four
+// k-values per ds_read_b128 feed four consecutive MFMAs: lane half h owns k = 8s+4h+j.
+// Workgroup ids are remapped so that the blocks sharing an A row-panel run on one XCD (shared L2).
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int KSTRIDE = BK + 4;           // k-contiguous LDS row stride (floats)
+constexpr int TILE_FLOATS = BM * KSTRIDE;  // 4608 >= 32*128
+constexpr int kThreads = 256;
+
+enum { KC = 0, MC = 1 };                       // operand layouts
+enum { EPI_BIAS_ACT = 0, EPI_MASK = 1, EPI_SLAB = 2 };
+
+struct GemmArgs {
+  const float* A; int64_t lda;
+  const float* B; int64_t ldb;
+  float* C; int64_t ldc;
+  int M, N, K;
+  int tiles_m, tiles_n, k_per_split;
+  int vecA, vecB;
+  int epi;
+  const float* bias; int relu;
+  float keep_prob; float inv_keep; uint64_t seed;
+  const float* mask_src; int64_t ldm;
+};
+
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {
+  x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ULL;
+  x ^= x >> 27; x *= 0x94d049bb133111ebULL;
+  x ^= x >> 31;
+  return x;
+}
+// counter-based dropout: keep element idx iff top 24 bits of mix64(seed + idx*phi) < keep*2^24
+__device__ __forceinline__ bool dropout_keep(uint64_t seed, uint64_t idx, uint32_t thresh) {
+  return static_cast<uint32_t>(mix64(seed + idx * 0x9E3779B97F4A7C15ULL) >> 40) < thresh;
+}
+
+template <int L>
+__device__ __forceinline__ void load_tile(const float* __restrict__ P, int64_t ld, int MN, int mn0,
+                                          int k0, int kend, bool vec, float4 (&r)[4], int t) {
+  if constexpr (L == KC) {
+    const int kk = k0 + (t & 7) * 4;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int mn = mn0 + (t >> 3) + 32 * p;
+      r[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (mn < MN) {
+        const float* q = P + static_cast<int64_t>(mn) * ld + kk;
+        if (vec) {
+          if (kk < kend) r[p] = *reinterpret_cast<const float4*>(q);
+        } else {
+          if (kk < kend) r[p].x = q[0];
+          if (kk + 1 < kend) r[p].y = q[1];
+          if (kk + 2 < kend) r[p].z = q[2];
+          if (kk + 3 < kend) r[p].w = q[3];
+        }
+      }
+    }
+  } else {
+    const int mn = mn0 + (t & 31) * 4;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int kk = k0 + (t >> 5) + 8 * p;
+      r[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (kk < kend) {
+        const float* q = P + static_cast<int64_t>(kk) * ld + mn;
+        if (vec) {
+          if (mn < MN) r[p] = *reinterpret_cast<const float4*>(q);
+        } else {
+          if (mn < MN) r[p].x = q[0];
+          if (mn + 1 < MN) r[p].y = q[1];
+          if (mn + 2 < MN) r[p].z = q[2];
+          if (mn + 3 < MN) r[p].w = q[3];
+        }
+      }
+    }
+  }
+}
+
+template <int L>
+__device__ __forceinline__ void store_tile(float* __restrict__ S, const float4 (&r)[4], int t) {
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    if constexpr (L == KC)
+      *reinterpret_cast<float4*>(S + ((t >> 3) + 32 * p) * KSTRIDE + (t & 7) * 4) = r[p];
+    else
+      *reinterpret_cast<float4*>(S + ((t >> 5) + 8 * p) * BM + (t & 31) * 4) = r[p];
+  }
+}
+
+// fragment of one 32-row MFMA tile for k-group s: four k values (k = 8s + 4h + j, j = 0..3)
+template <int L>
+__device__ __forceinline__ void read_frag(const float* __restrict__ S, int mn, int s, int h,
+                                          float (&f)[4]) {
+  if constexpr (L == KC) {
+    const float4 v = *reinterpret_cast<const float4*>(S + mn * KSTRIDE + 8 * s + 4 * h);
+    f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) f[j] = S[(8 * s + 4 * h + j) * BM + mn];
+  }
+}
+
+template <int LA, int LB>
+__global__ __launch_bounds__(kThreads, 2) void gemm_f32_k(const GemmArgs a) {
+  __shared__ __attribute__((aligned(16))) float smem[2][2][TILE_FLOATS];
+
+  // XCD-aware bijective remap: the 8 XCDs receive blocks round-robin; give each XCD a contiguous
+  // run of logical tiles so that the tiles_n column blocks of one A row-panel share an L2.
+  const int nb = gridDim.x, bid = blockIdx.x;
+  const int q = nb >> 3, rr = nb & 7, xcd = bid & 7, idx = bid >> 3;
+  const int lid = (xcd < rr) ? xcd * (q + 1) + idx : rr * (q + 1) + (xcd - rr) * q + idx;
+
+  const int tn = lid % a.tiles_n;
+  const int tm = (lid / a.tiles_n) % a.tiles_m;
+  const int split = lid / (a.tiles_n * a.tiles_m);
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int kbeg = split * a.k_per_split;
+  const int kend = min(a.K, kbeg + a.k_per_split);
+  const int nk = (kend - kbeg + BK - 1) / BK;
+
+  const int t = threadIdx.x;
+  const int w = t >> 6, lane = t & 63;
+  const int wm = w >> 1, wn = w & 1;
+  const int i = lane & 31, h = lane >> 5;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  float4 ra[4], rb[4];
+  if (nk > 0) {
+    load_tile<LA>(a.A, a.lda, a.M, m0, kbeg, kend, a.vecA, ra, t);
+    load_tile<LB>(a.B, a.ldb, a.N, n0, kbeg, kend, a.vecB, rb, t);
+    store_tile<LA>(smem[0][0], ra, t);
+    store_tile<LB>(smem[0][1], rb, t);
+  }
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    const bool more = kt + 1 < nk;
+    if (more) {
+      load_tile<LA>(a.A, a.lda, a.M, m0, kbeg + (kt + 1) * BK, kend, a.vecA, ra, t);
+      load_tile<LB>(a.B, a.ldb, a.N, n0, kbeg + (kt + 1) * BK, kend, a.vecB, rb, t);
+    }
+    const float* As = smem[cur][0];
+    const float* Bs = smem[cur][1];
+#pragma unroll
+    for (int s = 0; s < BK / 8; ++s) {
+      float fa[2][4], fb[2][4];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) read_frag<LA>(As, wm * 64 + mi * 32 + i, s, h, fa[mi]);
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) read_frag<LB>(Bs, wn * 64 + ni * 32 + i, s, h, fb[ni]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mi][j], fb[ni][j], acc[mi][ni], 0, 0, 0);
+    }
+    if (more) {
+      store_tile<LA>(smem[cur ^ 1][0], ra, t);
+      store_tile<LB>(smem[cur ^ 1][1], rb, t);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: C/D map of v_mfma_f32_32x32x2: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  float* Cb = a.C;
+  if (a.epi == EPI_SLAB) Cb += static_cast<int64_t>(split) * a.M * a.ldc;
+  const uint32_t thresh = static_cast<uint32_t>(a.keep_prob * 16777216.0f);
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const int col = n0 + wn * 64 + ni * 32 + i;
+    if (col >= a.N) continue;
+    const float bv = (a.epi == EPI_BIAS_ACT && a.bias) ? a.bias[col] : 0.f;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row >= a.M) continue;
+        float v = acc[mi][ni][r];
+        if (a.epi == EPI_BIAS_ACT) {
+          v += bv;
+          if (a.relu) v = fmaxf(v, 0.f);
+          if (a.keep_prob < 1.f) {
+            const uint64_t e = static_cast<uint64_t>(row) * static_cast<uint64_t>(a.N) + col;
+            v = dropout_keep(a.seed, e, thresh) ? v * a.inv_keep : 0.f;
+          }
+        } else if (a.epi == EPI_MASK) {
+          if (a.mask_src) {
+            const float x = a.mask_src[static_cast<int64_t>(row) * a.ldm + col];
+            v = (x > 0.f) ? v * a.inv_keep : 0.f;
+          }
+        }
+        Cb[static_cast<int64_t>(row) * a.ldc + col] = v;
+      }
+    }
+  }
+}
+
+// out[i] = sum_s slab[s][i] in fixed order (bitwise reproducible split-K)
+__global__ __launch_bounds__(kThreads) void slab_reduce_k(const float* __restrict__ slab, int nsplit,
+                                                          int64_t n, float* __restrict__ out) {
+  const int64_t i = (static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x) * 4;
+  if (i >= n) return;
+  if (i + 3 < n && (n & 3) == 0) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < nsplit; ++s) {
+      const float4 v = *reinterpret_cast<const float4*>(slab + static_cast<int64_t>(s) * n + i);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    out[i] = acc.x; out[i + 1] = acc.y; out[i + 2] = acc.z; out[i + 3] = acc.w;
+  } else {
+    for (int64_t j = i; j < n; ++j) {
+      float acc = 0.f;
+      for (int s = 0; s < nsplit; ++s) acc += slab[static_cast<int64_t>(s) * n + j];
+      out[j] = acc;
+    }
+  }
+}
+
+// column sums, stage 1: block = 64 columns x a slab of rows; thread (c, g) strides rows by 4.
+constexpr int kColsumRows = 512;
+__global__ __launch_bounds__(kThreads) void colsum_part_k(const float* __restrict__ X, int64_t ldx,
+                                                          int64_t M, int N, float* __restrict__ part) {
+  __shared__ float red[4][64];
+  const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + c;
+  const int64_t r0 = static_cast<int64_t>(blockIdx.y) * kColsumRows;
+  const int64_t r1 = min(M, r0 + kColsumRows);
+  float acc = 0.f;
+  if (col < N)
+    for (int64_t r = r0 + g; r < r1; r += 4) acc += X[r * ldx + col];
+  red[g][c] = acc;
+  __syncthreads();
+  if (g == 0 && col < N)
+    part[static_cast<int64_t>(blockIdx.y) * N + col] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+}
+
+__global__ __launch_bounds__(kThreads) void colsum_final_k(const float* __restrict__ part, int nparts,
+                                                           int N, float* __restrict__ out) {
+  const int c = blockIdx.x * kThreads + threadIdx.x;
+  if (c >= N) return;
+  float acc = 0.f;
+  for (int p = 0; p < nparts; ++p) acc += part[static_cast<int64_t>(p) * N + c];
+  out[c] = acc;
+}
+
+bool vec_ok(const float* p, int64_t ld, int contiguous_extent) {
+  return mi::aligned16(p) && (ld & 3) == 0 && (contiguous_extent & 3) == 0;
+}
+
+template <int LA, int LB>
+int32_t launch(GemmArgs& a, int splits, hipStream_t st, const char* what) {
+  a.tiles_m = (a.M + BM - 1) / BM;
+  a.tiles_n = (a.N + BN - 1) / BN;
+  const int64_t nblocks = static_cast<int64_t>(a.tiles_m) * a.tiles_n * splits;
+  if (nblocks <= 0 || nblocks > INT32_MAX) {
+    mi::set_error("%s: bad grid (%lld blocks)", what, (long long)nblocks);
+    return MI_ERR_INVALID;
+  }
+  gemm_f32_k<LA, LB><<<dim3((unsigned)nblocks), dim3(kThreads), 0, st>>>(a);
+  MI_CHECK_LAUNCH(what);
+  return MI_OK;
+}
+
+// split-K policy for the weight gradient: enough blocks to fill 256 CUs x 2, k slices multiple of BK
+int wgrad_splits(int64_t M, int N, int K) {
+  const int64_t tiles = mi::ceil_div(K, BM) * mi::ceil_div(N, BN);
+  int64_t s = mi::ceil_div(1024, tiles);
+  const int64_t max_s = mi::ceil_div(M, 4 * BK);  // at least 4 k-tiles per slice
+  if (s > max_s) s = max_s;
+  if (s < 1) s = 1;
+  if (s > 256) s = 256;
+  return static_cast<int>(s);
+}
+
+int64_t wgrad_k_per_split(int64_t M, int splits) {
+  return mi::ceil_div(mi::ceil_div(M, splits), BK) * BK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t mi_dense_fwd(const float* X, int64_t ldx, const float* W, const float* bias, float* Y,
+                     int64_t ldy, int64_t M, int32_t N, int32_t K, int32_t relu, float keep_prob,
+                     uint64_t seed, mi_stream_t stream) {
+  MI_REQUIRE(M >= 0 && M <= INT32_MAX && N > 0 && K > 0, "dense_fwd: M=%lld N=%d K=%d", (long long)M, N, K);
+  if (M == 0) return MI_OK;
+  MI_REQUIRE(X && W && Y, "dense_fwd: null buffer");
+  MI_REQUIRE(ldx >= K && ldy >= N, "dense_fwd: ldx=%lld ldy=%lld", (long long)ldx, (long long)ldy);
+  MI_REQUIRE(keep_prob > 0.f && keep_prob <= 1.f, "dense_fwd: keep_prob=%f", keep_prob);
+  GemmArgs a{};
+  a.A = X; a.lda = ldx; a.B = W; a.ldb = N; a.C = Y; a.ldc = ldy;
+  a.M = (int)M; a.N = N; a.K = K; a.k_per_split = ((K + BK - 1) / BK) * BK;
+  a.vecA = vec_ok(X, ldx, K); a.vecB = vec_ok(W, N, N);
+  a.epi = EPI_BIAS_ACT; a.bias = bias; a.relu = relu;
+  a.keep_prob = keep_prob; a.inv_keep = 1.f / keep_prob; a.seed = seed;
+  return launch<KC, MC>(a, 1, mi::as_stream(stream), "dense_fwd");
+}
+
+int32_t mi_dense_bwd_data(const float* dY, int64_t lddy, const float* W, const float* Xact,
+                          int64_t ldxa, float* dX, int64_t lddx, int64_t M, int32_t N, int32_t K,
+                          float keep_prob, mi_stream_t stream) {
+  MI_REQUIRE(M >= 0 && M <= INT32_MAX && N > 0 && K > 0, "dense_bwd_data: M=%lld N=%d K=%d", (long long)M, N, K);
+  if (M == 0) return MI_OK;
+  MI_REQUIRE(dY && W && dX, "dense_bwd_data: null buffer");
+  MI_REQUIRE(lddy >= N && lddx >= K && (!Xact || ldxa >= K), "dense_bwd_data: leading dimensions");
+  MI_REQUIRE(keep_prob > 0.f && keep_prob <= 1.f, "dense_bwd_data: keep_prob=%f", keep_prob);
+  GemmArgs a{};                       // dX[M,K] = dY[M,N] * W[K,N]^T : gemm M x K x (reduce N)
+  a.A = dY; a.lda = lddy; a.B = W; a.ldb = N; a.C = dX; a.ldc = lddx;
+  a.M = (int)M; a.N = K; a.K = N; a.k_per_split = ((N + BK - 1) / BK) * BK;
+  a.vecA = vec_ok(dY, lddy, N); a.vecB = vec_ok(W, N, N);
+  a.epi = EPI_MASK; a.mask_src = Xact; a.ldm = ldxa;
+  a.keep_prob = keep_prob; a.inv_keep = Xact ? 1.f / keep_prob : 1.f;
+  return launch<KC, KC>(a, 1, mi::as_stream(stream), "dense_bwd_data");
+}
+
+size_t mi_colsum_workspace_bytes(int64_t M, int32_t N) {
+  return static_cast<size_t>(mi::ceil_div(M > 0 ? M : 1, kColsumRows)) * N * sizeof(float);
+}
+
+int32_t mi_colsum(const float* X, int64_t ldx, int64_t M, int32_t N, float* out, void* workspace,
+                  size_t workspace_bytes, mi_stream_t stream) {
+  MI_REQUIRE(M > 0 && N > 0 && X && out && workspace && ldx >= N, "colsum: M=%lld N=%d", (long long)M, N);
+  if (workspace_bytes < mi_colsum_workspace_bytes(M, N)) {
+    mi::set_error("colsum: workspace %zu < %zu", workspace_bytes, mi_colsum_workspace_bytes(M, N));
+    return MI_ERR_WORKSPACE;
+  }
+  const int64_t nparts = mi::ceil_div(M, kColsumRows);
+  MI_REQUIRE(nparts <= 65535, "colsum: M=%lld too large", (long long)M);
+  hipStream_t st = mi::as_stream(stream);
+  float* part = static_cast<float*>(workspace);
+  colsum_part_k<<<dim3((unsigned)mi::ceil_div(N, 64), (unsigned)nparts), dim3(kThreads), 0, st>>>(X, ldx, M, N, part);
+  MI_CHECK_LAUNCH("colsum(part)");
+  colsum_final_k<<<dim3((unsigned)mi::ceil_div(N, kThreads)), dim3(kThreads), 0, st>>>(part, (int)nparts, N, out);
+  MI_CHECK_LAUNCH("colsum(final)");
+  return MI_OK;
+}
+
+size_t mi_dense_bwd_weight_workspace_bytes(int64_t M, int32_t N, int32_t K) {
+  const int splits = wgrad_splits(M, N, K);
+  const size_t slab = static_cast<size_t>(splits) * K * N * sizeof(float);
+  const size_t cs = mi_colsum_workspace_bytes(M, N);
+  return (slab > cs ? slab : cs) + 256;
+}
+
+int32_t mi_dense_bwd_weight(const float* X, int64_t ldx, const float* dY, int64_t lddy, float* dW,
+                            float* db, int64_t M, int32_t N, int32_t K, void* workspace,
+                            size_t workspace_bytes, mi_stream_t stream) {
+  MI_REQUIRE(M > 0 && M <= INT32_MAX && N > 0 && K > 0, "dense_bwd_weight: M=%lld N=%d K=%d", (long long)M, N, K);
+  MI_REQUIRE(X && dY && dW && workspace, "dense_bwd_weight: null buffer");
+  MI_REQUIRE(ldx >= K && lddy >= N, "dense_bwd_weight: leading dimensions");
+  MI_REQUIRE(mi::aligned16(workspace), "dense_bwd_weight: workspace must be 16-byte aligned");
+  if (workspace_bytes < mi_dense_bwd_weight_workspace_bytes(M, N, K)) {
+    mi::set_error("dense_bwd_weight: workspace %zu < %zu", workspace_bytes,
+                  mi_dense_bwd_weight_workspace_bytes(M, N, K));
+    return MI_ERR_WORKSPACE;
+  }
+  hipStream_t st = mi::as_stream(stream);
+  if (db) {  // bias gradient first: it shares the workspace with the slabs
+    if (int32_t rc = mi_colsum(dY, lddy, M, N, db, workspace, workspace_bytes, stream)) return rc;
+  }
+  const int splits = wgrad_splits(M, N, K);
+  GemmArgs a{};                       // dW[K,N] = X[M,K]^T * dY[M,N] : gemm K x N x (reduce M)
+  a.A = X; a.lda = ldx; a.B = dY; a.ldb = lddy;
+  a.M = K; a.N = N; a.K = (int)M; a.k_per_split = (int)wgrad_k_per_split(M, splits);
+  a.vecA = vec_ok(X, ldx, K); a.vecB = vec_ok(dY, lddy, N);
+  if (splits == 1) {
+    a.C = dW; a.ldc = N; a.epi = EPI_MASK; a.mask_src = nullptr; a.inv_keep = 1.f; a.keep_prob = 1.f;
+    return launch<MC, MC>(a, 1, st, "dense_bwd_weight");
+  }
+  a.C = static_cast<float*>(workspace); a.ldc = N; a.epi = EPI_SLAB; a.keep_prob = 1.f; a.inv_keep = 1.f;
+  if (int32_t rc = launch<MC, MC>(a, splits, st, "dense_bwd_weight(split-K)")) return rc;
+  const int64_t n = static_cast<int64_t>(K) * N;
+  slab_reduce_k<<<dim3((unsigned)mi::ceil_div(mi::ceil_div(n, 4), kThreads)), dim3(kThreads), 0, st>>>(
+      static_cast<const float*>(workspace), splits, n, dW);
+  MI_CHECK_LAUNCH("dense_bwd_weight(reduce)");
+  return MI_OK;
+}
+
+}  // extern "C"

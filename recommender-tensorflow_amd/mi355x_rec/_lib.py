@@ -1,0 +1,124 @@
+"""ctypes binding of libmi355x_rec.so (include/mi355x_rec.h).
+
+The library is the product: there is no Python / PyTorch fallback for any entry point.  If the
+shared object is missing or an entry fails, an exception is raised.
+
+torch must be imported before the library is loaded: PyTorch-ROCm bundles its own
+``libamdhip64.so`` (soname ``libamdhip64.so.7``) and the dynamic loader then resolves this
+library's DT_NEEDED ``libamdhip64.so.7`` to that already-loaded runtime, so device pointers and
+streams handed over by torch belong to the same HIP context.
+"""
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (loads the HIP runtime this library must share)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmi355x_rec.so")
+
+ABI_VERSION = 1
+
+
+class MiError(RuntimeError):
+    pass
+
+
+class OptHparams(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float),
+                ("epsilon", C.c_float), ("lr_t", C.c_float), ("decay", C.c_float),
+                ("momentum", C.c_float), ("lr_power", C.c_float), ("l1", C.c_float),
+                ("l2", C.c_float)]
+
+
+_p = C.c_void_p
+_i32, _i64, _u64, _f32, _sz = C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/mi355x_rec.h declaration by declaration
+SIGNATURES = {
+    "mi_abi_version": (_i32, []),
+    "mi_last_error": (C.c_char_p, []),
+    "mi_build_info": (C.c_char_p, []),
+    "mi_fingerprint64": (_u64, [_p, _sz]),
+    "mi_hash_bucket_i64": (_i32, [_p, _i64, _i64, _p]),
+    "mi_hash_bucket_bytes": (_i32, [_p, _p, _i64, _i64, _p]),
+    "mi_bucketize_f32": (_i32, [_p, _i64, _p, _i32, _p]),
+    "mi_embed_fm_linear_fwd": (_i32, [_p, _p, _p, _p, _i64, _i32, _i32, _p, _i64, _p, _p, _p, _p]),
+    "mi_gather_rows": (_i32, [_p, _p, _p, _i64, _i32, _p, _p, _p]),
+    "mi_numeric_embed_fwd": (_i32, [_p, _p, _p, _i64, _i32, _i32, _p, _i64, _i64, _p, _p, _p, _p]),
+    "mi_embed_fm_linear_bwd": (_i32, [_p, _i64, _p, _i64, _p, _p, _p, _p, _i64, _i32, _i32, _p, _p, _p]),
+    "mi_numeric_embed_bwd_workspace_bytes": (_sz, [_i64, _i32, _i32]),
+    "mi_numeric_embed_bwd": (_i32, [_p, _p, _i64, _p, _i64, _i64, _p, _p, _p, _i64, _i32, _i32, _p,
+                                    _p, _p, _sz, _p]),
+    "mi_sort_unique_workspace_bytes": (_sz, [_i64]),
+    "mi_sort_unique_rows": (_i32, [_p, _i64, _i64, _p, _p, _p, _p, _p, _sz, _p]),
+    "mi_global_rows": (_i32, [_p, _p, _i64, _i32, _p, _p]),
+    "mi_dense_apply": (_i32, [_p, _p, _p, _p, _i64, C.POINTER(OptHparams), _p]),
+    "mi_sparse_apply": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _p, _i32, _i32,
+                               C.POINTER(OptHparams), _p]),
+    "mi_sparse_catchup": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p, _f32, _f32,
+                                 _f32, _p]),
+    "mi_dense_fwd": (_i32, [_p, _i64, _p, _p, _p, _i64, _i64, _i32, _i32, _i32, _f32, _u64, _p]),
+    "mi_dense_bwd_data": (_i32, [_p, _i64, _p, _p, _i64, _p, _i64, _i64, _i32, _i32, _f32, _p]),
+    "mi_dense_bwd_weight_workspace_bytes": (_sz, [_i64, _i32, _i32]),
+    "mi_dense_bwd_weight": (_i32, [_p, _i64, _p, _i64, _p, _p, _i64, _i32, _i32, _p, _sz, _p]),
+    "mi_head_workspace_bytes": (_sz, [_i64]),
+    "mi_sigmoid_ce_head": (_i32, [_p, _p, _p, _p, _p, _i64, _f32, _p, _p, _p, _p, _sz, _p]),
+    "mi_colsum_workspace_bytes": (_sz, [_i64, _i32]),
+    "mi_colsum": (_i32, [_p, _i64, _i64, _i32, _p, _p, _sz, _p]),
+    "mi_layer_stats_workspace_bytes": (_sz, [_i64]),
+    "mi_layer_stats": (_i32, [_p, _i64, _p, _p, _sz, _p]),
+    "mi_eval_accumulate": (_i32, [_p, _p, _i64, _p, _p, _p, _p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library once; raises MiError if it is absent or has the wrong ABI."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MiError(
+            "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no fallback path." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise MiError("libmi355x_rec.so does not export %s (stale build?)" % name) from e
+        fn.restype = res
+        fn.argtypes = args
+    if lib.mi_abi_version() != ABI_VERSION:
+        raise MiError("ABI version %d != expected %d" % (lib.mi_abi_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise MiError("%s failed (%d): %s" % (what, rc, load().mi_last_error().decode()))
+
+
+def ptr(t):
+    """Device/host pointer of a torch tensor or numpy array (None -> NULL)."""
+    if t is None:
+        return None
+    if isinstance(t, torch.Tensor):
+        return t.data_ptr()
+    return t.ctypes.data
+
+
+def cur_stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def hip_runtime_paths():
+    """Every libamdhip64 mapped into this process — must be exactly one (see module docstring)."""
+    out = set()
+    with open("/proc/self/maps") as f:
+        for line in f:
+            if "libamdhip64" in line:
+                out.add(line.split()[-1])
+    return sorted(out)

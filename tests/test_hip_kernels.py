@@ -1,0 +1,367 @@
+"""-m gpu: every HIP kernel of libmi355x_rec.so, through the C ABI, against the CPU oracle.
+
+Tolerances: index / byte work and pure copies are compared bit for bit; fp32 reductions against
+the fp64 oracle at 1e-5 relative (north_star's bar) with the error measured against
+max(|ref|, rms(ref)) so that entries that cancel to ~0 do not blow the ratio up; optimizer kernels
+fed identical gradients are compared bit for bit with the fp32 oracle.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import deepfm as O
+from oracle import optimizers as OO
+from tests.util import dev, dropout_mask, max_err_scaled
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+def _st():
+    from mi355x_rec import _lib
+    return _lib.cur_stream()
+
+
+def _chk(rc, what="call"):
+    from mi355x_rec import _lib
+    _lib.check(rc, what)
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def test_single_hip_runtime(lib):
+    """The C ABI must share torch's HIP runtime (one libamdhip64 mapped), else pointers are foreign."""
+    from mi355x_rec import _lib
+    torch.zeros(1, device="cuda")
+    paths = _lib.hip_runtime_paths()
+    assert len(paths) == 1, paths
+
+
+@pytest.mark.parametrize("E", [4, 8, 12, 16, 64, 128, 256])
+@pytest.mark.parametrize("B,F", [(1, 1), (7, 5), (300, 26), (65, 40)])
+def test_embed_fm_linear_fwd(lib, E, B, F):
+    rng = np.random.default_rng(E * 1000 + B + F)
+    vocab = rng.integers(2, 50, F)
+    off = np.concatenate([[0], np.cumsum(vocab)]).astype(np.int64)
+    R = int(off[-1])
+    table = rng.standard_normal((R, E)).astype(np.float32)
+    lin_w = rng.standard_normal(R).astype(np.float32)
+    ids = np.stack([rng.integers(0, v, B) for v in vocab], 1).astype(np.int32)
+    t, lw, fo, di = dev(table), dev(lin_w), dev(off[:-1].copy()), dev(ids)
+    ld = F * E + 8                                     # exercise a padded leading dimension
+    concat = torch.full((B, ld), -7.0, device="cuda")
+    sumv = torch.empty(B, E, device="cuda")
+    fm = torch.empty(B, device="cuda")
+    lin = torch.empty(B, device="cuda")
+    _chk(lib.mi_embed_fm_linear_fwd(_p(t), _p(lw), _p(fo), _p(di), B, F, E, _p(concat), ld, _p(sumv), _p(fm),
+                                    _p(lin), _st()))
+    rows = off[:-1][None, :] + ids
+    ref = table[rows]                                  # [B,F,E]
+    got = concat.cpu().numpy()
+    assert np.array_equal(got[:, :F * E].reshape(B, F, E), ref)      # gather = exact copy
+    assert np.all(got[:, F * E:] == -7.0)                              # padding untouched
+    r64 = ref.astype(np.float64)
+    assert max_err_scaled(sumv.cpu().numpy(), r64.sum(1)) < TOL
+    assert max_err_scaled(fm.cpu().numpy(), O.fm_pairwise(ref)) < 5 * TOL  # s^2-q cancels: looser
+    assert max_err_scaled(lin.cpu().numpy(), lin_w[rows].astype(np.float64).sum(1)) < TOL
+
+
+def test_embed_fwd_linear_only_and_gather_rows(lib):
+    rng = np.random.default_rng(5)
+    F, B, E = 6, 100, 16
+    vocab = rng.integers(2, 30, F)
+    off = np.concatenate([[0], np.cumsum(vocab)]).astype(np.int64)
+    R = int(off[-1])
+    table = rng.standard_normal((R, E)).astype(np.float32)
+    lin_w = rng.standard_normal(R).astype(np.float32)
+    ids = np.stack([rng.integers(0, v, B) for v in vocab], 1).astype(np.int32)
+    lw, fo, di = dev(lin_w), dev(off[:-1].copy()), dev(ids)
+    lin = torch.empty(B, device="cuda")
+    _chk(lib.mi_embed_fm_linear_fwd(None, _p(lw), _p(fo), _p(di), B, F, E, None, 0, None, None, _p(lin), _st()))
+    rows = (off[:-1][None, :] + ids)
+    ref = np.zeros(B, np.float32)
+    for f in range(F):
+        ref = ref + lin_w[rows[:, f]]
+    assert np.array_equal(lin.cpu().numpy(), ref)       # same sequential fp32 order
+    # global rows + gather_rows
+    grow = torch.empty(B * F, dtype=torch.int32, device="cuda")
+    _chk(lib.mi_global_rows(_p(di), _p(fo), B, F, _p(grow), _st()))
+    assert np.array_equal(grow.cpu().numpy(), rows.reshape(-1).astype(np.int32))
+    out = torch.empty(B * F, E, device="cuda")
+    olin = torch.empty(B * F, device="cuda")
+    t = dev(table)
+    _chk(lib.mi_gather_rows(_p(t), _p(lw), _p(grow), B * F, E, _p(out), _p(olin), _st()))
+    assert np.array_equal(out.cpu().numpy(), table[rows.reshape(-1)])
+    assert np.array_equal(olin.cpu().numpy(), lin_w[rows.reshape(-1)])
+
+
+@pytest.mark.parametrize("E,F,B", [(4, 26, 33), (64, 26, 129), (16, 3, 50)])
+def test_embed_bwd_entries(lib, E, F, B):
+    rng = np.random.default_rng(E + F + B)
+    dc = rng.standard_normal((B, F * E)).astype(np.float32)
+    cc = rng.standard_normal((B, F * E)).astype(np.float32)
+    sv = cc.reshape(B, F, E).sum(1).astype(np.float32)
+    dl = rng.standard_normal(B).astype(np.float32)
+    pos = rng.permutation(B * F).astype(np.int32)
+    d_rows = torch.empty(B * F, E, device="cuda")
+    d_lin = torch.empty(B * F, device="cuda")
+    a = [dev(x) for x in (dc, cc, sv, dl, pos)]
+    _chk(lib.mi_embed_fm_linear_bwd(_p(a[0]), F * E, _p(a[1]), F * E, _p(a[2]), _p(a[3]), _p(a[3]), _p(a[4]), B, F,
+                                    E, _p(d_rows), _p(d_lin), _st()))
+    ref = dc.reshape(B, F, E).astype(np.float64) + dl[:, None, None].astype(np.float64) * (
+        sv[:, None, :].astype(np.float64) - cc.reshape(B, F, E))
+    g = d_rows.cpu().numpy()
+    assert max_err_scaled(g[pos], ref.reshape(B * F, E)) < TOL
+    assert np.array_equal(d_lin.cpu().numpy()[pos], np.repeat(dl, F))
+
+
+GEMM_SHAPES = [(32, 16, 104), (300, 128, 256), (1000, 1, 128), (257, 130, 70), (128, 128, 32), (513, 64, 1),
+               (4096, 512, 1664), (77, 3, 5)]
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+@pytest.mark.parametrize("relu", [0, 1])
+def test_dense_fwd(lib, M, N, K, relu):
+    rng = np.random.default_rng(M + N + K)
+    X = rng.standard_normal((M, K)).astype(np.float32)
+    W = (rng.standard_normal((K, N)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    Y = torch.empty(M, N, device="cuda")
+    x, w, bb = dev(X), dev(W), dev(b)
+    _chk(lib.mi_dense_fwd(_p(x), K, _p(w), _p(bb), _p(Y), N, M, N, K, relu, 1.0, 0, _st()))
+    ref = X.astype(np.float64) @ W.astype(np.float64) + b
+    pre = ref.copy()
+    if relu:
+        ref = np.maximum(ref, 0)
+    got = Y.cpu().numpy().astype(np.float64)
+    scale = np.sqrt(np.mean(pre * pre))
+    assert np.max(np.abs(got - ref)) / scale < TOL
+
+
+def test_dense_fwd_dropout_mask_matches_host_replica(lib):
+    M, N, K = 200, 48, 64
+    rng = np.random.default_rng(9)
+    X = rng.standard_normal((M, K)).astype(np.float32)
+    W = rng.standard_normal((K, N)).astype(np.float32)
+    b = np.zeros(N, np.float32)
+    x, w, bb = dev(X), dev(W), dev(b)
+    Y0 = torch.empty(M, N, device="cuda"); Y1 = torch.empty(M, N, device="cuda")
+    seed, keep = 0x1234567, 0.9
+    _chk(lib.mi_dense_fwd(_p(x), K, _p(w), _p(bb), _p(Y0), N, M, N, K, 1, 1.0, seed, _st()))
+    _chk(lib.mi_dense_fwd(_p(x), K, _p(w), _p(bb), _p(Y1), N, M, N, K, 1, keep, seed, _st()))
+    mask = dropout_mask(seed, M, N, keep)
+    assert 0.85 < (mask > 0).mean() < 0.95
+    assert np.array_equal(Y1.cpu().numpy(), Y0.cpu().numpy() * mask)   # bit exact: y * (1/keep) or 0
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+def test_dense_bwd_data_and_weight(lib, M, N, K):
+    rng = np.random.default_rng(M * 3 + N + K)
+    X = np.maximum(rng.standard_normal((M, K)), 0).astype(np.float32)     # a post-relu activation
+    W = (rng.standard_normal((K, N)) / np.sqrt(K)).astype(np.float32)
+    dY = rng.standard_normal((M, N)).astype(np.float32)
+    x, w, dy = dev(X), dev(W), dev(dY)
+    dX = torch.empty(M, K, device="cuda")
+    keep = 0.8
+    _chk(lib.mi_dense_bwd_data(_p(dy), N, _p(w), _p(x), K, _p(dX), K, M, N, K, keep, _st()))
+    full = dY.astype(np.float64) @ W.astype(np.float64).T
+    ref = full * (X > 0) * np.float64(np.float32(1.0) / np.float32(keep))
+    scale = np.sqrt(np.mean(full * full)) + 1e-30
+    assert np.max(np.abs(dX.cpu().numpy() - ref)) / scale < 2 * TOL
+    _chk(lib.mi_dense_bwd_data(_p(dy), N, _p(w), None, K, _p(dX), K, M, N, K, 1.0, _st()))
+    assert np.max(np.abs(dX.cpu().numpy() - full)) / scale < TOL
+    # weight + bias gradient (split-K over M)
+    nb = lib.mi_dense_bwd_weight_workspace_bytes(M, N, K)
+    ws = torch.empty(nb + 256, dtype=torch.uint8, device="cuda")
+    dW = torch.empty(K, N, device="cuda"); db = torch.empty(N, device="cuda")
+    _chk(lib.mi_dense_bwd_weight(_p(x), K, _p(dy), N, _p(dW), _p(db), M, N, K, _p(ws), ws.numel(), _st()))
+    refW = X.astype(np.float64).T @ dY.astype(np.float64)
+    sW = np.sqrt(np.mean(refW * refW)) + 1e-30
+    assert np.max(np.abs(dW.cpu().numpy() - refW)) / sW < TOL
+    refb = dY.astype(np.float64).sum(0)
+    assert np.max(np.abs(db.cpu().numpy() - refb)) / (np.sqrt(np.mean(refb * refb)) + 1e-30) < TOL
+    # reproducible: a second run gives the same bits
+    dW2 = torch.empty(K, N, device="cuda")
+    _chk(lib.mi_dense_bwd_weight(_p(x), K, _p(dy), N, _p(dW2), None, M, N, K, _p(ws), ws.numel(), _st()))
+    assert torch.equal(dW, dW2)
+
+
+@pytest.mark.parametrize("B", [1, 37, 5000])
+def test_sigmoid_ce_head(lib, B):
+    rng = np.random.default_rng(B)
+    lin = rng.standard_normal(B).astype(np.float32) * 3
+    fm = rng.standard_normal(B).astype(np.float32)
+    dnn = rng.standard_normal(B).astype(np.float32)
+    bias = np.array([0.25], np.float32)
+    y = (rng.random(B) < 0.4).astype(np.uint8)
+    a = [dev(v) for v in (lin, bias, fm, dnn, y)]
+    logits = torch.empty(B, device="cuda"); loss = torch.empty(1, device="cuda"); dl = torch.empty(B, device="cuda")
+    ws = torch.empty(lib.mi_head_workspace_bytes(B) + 256, dtype=torch.uint8, device="cuda")
+    for scale in (1.0 / B, 1.0):
+        _chk(lib.mi_sigmoid_ce_head(_p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), _p(a[4]), B, scale, _p(logits),
+                                    _p(loss), _p(dl), _p(ws), ws.numel(), _st()))
+        x32 = ((lin + bias[0]) + fm) + dnn                          # the reference's summation order
+        assert np.array_equal(logits.cpu().numpy(), x32)
+        l64, d64, _, _ = O.head(x32.astype(np.float64), y, "mean" if scale != 1.0 else "sum")
+        assert abs(loss.item() - l64) / abs(l64) < TOL
+        assert max_err_scaled(dl.cpu().numpy(), d64) < TOL
+    # a term left out is skipped, not read
+    _chk(lib.mi_sigmoid_ce_head(None, None, _p(a[2]), None, None, B, 1.0, _p(logits), None, None, None, 0, _st()))
+    assert np.array_equal(logits.cpu().numpy(), fm)
+
+
+@pytest.mark.parametrize("n,R", [(1, 10), (100, 7), (5000, 300), (70000, 4106), (200000, 26_000_000), (4097, 65536)])
+def test_sort_unique_rows(lib, n, R):
+    rng = np.random.default_rng(n + R)
+    rows = rng.integers(0, R, n).astype(np.int32)
+    if n > 10:
+        rows[n // 2:n // 2 + 5] = rows[0]
+    r = dev(rows)
+    se = torch.empty(n, dtype=torch.int32, device="cuda")
+    uq = torch.empty(n, dtype=torch.int32, device="cuda")
+    sg = torch.empty(n + 1, dtype=torch.int32, device="cuda")
+    nu = torch.empty(1, dtype=torch.int32, device="cuda")
+    ws = torch.empty(lib.mi_sort_unique_workspace_bytes(n) + 256, dtype=torch.uint8, device="cuda")
+    _chk(lib.mi_sort_unique_rows(_p(r), n, R, _p(se), _p(uq), _p(sg), _p(nu), _p(ws), ws.numel(), _st()))
+    order = np.argsort(rows, kind="stable").astype(np.int32)
+    assert np.array_equal(se.cpu().numpy(), order)                  # stable: bit exact
+    u = np.unique(rows)
+    U = int(nu.item())
+    assert U == len(u)
+    assert np.array_equal(uq.cpu().numpy()[:U], u)
+    sr = rows[order]
+    starts = np.flatnonzero(np.r_[True, sr[1:] != sr[:-1]])
+    assert np.array_equal(sg.cpu().numpy()[:U + 1], np.r_[starts, n].astype(np.int32))
+
+
+def test_colsum_and_layer_stats(lib):
+    rng = np.random.default_rng(3)
+    M, N = 3000, 70
+    X = np.maximum(rng.standard_normal((M, N)), 0).astype(np.float32)
+    x = dev(X)
+    out = torch.empty(N, device="cuda")
+    ws = torch.empty(lib.mi_colsum_workspace_bytes(M, N) + 256, dtype=torch.uint8, device="cuda")
+    _chk(lib.mi_colsum(_p(x), N, M, N, _p(out), _p(ws), ws.numel(), _st()))
+    assert max_err_scaled(out.cpu().numpy(), X.astype(np.float64).sum(0)) < TOL
+    o4 = torch.empty(4, device="cuda")
+    ws = torch.empty(lib.mi_layer_stats_workspace_bytes(M * N) + 256, dtype=torch.uint8, device="cuda")
+    _chk(lib.mi_layer_stats(_p(x), M * N, _p(o4), _p(ws), ws.numel(), _st()))
+    s = O.layer_summary(X)
+    g = o4.cpu().numpy()
+    assert abs(g[0] - s["fraction_of_zero_values"]) < 1e-6 and g[1] == s["min"] and g[2] == s["max"]
+    assert abs(g[3] - s["mean"]) < 1e-5
+
+
+def _hp(lib, spec, lr_t=0.0):
+    from mi355x_rec.engine import OptimizerSpec
+    return OptimizerSpec(**spec).hparams(lr_t)
+
+
+@pytest.mark.parametrize("name", OO.NAMES)
+def test_dense_apply_bit_exact(lib, name):
+    rng = np.random.default_rng(11)
+    n = 1000
+    hp = OO.Hyper(name, lr=0.05 if name != "Adam" else 0.001)
+    w = rng.standard_normal(n).astype(np.float32)
+    s0, s1 = OO.slot_init(hp, w)
+    s0 = s0.copy(); s1 = s1.copy()
+    dw, d0, d1 = dev(w), dev(s0), dev(s1)
+    powers = OO.AdamPowers(hp, np.float32) if name == "Adam" else None
+    from mi355x_rec.engine import OptimizerSpec
+    spec = OptimizerSpec(name, hp.lr)
+    for step in range(3):
+        g = rng.standard_normal(n).astype(np.float32)
+        lr_t = powers.lr_t(hp.lr) if powers else 0.0
+        OO.dense_apply(hp, w, s0, s1, g, lr_t)
+        if powers:
+            powers.finish()
+        h = spec.hparams(float(lr_t))
+        _chk(lib.mi_dense_apply(_p(dw), _p(d0) if name != "SGD" else None,
+                                _p(d1) if name in ("Adam", "Ftrl", "RMSProp") else None, _p(dev(g)), n,
+                                C.byref(h), _st()))
+    assert np.array_equal(dw.cpu().numpy(), w)
+    if name != "SGD":
+        assert np.array_equal(d0.cpu().numpy(), s0)
+
+
+@pytest.mark.parametrize("name", OO.NAMES)
+@pytest.mark.parametrize("E", [4, 64])
+def test_sparse_apply_and_catchup_bit_exact(lib, name, E):
+    """Sparse apply (+ for Adam the lazy catch-up) against the oracle's TF rule — for Adam that is
+    the literal whole-table sweep of adam.py _apply_sparse_shared, so equality here shows that
+    lazy catch-up == sweep, bit for bit, including rows that sit out several steps."""
+    from mi355x_rec.engine import OptimizerSpec, AdamSchedule
+    rng = np.random.default_rng(E)
+    R, steps = 50, 7
+    hp = OO.Hyper(name, lr=0.05 if name != "Adam" else 0.001)
+    spec = OptimizerSpec(name, hp.lr)
+    W = rng.standard_normal((R, E)).astype(np.float32)
+    L = rng.standard_normal((R, 1)).astype(np.float32)
+    ws0, ws1 = [a.copy() for a in OO.slot_init(hp, W)]
+    ls0, ls1 = [a.copy() for a in OO.slot_init(hp, L)]
+    dW, dL = dev(W), dev(L[:, 0].copy())
+    d_ws0, d_ws1, d_ls0, d_ls1 = dev(ws0), dev(ws1), dev(ls0[:, 0].copy()), dev(ls1[:, 0].copy())
+    last = torch.zeros(R, dtype=torch.int32, device="cuda")
+    powers = OO.AdamPowers(hp, np.float32) if name == "Adam" else None
+    sched = AdamSchedule(spec, "cuda", 64) if name == "Adam" else None
+    need0, need1 = name != "SGD", name in ("Adam", "Ftrl", "RMSProp")
+    for step in range(1, steps + 1):
+        n = 40
+        rows = rng.integers(0, R // 2 if step % 2 else R, n).astype(np.int32)   # some rows sit out
+        rows[5] = rows[0]; rows[6] = rows[0]
+        g = rng.standard_normal((n, E)).astype(np.float32)
+        gl = rng.standard_normal((n, 1)).astype(np.float32)
+        lr_t = powers.lr_t(hp.lr) if powers else 0.0
+        OO.sparse_apply(hp, W, ws0, ws1, rows, g, lr_t)
+        OO.sparse_apply(hp, L, ls0, ls1, rows, gl, lr_t)
+        if powers:
+            powers.finish()
+        r = dev(rows)
+        se = torch.empty(n, dtype=torch.int32, device="cuda"); uq = torch.empty(n, dtype=torch.int32, device="cuda")
+        sg = torch.empty(n + 1, dtype=torch.int32, device="cuda"); nu = torch.empty(1, dtype=torch.int32, device="cuda")
+        wsb = torch.empty(lib.mi_sort_unique_workspace_bytes(n) + 256, dtype=torch.uint8, device="cuda")
+        _chk(lib.mi_sort_unique_rows(_p(r), n, R, _p(se), _p(uq), _p(sg), _p(nu), _p(wsb), wsb.numel(), _st()))
+        if name == "Adam" and step > 1:
+            assert abs(sched.lr_t(step) - float(lr_t)) == 0.0
+            _chk(lib.mi_sparse_catchup(_p(dW), _p(d_ws0), _p(d_ws1), _p(dL), _p(d_ls0), _p(d_ls1), _p(last), _p(uq),
+                                       _p(nu), n, E, step - 1, _p(sched.table), hp.beta1, hp.beta2, hp.epsilon, _st()))
+        h = spec.hparams(float(lr_t))
+        _chk(lib.mi_sparse_apply(_p(dW), _p(d_ws0) if need0 else None, _p(d_ws1) if need1 else None, _p(dL),
+                                 _p(d_ls0) if need0 else None, _p(d_ls1) if need1 else None,
+                                 _p(last) if name == "Adam" else None, _p(uq), _p(sg), _p(se), _p(nu), n,
+                                 _p(dev(g)), _p(dev(gl[:, 0].copy())), E, step, C.byref(h), _st()))
+    if name == "Adam":   # bring the rows that sat out the last steps up to date: all-rows catch-up
+        _chk(lib.mi_sparse_catchup(_p(dW), _p(d_ws0), _p(d_ws1), _p(dL), _p(d_ls0), _p(d_ls1), _p(last), None, None,
+                                   R, E, steps, _p(sched.table), hp.beta1, hp.beta2, hp.epsilon, _st()))
+        assert np.all(last.cpu().numpy() == steps)
+    assert np.array_equal(dW.cpu().numpy(), W)
+    assert np.array_equal(dL.cpu().numpy(), L[:, 0])
+    if need0:
+        assert np.array_equal(d_ws0.cpu().numpy(), ws0)
+    if need1:
+        assert np.array_equal(d_ws1.cpu().numpy(), ws1)
+
+
+def test_eval_accumulate_matches_metrics_oracle(lib):
+    from oracle.metrics import BinaryMetrics
+    rng = np.random.default_rng(2)
+    hist = torch.zeros(2 * 201, dtype=torch.int64, device="cuda")
+    counts = torch.zeros(8, dtype=torch.int64, device="cuda")
+    sums = torch.zeros(4, dtype=torch.float64, device="cuda")
+    bm = BinaryMetrics()
+    for B in (1000, 37):
+        x = (rng.standard_normal(B) * 2).astype(np.float32)
+        x[:3] = [0.0, 30.0, -30.0]
+        y = (rng.random(B) < 0.3).astype(np.uint8)
+        bm.update(x, y)
+        _chk(lib.mi_eval_accumulate(_p(dev(x)), _p(dev(y)), B, _p(hist), _p(counts), _p(sums), _st()))
+    from mi355x_rec.metrics import metrics_from_counters
+    got = metrics_from_counters(hist.cpu().numpy(), counts.cpu().numpy(), sums.cpu().numpy())
+    ref = bm.result()
+    for k in ref:
+        assert abs(got[k] - ref[k]) < 1e-6, (k, got[k], ref[k])

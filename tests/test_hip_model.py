@@ -1,0 +1,193 @@
+"""-m gpu: the whole model_fn-shaped path (engine.DeepFM over the C ABI) against the oracle's
+restatement of trainers/deep_fm.py:36-125 on identical weights and inputs.
+
+Forward logits / loss: 1e-5 relative to the fp64 oracle (north_star's bar).
+Training: after k optimizer steps every variable must agree with the fp32 oracle to 2e-6 absolute
+(updates are ~lr = 1e-3 per step, so this is ~1e-3 of one step; Adam divides by sqrt(v)+1e-8, which
+amplifies the 1e-7-relative differences between MFMA and OpenBLAS summation order for gradients
+below ~3e-7 — see DESIGN.md "Parity").
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import deepfm as O
+from oracle import optimizers as OO
+from tests.util import dev, dropout_mask, make_problem, max_err_scaled
+
+pytestmark = pytest.mark.gpu
+
+ML100K_VOCAB = [2, 2, 7, 2, 2, 2, 2, 2, 2, 2, 2, 3, 2, 2000, 2, 2, 50, 8, 2, 2, 2, 2, 1000, 2, 2, 1000]  # sorted order
+
+
+def _engine(vocab, E, hidden, n_numeric=0, **kw):
+    from mi355x_rec.engine import DeepFM, OptimizerSpec
+    opt = kw.pop("optimizer", OptimizerSpec("Adam", 0.001))
+    return DeepFM(vocab, n_numeric=n_numeric, embedding_size=E, hidden_units=hidden, optimizer=opt, **kw)
+
+
+CONFIGS = [
+    # vocab, E, hidden, B, n_numeric
+    (ML100K_VOCAB, 4, [16, 16], 32, 0),              # trainers.deep_fm defaults (config 2)
+    ([50, 30, 20, 40], 64, [512, 256, 128], 300, 0),  # config-3 shaped, small vocab
+    ([11, 5, 9], 8, [32], 257, 2),                    # numeric columns (deep_fm.py:62-73)
+    ([7] * 40, 128, [64, 32], 65, 0),                 # config-5 shaped
+]
+
+
+@pytest.mark.parametrize("vocab,E,hidden,B,nn", CONFIGS)
+def test_forward_logits_and_loss(vocab, E, hidden, B, nn):
+    p, ids, x, y = make_problem(1, vocab, E, hidden, B, n_numeric=nn)
+    m = _engine(vocab, E, hidden, nn)
+    m.load_oracle_params(p)
+    loss, logits = m.loss(dev(ids), dev(y), dev(x))
+    p64 = p.astype(np.float64)
+    c = O.forward(p64, ids, None if x is None else x.astype(np.float64))
+    l64 = O.head(c["logits"], y)[0]
+    assert max_err_scaled(logits.cpu().numpy(), c["logits"]) < 1e-5
+    assert abs(loss.item() - l64) / abs(l64) < 1e-5
+
+
+@pytest.mark.parametrize("flags", [(True, True, True), (True, False, False), (False, True, False),
+                                   (False, False, True), (True, False, True), (False, True, True)])
+def test_component_flags(flags):
+    """use_linear / use_mf / use_dnn (deep_fm.py:16-18,37,76,93) incl. training."""
+    ul, um, ud = flags
+    vocab, E, hidden, B = [9, 13, 5, 6], 8, [16, 8], 64
+    p, ids, x, y = make_problem(2, vocab, E, hidden, B, use_dnn=ud)
+    m = _engine(vocab, E, hidden, use_linear=ul, use_mf=um, use_dnn=ud)
+    m.load_oracle_params(p)
+    st = O.TrainState(p, OO.Hyper("Adam", 0.001))
+    for _ in range(3):
+        loss_o, _ = O.train_step(p, st, ids, y, None, ul, um, ud)
+        loss_g, _ = m.train_step(dev(ids), dev(y))
+        assert abs(loss_g.item() - float(loss_o)) / abs(float(loss_o)) < 2e-5
+    _compare_vars(m, p, 2e-6)
+
+
+def test_model_fn_errors():
+    from mi355x_rec.engine import DeepFM
+    with pytest.raises(ValueError, match="At least 1 feature column"):
+        DeepFM([], n_numeric=0)
+    with pytest.raises(ValueError, match="At least 1 of linear, mf or dnn"):
+        DeepFM([3, 4], use_linear=False, use_mf=False, use_dnn=False)
+
+
+def _compare_vars(m, p, atol):
+    g = m.export_numpy()
+    for f in range(len(p.emb)):
+        if g["emb"] is not None:
+            assert np.max(np.abs(g["emb"][f] - p.emb[f])) < atol, ("emb", f)
+        if g["lin_w"] is not None:
+            assert np.max(np.abs(g["lin_w"][f] - p.lin_w[f])) < atol, ("lin_w", f)
+    for i, (k, b) in enumerate(g["mlp"]):
+        assert np.max(np.abs(k - p.mlp[i][0])) < atol, ("kernel", i)
+        assert np.max(np.abs(b - p.mlp[i][1])) < atol, ("bias", i)
+    assert abs(g["lin_bias"][0] - p.lin_bias[0]) < atol
+    if "num_emb" in g:
+        assert np.max(np.abs(g["num_emb"] - p.num_emb)) < atol
+        assert np.max(np.abs(g["lin_num"] - p.lin_num)) < atol
+
+
+@pytest.mark.parametrize("vocab,E,hidden,B,nn", CONFIGS)
+def test_adam_training_matches_oracle(vocab, E, hidden, B, nn):
+    """5 train steps with fresh batches (rows sit out steps, duplicates inside a batch): the lazy
+    catch-up path must reproduce TF Adam's dense-equivalent sparse update."""
+    p, ids, x, y = make_problem(3, vocab, E, hidden, B, n_numeric=nn)
+    m = _engine(vocab, E, hidden, nn)
+    m.load_oracle_params(p)
+    st = O.TrainState(p, OO.Hyper("Adam", 0.001))
+    rng = np.random.default_rng(0)
+    for step in range(5):
+        ids_s = np.stack([rng.integers(0, v, B) for v in vocab], 1).astype(np.int32)
+        ids_s[B // 2] = ids_s[0]
+        loss_o, logit_o = O.train_step(p, st, ids_s, y, x)
+        loss_g, logit_g = m.train_step(dev(ids_s), dev(y), dev(x))
+        assert abs(loss_g.item() - float(loss_o)) / abs(float(loss_o)) < 2e-5, step
+        assert max_err_scaled(logit_g.cpu().numpy(), logit_o) < 5e-5, step
+    _compare_vars(m, p, 2e-6)
+    assert m.step == 5
+
+
+@pytest.mark.parametrize("name,lr", [("Adagrad", 0.05), ("Ftrl", 0.1), ("RMSProp", 0.001), ("SGD", 0.05)])
+def test_other_optimizers_training(name, lr):
+    """get_optimizer's other choices (model_utils.py:58-64)."""
+    from mi355x_rec.engine import OptimizerSpec
+    vocab, E, hidden, B = [9, 13, 5, 6], 8, [16, 8], 64
+    p, ids, x, y = make_problem(4, vocab, E, hidden, B)
+    m = _engine(vocab, E, hidden, optimizer=OptimizerSpec(name, lr))
+    m.load_oracle_params(p)
+    st = O.TrainState(p, OO.Hyper(name, lr))
+    for _ in range(3):
+        loss_o, _ = O.train_step(p, st, ids, y)
+        loss_g, _ = m.train_step(dev(ids), dev(y))
+        assert abs(loss_g.item() - float(loss_o)) / abs(float(loss_o)) < 5e-5
+    _compare_vars(m, p, 2e-5 if name != "RMSProp" else 2e-4)
+
+
+def test_dropout_training_step_matches_oracle_with_same_mask():
+    """TRAIN-mode dropout (deep_fm.py:102-103): the kernel's counter-based mask is replayed on the
+    host and handed to the oracle, so both sides drop the same units."""
+    vocab, E, hidden, B = [9, 13, 5, 6], 8, [32, 16], 128
+    p, ids, x, y = make_problem(5, vocab, E, hidden, B)
+    m = _engine(vocab, E, hidden, dropout=0.25, seed=7)
+    m.load_oracle_params(p)
+    st = O.TrainState(p, OO.Hyper("Adam", 0.001))
+    for _ in range(2):
+        masks = [dropout_mask(m._layer_seed(i), B, h, 0.75) for i, h in enumerate(hidden)]
+        loss_o, _ = O.train_step(p, st, ids, y, dropout_masks=masks)
+        loss_g, _ = m.train_step(dev(ids), dev(y))
+        assert abs(loss_g.item() - float(loss_o)) / abs(float(loss_o)) < 2e-5
+    _compare_vars(m, p, 2e-6)
+
+
+def test_sum_reduction_head():
+    """canned estimators: loss_reduction=SUM."""
+    vocab, E, hidden, B = [9, 13, 5], 4, [8], 40
+    p, ids, x, y = make_problem(6, vocab, E, hidden, B)
+    m = _engine(vocab, E, hidden, reduction="sum")
+    m.load_oracle_params(p)
+    loss, logits = m.loss(dev(ids), dev(y))
+    c = O.forward(p.astype(np.float64), ids)
+    assert abs(loss.item() - O.head(c["logits"], y, "sum")[0]) / loss.item() < 1e-5
+
+
+def test_full_size_properties():
+    """BASELINE config 3 at full size (B=65536, 26 x 1M rows, E=64, [512,256,128]) through
+    size-independent properties: gather is an exact copy of the addressed rows, FM equals the
+    pairwise-dot identity on sampled examples, the loss falls over a few steps, only touched rows
+    change, and a replay from the same state gives the same bits (determinism)."""
+    F, V, E, B = 26, 1_000_000, 64, 65536
+    m = _engine([V] * F, E, [512, 256, 128])
+    g = torch.Generator(device="cuda"); g.manual_seed(1)
+    m.init_variables(g, lin_scale=1e-3)
+    ids = torch.randint(0, V, (B, F), device="cuda", dtype=torch.int32, generator=g)
+    y = (torch.rand(B, device="cuda", generator=g) < 0.25).to(torch.uint8)
+    table0 = m.table.clone()
+    loss0, logits0 = m.loss(ids, y)
+    l0 = loss0.item()
+    concat = m._ws["concat"][:B * F * E].view(B, F, E)
+    rows = (ids.long() + m.field_off[None, :])
+    sel = torch.arange(0, B, 997, device="cuda")
+    assert torch.equal(concat[sel], m.table[rows[sel]])
+    v = concat[sel].double()
+    pair = 0.5 * ((v.sum(1) ** 2).sum(1) - (v * v).sum((1, 2)))
+    fm = m._ws["fm"][:B][sel].double()
+    assert float(((fm - pair).abs() / pair.abs().clamp_min(pair.abs().mean())).max()) < 5e-5
+    losses = [m.train_step(ids, y)[0].item() for _ in range(4)]
+    assert losses[0] == pytest.approx(l0, rel=1e-6)
+    assert losses[-1] < losses[0]
+    changed = (m.table != table0).any(1)
+    touched = torch.zeros(m.R, dtype=torch.bool, device="cuda"); touched[rows.reshape(-1)] = True
+    assert not bool((changed & ~touched).any())
+    assert int(changed.sum()) > 0.9 * int(touched.sum())
+    # determinism: same state + same batch -> same bits
+    keys = ("table", "t_s0", "t_s1", "lin_w", "l_s0", "l_s1", "last_step", "dense", "d_s0", "d_s1")
+    snap = {k: getattr(m, k).clone() for k in keys}
+    step = m.step
+    a = m.train_step(ids, y)[1].clone(); ta = m.table.clone()
+    for k in keys:
+        getattr(m, k).copy_(snap[k])
+    m.step = step
+    b = m.train_step(ids, y)[1]
+    assert torch.equal(a, b) and torch.equal(ta, m.table)

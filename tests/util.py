@@ -1,0 +1,54 @@
+"""Shared helpers for the parity tests (oracle side = checker, HIP side = thing under test)."""
+import numpy as np
+import torch
+
+from oracle import deepfm as O
+from oracle import optimizers as OO
+
+MASK64 = (1 << 64) - 1
+
+
+def dropout_mask(seed, M, N, keep):
+    """Host replica of gemm.hip's counter-based dropout mask: multiplier {0, 1/keep} per element."""
+    idx = np.arange(M * N, dtype=np.uint64)
+    x = (np.uint64(seed) + idx * np.uint64(0x9E3779B97F4A7C15))
+    x ^= x >> np.uint64(30); x *= np.uint64(0xbf58476d1ce4e5b9)
+    x ^= x >> np.uint64(27); x *= np.uint64(0x94d049bb133111eb)
+    x ^= x >> np.uint64(31)
+    thresh = np.uint32(np.float32(keep) * np.float32(16777216.0))
+    kept = (x >> np.uint64(40)).astype(np.uint32) < thresh
+    return (kept.astype(np.float32) * np.float32(np.float32(1.0) / np.float32(keep))).reshape(M, N)
+
+
+def make_problem(seed, vocab, E, hidden, B, n_numeric=0, lin_scale=0.05, dup=True, use_dnn=True):
+    rng = np.random.default_rng(seed)
+    p = O.init_params(rng, vocab, E, hidden, n_numeric=n_numeric, dtype=np.float32, lin_scale=lin_scale,
+                      use_dnn=use_dnn)
+    p.lin_bias[:] = 0.1
+    for k, b in p.mlp:
+        b[:] = (rng.standard_normal(b.shape) * 0.05).astype(np.float32)
+    ids = np.stack([rng.integers(0, v, B) for v in vocab], 1).astype(np.int32)
+    if dup and B > 3:
+        ids[B // 2] = ids[0]          # duplicate rows inside one batch
+        ids[B - 1, 0] = ids[1, 0]
+    x = rng.standard_normal((B, n_numeric)).astype(np.float32) if n_numeric else None
+    y = (rng.random(B) < 0.3).astype(np.uint8)
+    return p, ids, x, y
+
+
+def dev(a, device="cuda"):
+    return None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(device)
+
+
+def rel_err(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return float(np.max(np.abs(a - b) / (np.abs(b) + 1e-30))) if a.size else 0.0
+
+
+def max_err_scaled(a, b):
+    """max |a-b| / max(|b|, rms(b)): a relative error that does not blow up on entries near 0."""
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    if a.size == 0:
+        return 0.0
+    floor = np.sqrt(np.mean(b * b)) + 1e-30
+    return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), floor)))
