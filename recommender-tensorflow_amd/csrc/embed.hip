@@ -68,8 +68,8 @@ __global__ __launch_bounds__(kBlock) void embed_fm_linear_fwd_k(
         for (int u = 0; u < U; ++u) {
           if (j0 + u < nf) {
             s.x += r[u].x; s.y += r[u].y; s.z += r[u].z; s.w += r[u].w;
-            q.x += r[u].x * r[u].x; q.y += r[u].y * r[u].y;
-            q.z += r[u].z * r[u].z; q.w += r[u].w * r[u].w;
+            q.x += __fmul_rn(r[u].x, r[u].x); q.y += __fmul_rn(r[u].y, r[u].y);
+            q.z += __fmul_rn(r[u].z, r[u].z); q.w += __fmul_rn(r[u].w, r[u].w);
             if (valid && lane_on) st4(crow + static_cast<int64_t>(fb + j0 + u) * E + eo, r[u]);
           }
         }
@@ -94,8 +94,8 @@ __global__ __launch_bounds__(kBlock) void embed_fm_linear_fwd_k(
       for (int u = 0; u < U; ++u) {
         if (f0 + u < F) {
           s.x += r[u].x; s.y += r[u].y; s.z += r[u].z; s.w += r[u].w;
-          q.x += r[u].x * r[u].x; q.y += r[u].y * r[u].y;
-          q.z += r[u].z * r[u].z; q.w += r[u].w * r[u].w;
+          q.x += __fmul_rn(r[u].x, r[u].x); q.y += __fmul_rn(r[u].y, r[u].y);
+          q.z += __fmul_rn(r[u].z, r[u].z); q.w += __fmul_rn(r[u].w, r[u].w);
           if (valid && lane_on) st4(crow + static_cast<int64_t>(f0 + u) * E + eo, r[u]);
         }
       }
@@ -103,7 +103,9 @@ __global__ __launch_bounds__(kBlock) void embed_fm_linear_fwd_k(
   }
 
   // deep_fm.py:81-87: 0.5 * sum_e( (sum_d v)^2 - sum_d v^2 )
-  float t = ((s.x * s.x - q.x) + (s.y * s.y - q.y)) + ((s.z * s.z - q.z) + (s.w * s.w - q.w));
+  // tf.square then subtract: products rounded on their own (no fma), so one field gives exactly 0
+  float t = ((__fmul_rn(s.x, s.x) - q.x) + (__fmul_rn(s.y, s.y) - q.y)) +
+            ((__fmul_rn(s.z, s.z) - q.z) + (__fmul_rn(s.w, s.w) - q.w));
   t = group_sum<LPR>(t);
   lacc = group_sum<LPR>(lacc);
   if (valid) {
