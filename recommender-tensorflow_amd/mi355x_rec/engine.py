@@ -183,7 +183,7 @@ class DeepFM:
             # wide-part dense variables (linear bias, numeric linear weights) follow linear_optimizer
             self.dl_s0, self.dl_s1 = self._slots(self.dense, self.lin_opt)
         self._ws = {}
-        self._cache = None
+        self.timers = None
 
     # ------------------------------------------------------------------ variables
     def _slots(self, like, spec):
@@ -268,6 +268,20 @@ class DeepFM:
             self._ws[name] = cur
         return cur
 
+    def _run(self, fn, *args):
+        """Launch one C-ABI entry on the current stream; with self.timers set, bracket it with HIP
+        events on that stream (bench.py reads per-kernel durations from them)."""
+        if self.timers is None:
+            rc = fn(*args)
+        else:
+            s = torch.cuda.Event(enable_timing=True)
+            e = torch.cuda.Event(enable_timing=True)
+            s.record()
+            rc = fn(*args)
+            e.record()
+            self.timers.setdefault(fn.__name__, []).append((s, e))
+        check(rc, fn.__name__)
+
     def _layer_seed(self, layer):
         return (self.seed * 0x9E3779B97F4A7C15 + (self.step + 1) * 1000003 + layer * 7919) & (2 ** 64 - 1)
 
@@ -285,16 +299,14 @@ class DeepFM:
             sumv = self._buf("sumv", (B, self.E)) if self.use_mf else None
             fm = self._buf("fm", (B,)) if self.use_mf else None
         lin = self._buf("lin", (B,)) if self.use_linear else None
-        check(L.mi_embed_fm_linear_fwd(ptr(self.table), ptr(self.lin_w), ptr(self.field_off), ptr(ids),
-                                       B, self.F, self.E, ptr(concat), ld, ptr(sumv), ptr(fm), ptr(lin), st),
-              "mi_embed_fm_linear_fwd")
+        self._run(L.mi_embed_fm_linear_fwd, ptr(self.table), ptr(self.lin_w), ptr(self.field_off), ptr(ids),
+                                       B, self.F, self.E, ptr(concat), ld, ptr(sumv), ptr(fm), ptr(lin), st)
         if self.n_numeric:
             V = self._seg(self.dense, self.num_emb_off, (self.n_numeric, self.E))
             wn = self._seg(self.dense, self.lin_num_off, (self.n_numeric,)) if self.use_linear else None
             if self.use_emb:
-                check(L.mi_numeric_embed_fwd(ptr(x_num), ptr(V), ptr(wn), B, self.n_numeric, self.E,
-                                             ptr(concat), ld, self.F * self.E, ptr(sumv), ptr(fm), ptr(lin), st),
-                      "mi_numeric_embed_fwd")
+                self._run(L.mi_numeric_embed_fwd, ptr(x_num), ptr(V), ptr(wn), B, self.n_numeric, self.E,
+                                             ptr(concat), ld, self.F * self.E, ptr(sumv), ptr(fm), ptr(lin), st)
             else:
                 raise NotImplementedError("numeric columns need the embedding path (use_mf or use_dnn)")
         acts = []
@@ -305,9 +317,8 @@ class DeepFM:
             for i, (k_off, b_off, fan, h) in enumerate(self.layers):
                 last = i == nh
                 y = self._buf("act%d" % i, (B, h))
-                check(L.mi_dense_fwd(ptr(x), ldx, ptr(self.kernel(i)), ptr(self.bias(i)), ptr(y), h, B, h, fan,
-                                     0 if last else 1, 1.0 if last else keep, self._layer_seed(i), st),
-                      "mi_dense_fwd")
+                self._run(L.mi_dense_fwd, ptr(x), ldx, ptr(self.kernel(i)), ptr(self.bias(i)), ptr(y), h, B, h, fan,
+                                     0 if last else 1, 1.0 if last else keep, self._layer_seed(i), st)
                 acts.append(y)
                 x, ldx = y, h
             dnn = acts[-1].view(B)
@@ -325,9 +336,8 @@ class DeepFM:
         scale = np.float32(1.0 / n) if self.reduction == "mean" else np.float32(1.0)
         ws = self._bytes("head_ws", L.mi_head_workspace_bytes(B))
         lb = self.dense[self.lin_bias_off:] if self.use_linear else None
-        check(L.mi_sigmoid_ce_head(ptr(c["lin"]), ptr(lb), ptr(c["fm"]), ptr(c["dnn"]), ptr(labels), B,
-                                   float(scale), ptr(logits), ptr(loss), ptr(dlogit), ptr(ws), ws.numel(), st),
-              "mi_sigmoid_ce_head")
+        self._run(L.mi_sigmoid_ce_head, ptr(c["lin"]), ptr(lb), ptr(c["fm"]), ptr(c["dnn"]), ptr(labels), B,
+                                   float(scale), ptr(logits), ptr(loss), ptr(dlogit), ptr(ws), ws.numel(), st)
         return logits, loss, dlogit
 
     # ------------------------------------------------------------------ public steps
@@ -379,12 +389,11 @@ class DeepFM:
         if not (t_adam or l_adam):
             return
         self.sched.lr_t(self.step)  # make sure the table covers step
-        check(self.lib.mi_sparse_catchup(ptr(self.table if t_adam else None), ptr(self.t_s0 if t_adam else None),
+        self._run(self.lib.mi_sparse_catchup, ptr(self.table if t_adam else None), ptr(self.t_s0 if t_adam else None),
                                          ptr(self.t_s1 if t_adam else None), ptr(self.lin_w if l_adam else None),
                                          ptr(self.l_s0 if l_adam else None), ptr(self.l_s1 if l_adam else None),
                                          ptr(self.last_step), ptr(uniq), ptr(num_uniq), n_max, self.E, self.step,
-                                         ptr(self.sched.table), s.beta1, s.beta2, s.epsilon, st),
-              "mi_sparse_catchup")
+                                         ptr(self.sched.table), s.beta1, s.beta2, s.epsilon, st)
 
     def train_step(self, ids, labels, x_num=None):
         """One optimizer.minimize(loss): returns (loss [1], logits [B]) device tensors, no host sync."""
@@ -399,14 +408,14 @@ class DeepFM:
         i32 = torch.int32
         # (1) which rows does this batch touch: sort + unique (TF: unique/unsorted_segment_sum)
         rows = self._buf("rows", (n,), i32)
-        check(L.mi_global_rows(ptr(ids), ptr(self.field_off), B, self.F, ptr(rows), st), "mi_global_rows")
+        self._run(L.mi_global_rows, ptr(ids), ptr(self.field_off), B, self.F, ptr(rows), st)
         sorted_entry = self._buf("sorted_entry", (n,), i32)
         uniq = self._buf("uniq", (n,), i32)
         seg = self._buf("seg", (n + 1,), i32)
         num_uniq = self._buf("num_uniq", (1,), i32)
         ws = self._bytes("sort_ws", L.mi_sort_unique_workspace_bytes(n))
-        check(L.mi_sort_unique_rows(ptr(rows), n, self.R, ptr(sorted_entry), ptr(uniq), ptr(seg), ptr(num_uniq),
-                                    ptr(ws), ws.numel(), st), "mi_sort_unique_rows")
+        self._run(L.mi_sort_unique_rows, ptr(rows), n, self.R, ptr(sorted_entry), ptr(uniq), ptr(seg), ptr(num_uniq),
+                                    ptr(ws), ws.numel(), st)
         # (2) TF Adam moved these rows on every step they sat out: replay that now
         if self.adam_rows and self.step > 0:
             self._catchup(uniq, num_uniq, n, st)
@@ -418,10 +427,10 @@ class DeepFM:
         # (5) per-entry row gradients, then the sparse apply on unique rows
         d_rows = self._buf("d_rows", (n, self.E)) if self.use_emb else None
         d_lin = self._buf("d_lin", (n,)) if self.use_linear else None
-        check(L.mi_embed_fm_linear_bwd(ptr(d_concat), self.D, ptr(c["concat"]), self.D, ptr(c["sumv"]),
+        self._run(L.mi_embed_fm_linear_bwd, ptr(d_concat), self.D, ptr(c["concat"]), self.D, ptr(c["sumv"]),
                                        ptr(dlogit if self.use_mf else None),
                                        ptr(dlogit if self.use_linear else None), None, B, self.F, self.E,
-                                       ptr(d_rows), ptr(d_lin), st), "mi_embed_fm_linear_bwd")
+                                       ptr(d_rows), ptr(d_lin), st)
         self._apply(uniq, seg, sorted_entry, num_uniq, n, d_rows, d_lin, st)
         return loss, logits
 
@@ -440,26 +449,24 @@ class DeepFM:
                 k_off, b_off, fan, h = self.layers[i]
                 x = c["acts"][i - 1] if i else c["concat"]
                 ldx = self.layers[i - 1][3] if i else self.D
-                check(L.mi_dense_bwd_weight(ptr(x), ldx, ptr(dy), lddy, ptr(self.kernel(i, self.d_grad)),
-                                            ptr(self.bias(i, self.d_grad)), B, h, fan, ptr(ws), ws.numel(), st),
-                      "mi_dense_bwd_weight")
+                self._run(L.mi_dense_bwd_weight, ptr(x), ldx, ptr(dy), lddy, ptr(self.kernel(i, self.d_grad)),
+                                            ptr(self.bias(i, self.d_grad)), B, h, fan, ptr(ws), ws.numel(), st)
                 dx = self._buf("dact%d" % i, (B, fan))
-                check(L.mi_dense_bwd_data(ptr(dy), lddy, ptr(self.kernel(i)), ptr(x if i else None), ldx,
-                                          ptr(dx), fan, B, h, fan, keep if i else 1.0, st), "mi_dense_bwd_data")
+                self._run(L.mi_dense_bwd_data, ptr(dy), lddy, ptr(self.kernel(i)), ptr(x if i else None), ldx,
+                                          ptr(dx), fan, B, h, fan, keep if i else 1.0, st)
                 dy, lddy = dx, fan
             d_concat = dy
         if self.use_linear:   # d loss / d linear bias = sum_b dlogit
             ws = self._bytes("colsum_ws", L.mi_colsum_workspace_bytes(B, 1))
-            check(L.mi_colsum(ptr(dlogit), 1, B, 1, ptr(self.d_grad[self.lin_bias_off:]), ptr(ws), ws.numel(), st),
-                  "mi_colsum")
+            self._run(L.mi_colsum, ptr(dlogit), 1, B, 1, ptr(self.d_grad[self.lin_bias_off:]), ptr(ws), ws.numel(), st)
         if self.n_numeric:
             ws = self._bytes("num_ws", L.mi_numeric_embed_bwd_workspace_bytes(B, self.n_numeric, self.E))
-            check(L.mi_numeric_embed_bwd(ptr(c["x_num"]), ptr(d_concat), self.D, ptr(c["concat"]), self.D,
+            self._run(L.mi_numeric_embed_bwd, ptr(c["x_num"]), ptr(d_concat), self.D, ptr(c["concat"]), self.D,
                                          self.F * self.E, ptr(c["sumv"]), ptr(dlogit if self.use_mf else None),
                                          ptr(dlogit if self.use_linear else None), B, self.n_numeric, self.E,
                                          ptr(self.d_grad[self.num_emb_off:]),
                                          ptr(self.d_grad[self.lin_num_off:] if self.use_linear else None),
-                                         ptr(ws), ws.numel(), st), "mi_numeric_embed_bwd")
+                                         ptr(ws), ws.numel(), st)
         return d_concat
 
     def _apply(self, uniq, seg, sorted_entry, num_uniq, n_max, d_rows, d_lin, st):
@@ -470,31 +477,31 @@ class DeepFM:
         hp = self.opt.hparams(lr_t)
         if self.lin_opt is None:
             if self.P:
-                check(L.mi_dense_apply(ptr(self.dense), ptr(self.d_s0), ptr(self.d_s1), ptr(self.d_grad), self.P,
-                                       C.byref(hp), st), "mi_dense_apply")
+                self._run(L.mi_dense_apply, ptr(self.dense), ptr(self.d_s0), ptr(self.d_s1), ptr(self.d_grad), self.P,
+                                       C.byref(hp), st)
             sparse_hp = [(True, True, hp)]
         else:
             lhp = self.lin_opt.hparams(lr_t)
             if self.dnn_end:
-                check(L.mi_dense_apply(ptr(self.dense), ptr(self.d_s0), ptr(self.d_s1), ptr(self.d_grad),
-                                       self.dnn_end, C.byref(hp), st), "mi_dense_apply")
+                self._run(L.mi_dense_apply, ptr(self.dense), ptr(self.d_s0), ptr(self.d_s1), ptr(self.d_grad),
+                                       self.dnn_end, C.byref(hp), st)
             o = self.dnn_end
             sl = lambda t: t[o:] if t is not None else None
-            check(L.mi_dense_apply(ptr(self.dense[o:]), ptr(sl(self.dl_s0)), ptr(sl(self.dl_s1)),
-                                   ptr(self.d_grad[o:]), self.P - o, C.byref(lhp), st), "mi_dense_apply(linear)")
+            self._run(L.mi_dense_apply, ptr(self.dense[o:]), ptr(sl(self.dl_s0)), ptr(sl(self.dl_s1)),
+                                   ptr(self.d_grad[o:]), self.P - o, C.byref(lhp), st)
             sparse_hp = [(True, False, hp), (False, True, lhp)]
         for do_table, do_lin, h in sparse_hp:
             tb = self.table if (do_table and self.use_emb) else None
             lw = self.lin_w if (do_lin and self.use_linear) else None
             if tb is None and lw is None:
                 continue
-            check(L.mi_sparse_apply(ptr(tb), ptr(self.t_s0 if tb is not None else None),
+            self._run(L.mi_sparse_apply, ptr(tb), ptr(self.t_s0 if tb is not None else None),
                                     ptr(self.t_s1 if tb is not None else None), ptr(lw),
                                     ptr(self.l_s0 if lw is not None else None),
                                     ptr(self.l_s1 if lw is not None else None), ptr(self.last_step),
                                     ptr(uniq), ptr(seg), ptr(sorted_entry), ptr(num_uniq), n_max,
                                     ptr(d_rows if tb is not None else None), ptr(d_lin if lw is not None else None),
-                                    self.E, step, C.byref(h), st), "mi_sparse_apply")
+                                    self.E, step, C.byref(h), st)
         self.step = step
 
     # ------------------------------------------------------------------ checkpoint
