@@ -40,7 +40,7 @@ enum mi_status {
 };
 
 /* ---- library ---------------------------------------------------------------------------- */
-int32_t mi_abi_version(void);       /* bumps when a signature changes */
+int32_t mi_abi_version(void);       /* bumps when a signature changes (currently 2) */
 const char* mi_last_error(void);    /* thread-local, never NULL */
 const char* mi_build_info(void);    /* "gfx950 hipcc <ver>" */
 
@@ -225,13 +225,14 @@ int32_t mi_dense_bwd_weight(const float* X, int64_t ldx, const float* dY, int64_
  *   loss_out[0] = sum_b loss_b * loss_scale   (loss_scale = 1/B_global for the contrib head's
  *                 SUM_OVER_BATCH_SIZE, 1 for the canned estimators' SUM)
  *   d_logit[b]  = (sigmoid(x) - y) * loss_scale
- * labels: uint8 0/1 (ml_100k.py:48 rating >= cutoff).  d_logit / loss_out may be NULL (eval /
- * predict).  workspace: mi_head_workspace_bytes(B). */
+ *   d_logit_sum[0] = sum_b d_logit[b]   (= gradient of the linear_model bias; fixed-order sum)
+ * labels: uint8 0/1 (ml_100k.py:48 rating >= cutoff).  d_logit / d_logit_sum / loss_out may be NULL
+ * (eval / predict).  workspace: mi_head_workspace_bytes(B). */
 size_t mi_head_workspace_bytes(int64_t B);
 int32_t mi_sigmoid_ce_head(const float* lin, const float* lin_bias, const float* fm,
                            const float* dnn, const uint8_t* labels, int64_t B, float loss_scale,
-                           float* logits, float* loss_out, float* d_logit, void* workspace,
-                           size_t workspace_bytes, mi_stream_t stream);
+                           float* logits, float* loss_out, float* d_logit, float* d_logit_sum,
+                           void* workspace, size_t workspace_bytes, mi_stream_t stream);
 
 /* column sums: out[j] = sum_b X[b,j] (used for bias-style gradients), deterministic. */
 size_t mi_colsum_workspace_bytes(int64_t M, int32_t N);

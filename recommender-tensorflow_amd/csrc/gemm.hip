@@ -40,38 +40,48 @@ struct GemmArgs {
   const float* bias; int relu;
   float keep_prob; float inv_keep; uint64_t seed;
   const float* mask_src; int64_t ldm;
+  float* colsum_part;   // TN only: [splits][N] partial column sums of B (bias gradient), or NULL
 };
 
-__device__ __forceinline__ uint64_t mix64(uint64_t x) {
-  x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ULL;
-  x ^= x >> 27; x *= 0x94d049bb133111ebULL;
-  x ^= x >> 31;
+// Counter-based dropout mask, 32-bit arithmetic only (64-bit multiplies are 4x quarter-rate ops
+// on CDNA and cost 10 % of the layer-1 forward): two rounds of a multiply-xorshift mixer over
+// (element index, seed).  keep element idx iff top 24 bits < keep_prob * 2^24.  tests/util.py
+// replays it on the host.
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU;
+  x ^= x >> 15; x *= 0x846ca68bU;
+  x ^= x >> 16;
   return x;
 }
-// counter-based dropout: keep element idx iff top 24 bits of mix64(seed + idx*phi) < keep*2^24
 __device__ __forceinline__ bool dropout_keep(uint64_t seed, uint64_t idx, uint32_t thresh) {
-  return static_cast<uint32_t>(mix64(seed + idx * 0x9E3779B97F4A7C15ULL) >> 40) < thresh;
+  const uint32_t lo = static_cast<uint32_t>(idx), hi = static_cast<uint32_t>(idx >> 32);
+  uint32_t h = mix32(lo ^ static_cast<uint32_t>(seed));
+  h = mix32(h ^ (hi * 0x9E3779B1U) ^ static_cast<uint32_t>(seed >> 32));
+  return (h >> 8) < thresh;
 }
 
-template <int L>
+// Stage one operand tile HBM -> registers.  Branch-free and consumer-free on purpose: an
+// out-of-range element reads the (always valid) first element of the buffer, and nothing touches
+// the loaded registers until mask_tile() just before the LDS store, so the loads of a tile issue
+// back to back and stay in flight under the MFMAs.  (With branches, or with the zero-select next
+// to the load, hipcc parks an s_waitcnt vmcnt(0) behind every load and nothing overlaps.)
+template <int L, bool VEC>
 __device__ __forceinline__ void load_tile(const float* __restrict__ P, int64_t ld, int MN, int mn0,
-                                          int k0, int kend, bool vec, float4 (&r)[4], int t) {
+                                          int k0, int kend, float4 (&r)[4], int t) {
   if constexpr (L == KC) {
     const int kk = k0 + (t & 7) * 4;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       const int mn = mn0 + (t >> 3) + 32 * p;
-      r[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (mn < MN) {
-        const float* q = P + static_cast<int64_t>(mn) * ld + kk;
-        if (vec) {
-          if (kk < kend) r[p] = *reinterpret_cast<const float4*>(q);
-        } else {
-          if (kk < kend) r[p].x = q[0];
-          if (kk + 1 < kend) r[p].y = q[1];
-          if (kk + 2 < kend) r[p].z = q[2];
-          if (kk + 3 < kend) r[p].w = q[3];
-        }
+      const bool row_ok = mn < MN;
+      const float* q = P + static_cast<int64_t>(row_ok ? mn : 0) * ld;
+      if constexpr (VEC) {
+        r[p] = *reinterpret_cast<const float4*>((row_ok && kk < kend) ? q + kk : P);
+      } else {
+        r[p].x = *((row_ok && kk < kend) ? q + kk : P);
+        r[p].y = *((row_ok && kk + 1 < kend) ? q + kk + 1 : P);
+        r[p].z = *((row_ok && kk + 2 < kend) ? q + kk + 2 : P);
+        r[p].w = *((row_ok && kk + 3 < kend) ? q + kk + 3 : P);
       }
     }
   } else {
@@ -79,17 +89,49 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ P, int64_t l
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       const int kk = k0 + (t >> 5) + 8 * p;
-      r[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (kk < kend) {
-        const float* q = P + static_cast<int64_t>(kk) * ld + mn;
-        if (vec) {
-          if (mn < MN) r[p] = *reinterpret_cast<const float4*>(q);
-        } else {
-          if (mn < MN) r[p].x = q[0];
-          if (mn + 1 < MN) r[p].y = q[1];
-          if (mn + 2 < MN) r[p].z = q[2];
-          if (mn + 3 < MN) r[p].w = q[3];
-        }
+      const bool k_ok = kk < kend;
+      const float* q = P + static_cast<int64_t>(k_ok ? kk : 0) * ld;
+      if constexpr (VEC) {
+        r[p] = *reinterpret_cast<const float4*>((k_ok && mn < MN) ? q + mn : P);
+      } else {
+        r[p].x = *((k_ok && mn < MN) ? q + mn : P);
+        r[p].y = *((k_ok && mn + 1 < MN) ? q + mn + 1 : P);
+        r[p].z = *((k_ok && mn + 2 < MN) ? q + mn + 2 : P);
+        r[p].w = *((k_ok && mn + 3 < MN) ? q + mn + 3 : P);
+      }
+    }
+  }
+}
+
+// zero the elements load_tile fetched from the dummy address (same predicates, evaluated late)
+template <int L, bool VEC>
+__device__ __forceinline__ void mask_tile(int MN, int mn0, int k0, int kend, float4 (&r)[4], int t) {
+  if constexpr (L == KC) {
+    const int kk = k0 + (t & 7) * 4;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const bool row_ok = mn0 + (t >> 3) + 32 * p < MN;
+      if constexpr (VEC) {
+        if (!(row_ok && kk < kend)) r[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+      } else {
+        r[p].x = (row_ok && kk < kend) ? r[p].x : 0.f;
+        r[p].y = (row_ok && kk + 1 < kend) ? r[p].y : 0.f;
+        r[p].z = (row_ok && kk + 2 < kend) ? r[p].z : 0.f;
+        r[p].w = (row_ok && kk + 3 < kend) ? r[p].w : 0.f;
+      }
+    }
+  } else {
+    const int mn = mn0 + (t & 31) * 4;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const bool k_ok = k0 + (t >> 5) + 8 * p < kend;
+      if constexpr (VEC) {
+        if (!(k_ok && mn < MN)) r[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+      } else {
+        r[p].x = (k_ok && mn < MN) ? r[p].x : 0.f;
+        r[p].y = (k_ok && mn + 1 < MN) ? r[p].y : 0.f;
+        r[p].z = (k_ok && mn + 2 < MN) ? r[p].z : 0.f;
+        r[p].w = (k_ok && mn + 3 < MN) ? r[p].w : 0.f;
       }
     }
   }
@@ -119,8 +161,11 @@ __device__ __forceinline__ void read_frag(const float* __restrict__ S, int mn, i
   }
 }
 
-template <int LA, int LB>
-__global__ __launch_bounds__(kThreads, 2) void gemm_f32_k(const GemmArgs a) {
+template <int LA, int LB, bool VA, bool VB, bool COLSUM>
+#ifndef GEMM_LB_WAVES
+#define GEMM_LB_WAVES 2
+#endif
+__global__ __launch_bounds__(kThreads, GEMM_LB_WAVES) void gemm_f32_k(const GemmArgs a) {
   __shared__ __attribute__((aligned(16))) float smem[2][2][TILE_FLOATS];
 
   // XCD-aware bijective remap: the 8 XCDs receive blocks round-robin; give each XCD a contiguous
@@ -141,6 +186,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_f32_k(const GemmArgs a) {
   const int w = t >> 6, lane = t & 63;
   const int wm = w >> 1, wn = w & 1;
   const int i = lane & 31, h = lane >> 5;
+  const int arow = wm * 64 + i, brow = wn * 64 + i;
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -151,43 +197,107 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_f32_k(const GemmArgs a) {
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
   float4 ra[4], rb[4];
+  // COLSUM (weight gradient only): the bias gradient rides along — the tm == 0 blocks add up the
+  // rows of the B (= dY) tiles they stage anyway; thread t owns columns 4*(t&31).. and k rows
+  // (t>>5)+8p.
+  const bool do_colsum = COLSUM && a.colsum_part != nullptr && tm == 0;
+  float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
   if (nk > 0) {
-    load_tile<LA>(a.A, a.lda, a.M, m0, kbeg, kend, a.vecA, ra, t);
-    load_tile<LB>(a.B, a.ldb, a.N, n0, kbeg, kend, a.vecB, rb, t);
+    load_tile<LA, VA>(a.A, a.lda, a.M, m0, kbeg, kend, ra, t);
+    load_tile<LB, VB>(a.B, a.ldb, a.N, n0, kbeg, kend, rb, t);
+    mask_tile<LA, VA>(a.M, m0, kbeg, kend, ra, t);
+    mask_tile<LB, VB>(a.N, n0, kbeg, kend, rb, t);
     store_tile<LA>(smem[0][0], ra, t);
     store_tile<LB>(smem[0][1], rb, t);
+    if (COLSUM && do_colsum) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) { cs.x += rb[p].x; cs.y += rb[p].y; cs.z += rb[p].z; cs.w += rb[p].w; }
+    }
   }
   __syncthreads();
 
+  // Per k-tile: the next tile's global loads are issued first and land in registers under the
+  // MFMAs; the staged registers go to the other LDS buffer (idle since the previous barrier)
+  // at GEMM_STORE_POS; one barrier per tile.
+#ifndef GEMM_STORE_POS
+#define GEMM_STORE_POS 2   /* after k-group n of 4 (4 = end of tile); A/B in tools/gemm_variants.py */
+#endif
+#ifndef GEMM_FRAG_DB
+#define GEMM_FRAG_DB 1
+#endif
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     const bool more = kt + 1 < nk;
     if (more) {
-      load_tile<LA>(a.A, a.lda, a.M, m0, kbeg + (kt + 1) * BK, kend, a.vecA, ra, t);
-      load_tile<LB>(a.B, a.ldb, a.N, n0, kbeg + (kt + 1) * BK, kend, a.vecB, rb, t);
+      load_tile<LA, VA>(a.A, a.lda, a.M, m0, kbeg + (kt + 1) * BK, kend, ra, t);
+      load_tile<LB, VB>(a.B, a.ldb, a.N, n0, kbeg + (kt + 1) * BK, kend, rb, t);
     }
     const float* As = smem[cur][0];
     const float* Bs = smem[cur][1];
+    auto stage = [&]() {
+      if (more) {
+        mask_tile<LA, VA>(a.M, m0, kbeg + (kt + 1) * BK, kend, ra, t);
+        mask_tile<LB, VB>(a.N, n0, kbeg + (kt + 1) * BK, kend, rb, t);
+        store_tile<LA>(smem[cur ^ 1][0], ra, t);
+        store_tile<LB>(smem[cur ^ 1][1], rb, t);
+        if (COLSUM && do_colsum) {
+#pragma unroll
+          for (int p = 0; p < 4; ++p) { cs.x += rb[p].x; cs.y += rb[p].y; cs.z += rb[p].z; cs.w += rb[p].w; }
+        }
+      }
+    };
+#if GEMM_FRAG_DB
+    float fa[2][2][4], fb[2][2][4];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) read_frag<LA>(As, arow + mi * 32, 0, h, fa[0][mi]);
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) read_frag<LB>(Bs, brow + ni * 32, 0, h, fb[0][ni]);
+#endif
 #pragma unroll
     for (int s = 0; s < BK / 8; ++s) {
+#if GEMM_FRAG_DB
+      const int c = s & 1;
+      if (s + 1 < BK / 8) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) read_frag<LA>(As, arow + mi * 32, s + 1, h, fa[c ^ 1][mi]);
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) read_frag<LB>(Bs, brow + ni * 32, s + 1, h, fb[c ^ 1][ni]);
+      }
+#define FA(mi, j) fa[c][mi][j]
+#define FB(ni, j) fb[c][ni][j]
+#else
       float fa[2][4], fb[2][4];
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi) read_frag<LA>(As, wm * 64 + mi * 32 + i, s, h, fa[mi]);
+      for (int mi = 0; mi < 2; ++mi) read_frag<LA>(As, arow + mi * 32, s, h, fa[mi]);
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni) read_frag<LB>(Bs, wn * 64 + ni * 32 + i, s, h, fb[ni]);
+      for (int ni = 0; ni < 2; ++ni) read_frag<LB>(Bs, brow + ni * 32, s, h, fb[ni]);
+#define FA(mi, j) fa[mi][j]
+#define FB(ni, j) fb[ni][j]
+#endif
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
           for (int ni = 0; ni < 2; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mi][j], fb[ni][j], acc[mi][ni], 0, 0, 0);
-    }
-    if (more) {
-      store_tile<LA>(smem[cur ^ 1][0], ra, t);
-      store_tile<LB>(smem[cur ^ 1][1], rb, t);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA(mi, j), FB(ni, j), acc[mi][ni], 0, 0, 0);
+#undef FA
+#undef FB
+      if (s + 1 == GEMM_STORE_POS) stage();
     }
     __syncthreads();
+  }
+
+  if (COLSUM && do_colsum) {   // fold the 8 k-row groups in a fixed order, one partial row per split
+    float* red = &smem[0][0][0];
+    *reinterpret_cast<float4*>(red + (t >> 5) * BN + (t & 31) * 4) = cs;
+    __syncthreads();
+    if (t < BN) {
+      float v = 0.f;
+#pragma unroll
+      for (int g = 0; g < 8; ++g) v += red[g * BN + t];
+      if (n0 + t < a.N) a.colsum_part[static_cast<int64_t>(split) * a.N + n0 + t] = v;
+    }
   }
 
   // ---- epilogue: C/D map of v_mfma_f32_32x32x2: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -225,25 +335,21 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_f32_k(const GemmArgs a) {
   }
 }
 
-// out[i] = sum_s slab[s][i] in fixed order (bitwise reproducible split-K)
+// out[i] = sum_s slab[s][i] in a fixed order (bitwise reproducible split-K).  64 outputs per block;
+// the 4 waves take every 4th slab each, then fold through LDS as (w0+w1)+(w2+w3).
 __global__ __launch_bounds__(kThreads) void slab_reduce_k(const float* __restrict__ slab, int nsplit,
                                                           int64_t n, float* __restrict__ out) {
-  const int64_t i = (static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x) * 4;
-  if (i >= n) return;
-  if (i + 3 < n && (n & 3) == 0) {
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int s = 0; s < nsplit; ++s) {
-      const float4 v = *reinterpret_cast<const float4*>(slab + static_cast<int64_t>(s) * n + i);
-      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-    }
-    out[i] = acc.x; out[i + 1] = acc.y; out[i + 2] = acc.z; out[i + 3] = acc.w;
-  } else {
-    for (int64_t j = i; j < n; ++j) {
-      float acc = 0.f;
-      for (int s = 0; s < nsplit; ++s) acc += slab[static_cast<int64_t>(s) * n + j];
-      out[j] = acc;
-    }
+  __shared__ float red[4][64];
+  const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 64 + c;
+  float acc = 0.f;
+  if (i < n) {
+#pragma unroll 4
+    for (int s = g; s < nsplit; s += 4) acc += slab[static_cast<int64_t>(s) * n + i];
   }
+  red[g][c] = acc;
+  __syncthreads();
+  if (g == 0 && i < n) out[i] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
 }
 
 // column sums, stage 1: block = 64 columns x a slab of rows; thread (c, g) strides rows by 4.
@@ -277,7 +383,7 @@ bool vec_ok(const float* p, int64_t ld, int contiguous_extent) {
   return mi::aligned16(p) && (ld & 3) == 0 && (contiguous_extent & 3) == 0;
 }
 
-template <int LA, int LB>
+template <int LA, int LB, bool COLSUM = false>
 int32_t launch(GemmArgs& a, int splits, hipStream_t st, const char* what) {
   a.tiles_m = (a.M + BM - 1) / BM;
   a.tiles_n = (a.N + BN - 1) / BN;
@@ -286,7 +392,11 @@ int32_t launch(GemmArgs& a, int splits, hipStream_t st, const char* what) {
     mi::set_error("%s: bad grid (%lld blocks)", what, (long long)nblocks);
     return MI_ERR_INVALID;
   }
-  gemm_f32_k<LA, LB><<<dim3((unsigned)nblocks), dim3(kThreads), 0, st>>>(a);
+  const dim3 g((unsigned)nblocks), b(kThreads);
+  if (a.vecA && a.vecB) gemm_f32_k<LA, LB, true, true, COLSUM><<<g, b, 0, st>>>(a);
+  else if (a.vecA) gemm_f32_k<LA, LB, true, false, COLSUM><<<g, b, 0, st>>>(a);
+  else if (a.vecB) gemm_f32_k<LA, LB, false, true, COLSUM><<<g, b, 0, st>>>(a);
+  else gemm_f32_k<LA, LB, false, false, COLSUM><<<g, b, 0, st>>>(a);
   MI_CHECK_LAUNCH(what);
   return MI_OK;
 }
@@ -294,7 +404,7 @@ int32_t launch(GemmArgs& a, int splits, hipStream_t st, const char* what) {
 // split-K policy for the weight gradient: enough blocks to fill 256 CUs x 2, k slices multiple of BK
 int wgrad_splits(int64_t M, int N, int K) {
   const int64_t tiles = mi::ceil_div(K, BM) * mi::ceil_div(N, BN);
-  int64_t s = mi::ceil_div(1024, tiles);
+  int64_t s = 1024 / tiles;             // <= 2 full rounds of 256 CUs x 2 resident blocks
   const int64_t max_s = mi::ceil_div(M, 4 * BK);  // at least 4 k-tiles per slice
   if (s > max_s) s = max_s;
   if (s < 1) s = 1;
@@ -368,9 +478,7 @@ int32_t mi_colsum(const float* X, int64_t ldx, int64_t M, int32_t N, float* out,
 
 size_t mi_dense_bwd_weight_workspace_bytes(int64_t M, int32_t N, int32_t K) {
   const int splits = wgrad_splits(M, N, K);
-  const size_t slab = static_cast<size_t>(splits) * K * N * sizeof(float);
-  const size_t cs = mi_colsum_workspace_bytes(M, N);
-  return (slab > cs ? slab : cs) + 256;
+  return (static_cast<size_t>(splits) * K * N + static_cast<size_t>(splits) * N) * sizeof(float) + 256;
 }
 
 int32_t mi_dense_bwd_weight(const float* X, int64_t ldx, const float* dY, int64_t lddy, float* dW,
@@ -386,24 +494,23 @@ int32_t mi_dense_bwd_weight(const float* X, int64_t ldx, const float* dY, int64_
     return MI_ERR_WORKSPACE;
   }
   hipStream_t st = mi::as_stream(stream);
-  if (db) {  // bias gradient first: it shares the workspace with the slabs
-    if (int32_t rc = mi_colsum(dY, lddy, M, N, db, workspace, workspace_bytes, stream)) return rc;
-  }
   const int splits = wgrad_splits(M, N, K);
+  const int64_t n = static_cast<int64_t>(K) * N;
+  float* slab = static_cast<float*>(workspace);
+  float* cpart = slab + static_cast<int64_t>(splits) * n;   // [splits][N] bias-gradient partials
   GemmArgs a{};                       // dW[K,N] = X[M,K]^T * dY[M,N] : gemm K x N x (reduce M)
   a.A = X; a.lda = ldx; a.B = dY; a.ldb = lddy;
   a.M = K; a.N = N; a.K = (int)M; a.k_per_split = (int)wgrad_k_per_split(M, splits);
   a.vecA = vec_ok(X, ldx, K); a.vecB = vec_ok(dY, lddy, N);
-  if (splits == 1) {
-    a.C = dW; a.ldc = N; a.epi = EPI_MASK; a.mask_src = nullptr; a.inv_keep = 1.f; a.keep_prob = 1.f;
-    return launch<MC, MC>(a, 1, st, "dense_bwd_weight");
-  }
-  a.C = static_cast<float*>(workspace); a.ldc = N; a.epi = EPI_SLAB; a.keep_prob = 1.f; a.inv_keep = 1.f;
-  if (int32_t rc = launch<MC, MC>(a, splits, st, "dense_bwd_weight(split-K)")) return rc;
-  const int64_t n = static_cast<int64_t>(K) * N;
-  slab_reduce_k<<<dim3((unsigned)mi::ceil_div(mi::ceil_div(n, 4), kThreads)), dim3(kThreads), 0, st>>>(
-      static_cast<const float*>(workspace), splits, n, dW);
+  a.C = slab; a.ldc = N; a.epi = EPI_SLAB; a.keep_prob = 1.f; a.inv_keep = 1.f;
+  a.colsum_part = db ? cpart : nullptr;
+  if (int32_t rc = launch<MC, MC, true>(a, splits, st, "dense_bwd_weight(split-K)")) return rc;
+  slab_reduce_k<<<dim3((unsigned)mi::ceil_div(n, 64)), dim3(kThreads), 0, st>>>(slab, splits, n, dW);
   MI_CHECK_LAUNCH("dense_bwd_weight(reduce)");
+  if (db) {
+    slab_reduce_k<<<dim3((unsigned)mi::ceil_div(N, 64)), dim3(kThreads), 0, st>>>(cpart, splits, N, db);
+    MI_CHECK_LAUNCH("dense_bwd_weight(reduce bias)");
+  }
   return MI_OK;
 }
 

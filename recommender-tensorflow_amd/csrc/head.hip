@@ -40,12 +40,13 @@ __global__ __launch_bounds__(kBlock) void head_k(const float* __restrict__ lin,
                                                  const uint8_t* __restrict__ labels, int64_t B,
                                                  float scale, float* __restrict__ logits,
                                                  float* __restrict__ d_logit,
-                                                 float* __restrict__ partial) {
+                                                 float* __restrict__ partial,
+                                                 float* __restrict__ partial_d) {
   __shared__ float red[4];
   const int64_t per = (B + gridDim.x - 1) / gridDim.x;
   const int64_t b0 = blockIdx.x * per, b1 = min(B, b0 + per);
   const float lb = (lin && lin_bias) ? lin_bias[0] : 0.f;
-  float acc = 0.f;
+  float acc = 0.f, dacc = 0.f;
   for (int64_t b = b0 + threadIdx.x; b < b1; b += kBlock) {
     float x = 0.f;                        // deep_fm.py:36
     if (lin) x += lin[b] + lb;            // :44   (linear_model adds its bias last)
@@ -56,11 +57,19 @@ __global__ __launch_bounds__(kBlock) void head_k(const float* __restrict__ lin,
       const float y = labels[b] ? 1.f : 0.f;
       const float l = fmaxf(x, 0.f) - x * y + log1pf(expf(-fabsf(x)));
       acc += l * scale;
-      if (d_logit) d_logit[b] = (sigmoid_stable(x) - y) * scale;
+      if (d_logit) {
+        const float d = (sigmoid_stable(x) - y) * scale;
+        d_logit[b] = d;
+        dacc += d;
+      }
     }
   }
   const float tot = block_sum(acc, red);
   if (threadIdx.x == 0 && partial) partial[blockIdx.x] = tot;
+  if (partial_d) {
+    const float dtot = block_sum(dacc, red);
+    if (threadIdx.x == 0) partial_d[blockIdx.x] = dtot;
+  }
 }
 
 __global__ __launch_bounds__(kBlock) void sum_partials_k(const float* __restrict__ partial, int n,
@@ -189,28 +198,35 @@ int blocks_for(int64_t n) {
 
 extern "C" {
 
-size_t mi_head_workspace_bytes(int64_t B) { (void)B; return kMaxBlocks * sizeof(float); }
+size_t mi_head_workspace_bytes(int64_t B) { (void)B; return 2 * kMaxBlocks * sizeof(float); }
 
 int32_t mi_sigmoid_ce_head(const float* lin, const float* lin_bias, const float* fm,
                            const float* dnn, const uint8_t* labels, int64_t B, float loss_scale,
-                           float* logits, float* loss_out, float* d_logit, void* workspace,
-                           size_t workspace_bytes, mi_stream_t stream) {
+                           float* logits, float* loss_out, float* d_logit, float* d_logit_sum,
+                           void* workspace, size_t workspace_bytes, mi_stream_t stream) {
   MI_REQUIRE(B > 0, "sigmoid_ce_head: B=%lld", (long long)B);
   MI_REQUIRE(lin || fm || dnn, "sigmoid_ce_head: no logit component (deep_fm.py:33-34)");
   MI_REQUIRE(labels || (!loss_out && !d_logit), "sigmoid_ce_head: loss / gradient need labels");
-  MI_REQUIRE(!loss_out || workspace, "sigmoid_ce_head: loss needs a workspace");
-  if (loss_out && workspace_bytes < mi_head_workspace_bytes(B)) {
+  MI_REQUIRE(!(loss_out || d_logit_sum) || workspace, "sigmoid_ce_head: loss / gradient sum need a workspace");
+  MI_REQUIRE(!d_logit_sum || d_logit, "sigmoid_ce_head: d_logit_sum needs d_logit");
+  if ((loss_out || d_logit_sum) && workspace_bytes < mi_head_workspace_bytes(B)) {
     mi::set_error("sigmoid_ce_head: workspace %zu < %zu", workspace_bytes, mi_head_workspace_bytes(B));
     return MI_ERR_WORKSPACE;
   }
   hipStream_t st = mi::as_stream(stream);
   const int nb = blocks_for(B);
   float* partial = loss_out ? static_cast<float*>(workspace) : nullptr;
-  head_k<<<dim3(nb), dim3(kBlock), 0, st>>>(lin, lin_bias, fm, dnn, labels, B, loss_scale, logits, d_logit, partial);
+  float* partial_d = d_logit_sum ? static_cast<float*>(workspace) + kMaxBlocks : nullptr;
+  head_k<<<dim3(nb), dim3(kBlock), 0, st>>>(lin, lin_bias, fm, dnn, labels, B, loss_scale, logits, d_logit, partial,
+                                            partial_d);
   MI_CHECK_LAUNCH("sigmoid_ce_head");
   if (loss_out) {
     sum_partials_k<<<dim3(1), dim3(kBlock), 0, st>>>(partial, nb, loss_out);
     MI_CHECK_LAUNCH("sigmoid_ce_head(reduce)");
+  }
+  if (d_logit_sum) {   // = d loss / d linear bias (and d / d logits-layer bias when the DNN has no hidden layer)
+    sum_partials_k<<<dim3(1), dim3(kBlock), 0, st>>>(partial_d, nb, d_logit_sum);
+    MI_CHECK_LAUNCH("sigmoid_ce_head(reduce d)");
   }
   return MI_OK;
 }

@@ -6,9 +6,14 @@
 // Integer work, bit exact: equal rows keep their entry order, so the later segment sum adds
 // duplicates in ascending example order like TF's CPU kernel.
 //
-// 8-bit digits; per pass: (1) per-tile digit histogram, (2) one-block exclusive scan over the
-// bin-major [256][tiles] counts, (3) stable scatter: lanes find equal-digit peers in their wave
-// with ballots, waves are chained through LDS counters, rounds through a running count.
+// Digits of up to 9 bits (26 M rows = 25 bits -> 3 passes).  Per pass:
+//   hist_k      per-tile digit histogram (LDS atomics) + per-digit totals (global integer atomics)
+//   bin_scan_k  one workgroup per digit: base = sum of the lower digits' totals, then an
+//               exclusive scan of that digit's per-tile counts (wave shuffles, carried in chunks)
+//   scatter_k   stable scatter: lanes find their equal-digit peers in the wave with ballots,
+//               waves are chained through LDS counters, rounds through a running count
+// then head_count_k / compact_k mark the first entry of every distinct row (coalesced reads,
+// ballot ranks) and emit uniq_rows / seg_start / sorted_entry.
 #include "common.h"
 
 namespace {
@@ -16,59 +21,83 @@ namespace {
 constexpr int kBlock = 256;
 constexpr int kItems = 16;                 // keys per thread per tile
 constexpr int kTile = kBlock * kItems;     // 4096
-constexpr int kBins = 256;
+constexpr int kMaxBits = 9;
+constexpr int kMaxBins = 1 << kMaxBits;    // 512
+constexpr int kMaxPasses = 4;
 
 __global__ __launch_bounds__(kBlock) void hist_k(const int32_t* __restrict__ keys, int64_t n, int shift,
-                                                 int ntiles, int32_t* __restrict__ hist) {
-  __shared__ unsigned int h[kBins];
-  h[threadIdx.x] = 0;
+                                                 int nbins, int ntiles, int32_t* __restrict__ hist,
+                                                 int32_t* __restrict__ bin_total) {
+  __shared__ unsigned int h[kMaxBins];
+  for (int b = threadIdx.x; b < nbins; b += kBlock) h[b] = 0;
   __syncthreads();
   const int64_t base = static_cast<int64_t>(blockIdx.x) * kTile;
+  const unsigned int mask = nbins - 1;
 #pragma unroll
   for (int r = 0; r < kItems; ++r) {
     const int64_t i = base + r * kBlock + threadIdx.x;
-    if (i < n) atomicAdd(&h[(static_cast<uint32_t>(keys[i]) >> shift) & (kBins - 1)], 1u);
+    if (i < n) atomicAdd(&h[(static_cast<uint32_t>(keys[i]) >> shift) & mask], 1u);
   }
   __syncthreads();
-  hist[static_cast<int64_t>(threadIdx.x) * ntiles + blockIdx.x] = static_cast<int32_t>(h[threadIdx.x]);
+  for (int b = threadIdx.x; b < nbins; b += kBlock) {
+    const unsigned int c = h[b];
+    hist[static_cast<int64_t>(b) * ntiles + blockIdx.x] = static_cast<int32_t>(c);
+    if (c) atomicAdd(&bin_total[b], static_cast<int32_t>(c));
+  }
 }
 
-// exclusive scan of `count` int32 values by ONE block of 1024 threads (count <= a few million)
-__global__ __launch_bounds__(1024) void scan_k(int32_t* __restrict__ data, int64_t count,
-                                               int32_t* __restrict__ total_out) {
-  __shared__ int32_t part[1024];
-  const int64_t per = (count + 1023) / 1024;
-  const int64_t i0 = threadIdx.x * per, i1 = min(count, i0 + per);
-  int32_t s = 0;
-  for (int64_t i = i0; i < i1; ++i) s += data[i];
-  part[threadIdx.x] = s;
+__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int u = __shfl_up(v, off, 64);
+    if (lane >= off) v += u;
+  }
+  return v;
+}
+
+// block b: hist[b, 0..ntiles) -> global offsets (exclusive scan + base of digit b)
+__global__ __launch_bounds__(kBlock) void bin_scan_k(int32_t* __restrict__ hist, int ntiles, int nbins,
+                                                     const int32_t* __restrict__ bin_total) {
+  __shared__ int32_t red[4];
+  __shared__ int32_t wsum[4];
+  const int t = threadIdx.x, w = t >> 6, lane = t & 63;
+  const int b = blockIdx.x;
+  int part = 0;
+  for (int j = t; j < b; j += kBlock) part += bin_total[j];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+  if (lane == 0) red[w] = part;
   __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {   // Hillis-Steele inclusive scan
-    int32_t v = (static_cast<int>(threadIdx.x) >= off) ? part[threadIdx.x - off] : 0;
+  int carry = red[0] + red[1] + red[2] + red[3];
+  int32_t* row = hist + static_cast<int64_t>(b) * ntiles;
+  for (int c0 = 0; c0 < ntiles; c0 += kBlock) {
+    const int i = c0 + t;
+    const int v = (i < ntiles) ? row[i] : 0;
+    const int incl = wave_incl_scan(v, lane);
+    __syncthreads();                     // previous chunk's wsum fully consumed
+    if (lane == 63) wsum[w] = incl;
     __syncthreads();
-    part[threadIdx.x] += v;
-    __syncthreads();
+    int pre = carry;
+    for (int ww = 0; ww < w; ++ww) pre += wsum[ww];
+    if (i < ntiles) row[i] = pre + incl - v;
+    carry += wsum[0] + wsum[1] + wsum[2] + wsum[3];
   }
-  int32_t run = part[threadIdx.x] - s;
-  for (int64_t i = i0; i < i1; ++i) {
-    const int32_t v = data[i];
-    data[i] = run;
-    run += v;
-  }
-  if (total_out && threadIdx.x == 1023) total_out[0] = part[1023];
 }
 
 __global__ __launch_bounds__(kBlock) void scatter_k(const int32_t* __restrict__ keys_in,
                                                     const int32_t* __restrict__ vals_in, int64_t n,
-                                                    int shift, int ntiles,
+                                                    int shift, int nbits, int ntiles,
                                                     const int32_t* __restrict__ offs,
                                                     int32_t* __restrict__ keys_out,
                                                     int32_t* __restrict__ vals_out) {
-  __shared__ int32_t running[kBins];       // global base + keys of earlier rounds, per digit
-  __shared__ int32_t wcount[4][kBins];     // this round's per-wave digit counts
+  __shared__ int32_t running[kMaxBins];       // global base + keys of earlier rounds, per digit
+  __shared__ int32_t wcount[4][kMaxBins];     // this round's per-wave digit counts
   const int t = threadIdx.x, w = t >> 6, lane = t & 63;
-  running[t] = offs[static_cast<int64_t>(t) * ntiles + blockIdx.x];
-  wcount[0][t] = 0; wcount[1][t] = 0; wcount[2][t] = 0; wcount[3][t] = 0;
+  const int nbins = 1 << nbits;
+  for (int b = t; b < nbins; b += kBlock) {
+    running[b] = offs[static_cast<int64_t>(b) * ntiles + blockIdx.x];
+    wcount[0][b] = 0; wcount[1][b] = 0; wcount[2][b] = 0; wcount[3][b] = 0;
+  }
   __syncthreads();
   const int64_t base = static_cast<int64_t>(blockIdx.x) * kTile;
   const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -77,11 +106,10 @@ __global__ __launch_bounds__(kBlock) void scatter_k(const int32_t* __restrict__ 
     const bool valid = i < n;
     const int32_t key = valid ? keys_in[i] : 0;
     const int32_t val = valid ? (vals_in ? vals_in[i] : static_cast<int32_t>(i)) : 0;
-    const unsigned int d = (static_cast<uint32_t>(key) >> shift) & (kBins - 1);
+    const unsigned int d = (static_cast<uint32_t>(key) >> shift) & (nbins - 1);
     // peers = lanes of this wave holding a valid key with the same digit
     unsigned long long peers = __ballot(valid);
-#pragma unroll
-    for (int b = 0; b < 8; ++b) {
+    for (int b = 0; b < nbits; ++b) {
       const unsigned long long m = __ballot((d >> b) & 1u);
       peers &= ((d >> b) & 1u) ? m : ~m;
     }
@@ -95,22 +123,28 @@ __global__ __launch_bounds__(kBlock) void scatter_k(const int32_t* __restrict__ 
       vals_out[dst] = val;
     }
     __syncthreads();
-    running[t] += wcount[0][t] + wcount[1][t] + wcount[2][t] + wcount[3][t];
-    wcount[0][t] = 0; wcount[1][t] = 0; wcount[2][t] = 0; wcount[3][t] = 0;
+    for (int b = t; b < nbins; b += kBlock) {
+      running[b] += wcount[0][b] + wcount[1][b] + wcount[2][b] + wcount[3][b];
+      wcount[0][b] = 0; wcount[1][b] = 0; wcount[2][b] = 0; wcount[3][b] = 0;
+    }
     __syncthreads();
   }
 }
 
-// head flags per tile: heads[tile] = number of i in the tile with key[i] != key[i-1]
+__device__ __forceinline__ bool is_head(const int32_t* __restrict__ keys, int64_t i) {
+  return i == 0 || keys[i] != keys[i - 1];
+}
+
+// heads[tile] = number of positions in the tile that start a new row
 __global__ __launch_bounds__(kBlock) void head_count_k(const int32_t* __restrict__ keys, int64_t n,
                                                        int32_t* __restrict__ tile_heads) {
   __shared__ int32_t red[4];
-  const int64_t base = static_cast<int64_t>(blockIdx.x) * kTile + static_cast<int64_t>(threadIdx.x) * kItems;
+  const int64_t base = static_cast<int64_t>(blockIdx.x) * kTile;
   int c = 0;
 #pragma unroll
   for (int r = 0; r < kItems; ++r) {
-    const int64_t i = base + r;
-    if (i < n && (i == 0 || keys[i] != keys[i - 1])) ++c;
+    const int64_t i = base + r * kBlock + threadIdx.x;
+    if (i < n && is_head(keys, i)) ++c;
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
@@ -119,7 +153,30 @@ __global__ __launch_bounds__(kBlock) void head_count_k(const int32_t* __restrict
   if (threadIdx.x == 0) tile_heads[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
-// each thread owns kItems consecutive sorted positions; writes uniq_rows / seg_start / sorted_entry
+// exclusive scan of `count` int32 values by ONE block (count = number of tiles: small)
+__global__ __launch_bounds__(1024) void scan_small_k(int32_t* __restrict__ data, int64_t count,
+                                                     int32_t* __restrict__ total_out) {
+  __shared__ int32_t wsum[16];
+  const int t = threadIdx.x, w = t >> 6, lane = t & 63;
+  int carry = 0;
+  for (int64_t c0 = 0; c0 < count; c0 += 1024) {
+    const int64_t i = c0 + t;
+    const int v = (i < count) ? data[i] : 0;
+    const int incl = wave_incl_scan(v, lane);
+    __syncthreads();
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    int pre = carry, tot = 0;
+    for (int ww = 0; ww < 16; ++ww) {
+      if (ww < w) pre += wsum[ww];
+      tot += wsum[ww];
+    }
+    if (i < count) data[i] = pre + incl - v;
+    carry += tot;
+  }
+  if (total_out && t == 0) total_out[0] = carry;
+}
+
 __global__ __launch_bounds__(kBlock) void compact_k(const int32_t* __restrict__ keys,
                                                     const int32_t* __restrict__ vals, int64_t n,
                                                     const int32_t* __restrict__ tile_base,
@@ -128,36 +185,32 @@ __global__ __launch_bounds__(kBlock) void compact_k(const int32_t* __restrict__ 
                                                     int32_t* __restrict__ uniq_rows,
                                                     int32_t* __restrict__ seg_start,
                                                     int32_t* __restrict__ num_uniq) {
-  __shared__ int32_t wsum[4];
+  __shared__ int32_t wc[4];
   const int t = threadIdx.x, w = t >> 6, lane = t & 63;
-  const int64_t base = static_cast<int64_t>(blockIdx.x) * kTile + static_cast<int64_t>(t) * kItems;
-  int c = 0;
-#pragma unroll
+  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  const int64_t base = static_cast<int64_t>(blockIdx.x) * kTile;
+  int run = tile_base[blockIdx.x];
   for (int r = 0; r < kItems; ++r) {
-    const int64_t i = base + r;
-    if (i < n && (i == 0 || keys[i] != keys[i - 1])) ++c;
-  }
-  int incl = c;                               // inclusive scan across the wave
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const int v = __shfl_up(incl, off, 64);
-    if (lane >= off) incl += v;
-  }
-  if (lane == 63) wsum[w] = incl;
-  __syncthreads();
-  int idx = tile_base[blockIdx.x] + incl - c;
-  for (int ww = 0; ww < w; ++ww) idx += wsum[ww];
-#pragma unroll
-  for (int r = 0; r < kItems; ++r) {
-    const int64_t i = base + r;
-    if (i < n) {
+    const int64_t i = base + r * kBlock + t;
+    const bool valid = i < n;
+    int32_t key = 0;
+    bool head = false;
+    if (valid) {
+      key = keys[i];
+      head = (i == 0) || key != keys[i - 1];
       sorted_entry[i] = vals[i];
-      if (i == 0 || keys[i] != keys[i - 1]) {
-        uniq_rows[idx] = keys[i];
-        seg_start[idx] = static_cast<int32_t>(i);
-        ++idx;
-      }
     }
+    const unsigned long long hb = __ballot(head);
+    __syncthreads();                       // previous round's wc consumed
+    if (lane == 0) wc[w] = __popcll(hb);
+    __syncthreads();
+    if (head) {
+      int idx = run + __popcll(hb & lt_mask);
+      for (int ww = 0; ww < w; ++ww) idx += wc[ww];
+      uniq_rows[idx] = key;
+      seg_start[idx] = static_cast<int32_t>(i);
+    }
+    run += wc[0] + wc[1] + wc[2] + wc[3];
   }
   if (blockIdx.x == 0 && t == 0) {
     const int32_t U = total[0];
@@ -169,7 +222,7 @@ __global__ __launch_bounds__(kBlock) void compact_k(const int32_t* __restrict__ 
 int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
 struct Layout {
-  int64_t ntiles, keysA, keysB, valsA, valsB, hist, heads, total, bytes;
+  int64_t ntiles, keysA, keysB, valsA, valsB, hist, heads, bin_total, total, bytes;
 };
 
 Layout layout_for(int64_t n) {
@@ -181,8 +234,9 @@ Layout layout_for(int64_t n) {
   L.keysB = o; o += nb;
   L.valsA = o; o += nb;
   L.valsB = o; o += nb;
-  L.hist = o; o += align_up(L.ntiles * kBins * 4, 256);
+  L.hist = o; o += align_up(L.ntiles * kMaxBins * 4, 256);
   L.heads = o; o += align_up(L.ntiles * 4, 256);
+  L.bin_total = o; o += kMaxPasses * kMaxBins * 4;
   L.total = o; o += 256;
   L.bytes = o;
   return L;
@@ -214,30 +268,38 @@ int32_t mi_sort_unique_rows(const int32_t* rows, int64_t n, int64_t num_rows_tot
   int32_t* vbuf[2] = {reinterpret_cast<int32_t*>(ws + L.valsA), reinterpret_cast<int32_t*>(ws + L.valsB)};
   int32_t* hist = reinterpret_cast<int32_t*>(ws + L.hist);
   int32_t* heads = reinterpret_cast<int32_t*>(ws + L.heads);
+  int32_t* bin_total = reinterpret_cast<int32_t*>(ws + L.bin_total);
   int32_t* total = reinterpret_cast<int32_t*>(ws + L.total);
   const int ntiles = static_cast<int>(L.ntiles);
 
   int bits = 1;
-  while (bits < 32 && (static_cast<int64_t>(1) << bits) < num_rows_total) ++bits;
-  const int passes = (bits + 7) / 8;
+  while (bits < 31 && (static_cast<int64_t>(1) << bits) < num_rows_total) ++bits;
+  const int passes = (bits + kMaxBits - 1) / kMaxBits;
+  const int nbits = (bits + passes - 1) / passes;   // digit width, <= 9
+  const int nbins = 1 << nbits;
 
+  if (hipMemsetAsync(bin_total, 0, kMaxPasses * kMaxBins * 4, st) != hipSuccess) {
+    mi::set_error("sort_unique_rows: memset failed");
+    return MI_ERR_LAUNCH;
+  }
   const int32_t* kin = rows;
   const int32_t* vin = nullptr;  // pass 0: value = position
   for (int p = 0; p < passes; ++p) {
     int32_t* kout = kbuf[p & 1];
     int32_t* vout = vbuf[p & 1];
-    hist_k<<<dim3(ntiles), dim3(kBlock), 0, st>>>(kin, n, 8 * p, ntiles, hist);
+    int32_t* bt = bin_total + p * kMaxBins;
+    hist_k<<<dim3(ntiles), dim3(kBlock), 0, st>>>(kin, n, nbits * p, nbins, ntiles, hist, bt);
     MI_CHECK_LAUNCH("sort_unique_rows(hist)");
-    scan_k<<<dim3(1), dim3(1024), 0, st>>>(hist, static_cast<int64_t>(ntiles) * kBins, nullptr);
+    bin_scan_k<<<dim3(nbins), dim3(kBlock), 0, st>>>(hist, ntiles, nbins, bt);
     MI_CHECK_LAUNCH("sort_unique_rows(scan)");
-    scatter_k<<<dim3(ntiles), dim3(kBlock), 0, st>>>(kin, vin, n, 8 * p, ntiles, hist, kout, vout);
+    scatter_k<<<dim3(ntiles), dim3(kBlock), 0, st>>>(kin, vin, n, nbits * p, nbits, ntiles, hist, kout, vout);
     MI_CHECK_LAUNCH("sort_unique_rows(scatter)");
     kin = kout;
     vin = vout;
   }
   head_count_k<<<dim3(ntiles), dim3(kBlock), 0, st>>>(kin, n, heads);
   MI_CHECK_LAUNCH("sort_unique_rows(heads)");
-  scan_k<<<dim3(1), dim3(1024), 0, st>>>(heads, ntiles, total);
+  scan_small_k<<<dim3(1), dim3(1024), 0, st>>>(heads, ntiles, total);
   MI_CHECK_LAUNCH("sort_unique_rows(scan heads)");
   compact_k<<<dim3(ntiles), dim3(kBlock), 0, st>>>(kin, vin, n, heads, total, sorted_entry, uniq_rows, seg_start, num_uniq);
   MI_CHECK_LAUNCH("sort_unique_rows(compact)");

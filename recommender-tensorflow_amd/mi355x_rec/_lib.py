@@ -16,7 +16,7 @@ import torch  # noqa: F401  (loads the HIP runtime this library must share)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmi355x_rec.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class MiError(RuntimeError):
@@ -62,7 +62,7 @@ SIGNATURES = {
     "mi_dense_bwd_weight_workspace_bytes": (_sz, [_i64, _i32, _i32]),
     "mi_dense_bwd_weight": (_i32, [_p, _i64, _p, _i64, _p, _p, _i64, _i32, _i32, _p, _sz, _p]),
     "mi_head_workspace_bytes": (_sz, [_i64]),
-    "mi_sigmoid_ce_head": (_i32, [_p, _p, _p, _p, _p, _i64, _f32, _p, _p, _p, _p, _sz, _p]),
+    "mi_sigmoid_ce_head": (_i32, [_p, _p, _p, _p, _p, _i64, _f32, _p, _p, _p, _p, _p, _sz, _p]),
     "mi_colsum_workspace_bytes": (_sz, [_i64, _i32]),
     "mi_colsum": (_i32, [_p, _i64, _i64, _i32, _p, _p, _sz, _p]),
     "mi_layer_stats_workspace_bytes": (_sz, [_i64]),

@@ -336,8 +336,9 @@ class DeepFM:
         scale = np.float32(1.0 / n) if self.reduction == "mean" else np.float32(1.0)
         ws = self._bytes("head_ws", L.mi_head_workspace_bytes(B))
         lb = self.dense[self.lin_bias_off:] if self.use_linear else None
+        dsum = self.d_grad[self.lin_bias_off:] if (want_grad and self.use_linear) else None
         self._run(L.mi_sigmoid_ce_head, ptr(c["lin"]), ptr(lb), ptr(c["fm"]), ptr(c["dnn"]), ptr(labels), B,
-                                   float(scale), ptr(logits), ptr(loss), ptr(dlogit), ptr(ws), ws.numel(), st)
+                  float(scale), ptr(logits), ptr(loss), ptr(dlogit), ptr(dsum), ptr(ws), ws.numel(), st)
         return logits, loss, dlogit
 
     # ------------------------------------------------------------------ public steps
@@ -456,9 +457,7 @@ class DeepFM:
                                           ptr(dx), fan, B, h, fan, keep if i else 1.0, st)
                 dy, lddy = dx, fan
             d_concat = dy
-        if self.use_linear:   # d loss / d linear bias = sum_b dlogit
-            ws = self._bytes("colsum_ws", L.mi_colsum_workspace_bytes(B, 1))
-            self._run(L.mi_colsum, ptr(dlogit), 1, B, 1, ptr(self.d_grad[self.lin_bias_off:]), ptr(ws), ws.numel(), st)
+        # d loss / d linear bias = sum_b dlogit was written into d_grad by the head kernel
         if self.n_numeric:
             ws = self._bytes("num_ws", L.mi_numeric_embed_bwd_workspace_bytes(B, self.n_numeric, self.E))
             self._run(L.mi_numeric_embed_bwd, ptr(c["x_num"]), ptr(d_concat), self.D, ptr(c["concat"]), self.D,

@@ -207,15 +207,18 @@ def test_sigmoid_ce_head(lib, B):
     logits = torch.empty(B, device="cuda"); loss = torch.empty(1, device="cuda"); dl = torch.empty(B, device="cuda")
     ws = torch.empty(lib.mi_head_workspace_bytes(B) + 256, dtype=torch.uint8, device="cuda")
     for scale in (1.0 / B, 1.0):
+        dsum = torch.empty(1, device="cuda")
         _chk(lib.mi_sigmoid_ce_head(_p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), _p(a[4]), B, scale, _p(logits),
-                                    _p(loss), _p(dl), _p(ws), ws.numel(), _st()))
+                                    _p(loss), _p(dl), _p(dsum), _p(ws), ws.numel(), _st()))
         x32 = ((lin + bias[0]) + fm) + dnn                          # the reference's summation order
         assert np.array_equal(logits.cpu().numpy(), x32)
         l64, d64, _, _ = O.head(x32.astype(np.float64), y, "mean" if scale != 1.0 else "sum")
         assert abs(loss.item() - l64) / abs(l64) < TOL
         assert max_err_scaled(dl.cpu().numpy(), d64) < TOL
+        assert abs(dsum.item() - d64.sum()) < TOL * np.abs(d64).sum()
     # a term left out is skipped, not read
-    _chk(lib.mi_sigmoid_ce_head(None, None, _p(a[2]), None, None, B, 1.0, _p(logits), None, None, None, 0, _st()))
+    _chk(lib.mi_sigmoid_ce_head(None, None, _p(a[2]), None, None, B, 1.0, _p(logits), None, None, None, None, 0,
+                                _st()))
     assert np.array_equal(logits.cpu().numpy(), fm)
 
 

@@ -8,15 +8,22 @@ from oracle import optimizers as OO
 MASK64 = (1 << 64) - 1
 
 
+def _mix32(x):
+    x = x ^ (x >> np.uint32(16)); x = x * np.uint32(0x7feb352d)
+    x = x ^ (x >> np.uint32(15)); x = x * np.uint32(0x846ca68b)
+    return x ^ (x >> np.uint32(16))
+
+
 def dropout_mask(seed, M, N, keep):
     """Host replica of gemm.hip's counter-based dropout mask: multiplier {0, 1/keep} per element."""
     idx = np.arange(M * N, dtype=np.uint64)
-    x = (np.uint64(seed) + idx * np.uint64(0x9E3779B97F4A7C15))
-    x ^= x >> np.uint64(30); x *= np.uint64(0xbf58476d1ce4e5b9)
-    x ^= x >> np.uint64(27); x *= np.uint64(0x94d049bb133111eb)
-    x ^= x >> np.uint64(31)
+    lo = (idx & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    hi = (idx >> np.uint64(32)).astype(np.uint32)
+    with np.errstate(over="ignore"):
+        h = _mix32(lo ^ np.uint32(seed & 0xFFFFFFFF))
+        h = _mix32(h ^ (hi * np.uint32(0x9E3779B1)) ^ np.uint32((seed >> 32) & 0xFFFFFFFF))
     thresh = np.uint32(np.float32(keep) * np.float32(16777216.0))
-    kept = (x >> np.uint64(40)).astype(np.uint32) < thresh
+    kept = (h >> np.uint32(8)) < thresh
     return (kept.astype(np.float32) * np.float32(np.float32(1.0) / np.float32(keep))).reshape(M, N)
 
 
