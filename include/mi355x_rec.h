@@ -134,6 +134,17 @@ int32_t mi_sort_unique_rows(const int32_t* rows, int64_t n, int64_t num_rows_tot
                             int32_t* num_uniq, void* workspace, size_t workspace_bytes,
                             mi_stream_t stream);
 
+/* Routing helpers of the row-sharded multi-GPU path (row r lives on rank r % world as local row
+ * r / world; the reference's own multi-worker mode is TF's parameter-server placement of whole
+ * variables, distributed.md:58-82 — see DESIGN.md "Multi-GPU").
+ *   mi_shard_route : owner[i] = rows[i] % world, local_row[i] = rows[i] / world
+ *   mi_invert_perm : inv[perm[i]] = i
+ *   mi_gather_u32  : out[i] = src[idx[i]] for 4-byte elements (int32 ids or f32 values) */
+int32_t mi_shard_route(const int32_t* rows, int64_t n, int32_t world, int32_t* owner,
+                       int32_t* local_row, mi_stream_t stream);
+int32_t mi_invert_perm(const int32_t* perm, int64_t n, int32_t* inv, mi_stream_t stream);
+int32_t mi_gather_u32(const void* src, const int32_t* idx, int64_t n, void* out, mi_stream_t stream);
+
 /* rows[b*F+f] = field_off[f] + ids[b*F+f]  (int32 global row per entry) */
 int32_t mi_global_rows(const int32_t* ids, const int64_t* field_off, int64_t B, int32_t F,
                        int32_t* rows, mi_stream_t stream);

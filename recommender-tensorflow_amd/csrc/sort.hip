@@ -307,3 +307,64 @@ int32_t mi_sort_unique_rows(const int32_t* rows, int64_t n, int64_t num_rows_tot
 }
 
 }  // extern "C"
+
+// ---- routing helpers of the row-sharded (multi-GPU) path ------------------------------------
+namespace {
+
+__global__ __launch_bounds__(kBlock) void shard_route_k(const int32_t* __restrict__ rows, int64_t n,
+                                                        int world, int32_t* __restrict__ owner,
+                                                        int32_t* __restrict__ local_row) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const int32_t r = rows[i];
+  owner[i] = r % world;
+  local_row[i] = r / world;
+}
+
+__global__ __launch_bounds__(kBlock) void invert_perm_k(const int32_t* __restrict__ perm, int64_t n,
+                                                        int32_t* __restrict__ inv) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i < n) inv[perm[i]] = static_cast<int32_t>(i);
+}
+
+__global__ __launch_bounds__(kBlock) void gather_u32_k(const uint32_t* __restrict__ src,
+                                                       const int32_t* __restrict__ idx, int64_t n,
+                                                       uint32_t* __restrict__ out) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i < n) out[i] = src[idx[i]];
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t mi_shard_route(const int32_t* rows, int64_t n, int32_t world, int32_t* owner,
+                       int32_t* local_row, mi_stream_t stream) {
+  MI_REQUIRE(n >= 0 && world > 0, "shard_route: n=%lld world=%d", (long long)n, world);
+  if (n == 0) return MI_OK;
+  MI_REQUIRE(rows && owner && local_row, "shard_route: null buffer");
+  shard_route_k<<<dim3((unsigned)mi::ceil_div(n, kBlock)), dim3(kBlock), 0, mi::as_stream(stream)>>>(rows, n, world, owner, local_row);
+  MI_CHECK_LAUNCH("shard_route");
+  return MI_OK;
+}
+
+int32_t mi_invert_perm(const int32_t* perm, int64_t n, int32_t* inv, mi_stream_t stream) {
+  MI_REQUIRE(n >= 0, "invert_perm: n=%lld", (long long)n);
+  if (n == 0) return MI_OK;
+  MI_REQUIRE(perm && inv, "invert_perm: null buffer");
+  invert_perm_k<<<dim3((unsigned)mi::ceil_div(n, kBlock)), dim3(kBlock), 0, mi::as_stream(stream)>>>(perm, n, inv);
+  MI_CHECK_LAUNCH("invert_perm");
+  return MI_OK;
+}
+
+int32_t mi_gather_u32(const void* src, const int32_t* idx, int64_t n, void* out, mi_stream_t stream) {
+  MI_REQUIRE(n >= 0, "gather_u32: n=%lld", (long long)n);
+  if (n == 0) return MI_OK;
+  MI_REQUIRE(src && idx && out, "gather_u32: null buffer");
+  gather_u32_k<<<dim3((unsigned)mi::ceil_div(n, kBlock)), dim3(kBlock), 0, mi::as_stream(stream)>>>(
+      static_cast<const uint32_t*>(src), idx, n, static_cast<uint32_t*>(out));
+  MI_CHECK_LAUNCH("gather_u32");
+  return MI_OK;
+}
+
+}  // extern "C"

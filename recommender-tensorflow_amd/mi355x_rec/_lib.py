@@ -52,6 +52,9 @@ SIGNATURES = {
     "mi_sort_unique_workspace_bytes": (_sz, [_i64]),
     "mi_sort_unique_rows": (_i32, [_p, _i64, _i64, _p, _p, _p, _p, _p, _sz, _p]),
     "mi_global_rows": (_i32, [_p, _p, _i64, _i32, _p, _p]),
+    "mi_shard_route": (_i32, [_p, _i64, _i32, _p, _p, _p]),
+    "mi_invert_perm": (_i32, [_p, _i64, _p, _p]),
+    "mi_gather_u32": (_i32, [_p, _p, _i64, _p, _p]),
     "mi_dense_apply": (_i32, [_p, _p, _p, _p, _i64, C.POINTER(OptHparams), _p]),
     "mi_sparse_apply": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _p, _i32, _i32,
                                C.POINTER(OptHparams), _p]),

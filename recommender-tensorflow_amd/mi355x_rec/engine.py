@@ -5,7 +5,7 @@ predict step as a fixed sequence of libmi355x_rec.so launches on torch's current
 It replaces what ``model_fn`` builds and TensorFlow executes in the reference
 (``trainers/deep_fm.py:36-125``): the feature-column lookups, FM term, MLP, head and the
 optimizer apply.  No autograd, no torch math on the data path: torch allocates buffers and
-(for N > 1 GPUs) runs the RCCL collectives.
+(for N > 1 GPUs, ``parallel.py``) runs the RCCL collectives.
 
 Variable layout in HBM
   table   [R, E] f32   all embedding tables stacked row-major; field f owns rows
@@ -17,6 +17,8 @@ Variable layout in HBM
   dense   [P]    f32   every dense variable back to back (16-float aligned segments):
                        kernel_0, bias_0, ..., kernel_logits, bias_logits, linear bias,
                        numeric_embeddings, numeric linear weights; d_s0/d_s1/d_grad mirror it
+With a RowShard (N > 1 GPUs) table / lin_w / slots / last_step hold only the rows r with
+r % world == rank, stored at r // world; the dense buffer is replicated.
 """
 import ctypes as C
 import math
@@ -32,6 +34,50 @@ OPT_KINDS = {"Adam": 0, "Adagrad": 1, "Ftrl": 2, "RMSProp": 3, "SGD": 4}
 
 def _align(n, a=16):
     return (n + a - 1) // a * a
+
+
+class HipKernels:
+    """The device entry points of libmi355x_rec.so, called with torch tensors.
+
+    ``k.mi_xxx(a, b, ...)`` turns tensors into device pointers, structs into byref, appends torch's
+    current HIP stream and raises MiError on a non-zero status.  With ``timers`` set, each launch is
+    bracketed by HIP events on that stream (bench.py reads per-entry durations from them).
+
+    Test seam only: the CPU (gloo) tests of the multi-rank exchange plumbing pass the engine an
+    object with the same method names implemented in numpy (tests/cpu_kernels.py).  The shipped
+    path always constructs this class, and this class cannot be constructed without the library.
+    """
+
+    def __init__(self):
+        self.lib = _lib.load()
+        self.timers = None
+
+    def query(self, name, *args):
+        """Host-side queries (``*_workspace_bytes``): no stream, returns the value."""
+        return getattr(self.lib, name)(*args)
+
+    def __getattr__(self, name):
+        if not name.startswith("mi_"):
+            raise AttributeError(name)
+        fn = getattr(self.lib, name)
+
+        def call(*args):
+            a = [ptr(x) if isinstance(x, torch.Tensor) else (C.byref(x) if isinstance(x, C.Structure) else x)
+                 for x in args]
+            a.append(_lib.cur_stream())
+            if self.timers is None:
+                rc = fn(*a)
+            else:
+                s = torch.cuda.Event(enable_timing=True)
+                e = torch.cuda.Event(enable_timing=True)
+                s.record()
+                rc = fn(*a)
+                e.record()
+                self.timers.setdefault(name, []).append((s, e))
+            check(rc, name)
+
+        self.__dict__[name] = call
+        return call
 
 
 class OptimizerSpec:
@@ -105,11 +151,13 @@ class DeepFM:
     vocab_sizes: rows per categorical field, already in sorted column-name order.
     reduction: "mean" (contrib head, DeepFM) or "sum" (canned estimators), SURVEY A.5.
     linear_optimizer: if given, the wide part (lin_w + linear bias [+ numeric linear weights]) uses
-    it and everything else uses ``optimizer`` (DNNLinearCombinedClassifier)."""
+    it and everything else uses ``optimizer`` (DNNLinearCombinedClassifier).
+    shard: parallel.RowShard for N > 1 GPUs (row-sharded tables, data-parallel MLP)."""
 
     def __init__(self, vocab_sizes, n_numeric=0, embedding_size=4, hidden_units=(16, 16),
                  use_linear=True, use_mf=True, use_dnn=True, dropout=0.0, optimizer=None,
-                 linear_optimizer=None, reduction="mean", device="cuda", seed=0, shard=None):
+                 linear_optimizer=None, reduction="mean", device="cuda", seed=0, shard=None,
+                 _kernels=None):
         if len(vocab_sizes) + n_numeric == 0:
             raise ValueError("At least 1 feature column of categorical_columns or numeric_columns "
                              "must be specified.")            # deep_fm.py:31-32
@@ -117,7 +165,7 @@ class DeepFM:
             raise ValueError("At least 1 of linear, mf or dnn component must be used.")  # :33-34
         if len(vocab_sizes) == 0:
             raise NotImplementedError("numeric-only models are not supported by the HIP path")
-        self.lib = _lib.load()
+        self.k = _kernels if _kernels is not None else HipKernels()
         self.device = torch.device(device)
         self.vocab_sizes = [int(v) for v in vocab_sizes]
         self.F = len(self.vocab_sizes)
@@ -131,10 +179,12 @@ class DeepFM:
         self.opt = optimizer or OptimizerSpec()
         self.lin_opt = linear_optimizer
         self.seed = int(seed)
-        self.shard = shard                      # parallel.RowShard or None
+        self.shard = shard
         self.step = 0
         if self.use_emb and (self.E % 4 or not 4 <= self.E <= 256):
             raise ValueError("embedding_size must be a multiple of 4 in [4, 256] on the HIP path")
+        if self.n_numeric and not self.use_emb:
+            raise NotImplementedError("numeric columns need the embedding path (use_mf or use_dnn)")
 
         off = np.zeros(self.F + 1, np.int64)
         off[1:] = np.cumsum(self.vocab_sizes)
@@ -152,15 +202,16 @@ class DeepFM:
         sparse_lin_opt = self.lin_opt or self.opt
         self.t_s0, self.t_s1 = self._slots(self.table, self.opt)
         self.l_s0, self.l_s1 = self._slots(self.lin_w, sparse_lin_opt)
-        self.adam_rows = self.opt.name == "Adam" or sparse_lin_opt.name == "Adam"
+        t_adam = self.opt.name == "Adam" and self.table is not None
+        l_adam = sparse_lin_opt.name == "Adam" and self.lin_w is not None
+        self.adam_rows = t_adam or l_adam
         self.last_step = torch.zeros(self.R_local, dtype=torch.int32, device=dev) if self.adam_rows else None
-        self.sched = AdamSchedule(self.opt if self.opt.name == "Adam" else sparse_lin_opt, dev) \
-            if (self.opt.name == "Adam" or sparse_lin_opt.name == "Adam") else None
+        adam_spec = self.opt if self.opt.name == "Adam" else (sparse_lin_opt if sparse_lin_opt.name == "Adam" else None)
+        self.sched = AdamSchedule(adam_spec, dev) if adam_spec is not None else None
 
         # dense variables: one flat buffer
         self.D = (self.F + self.n_numeric) * self.E if self.use_emb else 0
         self.layers = []                         # (kernel_off, bias_off, fan_in, fan_out)
-        segs = []
         o = 0
         if self.use_dnn:
             fan = self.D
@@ -183,7 +234,7 @@ class DeepFM:
             # wide-part dense variables (linear bias, numeric linear weights) follow linear_optimizer
             self.dl_s0, self.dl_s1 = self._slots(self.dense, self.lin_opt)
         self._ws = {}
-        self.timers = None
+        self._final_step = 0
 
     # ------------------------------------------------------------------ variables
     def _slots(self, like, spec):
@@ -208,11 +259,13 @@ class DeepFM:
 
     def init_variables(self, generator=None, lin_scale=0.0):
         """TF initialisers: truncated_normal(0, 1/sqrt(E)) embeddings, zero linear
-        weights / biases, glorot-uniform kernels.  torch's generator, not TF's Philox stream."""
+        weights / biases, glorot-uniform kernels.  torch's generator, not TF's Philox stream.
+        Dense variables must be identical on every rank: seed the generator identically or
+        broadcast afterwards (parallel.broadcast_dense)."""
         g = generator
         if self.table is not None:
-            torch.nn.init.trunc_normal_(self.table, 0.0, 1.0 / math.sqrt(self.E), -2.0 / math.sqrt(self.E),
-                                        2.0 / math.sqrt(self.E), generator=g)
+            s = 1.0 / math.sqrt(self.E)
+            torch.nn.init.trunc_normal_(self.table, 0.0, s, -2.0 * s, 2.0 * s, generator=g)
         if self.lin_w is not None and lin_scale:
             self.lin_w.normal_(0.0, lin_scale, generator=g)
         for i, (_, _, fan, h) in enumerate(self.layers):
@@ -222,14 +275,17 @@ class DeepFM:
             lim = math.sqrt(6.0 / (self.n_numeric + self.E))
             self._seg(self.dense, self.num_emb_off, (self.n_numeric, self.E)).uniform_(-lim, lim, generator=g)
 
+    def _my_rows(self, a):
+        """rows of a [R, ...] array that live on this rank, in local order"""
+        return a if self.shard is None else a[self.shard.rank::self.shard.world]
+
     def load_oracle_params(self, p):
         """Copy an ``oracle.deepfm.Params`` (numpy) into the device buffers (tests / smoke)."""
-        assert self.shard is None
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(self.device)
         if self.table is not None:
-            self.table.copy_(t(np.concatenate(p.emb, 0)))
+            self.table.copy_(t(self._my_rows(np.concatenate(p.emb, 0))))
         if self.lin_w is not None:
-            self.lin_w.copy_(t(np.concatenate(p.lin_w, 0)))
+            self.lin_w.copy_(t(self._my_rows(np.concatenate(p.lin_w, 0))))
         for i in range(len(self.layers)):
             self.kernel(i).copy_(t(p.mlp[i][0]))
             self.bias(i).copy_(t(p.mlp[i][1]))
@@ -239,13 +295,18 @@ class DeepFM:
             self._seg(self.dense, self.lin_num_off, (self.n_numeric,)).copy_(t(p.lin_num))
 
     def export_numpy(self):
-        """Variables as numpy arrays in the oracle's structure (after bringing Adam rows up to date)."""
+        """Variables as numpy arrays (after bringing Adam rows up to date).  Sparse variables are
+        returned per field for a single GPU, as the local shard ("table", "lin_w_local") otherwise."""
         self.finalize_rows()
-        off = self.field_off_host
-        sp = lambda a: [a[off[f]:off[f + 1]].cpu().numpy() for f in range(self.F)] if a is not None else None
-        out = {"emb": sp(self.table), "lin_w": sp(self.lin_w),
-               "mlp": [(self.kernel(i).cpu().numpy(), self.bias(i).cpu().numpy()) for i in range(len(self.layers))],
+        out = {"mlp": [(self.kernel(i).cpu().numpy(), self.bias(i).cpu().numpy()) for i in range(len(self.layers))],
                "lin_bias": self.dense[self.lin_bias_off:self.lin_bias_off + 1].cpu().numpy()}
+        if self.shard is None:
+            off = self.field_off_host
+            sp = lambda a: [a[off[f]:off[f + 1]].cpu().numpy() for f in range(self.F)] if a is not None else None
+            out.update(emb=sp(self.table), lin_w=sp(self.lin_w))
+        else:
+            out.update(table=None if self.table is None else self.table.cpu().numpy(),
+                       lin_w_local=None if self.lin_w is None else self.lin_w.cpu().numpy())
         if self.n_numeric:
             out["num_emb"] = self._seg(self.dense, self.num_emb_off, (self.n_numeric, self.E)).cpu().numpy()
             out["lin_num"] = self._seg(self.dense, self.lin_num_off, (self.n_numeric,)).cpu().numpy()
@@ -268,84 +329,79 @@ class DeepFM:
             self._ws[name] = cur
         return cur
 
-    def _run(self, fn, *args):
-        """Launch one C-ABI entry on the current stream; with self.timers set, bracket it with HIP
-        events on that stream (bench.py reads per-kernel durations from them)."""
-        if self.timers is None:
-            rc = fn(*args)
-        else:
-            s = torch.cuda.Event(enable_timing=True)
-            e = torch.cuda.Event(enable_timing=True)
-            s.record()
-            rc = fn(*args)
-            e.record()
-            self.timers.setdefault(fn.__name__, []).append((s, e))
-        check(rc, fn.__name__)
-
     def _layer_seed(self, layer):
-        return (self.seed * 0x9E3779B97F4A7C15 + (self.step + 1) * 1000003 + layer * 7919) & (2 ** 64 - 1)
+        rank = 0 if self.shard is None else self.shard.rank
+        return (self.seed * 0x9E3779B97F4A7C15 + (self.step + 1) * 1000003 + layer * 7919 + rank * 104729) & (2 ** 64 - 1)
+
+    @property
+    def timers(self):
+        return self.k.timers
+
+    @timers.setter
+    def timers(self, v):
+        self.k.timers = v
 
     # ------------------------------------------------------------------ forward
-    def _forward(self, ids, x_num, train, st):
-        """ids [B,F] int32 device; returns logits components, caches activations for backward."""
-        L = self.lib
+    def _forward(self, ids, x_num, train, src=None):
+        """ids [B,F] int32; returns the logit components and caches activations for the backward.
+        src = (table, lin_w, field_off, ids) overrides where rows are read from (sharded path: the
+        rows received from their owners, addressed by slot)."""
+        k = self.k
         B = ids.shape[0]
         c = {"B": B}
-        lin = fm = dnn = None
-        concat = sumv = None
+        table, lin_w, field_off, rid = src if src is not None else (self.table, self.lin_w, self.field_off, ids)
+        concat = sumv = fm = None
         ld = self.D
         if self.use_emb:
             concat = self._buf("concat", (B, ld))
             sumv = self._buf("sumv", (B, self.E)) if self.use_mf else None
             fm = self._buf("fm", (B,)) if self.use_mf else None
         lin = self._buf("lin", (B,)) if self.use_linear else None
-        self._run(L.mi_embed_fm_linear_fwd, ptr(self.table), ptr(self.lin_w), ptr(self.field_off), ptr(ids),
-                                       B, self.F, self.E, ptr(concat), ld, ptr(sumv), ptr(fm), ptr(lin), st)
+        k.mi_embed_fm_linear_fwd(table if self.use_emb else None, lin_w if self.use_linear else None, field_off, rid,
+                                 B, self.F, self.E, concat, ld, sumv, fm, lin)
         if self.n_numeric:
             V = self._seg(self.dense, self.num_emb_off, (self.n_numeric, self.E))
             wn = self._seg(self.dense, self.lin_num_off, (self.n_numeric,)) if self.use_linear else None
-            if self.use_emb:
-                self._run(L.mi_numeric_embed_fwd, ptr(x_num), ptr(V), ptr(wn), B, self.n_numeric, self.E,
-                                             ptr(concat), ld, self.F * self.E, ptr(sumv), ptr(fm), ptr(lin), st)
-            else:
-                raise NotImplementedError("numeric columns need the embedding path (use_mf or use_dnn)")
+            k.mi_numeric_embed_fwd(x_num, V, wn, B, self.n_numeric, self.E, concat, ld, self.F * self.E, sumv, fm, lin)
         acts = []
+        dnn = None
         if self.use_dnn:
             x, ldx = concat, ld
             keep = 1.0 - self.dropout if (train and self.dropout > 0) else 1.0
             nh = len(self.layers) - 1
-            for i, (k_off, b_off, fan, h) in enumerate(self.layers):
+            for i, (_, _, fan, h) in enumerate(self.layers):
                 last = i == nh
                 y = self._buf("act%d" % i, (B, h))
-                self._run(L.mi_dense_fwd, ptr(x), ldx, ptr(self.kernel(i)), ptr(self.bias(i)), ptr(y), h, B, h, fan,
-                                     0 if last else 1, 1.0 if last else keep, self._layer_seed(i), st)
+                k.mi_dense_fwd(x, ldx, self.kernel(i), self.bias(i), y, h, B, h, fan, 0 if last else 1,
+                               1.0 if last else keep, self._layer_seed(i))
                 acts.append(y)
                 x, ldx = y, h
             dnn = acts[-1].view(B)
             c["keep"] = keep
-        c.update(concat=concat, sumv=sumv, fm=fm, lin=lin, dnn=dnn, acts=acts, ids=ids, x_num=x_num)
+        c.update(concat=concat, sumv=sumv, fm=fm, lin=lin, dnn=dnn, acts=acts, x_num=x_num)
         return c
 
-    def _head(self, c, labels, st, want_grad, global_batch=None):
-        L = self.lib
+    def _head(self, c, labels, want_grad, global_batch=None):
+        k = self.k
         B = c["B"]
         logits = self._buf("logits", (B,))
         loss = self._buf("loss", (1,)) if labels is not None else None
         dlogit = self._buf("dlogit", (B,)) if want_grad else None
         n = global_batch if global_batch is not None else B
         scale = np.float32(1.0 / n) if self.reduction == "mean" else np.float32(1.0)
-        ws = self._bytes("head_ws", L.mi_head_workspace_bytes(B))
+        ws = self._bytes("head_ws", k.query("mi_head_workspace_bytes", B))
         lb = self.dense[self.lin_bias_off:] if self.use_linear else None
+        # d loss / d linear bias = sum_b dlogit lands straight in the dense gradient buffer
         dsum = self.d_grad[self.lin_bias_off:] if (want_grad and self.use_linear) else None
-        self._run(L.mi_sigmoid_ce_head, ptr(c["lin"]), ptr(lb), ptr(c["fm"]), ptr(c["dnn"]), ptr(labels), B,
-                  float(scale), ptr(logits), ptr(loss), ptr(dlogit), ptr(dsum), ptr(ws), ws.numel(), st)
+        k.mi_sigmoid_ce_head(c["lin"], lb, c["fm"], c["dnn"], labels, B, float(scale), logits, loss, dlogit, dsum,
+                             ws, ws.numel())
         return logits, loss, dlogit
 
     # ------------------------------------------------------------------ public steps
     def _prep(self, ids, labels, x_num):
         if ids.dtype != torch.int32 or not ids.is_contiguous() or ids.dim() != 2 or ids.shape[1] != self.F:
             raise ValueError("ids must be a contiguous int32 [B, %d] tensor" % self.F)
-        if ids.device != self.device and ids.device.type != self.device.type:
+        if ids.device.type != self.device.type:
             raise ValueError("ids must live on %s" % self.device)
         if labels is not None and (labels.dtype != torch.uint8 or labels.shape != (ids.shape[0],)):
             raise ValueError("labels must be uint8 [B]")
@@ -359,42 +415,50 @@ class DeepFM:
 
     def predict_logits(self, ids, x_num=None):
         """PREDICT / EVAL forward (no dropout).  Returns logits [B] (device)."""
-        self._prep(ids, None, x_num)
-        self.finalize_rows()
-        st = _lib.cur_stream()
-        c = self._forward(ids, x_num, False, st)
-        logits, _, _ = self._head(c, None, st, False)
-        return logits
+        return self.loss(ids, None, x_num)[1]
 
     def loss(self, ids, labels, x_num=None):
-        """EVAL forward: (loss [1], logits [B]) without touching any variable."""
+        """EVAL forward: (loss [1] or None, logits [B]) without touching any model variable
+        (Adam rows that TF would have moved meanwhile are first brought up to date)."""
         self._prep(ids, labels, x_num)
         self.finalize_rows()
-        st = _lib.cur_stream()
-        c = self._forward(ids, x_num, False, st)
-        logits, loss, _ = self._head(c, labels, st, False)
+        if self.shard is not None:
+            from . import parallel
+            return parallel.sharded_eval_step(self, ids, labels, x_num)
+        c = self._forward(ids, x_num, False)
+        logits, loss, _ = self._head(c, labels, False)
         return loss, logits
 
     def finalize_rows(self):
         """Bring every Adam row up to date (all-rows mi_sparse_catchup).  No-op when nothing is stale."""
-        if not self.adam_rows or self.step == 0 or getattr(self, "_final_step", -1) == self.step:
+        if not self.adam_rows or self._final_step == self.step:
             return
-        st = _lib.cur_stream()
-        self._catchup(None, None, self.R_local, st)
+        self._catchup(None, None, self.R_local)
         self._final_step = self.step
 
-    def _catchup(self, uniq, num_uniq, n_max, st):
+    def _catchup(self, uniq, num_uniq, n_max):
+        if self.sched is None or n_max == 0:
+            return
         s = self.sched.spec
         t_adam = self.opt.name == "Adam" and self.table is not None
         l_adam = (self.lin_opt or self.opt).name == "Adam" and self.lin_w is not None
-        if not (t_adam or l_adam):
-            return
         self.sched.lr_t(self.step)  # make sure the table covers step
-        self._run(self.lib.mi_sparse_catchup, ptr(self.table if t_adam else None), ptr(self.t_s0 if t_adam else None),
-                                         ptr(self.t_s1 if t_adam else None), ptr(self.lin_w if l_adam else None),
-                                         ptr(self.l_s0 if l_adam else None), ptr(self.l_s1 if l_adam else None),
-                                         ptr(self.last_step), ptr(uniq), ptr(num_uniq), n_max, self.E, self.step,
-                                         ptr(self.sched.table), s.beta1, s.beta2, s.epsilon, st)
+        self.k.mi_sparse_catchup(self.table if t_adam else None, self.t_s0 if t_adam else None,
+                                 self.t_s1 if t_adam else None, self.lin_w if l_adam else None,
+                                 self.l_s0 if l_adam else None, self.l_s1 if l_adam else None, self.last_step,
+                                 uniq, num_uniq, n_max, self.E, self.step, self.sched.table, s.beta1, s.beta2,
+                                 s.epsilon)
+
+    def _sort_unique(self, keys, n, key_range, tag):
+        """mi_sort_unique_rows into persistent buffers named after `tag`."""
+        i32 = torch.int32
+        sorted_entry = self._buf(tag + "_sorted", (n,), i32)
+        uniq = self._buf(tag + "_uniq", (n,), i32)
+        seg = self._buf(tag + "_seg", (n + 1,), i32)
+        num_uniq = self._buf(tag + "_nu", (1,), i32)
+        ws = self._bytes("sort_ws", self.k.query("mi_sort_unique_workspace_bytes", n))
+        self.k.mi_sort_unique_rows(keys, n, key_range, sorted_entry, uniq, seg, num_uniq, ws, ws.numel())
+        return sorted_entry, uniq, seg, num_uniq
 
     def train_step(self, ids, labels, x_num=None):
         """One optimizer.minimize(loss): returns (loss [1], logits [B]) device tensors, no host sync."""
@@ -402,121 +466,114 @@ class DeepFM:
         if self.shard is not None:
             from . import parallel
             return parallel.sharded_train_step(self, ids, labels, x_num)
-        L = self.lib
-        st = _lib.cur_stream()
+        k = self.k
         B = ids.shape[0]
         n = B * self.F
-        i32 = torch.int32
         # (1) which rows does this batch touch: sort + unique (TF: unique/unsorted_segment_sum)
-        rows = self._buf("rows", (n,), i32)
-        self._run(L.mi_global_rows, ptr(ids), ptr(self.field_off), B, self.F, ptr(rows), st)
-        sorted_entry = self._buf("sorted_entry", (n,), i32)
-        uniq = self._buf("uniq", (n,), i32)
-        seg = self._buf("seg", (n + 1,), i32)
-        num_uniq = self._buf("num_uniq", (1,), i32)
-        ws = self._bytes("sort_ws", L.mi_sort_unique_workspace_bytes(n))
-        self._run(L.mi_sort_unique_rows, ptr(rows), n, self.R, ptr(sorted_entry), ptr(uniq), ptr(seg), ptr(num_uniq),
-                                    ptr(ws), ws.numel(), st)
+        rows = self._buf("rows", (n,), torch.int32)
+        k.mi_global_rows(ids, self.field_off, B, self.F, rows)
+        sorted_entry, uniq, seg, num_uniq = self._sort_unique(rows, n, self.R, "own")
         # (2) TF Adam moved these rows on every step they sat out: replay that now
         if self.adam_rows and self.step > 0:
-            self._catchup(uniq, num_uniq, n, st)
+            self._catchup(uniq, num_uniq, n)
         # (3) forward + head
-        c = self._forward(ids, x_num, True, st)
-        logits, loss, dlogit = self._head(c, labels, st, True)
-        # (4) backward through the MLP
-        d_concat = self._backward_dense(c, dlogit, st)
+        c = self._forward(ids, x_num, True)
+        logits, loss, dlogit = self._head(c, labels, True)
+        # (4) backward through the MLP (+ numeric embeddings)
+        d_concat = self._backward_dense(c, dlogit)
         # (5) per-entry row gradients, then the sparse apply on unique rows
-        d_rows = self._buf("d_rows", (n, self.E)) if self.use_emb else None
-        d_lin = self._buf("d_lin", (n,)) if self.use_linear else None
-        self._run(L.mi_embed_fm_linear_bwd, ptr(d_concat), self.D, ptr(c["concat"]), self.D, ptr(c["sumv"]),
-                                       ptr(dlogit if self.use_mf else None),
-                                       ptr(dlogit if self.use_linear else None), None, B, self.F, self.E,
-                                       ptr(d_rows), ptr(d_lin), st)
-        self._apply(uniq, seg, sorted_entry, num_uniq, n, d_rows, d_lin, st)
+        d_rows, d_lin = self._entry_grads(c, d_concat, dlogit, None)
+        self._apply(uniq, seg, sorted_entry, num_uniq, n, d_rows, d_lin)
         return loss, logits
 
-    def _backward_dense(self, c, dlogit, st):
+    def _entry_grads(self, c, d_concat, dlogit, pos):
+        B = c["B"]
+        n = B * self.F
+        d_rows = self._buf("d_rows", (n, self.E)) if self.use_emb else None
+        d_lin = self._buf("d_lin", (n,)) if self.use_linear else None
+        self.k.mi_embed_fm_linear_bwd(d_concat, self.D, c["concat"], self.D, c["sumv"],
+                                      dlogit if self.use_mf else None, dlogit if self.use_linear else None, pos,
+                                      B, self.F, self.E, d_rows, d_lin)
+        return d_rows, d_lin
+
+    def _backward_dense(self, c, dlogit):
         """Fills self.d_grad (dense gradients) and returns d_concat [B, D] (or None)."""
-        L = self.lib
+        k = self.k
         B = c["B"]
         d_concat = None
         if self.use_dnn:
             nh = len(self.layers) - 1
             keep = c["keep"]
             dy, lddy = dlogit, 1
-            wsz = max(L.mi_dense_bwd_weight_workspace_bytes(B, h, fan) for (_, _, fan, h) in self.layers)
+            wsz = max(k.query("mi_dense_bwd_weight_workspace_bytes", B, h, fan) for (_, _, fan, h) in self.layers)
             ws = self._bytes("wgrad_ws", wsz)
             for i in range(nh, -1, -1):
-                k_off, b_off, fan, h = self.layers[i]
+                _, _, fan, h = self.layers[i]
                 x = c["acts"][i - 1] if i else c["concat"]
                 ldx = self.layers[i - 1][3] if i else self.D
-                self._run(L.mi_dense_bwd_weight, ptr(x), ldx, ptr(dy), lddy, ptr(self.kernel(i, self.d_grad)),
-                                            ptr(self.bias(i, self.d_grad)), B, h, fan, ptr(ws), ws.numel(), st)
+                k.mi_dense_bwd_weight(x, ldx, dy, lddy, self.kernel(i, self.d_grad), self.bias(i, self.d_grad), B, h,
+                                      fan, ws, ws.numel())
                 dx = self._buf("dact%d" % i, (B, fan))
-                self._run(L.mi_dense_bwd_data, ptr(dy), lddy, ptr(self.kernel(i)), ptr(x if i else None), ldx,
-                                          ptr(dx), fan, B, h, fan, keep if i else 1.0, st)
+                k.mi_dense_bwd_data(dy, lddy, self.kernel(i), x if i else None, ldx, dx, fan, B, h, fan,
+                                    keep if i else 1.0)
                 dy, lddy = dx, fan
             d_concat = dy
-        # d loss / d linear bias = sum_b dlogit was written into d_grad by the head kernel
         if self.n_numeric:
-            ws = self._bytes("num_ws", L.mi_numeric_embed_bwd_workspace_bytes(B, self.n_numeric, self.E))
-            self._run(L.mi_numeric_embed_bwd, ptr(c["x_num"]), ptr(d_concat), self.D, ptr(c["concat"]), self.D,
-                                         self.F * self.E, ptr(c["sumv"]), ptr(dlogit if self.use_mf else None),
-                                         ptr(dlogit if self.use_linear else None), B, self.n_numeric, self.E,
-                                         ptr(self.d_grad[self.num_emb_off:]),
-                                         ptr(self.d_grad[self.lin_num_off:] if self.use_linear else None),
-                                         ptr(ws), ws.numel(), st)
+            ws = self._bytes("num_ws", k.query("mi_numeric_embed_bwd_workspace_bytes", B, self.n_numeric, self.E))
+            k.mi_numeric_embed_bwd(c["x_num"], d_concat, self.D, c["concat"], self.D, self.F * self.E, c["sumv"],
+                                   dlogit if self.use_mf else None, dlogit if self.use_linear else None, B,
+                                   self.n_numeric, self.E, self.d_grad[self.num_emb_off:],
+                                   self.d_grad[self.lin_num_off:] if self.use_linear else None, ws, ws.numel())
         return d_concat
 
-    def _apply(self, uniq, seg, sorted_entry, num_uniq, n_max, d_rows, d_lin, st):
+    def _apply(self, uniq, seg, sorted_entry, num_uniq, n_max, d_rows, d_lin):
         """apply_gradients: dense Apply*, sparse apply on the unique rows, step += 1."""
-        L = self.lib
+        k = self.k
         step = self.step + 1
         lr_t = self.sched.lr_t(step) if self.sched else 0.0
         hp = self.opt.hparams(lr_t)
         if self.lin_opt is None:
             if self.P:
-                self._run(L.mi_dense_apply, ptr(self.dense), ptr(self.d_s0), ptr(self.d_s1), ptr(self.d_grad), self.P,
-                                       C.byref(hp), st)
+                k.mi_dense_apply(self.dense, self.d_s0, self.d_s1, self.d_grad, self.P, hp)
             sparse_hp = [(True, True, hp)]
         else:
             lhp = self.lin_opt.hparams(lr_t)
             if self.dnn_end:
-                self._run(L.mi_dense_apply, ptr(self.dense), ptr(self.d_s0), ptr(self.d_s1), ptr(self.d_grad),
-                                       self.dnn_end, C.byref(hp), st)
+                k.mi_dense_apply(self.dense, self.d_s0, self.d_s1, self.d_grad, self.dnn_end, hp)
             o = self.dnn_end
             sl = lambda t: t[o:] if t is not None else None
-            self._run(L.mi_dense_apply, ptr(self.dense[o:]), ptr(sl(self.dl_s0)), ptr(sl(self.dl_s1)),
-                                   ptr(self.d_grad[o:]), self.P - o, C.byref(lhp), st)
+            k.mi_dense_apply(self.dense[o:], sl(self.dl_s0), sl(self.dl_s1), self.d_grad[o:], self.P - o, lhp)
             sparse_hp = [(True, False, hp), (False, True, lhp)]
-        for do_table, do_lin, h in sparse_hp:
-            tb = self.table if (do_table and self.use_emb) else None
-            lw = self.lin_w if (do_lin and self.use_linear) else None
-            if tb is None and lw is None:
-                continue
-            self._run(L.mi_sparse_apply, ptr(tb), ptr(self.t_s0 if tb is not None else None),
-                                    ptr(self.t_s1 if tb is not None else None), ptr(lw),
-                                    ptr(self.l_s0 if lw is not None else None),
-                                    ptr(self.l_s1 if lw is not None else None), ptr(self.last_step),
-                                    ptr(uniq), ptr(seg), ptr(sorted_entry), ptr(num_uniq), n_max,
-                                    ptr(d_rows if tb is not None else None), ptr(d_lin if lw is not None else None),
-                                    self.E, step, C.byref(h), st)
+        if n_max > 0:
+            for do_table, do_lin, h in sparse_hp:
+                tb = self.table if (do_table and self.use_emb) else None
+                lw = self.lin_w if (do_lin and self.use_linear) else None
+                if tb is None and lw is None:
+                    continue
+                k.mi_sparse_apply(tb, self.t_s0 if tb is not None else None, self.t_s1 if tb is not None else None,
+                                  lw, self.l_s0 if lw is not None else None, self.l_s1 if lw is not None else None,
+                                  self.last_step, uniq, seg, sorted_entry, num_uniq, n_max,
+                                  d_rows if tb is not None else None, d_lin if lw is not None else None, self.E,
+                                  step, h)
         self.step = step
 
     # ------------------------------------------------------------------ checkpoint
+    _STATE_KEYS = ("dense", "d_s0", "d_s1", "table", "lin_w", "t_s0", "t_s1", "l_s0", "l_s1", "last_step",
+                   "dl_s0", "dl_s1")
+
     def state_dict(self):
+        """Everything needed to resume (reference: Estimator checkpoints, conf_utils.py:6-10)."""
         self.finalize_rows()
-        sd = {"step": self.step, "dense": self.dense, "d_s0": self.d_s0, "d_s1": self.d_s1,
-              "table": self.table, "lin_w": self.lin_w, "t_s0": self.t_s0, "t_s1": self.t_s1,
-              "l_s0": self.l_s0, "l_s1": self.l_s1, "last_step": self.last_step}
-        if self.lin_opt is not None:
-            sd.update(dl_s0=self.dl_s0, dl_s1=self.dl_s1)
-        return {k: (v.detach().cpu() if isinstance(v, torch.Tensor) else v) for k, v in sd.items() if v is not None}
+        sd = {"step": self.step}
+        for key in self._STATE_KEYS:
+            v = getattr(self, key, None)
+            if v is not None:
+                sd[key] = v.detach().cpu()
+        return sd
 
     def load_state_dict(self, sd):
         self.step = int(sd["step"])
-        for k, v in sd.items():
-            if k == "step":
-                continue
-            getattr(self, k).copy_(v.to(self.device))
+        for key, v in sd.items():
+            if key != "step":
+                getattr(self, key).copy_(v.to(self.device))
         self._final_step = self.step

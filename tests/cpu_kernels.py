@@ -1,0 +1,221 @@
+"""numpy stand-ins for the device entry points of libmi355x_rec.so — TEST INFRASTRUCTURE ONLY.
+
+The CPU (gloo, world_size 2) tests hand an instance to ``DeepFM(_kernels=...)`` so that the REAL
+host orchestration (engine.py) and the REAL multi-rank exchange plumbing (parallel.py) run without a
+GPU.  Every method restates the contract documented in include/mi355x_rec.h on CPU torch tensors
+(in place, through ``.numpy()`` views), using the oracle's update rules for the optimizers.  Nothing
+under recommender-tensorflow_amd/ imports this file.
+"""
+import numpy as np
+import torch
+
+from oracle import optimizers as OO
+from tests.util import dropout_mask
+
+_NAMES = {0: "Adam", 1: "Adagrad", 2: "Ftrl", 3: "RMSProp", 4: "SGD"}
+
+
+def _np(t):
+    return None if t is None else t.numpy()
+
+
+def _hyper(hp):
+    return OO.Hyper(_NAMES[hp.kind], lr=np.float32(hp.lr), beta1=np.float32(hp.beta1), beta2=np.float32(hp.beta2),
+                    epsilon=np.float32(hp.epsilon), decay=np.float32(hp.decay), momentum=np.float32(hp.momentum),
+                    lr_power=-0.5, l1=np.float32(hp.l1), l2=np.float32(hp.l2))
+
+
+class NumpyKernels:
+    timers = None
+
+    def query(self, name, *args):
+        return 256
+
+    # ---- ids / routing -----------------------------------------------------------------
+    def mi_global_rows(self, ids, field_off, B, F, rows):
+        _np(rows)[:] = (_np(ids).astype(np.int64) + _np(field_off)[None, :]).reshape(-1)
+
+    def mi_shard_route(self, rows, n, world, owner, local):
+        r = _np(rows)[:n]
+        _np(owner)[:n] = r % world
+        _np(local)[:n] = r // world
+
+    def mi_invert_perm(self, perm, n, inv):
+        _np(inv)[_np(perm)[:n]] = np.arange(n, dtype=np.int32)
+
+    def mi_gather_u32(self, src, idx, n, out):
+        _np(out)[:n] = _np(src)[_np(idx)[:n]]
+
+    def mi_sort_unique_rows(self, rows, n, total, sorted_entry, uniq, seg, num_uniq, ws, wsb):
+        r = _np(rows)[:n]
+        order = np.argsort(r, kind="stable").astype(np.int32)
+        sr = r[order]
+        starts = np.flatnonzero(np.r_[True, sr[1:] != sr[:-1]]).astype(np.int32)
+        U = len(starts)
+        _np(sorted_entry)[:n] = order
+        _np(uniq)[:U] = sr[starts]
+        _np(seg)[:U] = starts
+        _np(seg)[U] = n
+        _np(num_uniq)[0] = U
+
+    # ---- embedding side ------------------------------------------------------------------
+    def mi_embed_fm_linear_fwd(self, table, lin_w, field_off, ids, B, F, E, concat, ld, sumv, fm, lin):
+        rows = _np(ids).astype(np.int64) + _np(field_off)[None, :]
+        if table is not None:
+            v = _np(table)[rows]                               # [B,F,E]
+            _np(concat)[:, :F * E] = v.reshape(B, F * E)
+            s = v.sum(1)
+            if sumv is not None:
+                _np(sumv)[:] = s
+            if fm is not None:
+                _np(fm)[:] = np.float32(0.5) * (s * s - (v * v).sum(1)).sum(1)
+        if lin is not None:
+            _np(lin)[:] = _np(lin_w)[rows].sum(1)
+
+    def mi_gather_rows(self, table, lin_w, rows, n, E, out_rows, out_lin):
+        r = _np(rows)[:n]
+        _np(out_rows)[:n] = _np(table)[r]
+        if lin_w is not None and out_lin is not None:
+            _np(out_lin)[:n] = _np(lin_w)[r]
+
+    def mi_numeric_embed_fwd(self, x, V, w_num, B, nd, E, concat, ld, col0, sumv, fm, lin):
+        xv, Vv = _np(x), _np(V)
+        r = xv[:, :, None] * Vv[None, :, :]
+        _np(concat)[:, col0:col0 + nd * E] = r.reshape(B, nd * E)
+        if sumv is not None:
+            sc = _np(sumv).copy()
+            st = sc + r.sum(1)
+            _np(sumv)[:] = st
+            if fm is not None:
+                _np(fm)[:] += np.float32(0.5) * ((st * st - sc * sc) - (r * r).sum(1)).sum(1)
+        if lin is not None and w_num is not None:
+            _np(lin)[:] += xv @ _np(w_num)
+
+    def mi_embed_fm_linear_bwd(self, d_concat, lddc, concat, ldc, sumv, dlf, dll, pos, B, F, E, d_rows, d_lin):
+        p = np.arange(B * F) if pos is None else _np(pos)[:B * F].astype(np.int64)
+        if d_rows is not None:
+            g = np.zeros((B, F, E), np.float32)
+            if d_concat is not None:
+                g += _np(d_concat)[:, :F * E].reshape(B, F, E)
+            if dlf is not None:
+                v = _np(concat)[:, :F * E].reshape(B, F, E)
+                g += _np(dlf)[:, None, None] * (_np(sumv)[:, None, :] - v)
+            _np(d_rows)[p] = g.reshape(B * F, E)
+        if d_lin is not None:
+            _np(d_lin)[p] = np.repeat(_np(dll), F)
+
+    def mi_numeric_embed_bwd(self, x, d_concat, lddc, concat, ldc, col0, sumv, dlf, dll, B, nd, E, dV, dw, ws, wsb):
+        g = np.zeros((B, nd, E), np.float32)
+        if d_concat is not None:
+            g += _np(d_concat)[:, col0:col0 + nd * E].reshape(B, nd, E)
+        if dlf is not None:
+            v = _np(concat)[:, col0:col0 + nd * E].reshape(B, nd, E)
+            g += _np(dlf)[:, None, None] * (_np(sumv)[:, None, :] - v)
+        _np(dV)[:nd * E] = np.einsum("bj,bje->je", _np(x), g).reshape(-1)
+        if dw is not None:
+            _np(dw)[:nd] = (_np(dll)[:, None] * _np(x)).sum(0) if dll is not None else 0
+
+    # ---- MLP ----------------------------------------------------------------------------------
+    def mi_dense_fwd(self, X, ldx, W, bias, Y, ldy, M, N, K, relu, keep, seed):
+        y = _np(X)[:, :K] @ _np(W) + _np(bias)
+        if relu:
+            y = np.maximum(y, 0)
+        if keep < 1.0:
+            y = y * dropout_mask(seed, M, N, keep)
+        _np(Y)[:, :N] = y
+
+    def mi_dense_bwd_data(self, dY, lddy, W, Xact, ldxa, dX, lddx, M, N, K, keep):
+        dy = _np(dY).reshape(M, -1)[:, :N]
+        g = dy @ _np(W).T
+        if Xact is not None:
+            g = g * (_np(Xact)[:, :K] > 0) * np.float32(np.float32(1.0) / np.float32(keep))
+        _np(dX)[:, :K] = g
+
+    def mi_dense_bwd_weight(self, X, ldx, dY, lddy, dW, db, M, N, K, ws, wsb):
+        dy = _np(dY).reshape(M, -1)[:, :N]
+        _np(dW)[:] = _np(X)[:, :K].T @ dy
+        if db is not None:
+            _np(db)[:N] = dy.sum(0)
+
+    def mi_sigmoid_ce_head(self, lin, lin_bias, fm, dnn, labels, B, scale, logits, loss, dlogit, dsum, ws, wsb):
+        x = np.zeros(B, np.float32)
+        if lin is not None:
+            x = x + (_np(lin) + _np(lin_bias)[0])
+        if fm is not None:
+            x = x + _np(fm)
+        if dnn is not None:
+            x = x + _np(dnn)
+        _np(logits)[:] = x
+        if labels is not None:
+            y = _np(labels).astype(np.float32)
+            per = np.maximum(x, 0) - x * y + np.log1p(np.exp(-np.abs(x)))
+            if loss is not None:
+                _np(loss)[0] = (per * np.float32(scale)).sum(dtype=np.float32)
+            if dlogit is not None:
+                e = np.exp(-np.abs(x))
+                sig = np.where(x >= 0, 1 / (1 + e), e / (1 + e)).astype(np.float32)
+                d = (sig - y) * np.float32(scale)
+                _np(dlogit)[:] = d
+                if dsum is not None:
+                    _np(dsum)[0] = d.sum(dtype=np.float32)
+
+    # ---- optimizers ---------------------------------------------------------------------------
+    def mi_dense_apply(self, param, s0, s1, grad, n, hp):
+        h = _hyper(hp)
+        z = np.zeros(n, np.float32)
+        OO.dense_apply(h, _np(param)[:n], _np(s0)[:n] if s0 is not None else z, _np(s1)[:n] if s1 is not None else z,
+                       _np(grad)[:n], np.float32(hp.lr_t))
+
+    def mi_sparse_catchup(self, table, tm, tv, lin_w, lm, lv, last_step, uniq, num_uniq, n_max, E, step_to, lr_table,
+                          b1, b2, eps):
+        rows = np.arange(n_max) if uniq is None else _np(uniq)[:int(_np(num_uniq)[0])]
+        ls = _np(last_step)
+        lr = _np(lr_table)
+        b1, b2, eps = np.float32(b1), np.float32(b2), np.float32(eps)
+        for r in rows:
+            if ls[r] >= step_to:
+                continue
+            if ls[r] > 0:
+                for w, m, v in ((table, tm, tv), (lin_w, lm, lv)):
+                    if w is None:
+                        continue
+                    W, M, V = _np(w), _np(m), _np(v)
+                    for s in range(ls[r] + 1, step_to + 1):
+                        M[r] = M[r] * b1
+                        V[r] = V[r] * b2
+                        W[r] = W[r] - (lr[s] * M[r]) / (np.sqrt(V[r]) + eps)
+            ls[r] = step_to
+
+    def mi_sparse_apply(self, table, t0, t1, lin_w, l0, l1, last_step, uniq, seg, sorted_entry, num_uniq, n_max,
+                        d_rows, d_lin, E, step, hp):
+        h = _hyper(hp)
+        U = int(_np(num_uniq)[0])
+        rows = _np(uniq)[:U].astype(np.int64)
+        sg, se = _np(seg), _np(sorted_entry)
+        from mi355x_rec.engine import OptimizerSpec  # noqa: F401
+        for w, a, b, g, width in ((table, t0, t1, d_rows, E), (lin_w, l0, l1, d_lin, 1)):
+            if w is None:
+                continue
+            W = _np(w).reshape(-1, width)
+            A = _np(a).reshape(-1, width) if a is not None else np.zeros_like(W)
+            Bm = _np(b).reshape(-1, width) if b is not None else np.zeros_like(W)
+            G = _np(g).reshape(-1, width)
+            gsum = np.zeros((U, width), np.float32)
+            for u in range(U):
+                for kk in range(sg[u], sg[u + 1]):
+                    gsum[u] += G[se[kk]]
+            wv, av, bv = W[rows], A[rows], Bm[rows]
+            if h.name == "Adam":
+                b1, b2, eps = np.float32(h.beta1), np.float32(h.beta2), np.float32(h.epsilon)
+                av = av * b1 + gsum * (np.float32(1) - b1)
+                bv = bv * b2 + (gsum * gsum) * (np.float32(1) - b2)
+                wv = wv - (np.float32(hp.lr_t) * av) / (np.sqrt(bv) + eps)
+            else:
+                OO.dense_apply(h, wv, av, bv, gsum, None)
+            W[rows] = wv
+            if a is not None:
+                A[rows] = av
+            if b is not None:
+                Bm[rows] = bv
+        if last_step is not None:
+            _np(last_step)[rows] = step

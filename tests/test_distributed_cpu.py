@@ -1,0 +1,148 @@
+"""world_size-2 gloo tests (CPU) of the multi-rank step in mi355x_rec/parallel.py: the REAL routing /
+all-to-all / all-reduce plumbing with numpy stand-ins for the device kernels (tests/cpu_kernels.py).
+
+Parity statement: an N-rank synchronous step equals a 1-rank step on the concatenated
+batch — mean loss over the global batch, dense gradients summed, sparse gradients dedup-summed at
+the row's owner.  The 1-rank side here is the oracle."""
+import os
+import socket
+import sys
+import traceback
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import deepfm as O
+from oracle import optimizers as OO
+from tests.util import make_problem
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, cfg, out_q, device="cpu", backend="gloo"):
+    try:
+        for p in (ROOT, os.path.join(ROOT, "recommender-tensorflow_amd")):
+            if p not in sys.path:
+                sys.path.insert(0, p)
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        if device != "cpu":
+            torch.cuda.set_device(0)
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend, rank=rank, world_size=world)
+        from mi355x_rec.engine import DeepFM, OptimizerSpec
+        from mi355x_rec.parallel import RowShard
+        kernels = None                              # None -> HipKernels (the shipped binding)
+        if device == "cpu":
+            from tests.cpu_kernels import NumpyKernels
+            kernels = NumpyKernels()
+        vocab, E, hidden, B, nn, opt_name, lr, steps, flags = cfg
+        p, ids, x, y = make_problem(11, vocab, E, hidden, B * world, n_numeric=nn, use_dnn=flags[2])
+        m = DeepFM(vocab, n_numeric=nn, embedding_size=E, hidden_units=hidden, use_linear=flags[0], use_mf=flags[1],
+                   use_dnn=flags[2], optimizer=OptimizerSpec(opt_name, lr), device=device, shard=RowShard(rank, world),
+                   _kernels=kernels)
+        m.load_oracle_params(p)
+        rng = np.random.default_rng(5)
+        losses = []
+        t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(device)
+        for _ in range(steps):
+            ids_s = np.stack([rng.integers(0, v, B * world) for v in vocab], 1).astype(np.int32)
+            ids_s[1] = ids_s[0]
+            ids_s[B % len(ids_s)] = ids_s[0]         # the same rows requested from both ranks
+            sl = slice(rank * B, (rank + 1) * B)
+            loss, logits = m.train_step(t(ids_s[sl]), t(y[sl]), t(None if x is None else x[sl]))
+            tot = loss.detach().cpu().clone() if backend == "gloo" else loss.clone()
+            dist.all_reduce(tot)
+            losses.append((float(tot.item()), logits.cpu().numpy().copy()))
+        ev_loss, ev_logits = m.loss(t(ids[rank * B:(rank + 1) * B]), t(y[rank * B:(rank + 1) * B]),
+                                    t(None if x is None else x[rank * B:(rank + 1) * B]))
+        out_q.put((rank, "ok", losses, m.export_numpy(), ev_logits.cpu().numpy().copy()))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:                                  # surface the traceback in the parent
+        out_q.put((rank, "error", traceback.format_exc(), None, None))
+
+
+def _run(cfg, world=2, device="cpu", backend="gloo"):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, cfg, q, device, backend)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        rank, status, a, b, c = q.get(timeout=240)
+        assert status == "ok", a
+        res[rank] = (a, b, c)
+    for p in procs:
+        p.join(timeout=60)
+    return res
+
+
+CASES = [
+    ([9, 13, 5, 6], 8, [16, 8], 32, 0, "Adam", 0.001, 3, (True, True, True)),
+    ([11, 5, 9], 4, [12], 16, 2, "Adam", 0.001, 2, (True, True, True)),          # numeric columns
+    ([7, 6, 5], 4, [8], 16, 0, "Adagrad", 0.05, 2, (True, False, True)),          # no FM, Adagrad
+    ([7, 6, 5], 4, [], 16, 0, "Ftrl", 0.1, 2, (True, False, False)),              # wide part only
+]
+
+
+@pytest.mark.parametrize("cfg", CASES)
+def test_two_rank_step_equals_big_batch(cfg):
+    check_against_big_batch(cfg, _run(cfg, 2), 2)
+
+
+def check_against_big_batch(cfg, res, world, tol=1.0):
+    vocab, E, hidden, B, nn, opt_name, lr, steps, flags = cfg
+    # 1-rank reference: the oracle on the concatenated batch
+    p, ids, x, y = make_problem(11, vocab, E, hidden, B * world, n_numeric=nn, use_dnn=flags[2])
+    st = O.TrainState(p, OO.Hyper(opt_name, lr))
+    rng = np.random.default_rng(5)
+    for s in range(steps):
+        ids_s = np.stack([rng.integers(0, v, B * world) for v in vocab], 1).astype(np.int32)
+        ids_s[1] = ids_s[0]
+        ids_s[B % len(ids_s)] = ids_s[0]
+        lo, logit_o = O.train_step(p, st, ids_s, y, x, *flags)
+        for r in range(world):
+            tot, logits = res[r][0][s]
+            assert abs(tot - float(lo)) < tol * (1e-5 * abs(float(lo)) + 1e-7)
+            assert np.allclose(logits, logit_o[r * B:(r + 1) * B], rtol=1e-4 * tol, atol=2e-6 * tol)
+    tab = np.concatenate(p.emb, 0)
+    lw = np.concatenate(p.lin_w, 0)
+    for r in range(world):
+        g = res[r][1]
+        if g["table"] is not None:
+            assert np.max(np.abs(g["table"] - tab[r::world])) < 2e-6 * tol          # this rank's rows only
+        if g["lin_w_local"] is not None:
+            assert np.max(np.abs(g["lin_w_local"] - lw[r::world])) < 2e-6 * tol
+        for i, (k, b) in enumerate(g["mlp"]):
+            assert np.max(np.abs(k - p.mlp[i][0])) < 2e-6 * tol and np.max(np.abs(b - p.mlp[i][1])) < 2e-6 * tol
+        assert abs(g["lin_bias"][0] - p.lin_bias[0]) < 2e-6 * tol
+    # replicated dense variables stay bitwise identical across ranks
+    for i in range(len(res[0][1]["mlp"])):
+        for r in range(1, world):
+            assert np.array_equal(res[0][1]["mlp"][i][0], res[r][1]["mlp"][i][0])
+    # sharded eval forward agrees with the oracle forward on the updated variables
+    c = O.forward(p, ids, x, *flags)
+    for r in range(world):
+        assert np.allclose(res[r][2], c["logits"][r * B:(r + 1) * B], rtol=1e-4 * tol, atol=2e-6 * tol)
+
+
+def test_row_shard_layout():
+    from mi355x_rec.parallel import RowShard
+    R = 11
+    assert [RowShard(r, 4).local_rows(R) for r in range(4)] == [3, 3, 3, 2]
+    with pytest.raises(ValueError):
+        RowShard(4, 4)

@@ -1,0 +1,107 @@
+"""CPU tests of the host logic: the REAL engine.py orchestration (buffer layout, step sequencing,
+Adam schedule, lazy catch-up bookkeeping, checkpoint state) driven with numpy stand-ins for the
+device entry points (tests/cpu_kernels.py), checked against the oracle.  The HIP kernels themselves
+are covered by the -m gpu tests."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import deepfm as O
+from oracle import optimizers as OO
+from tests.cpu_kernels import NumpyKernels
+from tests.util import make_problem
+
+
+def _engine(vocab, E, hidden, nn=0, **kw):
+    from mi355x_rec.engine import DeepFM, OptimizerSpec
+    opt = kw.pop("optimizer", OptimizerSpec("Adam", 0.001))
+    return DeepFM(vocab, n_numeric=nn, embedding_size=E, hidden_units=hidden, optimizer=opt, device="cpu",
+                  _kernels=NumpyKernels(), **kw)
+
+
+def _t(a):
+    return None if a is None else torch.from_numpy(np.ascontiguousarray(a))
+
+
+def _check_vars(m, p, atol):
+    g = m.export_numpy()
+    for f in range(len(p.emb)):
+        assert np.max(np.abs(g["emb"][f] - p.emb[f])) < atol
+        assert np.max(np.abs(g["lin_w"][f] - p.lin_w[f])) < atol
+    for i, (k, b) in enumerate(g["mlp"]):
+        assert np.max(np.abs(k - p.mlp[i][0])) < atol and np.max(np.abs(b - p.mlp[i][1])) < atol
+    assert abs(g["lin_bias"][0] - p.lin_bias[0]) < atol
+
+
+@pytest.mark.parametrize("vocab,E,hidden,B,nn", [([9, 13, 5, 6], 8, [16, 8], 64, 0), ([11, 5, 9], 4, [12], 33, 2)])
+def test_engine_orchestration_matches_oracle(vocab, E, hidden, B, nn):
+    p, ids, x, y = make_problem(7, vocab, E, hidden, B, n_numeric=nn)
+    m = _engine(vocab, E, hidden, nn)
+    m.load_oracle_params(p)
+    st = O.TrainState(p, OO.Hyper("Adam", 0.001))
+    rng = np.random.default_rng(1)
+    for step in range(4):
+        ids_s = np.stack([rng.integers(0, v, B) for v in vocab], 1).astype(np.int32)
+        ids_s[1] = ids_s[0]
+        lo, logit_o = O.train_step(p, st, ids_s, y, x)
+        lg, logit_g = m.train_step(_t(ids_s), _t(y), _t(x))
+        assert abs(lg.item() - float(lo)) < 2e-6 * abs(float(lo)) + 1e-7
+        assert np.allclose(logit_g.numpy(), logit_o, rtol=1e-5, atol=1e-6)
+    _check_vars(m, p, 1e-6)
+    # eval path leaves variables alone and agrees with the oracle forward
+    loss, logits = m.loss(_t(ids), _t(y), _t(x))
+    c = O.forward(p, ids, x)
+    assert np.allclose(logits.numpy(), c["logits"], rtol=1e-5, atol=1e-6)
+
+
+def test_state_dict_roundtrip_resumes_bitwise():
+    vocab, E, hidden, B = [9, 13, 5], 4, [8], 32
+    p, ids, x, y = make_problem(8, vocab, E, hidden, B)
+    a = _engine(vocab, E, hidden)
+    a.load_oracle_params(p)
+    for _ in range(2):
+        a.train_step(_t(ids), _t(y))
+    sd = a.state_dict()
+    b = _engine(vocab, E, hidden)
+    b.load_state_dict(sd)
+    la, _ = a.train_step(_t(ids), _t(y))
+    lb, _ = b.train_step(_t(ids), _t(y))
+    assert la.item() == lb.item() and b.step == 3
+    assert torch.equal(a.table, b.table) and torch.equal(a.dense, b.dense)
+
+
+def test_input_validation():
+    m = _engine([3, 4], 4, [8])
+    with pytest.raises(ValueError, match="int32"):
+        m.train_step(torch.zeros(4, 2, dtype=torch.int64), torch.zeros(4, dtype=torch.uint8))
+    with pytest.raises(ValueError, match="labels"):
+        m.train_step(torch.zeros(4, 2, dtype=torch.int32), torch.zeros(4, dtype=torch.float32))
+    with pytest.raises(ValueError, match="no numeric"):
+        m.train_step(torch.zeros(4, 2, dtype=torch.int32), torch.zeros(4, dtype=torch.uint8), torch.zeros(4, 1))
+
+
+def test_optimizer_spec_defaults_and_unknown_name():
+    from mi355x_rec.engine import OptimizerSpec
+    with pytest.raises(KeyError):
+        OptimizerSpec("Nadam")                      # model_utils.py:65: dict lookup -> KeyError
+    assert OptimizerSpec("Adam").epsilon == 1e-8 and OptimizerSpec("RMSProp").epsilon == 1e-10
+    assert OptimizerSpec("Ftrl").slot_init == (0.1, 0.0) and OptimizerSpec("Adagrad").slot_init == (0.1, None)
+
+
+def test_adam_schedule_is_tf_running_product():
+    from mi355x_rec.engine import AdamSchedule, OptimizerSpec
+    s = AdamSchedule(OptimizerSpec("Adam", 0.001), "cpu", capacity=8)
+    pw = OO.AdamPowers(OO.Hyper("Adam", 0.001), np.float32)
+    for step in range(1, 40):                       # crosses the capacity: table must extend itself
+        assert s.lr_t(step) == float(pw.lr_t(0.001))
+        pw.finish()
+    assert float(s.table[39]) == s.lr_t(39)
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from mi355x_rec import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    from mi355x_rec.engine import DeepFM
+    with pytest.raises(_lib.MiError, match="no fallback"):
+        DeepFM([3, 4], device="cpu")

@@ -1,0 +1,21 @@
+"""-m gpu: the multi-rank step with the REAL HIP kernels.  The GPU box has one MI355X, so
+(a) two processes share cuda:0 and exchange through gloo (host-staged collectives): kernels +
+    routing + sharded optimizer state are the shipped ones, only the transport differs;
+(b) a single rank runs the RCCL ("nccl") code path end to end (all_to_all_single / all_reduce on
+    device tensors with world_size 1).
+The 8-GPU RCCL run itself is the driver's (bench.py --gpus N)."""
+import pytest
+
+from tests.test_distributed_cpu import CASES, _run, check_against_big_batch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("cfg", [CASES[0], CASES[1], ([50, 30, 20, 40], 64, [64, 32], 128, 0, "Adam", 0.001, 3, (True, True, True))])
+def test_two_ranks_one_gpu_gloo(cfg):
+    check_against_big_batch(cfg, _run(cfg, 2, device="cuda", backend="gloo"), 2, tol=3.0)
+
+
+def test_single_rank_rccl_path():
+    cfg = ([50, 30, 20, 40], 16, [32, 16], 96, 0, "Adam", 0.001, 3, (True, True, True))
+    check_against_big_batch(cfg, _run(cfg, 1, device="cuda", backend="nccl"), 1, tol=3.0)
