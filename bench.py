@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist", choices=["uniform", "zipf"], default="uniform", help="id distribution")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="nccl = RCCL over xGMI (the measured path); gloo only rehearses the N>1 flow on one GPU")
+    ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     return ap.parse_args()
 
 
@@ -106,11 +109,16 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs a torch.distributed.run launch with %d ranks" % (args.gpus, args.gpus))
+    if args.same_device:
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group("gloo")
 
     from mi355x_rec.engine import DeepFM, OptimizerSpec
     shard = None
@@ -122,6 +130,9 @@ def main():
     gen = torch.Generator(device=device)
     gen.manual_seed(SEED + rank)
     m.init_variables(gen, lin_scale=1e-3)
+    if world > 1:
+        from mi355x_rec.parallel import broadcast_dense
+        broadcast_dense(m)                       # replicated MLP must start identical on every rank
     batches = make_batches(8, gen, device, args.dist == "zipf")
 
     def sync():
@@ -143,7 +154,7 @@ def main():
     dt = time.perf_counter() - t0
     timers, m.timers = m.timers, None
     if world > 1:
-        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+        tmax = torch.tensor([dt], device=device if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     final_loss = float(loss.item())
