@@ -1,0 +1,205 @@
+"""A minimal Estimator loop with the knobs the reference configures (``trainers/conf_utils.py:6-34``)
+and the call shapes its trainers use (``tf.estimator.Estimator(model_fn, model_dir, config, params)``
++ ``train_and_evaluate``, ``trainers/deep_fm.py:153-178``).  Not a GPU target:
+plain Python around the engine.
+
+Differences from TensorFlow that matter to a user switching over:
+  * model_fn is called once per batch and EXECUTES the step (there is no graph); variables live
+    in ``params["_store"]``, which the Estimator owns and checkpoints;
+  * checkpoints are ``model.ckpt-<step>.pt`` (torch.save of engine.state_dict()), newest
+    ``keep_checkpoint_max`` kept, listed in ``checkpoint.json``; a TF-checkpoint importer would map
+    the variable names of SURVEY A.8;
+  * local mode only: multi-GPU runs launch one process per GPU (torch.distributed.run) instead of
+    TF_CONFIG parameter servers (distributed.md:58-82).
+"""
+import collections
+import glob
+import json
+import os
+import time
+
+import numpy as np
+import torch
+
+
+class ModeKeys:
+    TRAIN, EVAL, PREDICT = "train", "eval", "infer"
+
+
+EstimatorSpec = collections.namedtuple("EstimatorSpec", "mode predictions loss train_op eval_metric_ops export_outputs")
+EstimatorSpec.__new__.__defaults__ = (None,) * 5
+TrainSpec = collections.namedtuple("TrainSpec", "input_fn max_steps")
+EvalSpec = collections.namedtuple("EvalSpec", "input_fn steps exporters start_delay_secs throttle_secs")
+ServingInputReceiver = collections.namedtuple("ServingInputReceiver", "features receiver_tensors")
+
+
+class RunConfig:
+    def __init__(self, model_dir=None, save_checkpoints_secs=600, keep_checkpoint_max=5, save_summary_steps=100,
+                 log_step_count_steps=100, device="cuda"):
+        self.model_dir = model_dir
+        self.save_checkpoints_secs = save_checkpoints_secs
+        self.keep_checkpoint_max = keep_checkpoint_max
+        self.save_summary_steps = save_summary_steps
+        self.log_step_count_steps = log_step_count_steps
+        self.device = device
+
+
+class LatestExporter:
+    """Writes the newest model state + serving signature under <model_dir>/export/<name>/<ts>/,
+    keeping `exports_to_keep` (conf_utils.py:20-24)."""
+
+    def __init__(self, name, serving_input_receiver_fn, exports_to_keep=5):
+        self.name, self.fn, self.keep = name, serving_input_receiver_fn, exports_to_keep
+
+    def export(self, estimator, export_dir):
+        ts = str(int(time.time()))
+        out = os.path.join(export_dir, self.name, ts)
+        while os.path.exists(out):
+            ts = str(int(ts) + 1)
+            out = os.path.join(export_dir, self.name, ts)
+        os.makedirs(out)
+        recv = self.fn()
+        torch.save(estimator._engine().state_dict(), os.path.join(out, "variables.pt"))
+        with open(os.path.join(out, "signature.json"), "w") as f:
+            json.dump({"receiver_tensors": {k: str(v) for k, v in recv.receiver_tensors.items()},
+                       "outputs": ["logits", "logistic", "probabilities", "class_ids", "classes"],
+                       "global_step": estimator.global_step}, f, indent=1)
+        old = sorted(glob.glob(os.path.join(export_dir, self.name, "*")))
+        for d in old[:-self.keep]:
+            for fn in glob.glob(os.path.join(d, "*")):
+                os.remove(fn)
+            os.rmdir(d)
+        return out
+
+
+class Estimator:
+    def __init__(self, model_fn, model_dir=None, config=None, params=None):
+        self.model_fn = model_fn
+        self.config = config or RunConfig()
+        self.model_dir = model_dir or self.config.model_dir or "checkpoints/model"
+        self.params = dict(params or {})
+        self.params.setdefault("_store", {})
+        self.params.setdefault("device", self.config.device)
+        self._restored = False
+
+    # -- variable store -----------------------------------------------------------------
+    def _engine(self):
+        return self.params["_store"].get("engine")
+
+    @property
+    def global_step(self):
+        e = self._engine()
+        return e.step if e is not None else 0
+
+    def latest_checkpoint(self):
+        idx = os.path.join(self.model_dir, "checkpoint.json")
+        if not os.path.exists(idx):
+            return None
+        with open(idx) as f:
+            files = json.load(f)["all_model_checkpoint_paths"]
+        return os.path.join(self.model_dir, files[-1]) if files else None
+
+    def _maybe_restore(self):
+        if self._restored or self._engine() is None:
+            return
+        self._restored = True
+        ck = self.latest_checkpoint()
+        if ck:
+            self._engine().load_state_dict(torch.load(ck, weights_only=True))
+            print("INFO: restored %s (global_step %d)" % (ck, self.global_step))
+
+    def save_checkpoint(self):
+        os.makedirs(self.model_dir, exist_ok=True)
+        name = "model.ckpt-%d.pt" % self.global_step
+        torch.save(self._engine().state_dict(), os.path.join(self.model_dir, name))
+        idx = os.path.join(self.model_dir, "checkpoint.json")
+        files = []
+        if os.path.exists(idx):
+            with open(idx) as f:
+                files = json.load(f)["all_model_checkpoint_paths"]
+        files = [f for f in files if f != name] + [name]
+        for old in files[:-self.config.keep_checkpoint_max]:
+            p = os.path.join(self.model_dir, old)
+            if os.path.exists(p):
+                os.remove(p)
+        files = files[-self.config.keep_checkpoint_max:]
+        with open(idx, "w") as f:
+            json.dump({"model_checkpoint_path": name, "all_model_checkpoint_paths": files}, f)
+        return os.path.join(self.model_dir, name)
+
+    # -- modes ----------------------------------------------------------------------------
+    def _first_call(self, features, labels, mode):
+        """Build the variables (first model_fn call) and restore the latest checkpoint before any step."""
+        if self._engine() is None:
+            self.model_fn(features, labels, "_build", self.params)
+        self._maybe_restore()
+
+    def train(self, input_fn, steps=None, max_steps=None, on_checkpoint=None):
+        t_ckpt = t_log = time.time()
+        n_log = 0
+        done = 0
+        loss = None
+        for features, labels in input_fn():
+            self._first_call(features, labels, ModeKeys.TRAIN)
+            if max_steps is not None and self.global_step >= max_steps:
+                break
+            if steps is not None and done >= steps:
+                break
+            spec = self.model_fn(features, labels, ModeKeys.TRAIN, self.params)
+            loss = spec.loss
+            done += 1
+            n_log += 1
+            if self.global_step % self.config.log_step_count_steps == 0:
+                now = time.time()
+                print("INFO: loss = %.6f, step = %d (%.1f global_step/sec)" %
+                      (float(loss), self.global_step, n_log / max(now - t_log, 1e-9)))
+                t_log, n_log = now, 0
+            if self.config.save_checkpoints_secs and time.time() - t_ckpt >= self.config.save_checkpoints_secs:
+                self.save_checkpoint()
+                t_ckpt = time.time()
+                if on_checkpoint:
+                    on_checkpoint()
+        if self._engine() is not None and done:
+            self.save_checkpoint()
+            if on_checkpoint:
+                on_checkpoint()
+        return self
+
+    def evaluate(self, input_fn, steps=None):
+        store = self.params["_store"]
+        n = 0
+        for features, labels in input_fn():
+            self._first_call(features, labels, ModeKeys.EVAL)
+            if n == 0:
+                store["metrics_reset"] = True
+            self.model_fn(features, labels, ModeKeys.EVAL, self.params)
+            n += 1
+            if steps is not None and n >= steps:
+                break
+        out = store["metrics_result"]() if n else {}
+        out["global_step"] = self.global_step
+        print("INFO: Saving dict for global step %d: %s" % (self.global_step, ", ".join(
+            "%s = %.6g" % (k, v) for k, v in sorted(out.items()))))
+        return out
+
+    def predict(self, input_fn):
+        for batch in input_fn():
+            features = batch[0] if isinstance(batch, tuple) else batch
+            self._first_call(features, None, ModeKeys.PREDICT)
+            spec = self.model_fn(features, None, ModeKeys.PREDICT, self.params)
+            pr = {k: (v.cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in spec.predictions.items()}
+            for i in range(len(pr["logits"])):
+                yield {k: v[i] for k, v in pr.items()}
+
+
+def train_and_evaluate(estimator, train_spec, eval_spec):
+    """Local-mode tf.estimator.train_and_evaluate: train to max_steps; after every checkpoint
+    (every save_checkpoints_secs and at the end) evaluate on the whole eval input and export."""
+    def after_checkpoint():
+        estimator.evaluate(eval_spec.input_fn, steps=eval_spec.steps)
+        exporters = eval_spec.exporters
+        if exporters is not None:
+            for ex in (exporters if isinstance(exporters, (list, tuple)) else [exporters]):
+                ex.export(estimator, os.path.join(estimator.model_dir, "export"))
+    estimator.train(train_spec.input_fn, max_steps=train_spec.max_steps, on_checkpoint=after_checkpoint)
+    return estimator

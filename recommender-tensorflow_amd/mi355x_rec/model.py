@@ -1,0 +1,81 @@
+"""Glue between the Estimator-style surface and the engine: runs one batch in TRAIN / EVAL / PREDICT
+mode and returns an EstimatorSpec.  Shared by ``trainers.deep_fm.model_fn`` and the canned
+classifiers (``canned.py``).  Reference: the tail of model_fn, ``trainers/deep_fm.py:117-125``
+(``head.create_estimator_spec``; the prediction / metric keys are those of SURVEY A.5)."""
+import numpy as np
+import torch
+
+from . import _lib
+from .estimator import EstimatorSpec, ModeKeys
+from .feature_column import FieldPlan
+from .metrics import metrics_from_counters
+
+
+def binary_predictions(logits):
+    """logits [B] -> the head's PREDICT dict (same keys as the TF head)."""
+    x = logits.reshape(-1, 1)
+    p = torch.sigmoid(x)
+    cls = (p > 0.5).to(torch.int64)
+    return {"logits": x, "logistic": p, "probabilities": torch.cat([1 - p, p], 1), "class_ids": cls,
+            "classes": cls}
+
+
+class _EvalCounters:
+    def __init__(self, device):
+        self.hist = torch.zeros(2 * 201, dtype=torch.int64, device=device)
+        self.counts = torch.zeros(8, dtype=torch.int64, device=device)
+        self.sums = torch.zeros(4, dtype=torch.float64, device=device)
+        self.batch_losses = []
+
+    def reset(self):
+        self.hist.zero_(); self.counts.zero_(); self.sums.zero_()
+        self.batch_losses = []
+
+
+def run_batch(features, labels, mode, params, make_engine):
+    """make_engine(plan, device) -> engine.DeepFM; called once, the result lives in params['_store']."""
+    store = params.setdefault("_store", {})
+    if "engine" not in store:
+        plan = FieldPlan(params.get("categorical_columns", []), params.get("numeric_columns", []))
+        device = params.get("device", "cuda")
+        store["plan"] = plan
+        eng = store["engine"] = make_engine(plan, device)
+        gen = torch.Generator(device=eng.device)
+        gen.manual_seed(int(params.get("seed", 0)))
+        eng.init_variables(gen)                # TF initialisers; a checkpoint restore overrides
+        store["counters"] = None
+    if mode == "_build":
+        return None
+    plan, eng = store["plan"], store["engine"]
+    ids_np, x_np = plan.transform(features)
+    dev = eng.device
+    ids = torch.from_numpy(ids_np).to(dev)
+    x = torch.from_numpy(x_np).to(dev) if x_np is not None else None
+    y = None
+    if labels is not None:
+        y = torch.from_numpy(np.ascontiguousarray(np.asarray(labels).reshape(-1)).astype(np.uint8)).to(dev)
+
+    if mode == ModeKeys.TRAIN:
+        loss, logits = eng.train_step(ids, y, x)
+        return EstimatorSpec(mode, predictions=None, loss=loss, train_op=eng.step)
+    if mode == ModeKeys.EVAL:
+        loss, logits = eng.loss(ids, y, x)
+        if store["counters"] is None:
+            store["counters"] = _EvalCounters(dev)
+        ctr = store["counters"]
+        if store.pop("metrics_reset", False):
+            ctr.reset()
+        eng.k.mi_eval_accumulate(logits, y, ids.shape[0], ctr.hist, ctr.counts, ctr.sums)
+        ctr.batch_losses.append(loss.clone())
+
+        def result():
+            out = metrics_from_counters(ctr.hist.cpu().numpy(), ctr.counts.cpu().numpy(), ctr.sums.cpu().numpy())
+            out["loss"] = float(torch.stack(ctr.batch_losses).mean())     # tf.metrics.mean over batch losses
+            return out
+        store["metrics_result"] = result
+        return EstimatorSpec(mode, predictions=binary_predictions(logits), loss=loss, eval_metric_ops=result)
+    if mode == ModeKeys.PREDICT:
+        logits = eng.predict_logits(ids, x)
+        pr = binary_predictions(logits.clone())
+        return EstimatorSpec(mode, predictions=pr, export_outputs={"predict": pr})
+    raise ValueError("unknown mode %r" % (mode,))

@@ -1,0 +1,53 @@
+"""Shared argument table and run loop of the four trainer CLIs (flags and defaults of the
+reference: trainers/deep_fm.py:182-207, linear.py:50-65, deep.py:54-73, linear_deep.py:55-74)."""
+import shutil
+from argparse import ArgumentParser
+
+from mi355x_rec.estimator import ModeKeys, train_and_evaluate as _tae
+from trainers.conf_utils import get_eval_spec, get_exporter, get_run_config, get_train_spec
+from trainers.ml_100k import get_feature_columns, get_input_fn, serving_input_fn
+
+# flag -> (kwargs); every trainer takes the common ones, the model-specific ones are opted in by name
+_COMMON = [
+    ("--train-csv", dict(default="data/ml-100k/train.csv", help="path to the training csv data (default: %(default)s)")),
+    ("--test-csv", dict(default="data/ml-100k/test.csv", help="path to the test csv data (default: %(default)s)")),
+    ("--restore", dict(action="store_true", help="whether to restore from job_dir")),
+    ("--embedding-size", dict(type=int, default=4, help="embedding size (default: %(default)s)")),
+    ("--batch-size", dict(type=int, default=32, help="batch size (default: %(default)s)")),
+    ("--train-steps", dict(type=int, default=20000, help="number of training steps (default: %(default)s)")),
+    ("--device", dict(default="cuda", help="torch device of the MI355X to run on (default: %(default)s)")),
+]
+_OPTIONAL = {
+    "hidden_units": ("--hidden-units", dict(type=int, nargs="+", default=[16, 16],
+                                            help="hidden layer specification (default: %(default)s)")),
+    "dropout": ("--dropout", dict(type=float, default=0.1, help="dropout rate (default: %(default)s)")),
+    "exclude_linear": ("--exclude-linear", dict(action="store_true", help="flag to exclude linear component (default: %(default)s)")),
+    "exclude_mf": ("--exclude-mf", dict(action="store_true", help="flag to exclude mf component (default: %(default)s)")),
+    "exclude_dnn": ("--exclude-dnn", dict(action="store_true", help="flag to exclude dnn component (default: %(default)s)")),
+}
+
+
+def make_parser(model, extra=()):
+    p = ArgumentParser()
+    p.add_argument("--job-dir", default="checkpoints/" + model, help="job directory (default: %(default)s)")
+    for flag, kw in _COMMON:
+        p.add_argument(flag, **kw)
+    for name in extra:
+        flag, kw = _OPTIONAL[name]
+        p.add_argument(flag, **kw)
+    return p
+
+
+def run(args, make_estimator):
+    """Common body of train_and_evaluate(args): wipe job_dir unless --restore, build the estimator
+    from the MovieLens feature columns, train with periodic eval + export."""
+    if not args.restore:
+        shutil.rmtree(args.job_dir, ignore_errors=True)
+    columns = get_feature_columns(embedding_size=args.embedding_size)
+    config = get_run_config()
+    config.device = getattr(args, "device", "cuda")
+    estimator = make_estimator(columns, config)
+    train_spec = get_train_spec(get_input_fn(args.train_csv, batch_size=args.batch_size), args.train_steps)
+    eval_spec = get_eval_spec(get_input_fn(args.test_csv, ModeKeys.EVAL, batch_size=args.batch_size),
+                              get_exporter(serving_input_fn))
+    return _tae(estimator, train_spec, eval_spec)

@@ -1,0 +1,59 @@
+"""Counterpart of the reference's ``trainers/model_utils.py`` (same names, same dict keys).
+
+``layer_summary`` and ``get_optimizer`` are what ``deep_fm.model_fn`` imports (deep_fm.py:8); the
+other helpers are dead code in the reference but spell out the prediction / loss / metric
+contract, so they are kept as thin views over the engine's kernels."""
+import torch
+
+from mi355x_rec.engine import HipKernels, OptimizerSpec
+from mi355x_rec.metrics import metrics_from_counters
+
+_OPTIMIZERS = ("Adagrad", "Adam", "Ftrl", "RMSProp", "SGD")
+
+
+def layer_summary(value):
+    """zero fraction + range of an activation tensor (tf.summary.scalar / histogram in the reference)."""
+    k = HipKernels()
+    x = value.contiguous().view(-1)
+    out = torch.empty(4, device=x.device)
+    ws = torch.empty(k.query("mi_layer_stats_workspace_bytes", x.numel()) + 256, dtype=torch.uint8, device=x.device)
+    k.mi_layer_stats(x, x.numel(), out, ws, ws.numel())
+    z, mn, mx, mean = out.tolist()
+    return {"fraction_of_zero_values": z, "min": mn, "max": mx, "mean": mean}
+
+
+def get_binary_predictions(logits):
+    logistic = torch.sigmoid(logits)
+    return {"logits": logits, "logistic": logistic, "probabilities": logistic,
+            "class_id": (logistic > 0.5).to(torch.int32)}
+
+
+def get_binary_losses(labels, predictions):
+    x = predictions["logits"].reshape(-1)
+    y = labels.reshape(-1).to(x.dtype)
+    unreduced = torch.clamp(x, min=0) - x * y + torch.log1p(torch.exp(-x.abs()))
+    return {"unreduced_loss": unreduced.reshape(-1, 1), "average_loss": unreduced.mean(), "loss": unreduced.sum()}
+
+
+def get_binary_metric_ops(labels, predictions, losses):
+    k = HipKernels()
+    x = predictions["logits"].reshape(-1).contiguous()
+    y = labels.reshape(-1).to(torch.uint8).contiguous()
+    hist = torch.zeros(2 * 201, dtype=torch.int64, device=x.device)
+    counts = torch.zeros(8, dtype=torch.int64, device=x.device)
+    sums = torch.zeros(4, dtype=torch.float64, device=x.device)
+    k.mi_eval_accumulate(x, y, x.numel(), hist, counts, sums)
+    m = metrics_from_counters(hist.cpu().numpy(), counts.cpu().numpy(), sums.cpu().numpy())
+    return {key: m[key] for key in ("accuracy", "auc", "auc_precision_recall", "average_loss")}
+
+
+def get_optimizer(optimizer_name="Adam", learning_rate=0.001):
+    if optimizer_name not in _OPTIMIZERS:
+        raise KeyError(optimizer_name)
+    return OptimizerSpec(optimizer_name, learning_rate)
+
+
+def get_train_op(loss, optimizer):
+    raise NotImplementedError(
+        "there is no graph to attach a train op to: the step (forward, backward, optimizer apply) runs inside "
+        "model_fn(mode=TRAIN) / engine.DeepFM.train_step with the OptimizerSpec from get_optimizer()")

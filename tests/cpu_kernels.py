@@ -219,3 +219,21 @@ class NumpyKernels:
                 Bm[rows] = bv
         if last_step is not None:
             _np(last_step)[rows] = step
+
+    # ---- eval counters --------------------------------------------------------------------------
+    def mi_eval_accumulate(self, logits, labels, B, hist, counts, sums):
+        from oracle.metrics import auc_thresholds
+        x = _np(logits)[:B].astype(np.float32)
+        y = _np(labels)[:B].astype(np.int64)
+        e = np.exp(-np.abs(x))
+        p = np.where(x >= 0, 1 / (1 + e), e / (1 + e)).astype(np.float32)
+        kk = (auc_thresholds()[None, :] < p[:, None]).sum(1)
+        np.add.at(_np(hist), y * 201 + kk, 1)
+        cls = (p > 0.5).astype(np.int64)
+        c = _np(counts)
+        c[0] += B; c[1] += y.sum(); c[2] += cls.sum(); c[3] += (cls == y).sum()
+        c[4] += (cls & y).sum(); c[5] += (cls & (1 - y)).sum(); c[6] += ((1 - cls) & y).sum()
+        xd = x.astype(np.float64)
+        s = _np(sums)
+        s[0] += (np.maximum(xd, 0) - xd * y + np.log1p(np.exp(-np.abs(xd)))).sum()
+        s[1] += p.astype(np.float64).sum(); s[2] += y.sum()

@@ -1,0 +1,143 @@
+"""The drop-in surface: ``python -m trainers.{deep_fm,linear,deep,linear_deep}`` flags/defaults,
+``model_fn(features, labels, mode, params)`` with the reference's params keys and errors,
+``get_feature_columns / get_input_fn / serving_input_fn`` and the model_utils helpers
+(reference: trainers/*.py).  The same scenarios run on CPU with numpy stand-ins for the kernels
+(host logic) and, under -m gpu, on the real HIP path."""
+import csv
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from trainers import deep_fm, deep, linear, linear_deep, ml_100k, model_utils, conf_utils, _cli
+
+
+def _write_csv(path, n, seed):
+    rng = np.random.default_rng(seed)
+    occ = ["technician", "administrator", "student", "homemaker", "none", "engineer"]
+    with open(path, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(ml_100k.COLUMNS)
+        for _ in range(n):
+            row = {c: (0 if d[0] == 0 else "null") for c, d in zip(ml_100k.COLUMNS, ml_100k.DEFAULTS)}
+            uid, iid = int(rng.integers(1, 944)), int(rng.integers(1, 1683))
+            g = rng.integers(0, 2, len(ml_100k.GENRE))
+            # a learnable rule so that training visibly reduces the loss
+            like = (uid % 3 == 0) ^ (g[1] == 1)
+            row.update(user_id=uid, item_id=iid, rating=5 if like else int(rng.integers(1, 5)),
+                       age=int(rng.integers(7, 74)), gender=str(rng.choice(["F", "M", ""])),
+                       occupation=str(rng.choice(occ)), zipcode="%05d" % rng.integers(0, 99999),
+                       release_year=int(rng.integers(1922, 1999)))
+            row.update({k: int(v) for k, v in zip(ml_100k.GENRE, g)})
+            w.writerow([row[c] for c in ml_100k.COLUMNS])
+
+
+@pytest.fixture(params=["cpu", pytest.param("cuda", marks=pytest.mark.gpu)])
+def device(request, monkeypatch):
+    if request.param == "cpu":
+        from mi355x_rec import engine
+        from tests.cpu_kernels import NumpyKernels
+        monkeypatch.setattr(engine, "HipKernels", NumpyKernels)   # host-logic run: kernels stood in by numpy
+    return request.param
+
+
+@pytest.fixture
+def data(tmp_path):
+    _write_csv(tmp_path / "train.csv", 600, 1)
+    _write_csv(tmp_path / "test.csv", 150, 2)
+    return tmp_path
+
+
+def test_cli_flags_and_defaults_match_reference():
+    a = _cli.make_parser("deep_fm", ("exclude_linear", "exclude_mf", "exclude_dnn", "hidden_units", "dropout")).parse_args([])
+    assert (a.train_csv, a.test_csv, a.job_dir) == ("data/ml-100k/train.csv", "data/ml-100k/test.csv", "checkpoints/deep_fm")
+    assert (a.embedding_size, a.hidden_units, a.dropout, a.batch_size, a.train_steps) == (4, [16, 16], 0.1, 32, 20000)
+    assert not (a.restore or a.exclude_linear or a.exclude_mf or a.exclude_dnn)
+    for model, extra in (("linear", ()), ("deep", ("hidden_units", "dropout")), ("linear_deep", ("hidden_units", "dropout"))):
+        b = _cli.make_parser(model, extra).parse_args(["--batch-size", "8"])
+        assert b.job_dir == "checkpoints/" + model and b.batch_size == 8 and b.embedding_size == 4
+    assert conf_utils.EVAL_INTERVAL == 60 and conf_utils.get_run_config().keep_checkpoint_max == 5
+
+
+def test_input_fn_semantics(data):
+    ev = list(ml_100k.get_input_fn(str(data / "test.csv"), "eval", batch_size=32)())
+    assert [len(l) for _, l in ev] == [32, 32, 32, 32, 22]            # one pass, short last batch
+    f, l = ev[0]
+    assert set(f) == set(ml_100k.COLUMNS) - {"rating"} and l.dtype == bool
+    assert f["user_id"].dtype == np.int32 and f["gender"][0] in ("F", "M", "null")   # "" -> default "null"
+    it = ml_100k.get_input_fn(str(data / "train.csv"), batch_size=16, seed=3)()
+    seen = [next(it)[0]["user_id"] for _ in range(80)]                  # 1280 > 600 rows: it repeats
+    assert all(len(b) == 16 for b in seen)
+    first = np.concatenate(seen[:4])
+    assert not np.array_equal(first, list(ml_100k.get_input_fn(str(data / "train.csv"), "eval", 64)())[0][0]["user_id"])
+    recv = ml_100k.serving_input_fn()
+    assert set(recv.receiver_tensors) == {"user_id", "item_id", "age", "gender", "occupation", "zipcode",
+                                          "release_year", *ml_100k.GENRE}
+
+
+def test_model_fn_errors_and_params(device):
+    cols = ml_100k.get_feature_columns(4)["linear"]
+    with pytest.raises(ValueError, match="At least 1 feature column"):
+        deep_fm.model_fn({}, None, "train", {"device": device})
+    with pytest.raises(ValueError, match="At least 1 of linear, mf or dnn"):
+        deep_fm.model_fn({}, None, "train", {"categorical_columns": cols, "use_linear": False, "use_mf": False,
+                                             "use_dnn": False, "device": device})
+    with pytest.raises(KeyError):
+        model_utils.get_optimizer("Nadam")
+    assert model_utils.get_optimizer().name == "Adam" and model_utils.get_optimizer().lr == 0.001
+
+
+def test_model_fn_three_modes(device, data):
+    cols = ml_100k.get_feature_columns(4)["linear"]
+    params = {"categorical_columns": cols, "device": device}            # every other key at its default
+    feats, labels = next(ml_100k.get_input_fn(str(data / "train.csv"), batch_size=32, seed=0)())
+    l0 = float(deep_fm.model_fn(feats, labels, "eval", params).loss)
+    for _ in range(30):
+        spec = deep_fm.model_fn(feats, labels, "train", params)
+    assert float(spec.loss) < l0 and spec.train_op == 30
+    eng = params["_store"]["engine"]
+    assert (eng.E, eng.hidden, eng.dropout, eng.opt.name, eng.opt.lr) == (4, [16, 16], 0.0, "Adam", 0.001)
+    pr = deep_fm.model_fn(feats, None, "infer", params).predictions
+    assert set(pr) == {"logits", "logistic", "probabilities", "class_ids", "classes"}
+    assert pr["probabilities"].shape == (32, 2) and torch.allclose(pr["probabilities"].sum(1), torch.ones(32, device=pr["logits"].device))
+
+
+@pytest.mark.parametrize("trainer,extra", [(deep_fm, ["--hidden-units", "8", "8", "--dropout", "0.1"]), (linear, []),
+                                           (deep, ["--hidden-units", "8"]), (linear_deep, ["--hidden-units", "8"])])
+def test_train_and_evaluate_end_to_end(device, data, trainer, extra, capsys):
+    name = trainer.__name__.split(".")[-1]
+    opt = {"deep_fm": ("exclude_linear", "exclude_mf", "exclude_dnn", "hidden_units", "dropout"), "linear": (),
+           "deep": ("hidden_units", "dropout"), "linear_deep": ("hidden_units", "dropout")}[name]
+    job = str(data / "job")
+    argv = ["--train-csv", str(data / "train.csv"), "--test-csv", str(data / "test.csv"), "--job-dir", job,
+            "--train-steps", "120", "--batch-size", "32", "--device", device] + extra
+    est = trainer.train_and_evaluate(_cli.make_parser(name, opt).parse_args(argv))
+    assert est.global_step == 120
+    out = capsys.readouterr().out
+    assert "Saving dict for global step 120" in out and "auc = " in out and "average_loss = " in out
+    assert os.path.exists(os.path.join(job, "model.ckpt-120.pt")) and os.listdir(os.path.join(job, "export", "exporter"))
+    # --restore continues from the checkpoint; without it the job dir is wiped (deep_fm.py:147-148)
+    est2 = trainer.train_and_evaluate(_cli.make_parser(name, opt).parse_args(argv[:-len(extra) or None] + extra + ["--restore", "--train-steps", "150"]))
+    assert est2.global_step == 150 and "restored" in capsys.readouterr().out
+    m = est2.evaluate(ml_100k.get_input_fn(str(data / "test.csv"), "eval", 32))
+    assert {"accuracy", "auc", "auc_precision_recall", "average_loss", "loss", "precision", "recall", "label/mean",
+            "prediction/mean", "accuracy_baseline", "global_step"} <= set(m)
+    assert 0.5 < m["auc"] <= 1.0                                         # the synthetic rule is learnable
+    first = next(est2.predict(ml_100k.get_input_fn(str(data / "test.csv"), "eval", 32)))
+    assert first["probabilities"].shape == (2,)
+
+
+def test_model_utils_helpers(device):
+    if device == "cpu":
+        pytest.skip("helpers bind the HIP kernels directly")
+    x = torch.tensor([[-2.0], [0.0], [3.0]], device="cuda")
+    y = torch.tensor([0, 1, 1], device="cuda")
+    pr = model_utils.get_binary_predictions(x)
+    assert set(pr) == {"logits", "logistic", "probabilities", "class_id"} and pr["class_id"].flatten().tolist() == [0, 0, 1]
+    ls = model_utils.get_binary_losses(y, pr)
+    assert set(ls) == {"unreduced_loss", "average_loss", "loss"} and ls["loss"].item() == pytest.approx(3 * ls["average_loss"].item())
+    mt = model_utils.get_binary_metric_ops(y, pr, ls)
+    assert set(mt) == {"accuracy", "auc", "auc_precision_recall", "average_loss"} and mt["accuracy"] == pytest.approx(2 / 3)
+    s = model_utils.layer_summary(torch.tensor([[0.0, 1.0], [2.0, 0.0]], device="cuda"))
+    assert s["fraction_of_zero_values"] == 0.5 and s["max"] == 2.0
