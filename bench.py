@@ -166,7 +166,8 @@ def main():
         gather_bytes = B * F * 4 * E                     # algorithmic row bytes per launch
         total_bytes = B * (F * (4 * E + 8) + 4 * F * E + 4 * E + 8)   # + ids, lin weights, concat/sumv/fm/lin writes
         achieved = gather_bytes / (g_ms * 1e-3) / 1e9
-        gemm_ms = sum(v[2] for k, v in km.items() if k in ("mi_dense_fwd", "mi_dense_bwd_data", "mi_dense_bwd_weight")) / args.steps
+        gemm_ms = sum(v[2] for k, v in km.items() if k in ("mi_dense_fwd", "mi_dense_fwd_gathered", "mi_dense_bwd_data", "mi_dense_bwd_weight",
+                                                        "mi_dense_bwd_weight_gathered")) / args.steps
         dims = [F * E] + HIDDEN + [1]
         flops = 3 * 2 * B * sum(a * b for a, b in zip(dims[:-1], dims[1:]))
         out = {

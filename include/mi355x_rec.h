@@ -40,7 +40,7 @@ enum mi_status {
 };
 
 /* ---- library ---------------------------------------------------------------------------- */
-int32_t mi_abi_version(void);       /* bumps when a signature changes (currently 2) */
+int32_t mi_abi_version(void);       /* bumps when a signature changes (currently 3) */
 const char* mi_last_error(void);    /* thread-local, never NULL */
 const char* mi_build_info(void);    /* "gfx950 hipcc <ver>" */
 
@@ -78,7 +78,9 @@ int32_t mi_bucketize_f32(const float* values, int64_t n, const float* boundaries
  * table [R,E] f32, lin_w [R] f32 (may be NULL: lin not produced), field_off [F] int64 (device),
  * ids [B,F] int32 (device).  Outputs: concat [B,F*E] with leading dimension ld_concat (floats,
  * >= F*E: numeric-embedding columns may follow, deep_fm.py:73), sumv [B,E], fm [B], lin [B]
- * (fm / lin / sumv may be NULL).  E must be a multiple of 4 and <= 256.  Fields must already be
+ * (any of them may be NULL; with concat == NULL the kernel only READS rows — the form the
+ * single-GPU path uses, where layer 1 gathers its operand itself, and the one bench.py prices
+ * against the HBM read roofline; with table == NULL only the wide part lin is produced).  E must be a multiple of 4 and <= 256.  Fields must already be
  * in the reference's sorted-by-column-name order. */
 int32_t mi_embed_fm_linear_fwd(const float* table, const float* lin_w, const int64_t* field_off,
                                const int32_t* ids, int64_t B, int32_t F, int32_t E,
@@ -191,6 +193,18 @@ int32_t mi_sparse_apply(float* table, float* t_slot0, float* t_slot1, float* lin
                         const float* d_lin, int32_t E, int32_t step, const mi_opt_hparams* hp,
                         mi_stream_t stream);
 
+/* Single-GPU form of mi_sparse_apply with mi_embed_fm_linear_bwd folded in: the gradient of entry
+ * e = (b, f) = (e / F, e % F) is rebuilt inside the kernel as
+ *   d_concat[b, f*E:(f+1)*E] + d_logit_fm[b] * (sumv[b,:] - w)     (w = the row itself, not yet updated;
+ *   equals the concat slice the forward used)  and  d_logit_lin[b] for the linear weight,
+ * so the [B*F, E] per-entry gradient matrix is never written.  Same summation order, same bits. */
+int32_t mi_sparse_apply_fused(float* table, float* t_slot0, float* t_slot1, float* lin_w, float* l_slot0,
+                              float* l_slot1, int32_t* last_step, const int32_t* uniq_rows,
+                              const int32_t* seg_start, const int32_t* sorted_entry, const int32_t* num_uniq,
+                              int64_t n_max, const float* d_concat, int64_t ld_dconcat, const float* sumv,
+                              const float* d_logit_fm, const float* d_logit_lin, int32_t F, int32_t E,
+                              int32_t step, const mi_opt_hparams* hp, mi_stream_t stream);
+
 /* TF-1.12 AdamOptimizer._apply_sparse decays m and v of EVERY row and moves EVERY row each step
  * (SURVEY Appendix A.6).  Instead of sweeping the table, rows carry last_step[r] and are brought
  * up to date lazily: for s in (last_step[r], step_to]: m*=b1; v*=b2; w -= lr_t[s]*m/(sqrt(v)+eps)
@@ -212,6 +226,17 @@ int32_t mi_sparse_catchup(float* table, float* t_m, float* t_v, float* lin_w, fl
 int32_t mi_dense_fwd(const float* X, int64_t ldx, const float* W, const float* bias, float* Y,
                      int64_t ldy, int64_t M, int32_t N, int32_t K, int32_t relu, float keep_prob,
                      uint64_t seed, mi_stream_t stream);
+
+/* Layer 1 with the input_layer concat (deep_fm.py:54) read IN PLACE from the embedding table:
+ * X[b, f*E + e] = table[field_off[f] + ids[b*F+f], e], K = F*E.  The GEMM's A operand is gathered
+ * row by row (ids are fetched one k-tile ahead of the rows), so the [M, F*E] concat is never
+ * written to or re-read from HBM.  Otherwise identical to mi_dense_fwd / mi_dense_bwd_weight. */
+int32_t mi_dense_fwd_gathered(const float* table, const int64_t* field_off, const int32_t* ids, int32_t F,
+                              int32_t E, const float* W, const float* bias, float* Y, int64_t ldy, int64_t M,
+                              int32_t N, int32_t relu, float keep_prob, uint64_t seed, mi_stream_t stream);
+int32_t mi_dense_bwd_weight_gathered(const float* table, const int64_t* field_off, const int32_t* ids, int32_t F,
+                                     int32_t E, const float* dY, int64_t lddy, float* dW, float* db, int64_t M,
+                                     int32_t N, void* workspace, size_t workspace_bytes, mi_stream_t stream);
 
 /* dX[M,K] = (dY[M,N] * W[K,N]^T) .* mask.  When Xact != NULL (the previous layer's stored
  * post-relu, post-dropout output) mask = (Xact > 0) / keep_prob — a unit with Xact > 0 was both

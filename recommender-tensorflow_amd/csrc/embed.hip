@@ -70,7 +70,7 @@ __global__ __launch_bounds__(kBlock) void embed_fm_linear_fwd_k(
             s.x += r[u].x; s.y += r[u].y; s.z += r[u].z; s.w += r[u].w;
             q.x += __fmul_rn(r[u].x, r[u].x); q.y += __fmul_rn(r[u].y, r[u].y);
             q.z += __fmul_rn(r[u].z, r[u].z); q.w += __fmul_rn(r[u].w, r[u].w);
-            if (valid && lane_on) st4(crow + static_cast<int64_t>(fb + j0 + u) * E + eo, r[u]);
+            if (valid && lane_on && concat) st4(crow + static_cast<int64_t>(fb + j0 + u) * E + eo, r[u]);
           }
         }
       }
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(kBlock) void embed_fm_linear_fwd_k(
           s.x += r[u].x; s.y += r[u].y; s.z += r[u].z; s.w += r[u].w;
           q.x += __fmul_rn(r[u].x, r[u].x); q.y += __fmul_rn(r[u].y, r[u].y);
           q.z += __fmul_rn(r[u].z, r[u].z); q.w += __fmul_rn(r[u].w, r[u].w);
-          if (valid && lane_on) st4(crow + static_cast<int64_t>(f0 + u) * E + eo, r[u]);
+          if (valid && lane_on && concat) st4(crow + static_cast<int64_t>(f0 + u) * E + eo, r[u]);
         }
       }
     }
@@ -335,10 +335,11 @@ int32_t mi_embed_fm_linear_fwd(const float* table, const float* lin_w, const int
     return MI_OK;
   }
   if (int32_t rc = check_E("embed_fm_linear_fwd", E)) return rc;
-  MI_REQUIRE(table && field_off && ids && concat, "embed_fm_linear_fwd: null buffer");
-  MI_REQUIRE(ld_concat >= (int64_t)F * E && (ld_concat & 3) == 0,
+  MI_REQUIRE(table && field_off && ids, "embed_fm_linear_fwd: null buffer");
+  MI_REQUIRE(concat || sumv || fm || lin, "embed_fm_linear_fwd: no output requested");
+  MI_REQUIRE(!concat || (ld_concat >= (int64_t)F * E && (ld_concat & 3) == 0),
              "embed_fm_linear_fwd: ld_concat=%lld must be >= F*E and a multiple of 4", (long long)ld_concat);
-  MI_REQUIRE(mi::aligned16(table) && mi::aligned16(concat) && (!sumv || mi::aligned16(sumv)),
+  MI_REQUIRE(mi::aligned16(table) && (!concat || mi::aligned16(concat)) && (!sumv || mi::aligned16(sumv)),
              "embed_fm_linear_fwd: table/concat/sumv must be 16-byte aligned");
   MI_REQUIRE(!lin || lin_w, "embed_fm_linear_fwd: lin requested without lin_w");
   if (B == 0) return MI_OK;

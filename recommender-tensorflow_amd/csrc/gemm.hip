@@ -41,6 +41,10 @@ struct GemmArgs {
   float keep_prob; float inv_keep; uint64_t seed;
   const float* mask_src; int64_t ldm;
   float* colsum_part;   // TN only: [splits][N] partial column sums of B (bias gradient), or NULL
+  // Gathered A operand (layer 1 of the MLP): A is the embedding table and logical element
+  // (example b, column c) is table[(g_off[c / g_E] + g_ids[b * g_F + c / g_E]) * g_E + c % g_E] —
+  // the input_layer concat (deep_fm.py:54) read in place, never materialised.
+  const int32_t* g_ids; const int64_t* g_off; int g_F, g_E;
 };
 
 // Counter-based dropout mask, 32-bit arithmetic only (64-bit multiplies are 4x quarter-rate ops
@@ -137,6 +141,48 @@ __device__ __forceinline__ void mask_tile(int MN, int mn0, int k0, int kend, flo
   }
 }
 
+// ---- gathered A operand ------------------------------------------------------------------
+// Row numbers of one A tile (4 per thread, one per staging slot p), fetched ONE TILE AHEAD of the
+// row loads that use them so the id -> row dependent chain never sits in front of the MFMAs.
+// Out-of-range slots get row 0 (masked to zero later by mask_tile).
+template <int L>
+__device__ __forceinline__ void gather_rows_for_tile(const GemmArgs& a, int MN, int mn0, int k0, int kend,
+                                                     int (&row)[4], int t) {
+  if constexpr (L == KC) {           // forward: M = examples, K = concat columns
+    const int kk = k0 + (t & 7) * 4;
+    const bool k_ok = kk < kend;
+    const int f = k_ok ? kk / a.g_E : 0;
+    const int64_t off = a.g_off[f];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int m = mn0 + (t >> 3) + 32 * p;
+      const bool ok = k_ok && m < MN;
+      row[p] = static_cast<int>(off + a.g_ids[ok ? static_cast<int64_t>(m) * a.g_F + f : 0]);
+    }
+  } else {                           // weight gradient: M = concat columns, K = examples
+    const int mn = mn0 + (t & 31) * 4;
+    const bool m_ok = mn < MN;
+    const int f = m_ok ? mn / a.g_E : 0;
+    const int64_t off = a.g_off[f];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int b = k0 + (t >> 5) + 8 * p;
+      const bool ok = m_ok && b < kend;
+      row[p] = static_cast<int>(off + a.g_ids[ok ? static_cast<int64_t>(b) * a.g_F + f : 0]);
+    }
+  }
+}
+
+template <int L>
+__device__ __forceinline__ void load_tile_gathered(const GemmArgs& a, int mn0, int k0, const int (&row)[4],
+                                                   float4 (&r)[4], int t) {
+  const int c = (L == KC) ? k0 + (t & 7) * 4 : mn0 + (t & 31) * 4;   // concat column of this thread's float4
+  const int e = c % a.g_E;
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+    r[p] = *reinterpret_cast<const float4*>(a.A + static_cast<int64_t>(row[p]) * a.g_E + e);
+}
+
 template <int L>
 __device__ __forceinline__ void store_tile(float* __restrict__ S, const float4 (&r)[4], int t) {
 #pragma unroll
@@ -161,7 +207,7 @@ __device__ __forceinline__ void read_frag(const float* __restrict__ S, int mn, i
   }
 }
 
-template <int LA, int LB, bool VA, bool VB, bool COLSUM>
+template <int LA, int LB, bool VA, bool VB, bool COLSUM, bool GATHER>
 #ifndef GEMM_LB_WAVES
 #define GEMM_LB_WAVES 2
 #endif
@@ -202,8 +248,15 @@ __global__ __launch_bounds__(kThreads, GEMM_LB_WAVES) void gemm_f32_k(const Gemm
   // (t>>5)+8p.
   const bool do_colsum = COLSUM && a.colsum_part != nullptr && tm == 0;
   float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+  int grow[4] = {0, 0, 0, 0};        // GATHER: rows of the NEXT A tile to load
   if (nk > 0) {
-    load_tile<LA, VA>(a.A, a.lda, a.M, m0, kbeg, kend, ra, t);
+    if constexpr (GATHER) {
+      gather_rows_for_tile<LA>(a, a.M, m0, kbeg, kend, grow, t);
+      load_tile_gathered<LA>(a, m0, kbeg, grow, ra, t);
+      if (nk > 1) gather_rows_for_tile<LA>(a, a.M, m0, kbeg + BK, kend, grow, t);
+    } else {
+      load_tile<LA, VA>(a.A, a.lda, a.M, m0, kbeg, kend, ra, t);
+    }
     load_tile<LB, VB>(a.B, a.ldb, a.N, n0, kbeg, kend, rb, t);
     mask_tile<LA, VA>(a.M, m0, kbeg, kend, ra, t);
     mask_tile<LB, VB>(a.N, n0, kbeg, kend, rb, t);
@@ -229,7 +282,12 @@ __global__ __launch_bounds__(kThreads, GEMM_LB_WAVES) void gemm_f32_k(const Gemm
     const int cur = kt & 1;
     const bool more = kt + 1 < nk;
     if (more) {
-      load_tile<LA, VA>(a.A, a.lda, a.M, m0, kbeg + (kt + 1) * BK, kend, ra, t);
+      if constexpr (GATHER) {
+        load_tile_gathered<LA>(a, m0, kbeg + (kt + 1) * BK, grow, ra, t);
+        if (kt + 2 < nk) gather_rows_for_tile<LA>(a, a.M, m0, kbeg + (kt + 2) * BK, kend, grow, t);
+      } else {
+        load_tile<LA, VA>(a.A, a.lda, a.M, m0, kbeg + (kt + 1) * BK, kend, ra, t);
+      }
       load_tile<LB, VB>(a.B, a.ldb, a.N, n0, kbeg + (kt + 1) * BK, kend, rb, t);
     }
     const float* As = smem[cur][0];
@@ -383,7 +441,7 @@ bool vec_ok(const float* p, int64_t ld, int contiguous_extent) {
   return mi::aligned16(p) && (ld & 3) == 0 && (contiguous_extent & 3) == 0;
 }
 
-template <int LA, int LB, bool COLSUM = false>
+template <int LA, int LB, bool COLSUM = false, bool GATHER = false>
 int32_t launch(GemmArgs& a, int splits, hipStream_t st, const char* what) {
   a.tiles_m = (a.M + BM - 1) / BM;
   a.tiles_n = (a.N + BN - 1) / BN;
@@ -393,10 +451,15 @@ int32_t launch(GemmArgs& a, int splits, hipStream_t st, const char* what) {
     return MI_ERR_INVALID;
   }
   const dim3 g((unsigned)nblocks), b(kThreads);
-  if (a.vecA && a.vecB) gemm_f32_k<LA, LB, true, true, COLSUM><<<g, b, 0, st>>>(a);
-  else if (a.vecA) gemm_f32_k<LA, LB, true, false, COLSUM><<<g, b, 0, st>>>(a);
-  else if (a.vecB) gemm_f32_k<LA, LB, false, true, COLSUM><<<g, b, 0, st>>>(a);
-  else gemm_f32_k<LA, LB, false, false, COLSUM><<<g, b, 0, st>>>(a);
+  if constexpr (GATHER) {       // the gathered operand is always float4-addressable (E % 4 == 0)
+    if (a.vecB) gemm_f32_k<LA, LB, true, true, COLSUM, true><<<g, b, 0, st>>>(a);
+    else gemm_f32_k<LA, LB, true, false, COLSUM, true><<<g, b, 0, st>>>(a);
+  } else {
+    if (a.vecA && a.vecB) gemm_f32_k<LA, LB, true, true, COLSUM, false><<<g, b, 0, st>>>(a);
+    else if (a.vecA) gemm_f32_k<LA, LB, true, false, COLSUM, false><<<g, b, 0, st>>>(a);
+    else if (a.vecB) gemm_f32_k<LA, LB, false, true, COLSUM, false><<<g, b, 0, st>>>(a);
+    else gemm_f32_k<LA, LB, false, false, COLSUM, false><<<g, b, 0, st>>>(a);
+  }
   MI_CHECK_LAUNCH(what);
   return MI_OK;
 }
@@ -454,6 +517,32 @@ int32_t mi_dense_bwd_data(const float* dY, int64_t lddy, const float* W, const f
   return launch<KC, KC>(a, 1, mi::as_stream(stream), "dense_bwd_data");
 }
 
+static int32_t check_gather(const char* who, const float* table, const int64_t* field_off, const int32_t* ids,
+                            int32_t F, int32_t E) {
+  MI_REQUIRE(table && field_off && ids && F > 0, "%s: null gather operand", who);
+  MI_REQUIRE(E >= 4 && (E & 3) == 0 && mi::aligned16(table), "%s: embedding size %d must be a multiple of 4", who, E);
+  return MI_OK;
+}
+
+int32_t mi_dense_fwd_gathered(const float* table, const int64_t* field_off, const int32_t* ids, int32_t F,
+                              int32_t E, const float* W, const float* bias, float* Y, int64_t ldy, int64_t M,
+                              int32_t N, int32_t relu, float keep_prob, uint64_t seed, mi_stream_t stream) {
+  if (int32_t rc = check_gather("dense_fwd_gathered", table, field_off, ids, F, E)) return rc;
+  MI_REQUIRE(M >= 0 && M <= INT32_MAX && N > 0, "dense_fwd_gathered: M=%lld N=%d", (long long)M, N);
+  if (M == 0) return MI_OK;
+  MI_REQUIRE(W && Y && ldy >= N, "dense_fwd_gathered: null buffer / ldy");
+  MI_REQUIRE(keep_prob > 0.f && keep_prob <= 1.f, "dense_fwd_gathered: keep_prob=%f", keep_prob);
+  const int K = F * E;
+  GemmArgs a{};
+  a.A = table; a.lda = 0; a.B = W; a.ldb = N; a.C = Y; a.ldc = ldy;
+  a.M = (int)M; a.N = N; a.K = K; a.k_per_split = ((K + BK - 1) / BK) * BK;
+  a.vecA = 1; a.vecB = vec_ok(W, N, N);
+  a.epi = EPI_BIAS_ACT; a.bias = bias; a.relu = relu;
+  a.keep_prob = keep_prob; a.inv_keep = 1.f / keep_prob; a.seed = seed;
+  a.g_ids = ids; a.g_off = field_off; a.g_F = F; a.g_E = E;
+  return launch<KC, MC, false, true>(a, 1, mi::as_stream(stream), "dense_fwd_gathered");
+}
+
 size_t mi_colsum_workspace_bytes(int64_t M, int32_t N) {
   return static_cast<size_t>(mi::ceil_div(M > 0 ? M : 1, kColsumRows)) * N * sizeof(float);
 }
@@ -481,12 +570,33 @@ size_t mi_dense_bwd_weight_workspace_bytes(int64_t M, int32_t N, int32_t K) {
   return (static_cast<size_t>(splits) * K * N + static_cast<size_t>(splits) * N) * sizeof(float) + 256;
 }
 
+static int32_t bwd_weight_impl(const float* X, int64_t ldx, const float* dY, int64_t lddy, float* dW, float* db,
+                               int64_t M, int32_t N, int32_t K, void* workspace, size_t workspace_bytes,
+                               mi_stream_t stream, const int32_t* g_ids, const int64_t* g_off, int32_t g_F,
+                               int32_t g_E);
+
 int32_t mi_dense_bwd_weight(const float* X, int64_t ldx, const float* dY, int64_t lddy, float* dW,
                             float* db, int64_t M, int32_t N, int32_t K, void* workspace,
                             size_t workspace_bytes, mi_stream_t stream) {
+  MI_REQUIRE(X && ldx >= K, "dense_bwd_weight: X / ldx");
+  return bwd_weight_impl(X, ldx, dY, lddy, dW, db, M, N, K, workspace, workspace_bytes, stream, nullptr, nullptr, 0, 0);
+}
+
+int32_t mi_dense_bwd_weight_gathered(const float* table, const int64_t* field_off, const int32_t* ids, int32_t F,
+                                     int32_t E, const float* dY, int64_t lddy, float* dW, float* db, int64_t M,
+                                     int32_t N, void* workspace, size_t workspace_bytes, mi_stream_t stream) {
+  if (int32_t rc = check_gather("dense_bwd_weight_gathered", table, field_off, ids, F, E)) return rc;
+  return bwd_weight_impl(table, 0, dY, lddy, dW, db, M, N, F * E, workspace, workspace_bytes, stream, ids, field_off,
+                         F, E);
+}
+
+static int32_t bwd_weight_impl(const float* X, int64_t ldx, const float* dY, int64_t lddy, float* dW, float* db,
+                               int64_t M, int32_t N, int32_t K, void* workspace, size_t workspace_bytes,
+                               mi_stream_t stream, const int32_t* g_ids, const int64_t* g_off, int32_t g_F,
+                               int32_t g_E) {
   MI_REQUIRE(M > 0 && M <= INT32_MAX && N > 0 && K > 0, "dense_bwd_weight: M=%lld N=%d K=%d", (long long)M, N, K);
   MI_REQUIRE(X && dY && dW && workspace, "dense_bwd_weight: null buffer");
-  MI_REQUIRE(ldx >= K && lddy >= N, "dense_bwd_weight: leading dimensions");
+  MI_REQUIRE(lddy >= N, "dense_bwd_weight: leading dimensions");
   MI_REQUIRE(mi::aligned16(workspace), "dense_bwd_weight: workspace must be 16-byte aligned");
   if (workspace_bytes < mi_dense_bwd_weight_workspace_bytes(M, N, K)) {
     mi::set_error("dense_bwd_weight: workspace %zu < %zu", workspace_bytes,
@@ -504,7 +614,10 @@ int32_t mi_dense_bwd_weight(const float* X, int64_t ldx, const float* dY, int64_
   a.vecA = vec_ok(X, ldx, K); a.vecB = vec_ok(dY, lddy, N);
   a.C = slab; a.ldc = N; a.epi = EPI_SLAB; a.keep_prob = 1.f; a.inv_keep = 1.f;
   a.colsum_part = db ? cpart : nullptr;
-  if (int32_t rc = launch<MC, MC, true>(a, splits, st, "dense_bwd_weight(split-K)")) return rc;
+  if (g_ids) {
+    a.vecA = 1; a.g_ids = g_ids; a.g_off = g_off; a.g_F = g_F; a.g_E = g_E;
+    if (int32_t rc = launch<MC, MC, true, true>(a, splits, st, "dense_bwd_weight_gathered(split-K)")) return rc;
+  } else if (int32_t rc = launch<MC, MC, true>(a, splits, st, "dense_bwd_weight(split-K)")) return rc;
   slab_reduce_k<<<dim3((unsigned)mi::ceil_div(n, 64)), dim3(kThreads), 0, st>>>(slab, splits, n, dW);
   MI_CHECK_LAUNCH("dense_bwd_weight(reduce)");
   if (db) {

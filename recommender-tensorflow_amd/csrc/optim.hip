@@ -87,14 +87,23 @@ __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<floa
 
 // One group of LPR lanes per unique row; lane l owns elements 4l..4l+3; lane 0 also owns the
 // row's linear weight.  Duplicates are summed in ascending entry order.
-template <int LPR>
+// FUSED: the per-entry gradients are not read from d_rows / d_lin but rebuilt in place from what
+// the backward left behind (single-GPU path): entry e = (b, f) contributes
+//   d_concat[b, f*E:(f+1)*E] + dlf[b] * (sumv[b,:] - w)      (w = this row, still un-updated)
+// to the row and dll[b] to its linear weight — mi_embed_fm_linear_bwd folded into the apply, so the
+// [B*F, E] gradient matrix is never written or re-read.
+struct FusedGrad {
+  const float* d_concat; int64_t ldd; const float* sumv; const float* dlf; const float* dll; int F;
+};
+
+template <int LPR, bool FUSED>
 __global__ __launch_bounds__(kBlock) void sparse_apply_k(
     float* __restrict__ table, float* __restrict__ t0, float* __restrict__ t1,
     float* __restrict__ lin_w, float* __restrict__ l0, float* __restrict__ l1,
     int32_t* __restrict__ last_step, const int32_t* __restrict__ uniq_rows,
     const int32_t* __restrict__ seg_start, const int32_t* __restrict__ sorted_entry,
     const int32_t* __restrict__ num_uniq, const float* __restrict__ d_rows,
-    const float* __restrict__ d_lin, int E, int step, const Hp h) {
+    const float* __restrict__ d_lin, int E, int step, const Hp h, const FusedGrad fg) {
   const int64_t u = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) / LPR;
   const int l = threadIdx.x & (LPR - 1);
   if (u >= *num_uniq) return;
@@ -103,17 +112,35 @@ __global__ __launch_bounds__(kBlock) void sparse_apply_k(
   const bool lane_on = 4 * l < E;
   float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
   float gl = 0.f;
+  float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (table && lane_on) w = ld4(table + r * E + 4 * l);
   for (int k = s_beg; k < s_end; ++k) {
     const int64_t e = sorted_entry[k];
-    if (table && lane_on) {
-      const float4 v = ld4(d_rows + e * E + 4 * l);
-      g.x += v.x; g.y += v.y; g.z += v.z; g.w += v.w;
+    if constexpr (FUSED) {
+      const int64_t b = e / fg.F;
+      const int f = static_cast<int>(e - b * fg.F);
+      if (table && lane_on) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (fg.d_concat) v = ld4(fg.d_concat + b * fg.ldd + static_cast<int64_t>(f) * E + 4 * l);
+        if (fg.dlf) {
+          const float gf = fg.dlf[b];
+          const float4 sv = ld4(fg.sumv + b * E + 4 * l);
+          v.x += gf * (sv.x - w.x); v.y += gf * (sv.y - w.y);
+          v.z += gf * (sv.z - w.z); v.w += gf * (sv.w - w.w);
+        }
+        g.x += v.x; g.y += v.y; g.z += v.z; g.w += v.w;
+      }
+      if (lin_w && l == 0) gl += fg.dll[b];
+    } else {
+      if (table && lane_on) {
+        const float4 v = ld4(d_rows + e * E + 4 * l);
+        g.x += v.x; g.y += v.y; g.z += v.z; g.w += v.w;
+      }
+      if (lin_w && l == 0) gl += d_lin[e];
     }
-    if (lin_w && l == 0) gl += d_lin[e];
   }
   if (table && lane_on) {
     const int64_t o = r * E + 4 * l;
-    float4 w = ld4(table + o);
     float4 a = t0 ? ld4(t0 + o) : make_float4(0.f, 0.f, 0.f, 0.f);
     float4 b = t1 ? ld4(t1 + o) : make_float4(0.f, 0.f, 0.f, 0.f);
     sparse_rule(h, w.x, a.x, b.x, g.x);
@@ -253,10 +280,44 @@ int32_t mi_sparse_apply(float* table, float* t_slot0, float* t_slot1, float* lin
   const int64_t blocks = mi::ceil_div(n_max * lpr, kBlock);
   MI_REQUIRE(blocks <= INT32_MAX, "sparse_apply: grid too large");
   const Hp h = make_hp(hp);
-  MI_DISPATCH_LPR(lpr, (sparse_apply_k<L><<<dim3((unsigned)blocks), dim3(kBlock), 0, mi::as_stream(stream)>>>(
+  MI_DISPATCH_LPR(lpr, (sparse_apply_k<L, false><<<dim3((unsigned)blocks), dim3(kBlock), 0, mi::as_stream(stream)>>>(
                            table, t_slot0, t_slot1, lin_w, l_slot0, l_slot1, last_step, uniq_rows, seg_start,
-                           sorted_entry, num_uniq, d_rows, d_lin, E, step, h)));
+                           sorted_entry, num_uniq, d_rows, d_lin, E, step, h, FusedGrad{})));
   MI_CHECK_LAUNCH("sparse_apply");
+  return MI_OK;
+}
+
+int32_t mi_sparse_apply_fused(float* table, float* t_slot0, float* t_slot1, float* lin_w, float* l_slot0,
+                              float* l_slot1, int32_t* last_step, const int32_t* uniq_rows,
+                              const int32_t* seg_start, const int32_t* sorted_entry, const int32_t* num_uniq,
+                              int64_t n_max, const float* d_concat, int64_t ld_dconcat, const float* sumv,
+                              const float* d_logit_fm, const float* d_logit_lin, int32_t F, int32_t E,
+                              int32_t step, const mi_opt_hparams* hp, mi_stream_t stream) {
+  if (int32_t rc = check_hp("sparse_apply_fused", hp)) return rc;
+  MI_REQUIRE(n_max >= 0 && F > 0, "sparse_apply_fused: n_max=%lld F=%d", (long long)n_max, F);
+  if (n_max == 0) return MI_OK;
+  MI_REQUIRE(table || lin_w, "sparse_apply_fused: nothing to update");
+  MI_REQUIRE(uniq_rows && seg_start && sorted_entry && num_uniq, "sparse_apply_fused: null index buffer");
+  MI_REQUIRE(!table || (E >= 4 && E <= 256 && (E & 3) == 0 && mi::aligned16(table)),
+             "sparse_apply_fused: E multiple of 4 in [4,256], 16-byte alignment");
+  MI_REQUIRE(!table || d_concat || d_logit_fm, "sparse_apply_fused: table update needs d_concat and/or d_logit_fm");
+  MI_REQUIRE(!d_concat || (ld_dconcat >= (int64_t)F * E && (ld_dconcat & 3) == 0 && mi::aligned16(d_concat)),
+             "sparse_apply_fused: d_concat leading dimension / alignment");
+  MI_REQUIRE(!d_logit_fm || (sumv && mi::aligned16(sumv)), "sparse_apply_fused: FM gradient needs sumv");
+  MI_REQUIRE(!lin_w || d_logit_lin, "sparse_apply_fused: lin_w needs d_logit_lin");
+  const bool need0 = hp->kind != MI_OPT_SGD;
+  const bool need1 = hp->kind == MI_OPT_ADAM || hp->kind == MI_OPT_FTRL || hp->kind == MI_OPT_RMSPROP;
+  MI_REQUIRE(!table || ((!need0 || t_slot0) && (!need1 || t_slot1)), "sparse_apply_fused: table slots missing");
+  MI_REQUIRE(!lin_w || ((!need0 || l_slot0) && (!need1 || l_slot1)), "sparse_apply_fused: linear slots missing");
+  const int lpr = table ? lanes_per_row(E) : 1;
+  const int64_t blocks = mi::ceil_div(n_max * lpr, kBlock);
+  MI_REQUIRE(blocks <= INT32_MAX, "sparse_apply_fused: grid too large");
+  const Hp h = make_hp(hp);
+  const FusedGrad fg{d_concat, ld_dconcat, sumv, d_logit_fm, d_logit_lin, F};
+  MI_DISPATCH_LPR(lpr, (sparse_apply_k<L, true><<<dim3((unsigned)blocks), dim3(kBlock), 0, mi::as_stream(stream)>>>(
+                           table, t_slot0, t_slot1, lin_w, l_slot0, l_slot1, last_step, uniq_rows, seg_start,
+                           sorted_entry, num_uniq, nullptr, nullptr, E, step, h, fg)));
+  MI_CHECK_LAUNCH("sparse_apply_fused");
   return MI_OK;
 }
 

@@ -16,7 +16,7 @@ import torch  # noqa: F401  (loads the HIP runtime this library must share)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmi355x_rec.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class MiError(RuntimeError):
@@ -58,6 +58,10 @@ SIGNATURES = {
     "mi_dense_apply": (_i32, [_p, _p, _p, _p, _i64, C.POINTER(OptHparams), _p]),
     "mi_sparse_apply": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _p, _i32, _i32,
                                C.POINTER(OptHparams), _p]),
+    "mi_sparse_apply_fused": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _i64, _p, _p, _p, _i32,
+                                     _i32, _i32, C.POINTER(OptHparams), _p]),
+    "mi_dense_fwd_gathered": (_i32, [_p, _p, _p, _i32, _i32, _p, _p, _p, _i64, _i64, _i32, _i32, _f32, _u64, _p]),
+    "mi_dense_bwd_weight_gathered": (_i32, [_p, _p, _p, _i32, _i32, _p, _i64, _p, _p, _i64, _i32, _p, _sz, _p]),
     "mi_sparse_catchup": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p, _f32, _f32,
                                  _f32, _p]),
     "mi_dense_fwd": (_i32, [_p, _i64, _p, _p, _p, _i64, _i64, _i32, _i32, _i32, _f32, _u64, _p]),

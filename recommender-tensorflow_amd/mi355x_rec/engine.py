@@ -235,6 +235,9 @@ class DeepFM:
             self.dl_s0, self.dl_s1 = self._slots(self.dense, self.lin_opt)
         self._ws = {}
         self._final_step = 0
+        # Single GPU without numeric columns: layer 1 of the MLP reads its input straight from the
+        # embedding table (gathered GEMM operand) and the concat [B, F*E] is never materialised.
+        self.gather_mlp = self.use_dnn and self.n_numeric == 0 and self.shard is None
 
     # ------------------------------------------------------------------ variables
     def _slots(self, like, spec):
@@ -352,13 +355,15 @@ class DeepFM:
         table, lin_w, field_off, rid = src if src is not None else (self.table, self.lin_w, self.field_off, ids)
         concat = sumv = fm = None
         ld = self.D
+        gathered = self.gather_mlp and src is None
         if self.use_emb:
-            concat = self._buf("concat", (B, ld))
+            concat = None if gathered else self._buf("concat", (B, ld))
             sumv = self._buf("sumv", (B, self.E)) if self.use_mf else None
             fm = self._buf("fm", (B,)) if self.use_mf else None
         lin = self._buf("lin", (B,)) if self.use_linear else None
-        k.mi_embed_fm_linear_fwd(table if self.use_emb else None, lin_w if self.use_linear else None, field_off, rid,
-                                 B, self.F, self.E, concat, ld, sumv, fm, lin)
+        if concat is not None or sumv is not None or lin is not None:
+            k.mi_embed_fm_linear_fwd(table if self.use_emb else None, lin_w if self.use_linear else None, field_off,
+                                     rid, B, self.F, self.E, concat, ld, sumv, fm, lin)
         if self.n_numeric:
             V = self._seg(self.dense, self.num_emb_off, (self.n_numeric, self.E))
             wn = self._seg(self.dense, self.lin_num_off, (self.n_numeric,)) if self.use_linear else None
@@ -372,13 +377,18 @@ class DeepFM:
             for i, (_, _, fan, h) in enumerate(self.layers):
                 last = i == nh
                 y = self._buf("act%d" % i, (B, h))
-                k.mi_dense_fwd(x, ldx, self.kernel(i), self.bias(i), y, h, B, h, fan, 0 if last else 1,
-                               1.0 if last else keep, self._layer_seed(i))
+                if i == 0 and gathered:
+                    k.mi_dense_fwd_gathered(table, field_off, rid, self.F, self.E, self.kernel(0), self.bias(0), y, h,
+                                            B, h, 0 if last else 1, 1.0 if last else keep, self._layer_seed(0))
+                else:
+                    k.mi_dense_fwd(x, ldx, self.kernel(i), self.bias(i), y, h, B, h, fan, 0 if last else 1,
+                                   1.0 if last else keep, self._layer_seed(i))
                 acts.append(y)
                 x, ldx = y, h
             dnn = acts[-1].view(B)
             c["keep"] = keep
-        c.update(concat=concat, sumv=sumv, fm=fm, lin=lin, dnn=dnn, acts=acts, x_num=x_num)
+        c.update(concat=concat, sumv=sumv, fm=fm, lin=lin, dnn=dnn, acts=acts, x_num=x_num, ids=rid,
+                 gathered=gathered)
         return c
 
     def _head(self, c, labels, want_grad, global_batch=None):
@@ -481,9 +491,9 @@ class DeepFM:
         logits, loss, dlogit = self._head(c, labels, True)
         # (4) backward through the MLP (+ numeric embeddings)
         d_concat = self._backward_dense(c, dlogit)
-        # (5) per-entry row gradients, then the sparse apply on unique rows
-        d_rows, d_lin = self._entry_grads(c, d_concat, dlogit, None)
-        self._apply(uniq, seg, sorted_entry, num_uniq, n, d_rows, d_lin)
+        # (5) sparse apply on the unique rows; the per-entry row gradients (deep_fm.py:54,81-87,39
+        #     backward) are rebuilt inside the kernel from d_concat / sumv / dlogit
+        self._apply(uniq, seg, sorted_entry, num_uniq, n, None, None, fused=(d_concat, c["sumv"], dlogit))
         return loss, logits
 
     def _entry_grads(self, c, d_concat, dlogit, pos):
@@ -511,8 +521,13 @@ class DeepFM:
                 _, _, fan, h = self.layers[i]
                 x = c["acts"][i - 1] if i else c["concat"]
                 ldx = self.layers[i - 1][3] if i else self.D
-                k.mi_dense_bwd_weight(x, ldx, dy, lddy, self.kernel(i, self.d_grad), self.bias(i, self.d_grad), B, h,
-                                      fan, ws, ws.numel())
+                if i == 0 and c["gathered"]:
+                    k.mi_dense_bwd_weight_gathered(self.table, self.field_off, c["ids"], self.F, self.E, dy, lddy,
+                                                   self.kernel(0, self.d_grad), self.bias(0, self.d_grad), B, h, ws,
+                                                   ws.numel())
+                else:
+                    k.mi_dense_bwd_weight(x, ldx, dy, lddy, self.kernel(i, self.d_grad), self.bias(i, self.d_grad), B,
+                                          h, fan, ws, ws.numel())
                 dx = self._buf("dact%d" % i, (B, fan))
                 k.mi_dense_bwd_data(dy, lddy, self.kernel(i), x if i else None, ldx, dx, fan, B, h, fan,
                                     keep if i else 1.0)
@@ -526,8 +541,9 @@ class DeepFM:
                                    self.d_grad[self.lin_num_off:] if self.use_linear else None, ws, ws.numel())
         return d_concat
 
-    def _apply(self, uniq, seg, sorted_entry, num_uniq, n_max, d_rows, d_lin):
-        """apply_gradients: dense Apply*, sparse apply on the unique rows, step += 1."""
+    def _apply(self, uniq, seg, sorted_entry, num_uniq, n_max, d_rows, d_lin, fused=None):
+        """apply_gradients: dense Apply*, sparse apply on the unique rows, step += 1.
+        fused = (d_concat, sumv, dlogit): single-GPU form, entry gradients rebuilt in the kernel."""
         k = self.k
         step = self.step + 1
         lr_t = self.sched.lr_t(step) if self.sched else 0.0
@@ -550,11 +566,19 @@ class DeepFM:
                 lw = self.lin_w if (do_lin and self.use_linear) else None
                 if tb is None and lw is None:
                     continue
-                k.mi_sparse_apply(tb, self.t_s0 if tb is not None else None, self.t_s1 if tb is not None else None,
-                                  lw, self.l_s0 if lw is not None else None, self.l_s1 if lw is not None else None,
-                                  self.last_step, uniq, seg, sorted_entry, num_uniq, n_max,
-                                  d_rows if tb is not None else None, d_lin if lw is not None else None, self.E,
-                                  step, h)
+                slots = (tb, self.t_s0 if tb is not None else None, self.t_s1 if tb is not None else None,
+                         lw, self.l_s0 if lw is not None else None, self.l_s1 if lw is not None else None)
+                if fused is not None:
+                    d_concat, sumv, dlogit = fused
+                    k.mi_sparse_apply_fused(*slots, self.last_step, uniq, seg, sorted_entry, num_uniq, n_max,
+                                            d_concat if tb is not None else None, self.D,
+                                            sumv if (tb is not None and self.use_mf) else None,
+                                            dlogit if (tb is not None and self.use_mf) else None,
+                                            dlogit if lw is not None else None, self.F, self.E, step, h)
+                else:
+                    k.mi_sparse_apply(*slots, self.last_step, uniq, seg, sorted_entry, num_uniq, n_max,
+                                      d_rows if tb is not None else None, d_lin if lw is not None else None, self.E,
+                                      step, h)
         self.step = step
 
     # ------------------------------------------------------------------ checkpoint

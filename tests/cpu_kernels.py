@@ -63,7 +63,8 @@ class NumpyKernels:
         rows = _np(ids).astype(np.int64) + _np(field_off)[None, :]
         if table is not None:
             v = _np(table)[rows]                               # [B,F,E]
-            _np(concat)[:, :F * E] = v.reshape(B, F * E)
+            if concat is not None:
+                _np(concat)[:, :F * E] = v.reshape(B, F * E)
             s = v.sum(1)
             if sumv is not None:
                 _np(sumv)[:] = s
@@ -219,6 +220,43 @@ class NumpyKernels:
                 Bm[rows] = bv
         if last_step is not None:
             _np(last_step)[rows] = step
+
+    # ---- gathered / fused single-GPU forms --------------------------------------------------------
+    def _concat(self, table, field_off, ids, F, E):
+        rows = _np(ids).astype(np.int64) + _np(field_off)[None, :]
+        return _np(table)[rows].reshape(len(rows), F * E)
+
+    def mi_dense_fwd_gathered(self, table, field_off, ids, F, E, W, bias, Y, ldy, M, N, relu, keep, seed):
+        X = torch.from_numpy(self._concat(table, field_off, ids, F, E))
+        self.mi_dense_fwd(X, F * E, W, bias, Y, ldy, M, N, F * E, relu, keep, seed)
+
+    def mi_dense_bwd_weight_gathered(self, table, field_off, ids, F, E, dY, lddy, dW, db, M, N, ws, wsb):
+        X = torch.from_numpy(self._concat(table, field_off, ids, F, E))
+        self.mi_dense_bwd_weight(X, F * E, dY, lddy, dW, db, M, N, F * E, ws, wsb)
+
+    def mi_sparse_apply_fused(self, table, t0, t1, lin_w, l0, l1, last_step, uniq, seg, sorted_entry, num_uniq,
+                              n_max, d_concat, ldd, sumv, dlf, dll, F, E, step, hp):
+        n = int(_np(seg)[int(_np(num_uniq)[0])])
+        e = np.arange(n)
+        b, f = e // F, e % F
+        d_rows = d_lin = None
+        if table is not None:
+            g = np.zeros((n, E), np.float32)
+            if d_concat is not None:
+                g += _np(d_concat)[:, :F * E].reshape(-1, F, E)[b, f]
+            if dlf is not None:
+                # w = the row as it is before this update
+                U = int(_np(num_uniq)[0])
+                row_of = np.empty(n, np.int64)
+                sg, se = _np(seg), _np(sorted_entry)
+                for u in range(U):
+                    row_of[se[sg[u]:sg[u + 1]]] = _np(uniq)[u]
+                g += _np(dlf)[b][:, None] * (_np(sumv)[b] - _np(table)[row_of])
+            d_rows = torch.from_numpy(g)
+        if lin_w is not None:
+            d_lin = torch.from_numpy(_np(dll)[b].astype(np.float32))
+        self.mi_sparse_apply(table, t0, t1, lin_w, l0, l1, last_step, uniq, seg, sorted_entry, num_uniq, n_max,
+                             d_rows, d_lin, E, step, hp)
 
     # ---- eval counters --------------------------------------------------------------------------
     def mi_eval_accumulate(self, logits, labels, B, hist, counts, sums):

@@ -195,6 +195,86 @@ def test_dense_bwd_data_and_weight(lib, M, N, K):
     assert torch.equal(dW, dW2)
 
 
+@pytest.mark.parametrize("B,F,E,N", [(300, 26, 64, 512), (33, 26, 4, 16), (129, 5, 12, 40), (4096, 3, 128, 64)])
+def test_gathered_layer1_matches_materialised_bitwise(lib, B, F, E, N):
+    """mi_dense_fwd_gathered / mi_dense_bwd_weight_gathered read the concat in place from the table:
+    same tiles, same MFMA order as the materialised operand => identical bits."""
+    rng = np.random.default_rng(B + F + E)
+    vocab = rng.integers(2, 60, F)
+    off = np.concatenate([[0], np.cumsum(vocab)]).astype(np.int64)
+    table = rng.standard_normal((int(off[-1]), E)).astype(np.float32)
+    ids = np.stack([rng.integers(0, v, B) for v in vocab], 1).astype(np.int32)
+    K = F * E
+    W = (rng.standard_normal((K, N)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    dY = rng.standard_normal((B, N)).astype(np.float32)
+    t, fo, di, w, bb, dy = dev(table), dev(off[:-1].copy()), dev(ids), dev(W), dev(b), dev(dY)
+    concat = torch.empty(B, K, device="cuda")
+    _chk(lib.mi_embed_fm_linear_fwd(_p(t), None, _p(fo), _p(di), B, F, E, _p(concat), K, None, None, None, _st()))
+    Y0 = torch.empty(B, N, device="cuda"); Y1 = torch.empty(B, N, device="cuda")
+    _chk(lib.mi_dense_fwd(_p(concat), K, _p(w), _p(bb), _p(Y0), N, B, N, K, 1, 0.9, 77, _st()))
+    _chk(lib.mi_dense_fwd_gathered(_p(t), _p(fo), _p(di), F, E, _p(w), _p(bb), _p(Y1), N, B, N, 1, 0.9, 77, _st()))
+    assert torch.equal(Y0, Y1)
+    ws = torch.empty(lib.mi_dense_bwd_weight_workspace_bytes(B, N, K) + 256, dtype=torch.uint8, device="cuda")
+    dW0 = torch.empty(K, N, device="cuda"); dW1 = torch.empty(K, N, device="cuda")
+    db0 = torch.empty(N, device="cuda"); db1 = torch.empty(N, device="cuda")
+    _chk(lib.mi_dense_bwd_weight(_p(concat), K, _p(dy), N, _p(dW0), _p(db0), B, N, K, _p(ws), ws.numel(), _st()))
+    _chk(lib.mi_dense_bwd_weight_gathered(_p(t), _p(fo), _p(di), F, E, _p(dy), N, _p(dW1), _p(db1), B, N, _p(ws),
+                                          ws.numel(), _st()))
+    assert torch.equal(dW0, dW1) and torch.equal(db0, db1)
+    ref = table[off[:-1][None, :] + ids].reshape(B, K).astype(np.float64).T @ dY.astype(np.float64)
+    assert np.max(np.abs(dW1.cpu().numpy() - ref)) / (np.sqrt(np.mean(ref * ref)) + 1e-30) < TOL
+
+
+@pytest.mark.parametrize("name", ["Adam", "Ftrl"])
+def test_sparse_apply_fused_equals_bwd_then_apply_bitwise(lib, name):
+    """mi_sparse_apply_fused == mi_embed_fm_linear_bwd followed by mi_sparse_apply, bit for bit."""
+    from mi355x_rec.engine import OptimizerSpec
+    rng = np.random.default_rng(4)
+    B, F, E = 200, 6, 16
+    vocab = rng.integers(2, 15, F)                       # small vocab: many duplicates
+    off = np.concatenate([[0], np.cumsum(vocab)]).astype(np.int64)
+    R = int(off[-1])
+    ids = np.stack([rng.integers(0, v, B) for v in vocab], 1).astype(np.int32)
+    rows = (off[:-1][None, :] + ids).reshape(-1).astype(np.int32)
+    table = rng.standard_normal((R, E)).astype(np.float32)
+    lin_w = rng.standard_normal(R).astype(np.float32)
+    cc = table[rows].reshape(B, F * E)
+    sv = cc.reshape(B, F, E).sum(1).astype(np.float32)
+    dc = rng.standard_normal((B, F * E)).astype(np.float32)
+    dl = rng.standard_normal(B).astype(np.float32)
+    n = B * F
+    r = dev(rows)
+    se = torch.empty(n, dtype=torch.int32, device="cuda"); uq = torch.empty(n, dtype=torch.int32, device="cuda")
+    sg = torch.empty(n + 1, dtype=torch.int32, device="cuda"); nu = torch.empty(1, dtype=torch.int32, device="cuda")
+    wsb = torch.empty(lib.mi_sort_unique_workspace_bytes(n) + 256, dtype=torch.uint8, device="cuda")
+    _chk(lib.mi_sort_unique_rows(_p(r), n, R, _p(se), _p(uq), _p(sg), _p(nu), _p(wsb), wsb.numel(), _st()))
+    spec = OptimizerSpec(name, 0.01)
+    h = spec.hparams(0.00316)
+    a, b = spec.slot_init
+    res = []
+    d_dc, d_cc, d_sv, d_dl = dev(dc), dev(cc), dev(sv), dev(dl)
+    for fused in (False, True):
+        T, L = dev(table), dev(lin_w)
+        t0, t1 = torch.full_like(T, a), torch.full_like(T, b)
+        l0, l1 = torch.full_like(L, a), torch.full_like(L, b)
+        if fused:
+            _chk(lib.mi_sparse_apply_fused(_p(T), _p(t0), _p(t1), _p(L), _p(l0), _p(l1), None, _p(uq), _p(sg), _p(se),
+                                           _p(nu), n, _p(d_dc), F * E, _p(d_sv), _p(d_dl), _p(d_dl), F, E, 1,
+                                           C.byref(h), _st()))
+        else:
+            d_rows = torch.empty(n, E, device="cuda"); d_lin = torch.empty(n, device="cuda")
+            _chk(lib.mi_embed_fm_linear_bwd(_p(d_dc), F * E, _p(d_cc), F * E, _p(d_sv), _p(d_dl), _p(d_dl), None, B, F,
+                                            E, _p(d_rows), _p(d_lin), _st()))
+            _chk(lib.mi_sparse_apply(_p(T), _p(t0), _p(t1), _p(L), _p(l0), _p(l1), None, _p(uq), _p(sg), _p(se),
+                                     _p(nu), n, _p(d_rows), _p(d_lin), E, 1, C.byref(h), _st()))
+        torch.cuda.synchronize()
+        res.append((T.cpu(), L.cpu(), t0.cpu(), t1.cpu()))
+    for x, y in zip(*res):
+        assert torch.equal(x, y)
+    assert not torch.equal(res[0][0], torch.from_numpy(table))
+
+
 @pytest.mark.parametrize("B", [1, 37, 5000])
 def test_sigmoid_ce_head(lib, B):
     rng = np.random.default_rng(B)

@@ -166,10 +166,16 @@ def test_full_size_properties():
     table0 = m.table.clone()
     loss0, logits0 = m.loss(ids, y)
     l0 = loss0.item()
-    concat = m._ws["concat"][:B * F * E].view(B, F, E)
     rows = (ids.long() + m.field_off[None, :])
     sel = torch.arange(0, B, 997, device="cuda")
+    # the materialising form of the gather kernel is an exact copy of the addressed rows
+    concat = torch.empty(B, F * E, device="cuda")
+    m.k.mi_embed_fm_linear_fwd(m.table, None, m.field_off, ids, B, F, E, concat, F * E, None, None, None)
+    concat = concat.view(B, F, E)
     assert torch.equal(concat[sel], m.table[rows[sel]])
+    assert "concat" not in m._ws          # the training path never materialises it (gathered layer-1 operand)
+    sumv = m._ws["sumv"][:B * E].view(B, E)
+    assert float((sumv[sel].double() - concat[sel].double().sum(1)).abs().max()) < 1e-5
     v = concat[sel].double()
     pair = 0.5 * ((v.sum(1) ** 2).sum(1) - (v * v).sum((1, 2)))
     fm = m._ws["fm"][:B][sel].double()

@@ -24,7 +24,7 @@ def _write_csv(path, n, seed):
             uid, iid = int(rng.integers(1, 944)), int(rng.integers(1, 1683))
             g = rng.integers(0, 2, len(ml_100k.GENRE))
             # a learnable rule so that training visibly reduces the loss
-            like = (uid % 3 == 0) ^ (g[1] == 1)
+            like = (g[1] == 1) if rng.random() < 0.9 else (g[1] == 0)
             row.update(user_id=uid, item_id=iid, rating=5 if like else int(rng.integers(1, 5)),
                        age=int(rng.integers(7, 74)), gender=str(rng.choice(["F", "M", ""])),
                        occupation=str(rng.choice(occ)), zipcode="%05d" % rng.integers(0, 99999),
