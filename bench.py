@@ -164,12 +164,18 @@ def main():
         ms_step = dt / args.steps * 1e3
         g_ms = km["mi_embed_fm_linear_fwd"][0]
         gather_bytes = B * F * 4 * E                     # algorithmic row bytes per launch
-        total_bytes = B * (F * (4 * E + 8) + 4 * F * E + 4 * E + 8)   # + ids, lin weights, concat/sumv/fm/lin writes
+        total_bytes = B * (F * (4 * E + 8) + 4 * E + 8)   # rows + ids + linear weights read; sumv / fm / lin written
         achieved = gather_bytes / (g_ms * 1e-3) / 1e9
         gemm_ms = sum(v[2] for k, v in km.items() if k in ("mi_dense_fwd", "mi_dense_fwd_gathered", "mi_dense_bwd_data", "mi_dense_bwd_weight",
                                                         "mi_dense_bwd_weight_gathered")) / args.steps
         dims = [F * E] + HIDDEN + [1]
         flops = 3 * 2 * B * sum(a * b for a, b in zip(dims[:-1], dims[1:]))
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+                traffic = json.load(f)["embed_fm_linear_fwd_k"]["bytes_per_launch"] if world == 1 else None
+        except (OSError, KeyError, ValueError):
+            pass
         out = {
             "metric": "examples/sec DeepFM batch=65536 (full train step)",
             "value": world * B * args.steps / dt,
@@ -186,11 +192,14 @@ def main():
                        "per_gpu_batch": B, "global_batch": world * B, "fields": F, "vocab_per_field": V,
                        "embedding_size": E, "hidden_units": HIDDEN,
                        "parallelism": "dp%d + row-sharded embeddings (all-to-all)" % world if world > 1 else "single GPU"},
-            "roofline": {"kernel": "embed_fm_linear_fwd_k (embedding gather + FM + wide linear)", "bound": "hbm",
+            "roofline": {"kernel": "embed_fm_linear_fwd_k (embedding gather + FM + wide linear; read-only form, the "
+                                   "MLP gathers its own operand)", "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "frac_of_measured_copy_peak": achieved / HBM_MEASURED_GBS,
                          "algorithmic_bytes_per_launch": gather_bytes, "avg_launch_ms": g_ms,
-                         "achieved_total_rw_GBs": total_bytes / (g_ms * 1e-3) / 1e9, "traffic": None},
+                         "achieved_total_rw_GBs": total_bytes / (g_ms * 1e-3) / 1e9, "traffic": traffic,
+                         "traffic_note": "HBM bytes/launch from rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE), "
+                                         "profiles/r01_pmc_hbm_traffic.md"},
             "roofline_mlp": {"kernel": "gemm_f32_k (all dense fwd/bwd GEMMs)", "bound": "mfma",
                              "achieved": flops / (gemm_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS,
                              "unit": "TFLOP/s", "frac": flops / (gemm_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
