@@ -40,7 +40,7 @@ enum mi_status {
 };
 
 /* ---- library ---------------------------------------------------------------------------- */
-int32_t mi_abi_version(void);       /* bumps when a signature changes (currently 3) */
+int32_t mi_abi_version(void);       /* bumps when a signature changes (currently 5) */
 const char* mi_last_error(void);    /* thread-local, never NULL */
 const char* mi_build_info(void);    /* "gfx950 hipcc <ver>" */
 
@@ -219,6 +219,16 @@ int32_t mi_sparse_catchup(float* table, float* t_m, float* t_v, float* lin_w, fl
 /* ---- (a6) the [hidden_units] MLP: fp32-input MFMA GEMMs with fused epilogues ------------------
  * replaces tf.layers.dense / tf.layers.dropout (deep_fm.py:98-108).  Row-major everywhere.
  * v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate (needed for the 1e-5 logit bar). */
+
+/* Matrix-pipe path of the GEMMs below (process-wide switch):
+ *   1 (default) "bf16x3": every fp32 operand is split exactly into three bf16 terms and the six
+ *      leading partial products run on v_mfma_f32_32x32x16_bf16 with fp32 accumulation — fp32-level
+ *      error (dropped terms <= 3*2^-24 |ab| per product; measured equal to the fp32-input MFMA
+ *      against fp64) at 2.7x its matrix throughput;
+ *   0 "fp32": v_mfma_f32_32x32x2_f32 (exact fp32 products).
+ * Operands that cannot be read as float4 (e.g. the N = 1 logits layer) always take path 0. */
+int32_t mi_set_gemm_mode(int32_t mode);
+int32_t mi_get_gemm_mode(void);
 
 /* Y[M,N] = act( X[M,K] * W[K,N] + bias[N] ), act = relu if relu != 0.  If keep_prob < 1 the
  * TRAIN-mode dropout of deep_fm.py:102-103 is applied after the activation with a counter-based

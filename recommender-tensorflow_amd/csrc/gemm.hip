@@ -47,21 +47,19 @@ struct GemmArgs {
   const int32_t* g_ids; const int64_t* g_off; int g_F, g_E;
 };
 
-// Counter-based dropout mask, 32-bit arithmetic only (64-bit multiplies are 4x quarter-rate ops
-// on CDNA and cost 10 % of the layer-1 forward): two rounds of a multiply-xorshift mixer over
-// (element index, seed).  keep element idx iff top 24 bits < keep_prob * 2^24.  tests/util.py
-// replays it on the host.
+// Counter-based dropout mask in 32-bit arithmetic only (64-bit multiplies are several quarter-rate
+// ops on CDNA; the first version cost 10 % of the layer-1 forward): one multiply-xorshift mixer over
+// (row, col, seed).  Element (row, col) of a layer's output is kept iff the top 24 bits of the hash
+// are below keep_prob * 2^24.  tests/util.py replays it on the host.
 __device__ __forceinline__ uint32_t mix32(uint32_t x) {
   x ^= x >> 16; x *= 0x7feb352dU;
   x ^= x >> 15; x *= 0x846ca68bU;
   x ^= x >> 16;
   return x;
 }
-__device__ __forceinline__ bool dropout_keep(uint64_t seed, uint64_t idx, uint32_t thresh) {
-  const uint32_t lo = static_cast<uint32_t>(idx), hi = static_cast<uint32_t>(idx >> 32);
-  uint32_t h = mix32(lo ^ static_cast<uint32_t>(seed));
-  h = mix32(h ^ (hi * 0x9E3779B1U) ^ static_cast<uint32_t>(seed >> 32));
-  return (h >> 8) < thresh;
+__device__ __forceinline__ bool dropout_keep(uint64_t seed, uint32_t row, uint32_t col, uint32_t thresh) {
+  const uint32_t s = static_cast<uint32_t>(seed) ^ (static_cast<uint32_t>(seed >> 32) * 0xC2B2AE35U);
+  return (mix32((row * 0x9E3779B1U) ^ (col * 0x85EBCA77U) ^ s) >> 8) < thresh;
 }
 
 // Stage one operand tile HBM -> registers.  Branch-free and consumer-free on purpose: an
@@ -204,6 +202,42 @@ __device__ __forceinline__ void read_frag(const float* __restrict__ S, int mn, i
   } else {
 #pragma unroll
     for (int j = 0; j < 4; ++j) f[j] = S[(8 * s + 4 * h + j) * BM + mn];
+  }
+}
+
+// ---- epilogue shared by the fp32-MFMA and the bf16x3-split kernels --------------------------
+// C/D register map of every 32x32 MFMA (dtype independent): col = lane&31,
+// row = (r&3) + 8*(r>>2) + 4*(lane>>5).  i = lane&31, h = lane>>5.
+__device__ __forceinline__ void store_tile_c(const GemmArgs& a, const f32x16 (&acc)[2][2], int m0, int n0, int wm,
+                                             int wn, int i, int h, int split) {
+  float* Cb = a.C;
+  if (a.epi == EPI_SLAB) Cb += static_cast<int64_t>(split) * a.M * a.ldc;
+  const uint32_t thresh = static_cast<uint32_t>(a.keep_prob * 16777216.0f);
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const int col = n0 + wn * 64 + ni * 32 + i;
+    if (col >= a.N) continue;
+    const float bv = (a.epi == EPI_BIAS_ACT && a.bias) ? a.bias[col] : 0.f;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row >= a.M) continue;
+        float v = acc[mi][ni][r];
+        if (a.epi == EPI_BIAS_ACT) {
+          v += bv;
+          if (a.relu) v = fmaxf(v, 0.f);
+          if (a.keep_prob < 1.f) v = dropout_keep(a.seed, row, col, thresh) ? v * a.inv_keep : 0.f;
+        } else if (a.epi == EPI_MASK) {
+          if (a.mask_src) {
+            const float x = a.mask_src[static_cast<int64_t>(row) * a.ldm + col];
+            v = (x > 0.f) ? v * a.inv_keep : 0.f;
+          }
+        }
+        Cb[static_cast<int64_t>(row) * a.ldc + col] = v;
+      }
+    }
   }
 }
 
@@ -358,40 +392,13 @@ __global__ __launch_bounds__(kThreads, GEMM_LB_WAVES) void gemm_f32_k(const Gemm
     }
   }
 
-  // ---- epilogue: C/D map of v_mfma_f32_32x32x2: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-  float* Cb = a.C;
-  if (a.epi == EPI_SLAB) Cb += static_cast<int64_t>(split) * a.M * a.ldc;
-  const uint32_t thresh = static_cast<uint32_t>(a.keep_prob * 16777216.0f);
-#pragma unroll
-  for (int ni = 0; ni < 2; ++ni) {
-    const int col = n0 + wn * 64 + ni * 32 + i;
-    if (col >= a.N) continue;
-    const float bv = (a.epi == EPI_BIAS_ACT && a.bias) ? a.bias[col] : 0.f;
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (row >= a.M) continue;
-        float v = acc[mi][ni][r];
-        if (a.epi == EPI_BIAS_ACT) {
-          v += bv;
-          if (a.relu) v = fmaxf(v, 0.f);
-          if (a.keep_prob < 1.f) {
-            const uint64_t e = static_cast<uint64_t>(row) * static_cast<uint64_t>(a.N) + col;
-            v = dropout_keep(a.seed, e, thresh) ? v * a.inv_keep : 0.f;
-          }
-        } else if (a.epi == EPI_MASK) {
-          if (a.mask_src) {
-            const float x = a.mask_src[static_cast<int64_t>(row) * a.ldm + col];
-            v = (x > 0.f) ? v * a.inv_keep : 0.f;
-          }
-        }
-        Cb[static_cast<int64_t>(row) * a.ldc + col] = v;
-      }
-    }
-  }
+  store_tile_c(a, acc, m0, n0, wm, wn, i, h, split);
 }
+
+#include "gemm_split.inc"
+
+// which matrix-pipe path the vectorisable GEMMs take: 1 = bf16x3 split (default), 0 = fp32-input MFMA
+int g_gemm_mode = 1;
 
 // out[i] = sum_s slab[s][i] in a fixed order (bitwise reproducible split-K).  64 outputs per block;
 // the 4 waves take every 4th slab each, then fold through LDS as (w0+w1)+(w2+w3).
@@ -451,6 +458,11 @@ int32_t launch(GemmArgs& a, int splits, hipStream_t st, const char* what) {
     return MI_ERR_INVALID;
   }
   const dim3 g((unsigned)nblocks), b(kThreads);
+  if (g_gemm_mode == 1 && a.vecA && a.vecB) {
+    gemm_bf16x3_k<LA, LB, COLSUM, GATHER><<<g, b, 0, st>>>(a);
+    MI_CHECK_LAUNCH(what);
+    return MI_OK;
+  }
   if constexpr (GATHER) {       // the gathered operand is always float4-addressable (E % 4 == 0)
     if (a.vecB) gemm_f32_k<LA, LB, true, true, COLSUM, true><<<g, b, 0, st>>>(a);
     else gemm_f32_k<LA, LB, true, false, COLSUM, true><<<g, b, 0, st>>>(a);
@@ -464,10 +476,11 @@ int32_t launch(GemmArgs& a, int splits, hipStream_t st, const char* what) {
   return MI_OK;
 }
 
-// split-K policy for the weight gradient: enough blocks to fill 256 CUs x 2, k slices multiple of BK
+// split-K policy for the weight gradient: about two full rounds of resident workgroups (2 per CU),
+// k slices a multiple of BK
 int wgrad_splits(int64_t M, int N, int K) {
   const int64_t tiles = mi::ceil_div(K, BM) * mi::ceil_div(N, BN);
-  int64_t s = 1024 / tiles;             // <= 2 full rounds of 256 CUs x 2 resident blocks
+  int64_t s = 1024 / tiles;
   const int64_t max_s = mi::ceil_div(M, 4 * BK);  // at least 4 k-tiles per slice
   if (s > max_s) s = max_s;
   if (s < 1) s = 1;
@@ -482,6 +495,14 @@ int64_t wgrad_k_per_split(int64_t M, int splits) {
 }  // namespace
 
 extern "C" {
+
+int32_t mi_set_gemm_mode(int32_t mode) {
+  MI_REQUIRE(mode == 0 || mode == 1, "set_gemm_mode: %d (0 = fp32-input MFMA, 1 = bf16x3 split)", mode);
+  g_gemm_mode = mode;
+  return MI_OK;
+}
+
+int32_t mi_get_gemm_mode(void) { return g_gemm_mode; }
 
 int32_t mi_dense_fwd(const float* X, int64_t ldx, const float* W, const float* bias, float* Y,
                      int64_t ldy, int64_t M, int32_t N, int32_t K, int32_t relu, float keep_prob,

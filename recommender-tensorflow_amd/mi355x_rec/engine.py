@@ -157,7 +157,7 @@ class DeepFM:
     def __init__(self, vocab_sizes, n_numeric=0, embedding_size=4, hidden_units=(16, 16),
                  use_linear=True, use_mf=True, use_dnn=True, dropout=0.0, optimizer=None,
                  linear_optimizer=None, reduction="mean", device="cuda", seed=0, shard=None,
-                 _kernels=None):
+                 gemm="bf16x3", _kernels=None):
         if len(vocab_sizes) + n_numeric == 0:
             raise ValueError("At least 1 feature column of categorical_columns or numeric_columns "
                              "must be specified.")            # deep_fm.py:31-32
@@ -238,6 +238,11 @@ class DeepFM:
         # Single GPU without numeric columns: layer 1 of the MLP reads its input straight from the
         # embedding table (gathered GEMM operand) and the concat [B, F*E] is never materialised.
         self.gather_mlp = self.use_dnn and self.n_numeric == 0 and self.shard is None
+        # Matrix-pipe path of the MLP GEMMs: "bf16x3" (exact 3-way bf16 split of the fp32 operands,
+        # fp32 accumulate: fp32-level error at 2.7x the MFMA rate) or "fp32" (fp32-input MFMA).
+        if gemm not in ("bf16x3", "fp32"):
+            raise ValueError("gemm must be 'bf16x3' or 'fp32'")
+        self.gemm = gemm
 
     # ------------------------------------------------------------------ variables
     def _slots(self, like, spec):
@@ -370,6 +375,7 @@ class DeepFM:
             k.mi_numeric_embed_fwd(x_num, V, wn, B, self.n_numeric, self.E, concat, ld, self.F * self.E, sumv, fm, lin)
         acts = []
         dnn = None
+        k.query("mi_set_gemm_mode", 1 if self.gemm == "bf16x3" else 0)
         if self.use_dnn:
             x, ldx = concat, ld
             keep = 1.0 - self.dropout if (train and self.dropout > 0) else 1.0

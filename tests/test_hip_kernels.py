@@ -226,6 +226,56 @@ def test_gathered_layer1_matches_materialised_bitwise(lib, B, F, E, N):
     assert np.max(np.abs(dW1.cpu().numpy() - ref)) / (np.sqrt(np.mean(ref * ref)) + 1e-30) < TOL
 
 
+@pytest.mark.parametrize("M,N,K", [(1000, 512, 1664), (300, 256, 512), (129, 1664, 512), (4096, 384, 264)])
+def test_bf16x3_and_fp32_gemm_modes_agree(lib, M, N, K):
+    """Both matrix-pipe paths (bf16x3 split, fp32-input MFMA) against the fp64 reference, forward
+    (bias + relu + dropout) and masked data gradient."""
+    rng = np.random.default_rng(M + N + K)
+    X = rng.standard_normal((M, K)).astype(np.float32)
+    W = (rng.standard_normal((K, N)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    dY = rng.standard_normal((M, N)).astype(np.float32)
+    x, w, bb, dy = dev(X), dev(W), dev(b), dev(dY)
+    assert lib.mi_get_gemm_mode() == 1
+    outs = {}
+    for tag, mode in (("bf16x3", 1), ("fp32", 0)):
+        _chk(lib.mi_set_gemm_mode(mode))
+        Y = torch.empty(M, N, device="cuda"); dX = torch.empty(M, K, device="cuda")
+        _chk(lib.mi_dense_fwd(_p(x), K, _p(w), _p(bb), _p(Y), N, M, N, K, 1, 0.9, 5, _st()))
+        _chk(lib.mi_dense_bwd_data(_p(dy), N, _p(w), _p(x), K, _p(dX), K, M, N, K, 0.9, _st()))
+        outs[tag] = (Y.cpu(), dX.cpu())
+    _chk(lib.mi_set_gemm_mode(1))
+    pre = X.astype(np.float64) @ W.astype(np.float64) + b
+    ref = np.maximum(pre, 0) * dropout_mask(5, M, N, 0.9)
+    sc = np.sqrt(np.mean(pre * pre))
+    full = dY.astype(np.float64) @ W.astype(np.float64).T
+    refd = full * (X > 0) * np.float64(np.float32(1.0) / np.float32(0.9))
+    for tag in ("bf16x3", "fp32"):
+        assert np.max(np.abs(outs[tag][0].numpy() - ref)) / sc < TOL, tag
+        assert np.max(np.abs(outs[tag][1].numpy() - refd)) / np.sqrt(np.mean(full * full)) < 2 * TOL, tag
+
+
+def test_bf16x3_split_error_is_fp32_level(lib):
+    """Against fp64 the split path must be as accurate as the fp32-input MFMA (within 2x), also for
+    operands with a wide dynamic range — the split is exact, only terms below 2^-24 are dropped."""
+    rng = np.random.default_rng(1)
+    M, N, K = 512, 256, 2048
+    X = (rng.standard_normal((M, K)) * np.exp(rng.uniform(-8, 8, (M, K)))).astype(np.float32)
+    W = (rng.standard_normal((K, N)) * np.exp(rng.uniform(-8, 8, (K, N)))).astype(np.float32)
+    x, w, bb = dev(X), dev(W), dev(np.zeros(N, np.float32))
+    ref = X.astype(np.float64) @ W.astype(np.float64)
+    mag = np.abs(X).astype(np.float64) @ np.abs(W).astype(np.float64)      # sum |a||b|: the natural error scale
+    err = {}
+    for mode in (0, 1):
+        _chk(lib.mi_set_gemm_mode(mode))
+        Y = torch.empty(M, N, device="cuda")
+        _chk(lib.mi_dense_fwd(_p(x), K, _p(w), _p(bb), _p(Y), N, M, N, K, 0, 1.0, 0, _st()))
+        err[mode] = float(np.max(np.abs(Y.cpu().numpy() - ref) / mag))
+    _chk(lib.mi_set_gemm_mode(1))
+    assert err[0] < 2e-6 and err[1] < 2e-6, err            # both ~ a few fp32 ulps of sum|a||b|
+    assert err[1] < 4 * err[0] + 1e-7, err
+
+
 @pytest.mark.parametrize("name", ["Adam", "Ftrl"])
 def test_sparse_apply_fused_equals_bwd_then_apply_bitwise(lib, name):
     """mi_sparse_apply_fused == mi_embed_fm_linear_bwd followed by mi_sparse_apply, bit for bit."""

@@ -16,15 +16,14 @@ def _mix32(x):
 
 def dropout_mask(seed, M, N, keep):
     """Host replica of gemm.hip's counter-based dropout mask: multiplier {0, 1/keep} per element."""
-    idx = np.arange(M * N, dtype=np.uint64)
-    lo = (idx & np.uint64(0xFFFFFFFF)).astype(np.uint32)
-    hi = (idx >> np.uint64(32)).astype(np.uint32)
+    row = np.arange(M, dtype=np.uint32)[:, None]
+    col = np.arange(N, dtype=np.uint32)[None, :]
     with np.errstate(over="ignore"):
-        h = _mix32(lo ^ np.uint32(seed & 0xFFFFFFFF))
-        h = _mix32(h ^ (hi * np.uint32(0x9E3779B1)) ^ np.uint32((seed >> 32) & 0xFFFFFFFF))
+        s = np.uint32(seed & 0xFFFFFFFF) ^ (np.uint32((seed >> 32) & 0xFFFFFFFF) * np.uint32(0xC2B2AE35))
+        h = _mix32((row * np.uint32(0x9E3779B1)) ^ (col * np.uint32(0x85EBCA77)) ^ s)
     thresh = np.uint32(np.float32(keep) * np.float32(16777216.0))
     kept = (h >> np.uint32(8)) < thresh
-    return (kept.astype(np.float32) * np.float32(np.float32(1.0) / np.float32(keep))).reshape(M, N)
+    return kept.astype(np.float32) * np.float32(np.float32(1.0) / np.float32(keep))
 
 
 def make_problem(seed, vocab, E, hidden, B, n_numeric=0, lin_scale=0.05, dup=True, use_dnn=True):
