@@ -40,7 +40,7 @@ enum mi_status {
 };
 
 /* ---- library ---------------------------------------------------------------------------- */
-int32_t mi_abi_version(void);       /* bumps when a signature changes (currently 5) */
+int32_t mi_abi_version(void);       /* bumps when a signature changes (currently 6) */
 const char* mi_last_error(void);    /* thread-local, never NULL */
 const char* mi_build_info(void);    /* "gfx950 hipcc <ver>" */
 
@@ -78,14 +78,15 @@ int32_t mi_bucketize_f32(const float* values, int64_t n, const float* boundaries
  * table [R,E] f32, lin_w [R] f32 (may be NULL: lin not produced), field_off [F] int64 (device),
  * ids [B,F] int32 (device).  Outputs: concat [B,F*E] with leading dimension ld_concat (floats,
  * >= F*E: numeric-embedding columns may follow, deep_fm.py:73), sumv [B,E], fm [B], lin [B]
- * (any of them may be NULL; with concat == NULL the kernel only READS rows — the form the
+ * (any of them may be NULL; amax_rows, if not NULL, is an abs-max vector — see mi_gemm_amax_t — that
+ * receives max |table[row(b,f), :]| over the rows read, for the MLP's layer-1 GEMMs; with concat == NULL the kernel only READS rows — the form the
  * single-GPU path uses, where layer 1 gathers its operand itself, and the one bench.py prices
  * against the HBM read roofline; with table == NULL only the wide part lin is produced).  E must be a multiple of 4 and <= 256.  Fields must already be
  * in the reference's sorted-by-column-name order. */
 int32_t mi_embed_fm_linear_fwd(const float* table, const float* lin_w, const int64_t* field_off,
                                const int32_t* ids, int64_t B, int32_t F, int32_t E,
                                float* concat, int64_t ld_concat, float* sumv, float* fm, float* lin,
-                               mi_stream_t stream);
+                               float* amax_rows, mi_stream_t stream);
 
 /* Owner-side half of the row-sharded path (multi-GPU): out_rows[i,:] = table[rows[i],:],
  * out_lin[i] = lin_w[rows[i]].  rows [n] int32 local row ids. */
@@ -216,26 +217,46 @@ int32_t mi_sparse_catchup(float* table, float* t_m, float* t_v, float* lin_w, fl
                           int64_t n_max, int32_t E, int32_t step_to, const float* lr_table,
                           float beta1, float beta2, float epsilon, mi_stream_t stream);
 
-/* ---- (a6) the [hidden_units] MLP: fp32-input MFMA GEMMs with fused epilogues ------------------
+/* ---- (a6) the [hidden_units] MLP: fp32 GEMMs on the matrix cores with fused epilogues -----------
  * replaces tf.layers.dense / tf.layers.dropout (deep_fm.py:98-108).  Row-major everywhere.
- * v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate (needed for the 1e-5 logit bar). */
+ * fp32 in, fp32 accumulate, fp32 out; error at the level of an fp32 GEMM (the 1e-5 logit bar). */
 
 /* Matrix-pipe path of the GEMMs below (process-wide switch):
- *   1 (default) "bf16x3": every fp32 operand is split exactly into three bf16 terms and the six
- *      leading partial products run on v_mfma_f32_32x32x16_bf16 with fp32 accumulation — fp32-level
- *      error (dropped terms <= 3*2^-24 |ab| per product; measured equal to the fp32-input MFMA
- *      against fp64) at 2.7x its matrix throughput;
+ *   1 (default) 16-bit operand split.  On CDNA4 the fp32-input MFMA runs at 1/16 of the f16/bf16
+ *      rate; a product of two 16-bit floats is exact in fp32 and the MFMA accumulates in fp32.
+ *      - "f16x2", when the call carries both operands' abs-max (mi_gemm_amax_t): each operand is
+ *        scaled by a power of two (largest magnitude -> [2^14, 2^15)) and split into fp16 high + low
+ *        parts; three products per k-step (dropped terms <= 2^-21 |ab|);
+ *      - "bf16x3" otherwise: three bf16 parts, six products (dropped <= 3*2^-24 |ab|), any input.
+ *      Both measure the same max error against fp64 as the fp32-input MFMA on the layer shapes.
  *   0 "fp32": v_mfma_f32_32x32x2_f32 (exact fp32 products).
  * Operands that cannot be read as float4 (e.g. the N = 1 logits layer) always take path 0. */
 int32_t mi_set_gemm_mode(int32_t mode);
 int32_t mi_get_gemm_mode(void);
+
+/* Abs-max vectors.  An abs-max "scalar" is MI_AMAX_SLOTS floats in device memory whose largest entry
+ * is the value (producers spread their atomic max over the slots); zero it (hipMemsetAsync) before
+ * the producer runs.  a / b: abs-max of the first / second matrix operand of the call, or an upper
+ * bound of it (an under-estimate overflows fp16).  out: receives max |result| — every GEMM epilogue
+ * can emit it, so the next layer's operand arrives with its abs-max already known.  A NULL struct, or
+ * a NULL a or b, selects the bf16x3 split; out may always be NULL. */
+#define MI_AMAX_SLOTS 64
+typedef struct mi_gemm_amax {
+  const float* a;
+  const float* b;
+  float* out;
+} mi_gemm_amax_t;
+
+/* amax_out[slot] = max(amax_out[slot], max_i |x[i]|) for buffers no kernel here produced (weights
+ * after the optimizer step, a concat received from an all-to-all). */
+int32_t mi_absmax(const float* x, int64_t n, float* amax_out, mi_stream_t stream);
 
 /* Y[M,N] = act( X[M,K] * W[K,N] + bias[N] ), act = relu if relu != 0.  If keep_prob < 1 the
  * TRAIN-mode dropout of deep_fm.py:102-103 is applied after the activation with a counter-based
  * mask (seed, layer, element index): survivors scaled by 1/keep_prob. */
 int32_t mi_dense_fwd(const float* X, int64_t ldx, const float* W, const float* bias, float* Y,
                      int64_t ldy, int64_t M, int32_t N, int32_t K, int32_t relu, float keep_prob,
-                     uint64_t seed, mi_stream_t stream);
+                     uint64_t seed, const mi_gemm_amax_t* amax, mi_stream_t stream);
 
 /* Layer 1 with the input_layer concat (deep_fm.py:54) read IN PLACE from the embedding table:
  * X[b, f*E + e] = table[field_off[f] + ids[b*F+f], e], K = F*E.  The GEMM's A operand is gathered
@@ -243,10 +264,12 @@ int32_t mi_dense_fwd(const float* X, int64_t ldx, const float* W, const float* b
  * written to or re-read from HBM.  Otherwise identical to mi_dense_fwd / mi_dense_bwd_weight. */
 int32_t mi_dense_fwd_gathered(const float* table, const int64_t* field_off, const int32_t* ids, int32_t F,
                               int32_t E, const float* W, const float* bias, float* Y, int64_t ldy, int64_t M,
-                              int32_t N, int32_t relu, float keep_prob, uint64_t seed, mi_stream_t stream);
+                              int32_t N, int32_t relu, float keep_prob, uint64_t seed,
+                              const mi_gemm_amax_t* amax, mi_stream_t stream);
 int32_t mi_dense_bwd_weight_gathered(const float* table, const int64_t* field_off, const int32_t* ids, int32_t F,
                                      int32_t E, const float* dY, int64_t lddy, float* dW, float* db, int64_t M,
-                                     int32_t N, void* workspace, size_t workspace_bytes, mi_stream_t stream);
+                                     int32_t N, void* workspace, size_t workspace_bytes,
+                                     const mi_gemm_amax_t* amax, mi_stream_t stream);
 
 /* dX[M,K] = (dY[M,N] * W[K,N]^T) .* mask.  When Xact != NULL (the previous layer's stored
  * post-relu, post-dropout output) mask = (Xact > 0) / keep_prob — a unit with Xact > 0 was both
@@ -254,14 +277,14 @@ int32_t mi_dense_bwd_weight_gathered(const float* table, const int64_t* field_of
  * previous layer's PRE-activation, ready to be that layer's dY. */
 int32_t mi_dense_bwd_data(const float* dY, int64_t lddy, const float* W, const float* Xact,
                           int64_t ldxa, float* dX, int64_t lddx, int64_t M, int32_t N, int32_t K,
-                          float keep_prob, mi_stream_t stream);
+                          float keep_prob, const mi_gemm_amax_t* amax, mi_stream_t stream);
 
 /* dW[K,N] = X[M,K]^T * dY[M,N], db[N] = column sums of dY.  Split-K over M with a
  * fixed-order slab reduction (bitwise reproducible). */
 size_t mi_dense_bwd_weight_workspace_bytes(int64_t M, int32_t N, int32_t K);
 int32_t mi_dense_bwd_weight(const float* X, int64_t ldx, const float* dY, int64_t lddy, float* dW,
                             float* db, int64_t M, int32_t N, int32_t K, void* workspace,
-                            size_t workspace_bytes, mi_stream_t stream);
+                            size_t workspace_bytes, const mi_gemm_amax_t* amax, mi_stream_t stream);
 
 /* ---- (a7,a8) logits sum + sigmoid cross-entropy head -----------------------------------------
  * replaces `logits += ...` (deep_fm.py:36,44,90,111) and

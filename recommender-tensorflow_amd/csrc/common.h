@@ -22,6 +22,25 @@ inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 }  // namespace mi
 
+// Publish a workgroup's abs-max into an abs-max vector (MI_AMAX_SLOTS floats, value = largest entry).
+// Every thread of the workgroup must call it (it contains a barrier).  One atomic per workgroup at
+// most, spread over the slots, and only when the slot does not already hold a larger value: same-
+// address atomics serialise at ~0.2 us each, and a kernel's first generation of workgroups ends together.
+__device__ __forceinline__ void mi_amax_publish(float* __restrict__ vec, float mx) {
+  __shared__ float part[16];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int nw = (blockDim.x + 63) >> 6;
+    for (int w = 1; w < nw; ++w) mx = fmaxf(mx, part[w]);
+    unsigned int* slot = reinterpret_cast<unsigned int*>(vec) + (blockIdx.x & (MI_AMAX_SLOTS - 1));
+    const unsigned int bits = __float_as_uint(mx);
+    if (bits > *reinterpret_cast<volatile unsigned int*>(slot)) atomicMax(slot, bits);
+  }
+}
+
 #define MI_REQUIRE(cond, ...)            \
   do {                                   \
     if (!(cond)) {                       \

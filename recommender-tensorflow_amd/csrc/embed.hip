@@ -33,8 +33,9 @@ __global__ __launch_bounds__(kBlock) void embed_fm_linear_fwd_k(
     const float* __restrict__ table, const float* __restrict__ lin_w,
     const int64_t* __restrict__ field_off, const int32_t* __restrict__ ids, int64_t B, int F, int E,
     float* __restrict__ concat, int64_t ldc, float* __restrict__ sumv, float* __restrict__ fm,
-    float* __restrict__ lin) {
+    float* __restrict__ lin, float* __restrict__ amax_rows) {
   constexpr int U = kRowsInFlight;
+  float mx = 0.f;                   // largest |row element| seen (scale of the layer-1 GEMM operand)
   const int64_t g = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) / LPR;
   const int l = threadIdx.x & (LPR - 1);
   const bool valid = g < B;
@@ -70,6 +71,7 @@ __global__ __launch_bounds__(kBlock) void embed_fm_linear_fwd_k(
             s.x += r[u].x; s.y += r[u].y; s.z += r[u].z; s.w += r[u].w;
             q.x += __fmul_rn(r[u].x, r[u].x); q.y += __fmul_rn(r[u].y, r[u].y);
             q.z += __fmul_rn(r[u].z, r[u].z); q.w += __fmul_rn(r[u].w, r[u].w);
+            mx = fmaxf(fmaxf(mx, fmaxf(fabsf(r[u].x), fabsf(r[u].y))), fmaxf(fabsf(r[u].z), fabsf(r[u].w)));
             if (valid && lane_on && concat) st4(crow + static_cast<int64_t>(fb + j0 + u) * E + eo, r[u]);
           }
         }
@@ -96,6 +98,7 @@ __global__ __launch_bounds__(kBlock) void embed_fm_linear_fwd_k(
           s.x += r[u].x; s.y += r[u].y; s.z += r[u].z; s.w += r[u].w;
           q.x += __fmul_rn(r[u].x, r[u].x); q.y += __fmul_rn(r[u].y, r[u].y);
           q.z += __fmul_rn(r[u].z, r[u].z); q.w += __fmul_rn(r[u].w, r[u].w);
+          mx = fmaxf(fmaxf(mx, fmaxf(fabsf(r[u].x), fabsf(r[u].y))), fmaxf(fabsf(r[u].z), fabsf(r[u].w)));
           if (valid && lane_on && concat) st4(crow + static_cast<int64_t>(f0 + u) * E + eo, r[u]);
         }
       }
@@ -115,6 +118,7 @@ __global__ __launch_bounds__(kBlock) void embed_fm_linear_fwd_k(
       if (lin) lin[b] = lacc;
     }
   }
+  if (amax_rows) mi_amax_publish(amax_rows, mx);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -322,7 +326,7 @@ extern "C" {
 
 int32_t mi_embed_fm_linear_fwd(const float* table, const float* lin_w, const int64_t* field_off,
                                const int32_t* ids, int64_t B, int32_t F, int32_t E, float* concat,
-                               int64_t ld_concat, float* sumv, float* fm, float* lin,
+                               int64_t ld_concat, float* sumv, float* fm, float* lin, float* amax_rows,
                                mi_stream_t stream) {
   MI_REQUIRE(B >= 0 && F > 0, "embed_fm_linear_fwd: B=%lld F=%d", (long long)B, F);
   if (!table) {  // wide part only
@@ -336,7 +340,7 @@ int32_t mi_embed_fm_linear_fwd(const float* table, const float* lin_w, const int
   }
   if (int32_t rc = check_E("embed_fm_linear_fwd", E)) return rc;
   MI_REQUIRE(table && field_off && ids, "embed_fm_linear_fwd: null buffer");
-  MI_REQUIRE(concat || sumv || fm || lin, "embed_fm_linear_fwd: no output requested");
+  MI_REQUIRE(concat || sumv || fm || lin || amax_rows, "embed_fm_linear_fwd: no output requested");
   MI_REQUIRE(!concat || (ld_concat >= (int64_t)F * E && (ld_concat & 3) == 0),
              "embed_fm_linear_fwd: ld_concat=%lld must be >= F*E and a multiple of 4", (long long)ld_concat);
   MI_REQUIRE(mi::aligned16(table) && (!concat || mi::aligned16(concat)) && (!sumv || mi::aligned16(sumv)),
@@ -347,7 +351,8 @@ int32_t mi_embed_fm_linear_fwd(const float* table, const float* lin_w, const int
   const int64_t blocks = mi::ceil_div(B * lpr, kBlock);
   MI_REQUIRE(blocks <= INT32_MAX, "embed_fm_linear_fwd: grid too large");
   MI_DISPATCH_LPR(lpr, (embed_fm_linear_fwd_k<L><<<dim3((unsigned)blocks), dim3(kBlock), 0, mi::as_stream(stream)>>>(
-                           table, lin ? lin_w : nullptr, field_off, ids, B, F, E, concat, ld_concat, sumv, fm, lin)));
+                           table, lin ? lin_w : nullptr, field_off, ids, B, F, E, concat, ld_concat, sumv, fm, lin,
+                           amax_rows)));
   MI_CHECK_LAUNCH("embed_fm_linear_fwd");
   return MI_OK;
 }

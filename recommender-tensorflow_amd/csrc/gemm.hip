@@ -16,6 +16,7 @@
 // k-values per ds_read_b128 feed four consecutive MFMAs: lane half h owns k = 8s+4h+j.
 // Workgroup ids are remapped so that the blocks sharing an A row-panel run on one XCD (shared L2).
 #include "common.h"
+#include <algorithm>
 
 namespace {
 
@@ -45,6 +46,9 @@ struct GemmArgs {
   // (example b, column c) is table[(g_off[c / g_E] + g_ids[b * g_F + c / g_E]) * g_E + c % g_E] —
   // the input_layer concat (deep_fm.py:54) read in place, never materialised.
   const int32_t* g_ids; const int64_t* g_off; int g_F, g_E;
+  // abs-max vectors (MI_AMAX_SLOTS floats each, value = largest entry): of the operands, for the
+  // f16x2 split's scales; of the result, accumulated by the epilogue.  Any may be NULL.
+  const float* amax_a; const float* amax_b; float* amax_c;
 };
 
 // Counter-based dropout mask in 32-bit arithmetic only (64-bit multiplies are several quarter-rate
@@ -208,9 +212,13 @@ __device__ __forceinline__ void read_frag(const float* __restrict__ S, int mn, i
 // ---- epilogue shared by the fp32-MFMA and the bf16x3-split kernels --------------------------
 // C/D register map of every 32x32 MFMA (dtype independent): col = lane&31,
 // row = (r&3) + 8*(r>>2) + 4*(lane>>5).  i = lane&31, h = lane>>5.
+// sa * sb undoes the operand scales of the f16x2 split (powers of two; 1 elsewhere).  When a.amax_c
+// is set the largest |value stored| goes into one of its MI_AMAX_SLOTS entries (atomic max on the
+// bit pattern; spread over slots so that 8k waves do not queue on one address).
 __device__ __forceinline__ void store_tile_c(const GemmArgs& a, const f32x16 (&acc)[2][2], int m0, int n0, int wm,
-                                             int wn, int i, int h, int split) {
+                                             int wn, int i, int h, int split, float sa, float sb) {
   float* Cb = a.C;
+  float mx = 0.f;
   if (a.epi == EPI_SLAB) Cb += static_cast<int64_t>(split) * a.M * a.ldc;
   const uint32_t thresh = static_cast<uint32_t>(a.keep_prob * 16777216.0f);
 #pragma unroll
@@ -224,7 +232,7 @@ __device__ __forceinline__ void store_tile_c(const GemmArgs& a, const f32x16 (&a
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         if (row >= a.M) continue;
-        float v = acc[mi][ni][r];
+        float v = acc[mi][ni][r] * sa * sb;
         if (a.epi == EPI_BIAS_ACT) {
           v += bv;
           if (a.relu) v = fmaxf(v, 0.f);
@@ -236,9 +244,11 @@ __device__ __forceinline__ void store_tile_c(const GemmArgs& a, const f32x16 (&a
           }
         }
         Cb[static_cast<int64_t>(row) * a.ldc + col] = v;
+        mx = fmaxf(mx, fabsf(v));
       }
     }
   }
+  if (a.amax_c) mi_amax_publish(a.amax_c, mx);
 }
 
 template <int LA, int LB, bool VA, bool VB, bool COLSUM, bool GATHER>
@@ -307,7 +317,7 @@ __global__ __launch_bounds__(kThreads, GEMM_LB_WAVES) void gemm_f32_k(const Gemm
   // MFMAs; the staged registers go to the other LDS buffer (idle since the previous barrier)
   // at GEMM_STORE_POS; one barrier per tile.
 #ifndef GEMM_STORE_POS
-#define GEMM_STORE_POS 2   /* after k-group n of 4 (4 = end of tile); A/B in tools/gemm_variants.py */
+#define GEMM_STORE_POS 2   /* after k-group n of 4 (4 = end of tile); A/B in tools/gemm_bench.py */
 #endif
 #ifndef GEMM_FRAG_DB
 #define GEMM_FRAG_DB 1
@@ -392,13 +402,29 @@ __global__ __launch_bounds__(kThreads, GEMM_LB_WAVES) void gemm_f32_k(const Gemm
     }
   }
 
-  store_tile_c(a, acc, m0, n0, wm, wn, i, h, split);
+  store_tile_c(a, acc, m0, n0, wm, wn, i, h, split, 1.f, 1.f);
 }
 
 #include "gemm_split.inc"
 
-// which matrix-pipe path the vectorisable GEMMs take: 1 = bf16x3 split (default), 0 = fp32-input MFMA
+// which matrix-pipe path the vectorisable GEMMs take: 1 = 16-bit operand split (default; f16x2 when
+// the call carries the operands' abs-max, bf16x3 otherwise), 0 = fp32-input MFMA
 int g_gemm_mode = 1;
+
+// abs-max of a buffer into an abs-max vector (grid-stride, float4 body; one atomic per wave)
+__global__ __launch_bounds__(kThreads) void absmax_k(const float* __restrict__ x, int64_t n, float* __restrict__ out) {
+  float mx = 0.f;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kThreads;
+  const int64_t n4 = (reinterpret_cast<uintptr_t>(x) & 15u) == 0 ? n >> 2 : 0;
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  for (int64_t j = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; j < n4; j += stride) {
+    const float4 v = x4[j];
+    mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+  for (int64_t j = 4 * n4 + static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; j < n; j += stride)
+    mx = fmaxf(mx, fabsf(x[j]));
+  mi_amax_publish(out, mx);
+}
 
 // out[i] = sum_s slab[s][i] in a fixed order (bitwise reproducible split-K).  64 outputs per block;
 // the 4 waves take every 4th slab each, then fold through LDS as (w0+w1)+(w2+w3).
@@ -459,7 +485,16 @@ int32_t launch(GemmArgs& a, int splits, hipStream_t st, const char* what) {
   }
   const dim3 g((unsigned)nblocks), b(kThreads);
   if (g_gemm_mode == 1 && a.vecA && a.vecB) {
-    gemm_bf16x3_k<LA, LB, COLSUM, GATHER><<<g, b, 0, st>>>(a);
+    if (a.amax_a && a.amax_b) {
+      // whole tiles, lane offsets that fit 32 bits, and (forward gather) k-tiles inside one field
+      const bool whole = a.M % BM == 0 && a.N % BN == 0 && a.K % BK == 0 && a.k_per_split % BK == 0 &&
+                         a.lda < (1 << 22) && a.ldb < (1 << 22) &&
+                         (!GATHER || (a.g_F < (1 << 20) && (LA != KC || a.g_E % BK == 0)));
+      if (whole) gemm_split_k<FMT_F16X2, LA, LB, COLSUM, GATHER, false><<<g, b, 0, st>>>(a);
+      else gemm_split_k<FMT_F16X2, LA, LB, COLSUM, GATHER, true><<<g, b, 0, st>>>(a);
+    } else {
+      gemm_split_k<FMT_BF16X3, LA, LB, COLSUM, GATHER, true><<<g, b, 0, st>>>(a);
+    }
     MI_CHECK_LAUNCH(what);
     return MI_OK;
   }
@@ -492,12 +527,26 @@ int64_t wgrad_k_per_split(int64_t M, int splits) {
   return mi::ceil_div(mi::ceil_div(M, splits), BK) * BK;
 }
 
+void set_amax(GemmArgs& a, const mi_gemm_amax_t* amax) {
+  if (!amax) return;
+  a.amax_a = amax->a; a.amax_b = amax->b; a.amax_c = amax->out;
+}
+
 }  // namespace
 
 extern "C" {
 
+int32_t mi_absmax(const float* x, int64_t n, float* amax_out, mi_stream_t stream) {
+  MI_REQUIRE(n >= 0 && amax_out && (n == 0 || x), "absmax: n=%lld", (long long)n);
+  if (n == 0) return MI_OK;
+  const int64_t blocks = std::min<int64_t>(mi::ceil_div(n, 16 * kThreads), 1024);
+  absmax_k<<<dim3((unsigned)blocks), dim3(kThreads), 0, mi::as_stream(stream)>>>(x, n, amax_out);
+  MI_CHECK_LAUNCH("absmax");
+  return MI_OK;
+}
+
 int32_t mi_set_gemm_mode(int32_t mode) {
-  MI_REQUIRE(mode == 0 || mode == 1, "set_gemm_mode: %d (0 = fp32-input MFMA, 1 = bf16x3 split)", mode);
+  MI_REQUIRE(mode == 0 || mode == 1, "set_gemm_mode: %d (0 = fp32-input MFMA, 1 = 16-bit operand split)", mode);
   g_gemm_mode = mode;
   return MI_OK;
 }
@@ -506,7 +555,7 @@ int32_t mi_get_gemm_mode(void) { return g_gemm_mode; }
 
 int32_t mi_dense_fwd(const float* X, int64_t ldx, const float* W, const float* bias, float* Y,
                      int64_t ldy, int64_t M, int32_t N, int32_t K, int32_t relu, float keep_prob,
-                     uint64_t seed, mi_stream_t stream) {
+                     uint64_t seed, const mi_gemm_amax_t* amax, mi_stream_t stream) {
   MI_REQUIRE(M >= 0 && M <= INT32_MAX && N > 0 && K > 0, "dense_fwd: M=%lld N=%d K=%d", (long long)M, N, K);
   if (M == 0) return MI_OK;
   MI_REQUIRE(X && W && Y, "dense_fwd: null buffer");
@@ -518,12 +567,13 @@ int32_t mi_dense_fwd(const float* X, int64_t ldx, const float* W, const float* b
   a.vecA = vec_ok(X, ldx, K); a.vecB = vec_ok(W, N, N);
   a.epi = EPI_BIAS_ACT; a.bias = bias; a.relu = relu;
   a.keep_prob = keep_prob; a.inv_keep = 1.f / keep_prob; a.seed = seed;
+  set_amax(a, amax);
   return launch<KC, MC>(a, 1, mi::as_stream(stream), "dense_fwd");
 }
 
 int32_t mi_dense_bwd_data(const float* dY, int64_t lddy, const float* W, const float* Xact,
                           int64_t ldxa, float* dX, int64_t lddx, int64_t M, int32_t N, int32_t K,
-                          float keep_prob, mi_stream_t stream) {
+                          float keep_prob, const mi_gemm_amax_t* amax, mi_stream_t stream) {
   MI_REQUIRE(M >= 0 && M <= INT32_MAX && N > 0 && K > 0, "dense_bwd_data: M=%lld N=%d K=%d", (long long)M, N, K);
   if (M == 0) return MI_OK;
   MI_REQUIRE(dY && W && dX, "dense_bwd_data: null buffer");
@@ -535,6 +585,7 @@ int32_t mi_dense_bwd_data(const float* dY, int64_t lddy, const float* W, const f
   a.vecA = vec_ok(dY, lddy, N); a.vecB = vec_ok(W, N, N);
   a.epi = EPI_MASK; a.mask_src = Xact; a.ldm = ldxa;
   a.keep_prob = keep_prob; a.inv_keep = Xact ? 1.f / keep_prob : 1.f;
+  set_amax(a, amax);
   return launch<KC, KC>(a, 1, mi::as_stream(stream), "dense_bwd_data");
 }
 
@@ -547,7 +598,8 @@ static int32_t check_gather(const char* who, const float* table, const int64_t* 
 
 int32_t mi_dense_fwd_gathered(const float* table, const int64_t* field_off, const int32_t* ids, int32_t F,
                               int32_t E, const float* W, const float* bias, float* Y, int64_t ldy, int64_t M,
-                              int32_t N, int32_t relu, float keep_prob, uint64_t seed, mi_stream_t stream) {
+                              int32_t N, int32_t relu, float keep_prob, uint64_t seed, const mi_gemm_amax_t* amax,
+                              mi_stream_t stream) {
   if (int32_t rc = check_gather("dense_fwd_gathered", table, field_off, ids, F, E)) return rc;
   MI_REQUIRE(M >= 0 && M <= INT32_MAX && N > 0, "dense_fwd_gathered: M=%lld N=%d", (long long)M, N);
   if (M == 0) return MI_OK;
@@ -561,6 +613,7 @@ int32_t mi_dense_fwd_gathered(const float* table, const int64_t* field_off, cons
   a.epi = EPI_BIAS_ACT; a.bias = bias; a.relu = relu;
   a.keep_prob = keep_prob; a.inv_keep = 1.f / keep_prob; a.seed = seed;
   a.g_ids = ids; a.g_off = field_off; a.g_F = F; a.g_E = E;
+  set_amax(a, amax);
   return launch<KC, MC, false, true>(a, 1, mi::as_stream(stream), "dense_fwd_gathered");
 }
 
@@ -593,28 +646,30 @@ size_t mi_dense_bwd_weight_workspace_bytes(int64_t M, int32_t N, int32_t K) {
 
 static int32_t bwd_weight_impl(const float* X, int64_t ldx, const float* dY, int64_t lddy, float* dW, float* db,
                                int64_t M, int32_t N, int32_t K, void* workspace, size_t workspace_bytes,
-                               mi_stream_t stream, const int32_t* g_ids, const int64_t* g_off, int32_t g_F,
-                               int32_t g_E);
+                               const mi_gemm_amax_t* amax, mi_stream_t stream, const int32_t* g_ids,
+                               const int64_t* g_off, int32_t g_F, int32_t g_E);
 
 int32_t mi_dense_bwd_weight(const float* X, int64_t ldx, const float* dY, int64_t lddy, float* dW,
                             float* db, int64_t M, int32_t N, int32_t K, void* workspace,
-                            size_t workspace_bytes, mi_stream_t stream) {
+                            size_t workspace_bytes, const mi_gemm_amax_t* amax, mi_stream_t stream) {
   MI_REQUIRE(X && ldx >= K, "dense_bwd_weight: X / ldx");
-  return bwd_weight_impl(X, ldx, dY, lddy, dW, db, M, N, K, workspace, workspace_bytes, stream, nullptr, nullptr, 0, 0);
+  return bwd_weight_impl(X, ldx, dY, lddy, dW, db, M, N, K, workspace, workspace_bytes, amax, stream, nullptr, nullptr,
+                         0, 0);
 }
 
 int32_t mi_dense_bwd_weight_gathered(const float* table, const int64_t* field_off, const int32_t* ids, int32_t F,
                                      int32_t E, const float* dY, int64_t lddy, float* dW, float* db, int64_t M,
-                                     int32_t N, void* workspace, size_t workspace_bytes, mi_stream_t stream) {
+                                     int32_t N, void* workspace, size_t workspace_bytes,
+                                     const mi_gemm_amax_t* amax, mi_stream_t stream) {
   if (int32_t rc = check_gather("dense_bwd_weight_gathered", table, field_off, ids, F, E)) return rc;
-  return bwd_weight_impl(table, 0, dY, lddy, dW, db, M, N, F * E, workspace, workspace_bytes, stream, ids, field_off,
-                         F, E);
+  return bwd_weight_impl(table, 0, dY, lddy, dW, db, M, N, F * E, workspace, workspace_bytes, amax, stream, ids,
+                         field_off, F, E);
 }
 
 static int32_t bwd_weight_impl(const float* X, int64_t ldx, const float* dY, int64_t lddy, float* dW, float* db,
                                int64_t M, int32_t N, int32_t K, void* workspace, size_t workspace_bytes,
-                               mi_stream_t stream, const int32_t* g_ids, const int64_t* g_off, int32_t g_F,
-                               int32_t g_E) {
+                               const mi_gemm_amax_t* amax, mi_stream_t stream, const int32_t* g_ids,
+                               const int64_t* g_off, int32_t g_F, int32_t g_E) {
   MI_REQUIRE(M > 0 && M <= INT32_MAX && N > 0 && K > 0, "dense_bwd_weight: M=%lld N=%d K=%d", (long long)M, N, K);
   MI_REQUIRE(X && dY && dW && workspace, "dense_bwd_weight: null buffer");
   MI_REQUIRE(lddy >= N, "dense_bwd_weight: leading dimensions");
@@ -635,6 +690,8 @@ static int32_t bwd_weight_impl(const float* X, int64_t ldx, const float* dY, int
   a.vecA = vec_ok(X, ldx, K); a.vecB = vec_ok(dY, lddy, N);
   a.C = slab; a.ldc = N; a.epi = EPI_SLAB; a.keep_prob = 1.f; a.inv_keep = 1.f;
   a.colsum_part = db ? cpart : nullptr;
+  set_amax(a, amax);
+  a.amax_c = nullptr;                 // the slabs are partial sums; dW is nobody's matrix operand
   if (g_ids) {
     a.vecA = 1; a.g_ids = g_ids; a.g_off = g_off; a.g_F = g_F; a.g_E = g_E;
     if (int32_t rc = launch<MC, MC, true, true>(a, splits, st, "dense_bwd_weight_gathered(split-K)")) return rc;
@@ -649,3 +706,9 @@ static int32_t bwd_weight_impl(const float* X, int64_t ldx, const float* dY, int
 }
 
 }  // extern "C"
+
+#ifdef MI_GEMM_STAMPS
+extern "C" int32_t mi_gemm_stamps_read(void* dst, size_t nbytes) {
+  return static_cast<int32_t>(hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stamps), nbytes, 0, hipMemcpyDeviceToHost));
+}
+#endif

@@ -16,7 +16,7 @@ import torch  # noqa: F401  (loads the HIP runtime this library must share)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmi355x_rec.so")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class MiError(RuntimeError):
@@ -30,8 +30,17 @@ class OptHparams(C.Structure):
                 ("l2", C.c_float)]
 
 
+AMAX_SLOTS = 64      # MI_AMAX_SLOTS: floats per abs-max vector
+
+
+class GemmAmax(C.Structure):
+    """mi_gemm_amax_t: device pointers to the abs-max vectors of a GEMM's operands / result."""
+    _fields_ = [("a", C.c_void_p), ("b", C.c_void_p), ("out", C.c_void_p)]
+
+
 _p = C.c_void_p
 _i32, _i64, _u64, _f32, _sz = C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_size_t
+_amax = C.POINTER(GemmAmax)
 
 # name -> (restype, argtypes); mirrors include/mi355x_rec.h declaration by declaration
 SIGNATURES = {
@@ -42,7 +51,7 @@ SIGNATURES = {
     "mi_hash_bucket_i64": (_i32, [_p, _i64, _i64, _p]),
     "mi_hash_bucket_bytes": (_i32, [_p, _p, _i64, _i64, _p]),
     "mi_bucketize_f32": (_i32, [_p, _i64, _p, _i32, _p]),
-    "mi_embed_fm_linear_fwd": (_i32, [_p, _p, _p, _p, _i64, _i32, _i32, _p, _i64, _p, _p, _p, _p]),
+    "mi_embed_fm_linear_fwd": (_i32, [_p, _p, _p, _p, _i64, _i32, _i32, _p, _i64, _p, _p, _p, _p, _p]),
     "mi_gather_rows": (_i32, [_p, _p, _p, _i64, _i32, _p, _p, _p]),
     "mi_numeric_embed_fwd": (_i32, [_p, _p, _p, _i64, _i32, _i32, _p, _i64, _i64, _p, _p, _p, _p]),
     "mi_embed_fm_linear_bwd": (_i32, [_p, _i64, _p, _i64, _p, _p, _p, _p, _i64, _i32, _i32, _p, _p, _p]),
@@ -60,16 +69,17 @@ SIGNATURES = {
                                C.POINTER(OptHparams), _p]),
     "mi_sparse_apply_fused": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _i64, _p, _p, _p, _i32,
                                      _i32, _i32, C.POINTER(OptHparams), _p]),
-    "mi_dense_fwd_gathered": (_i32, [_p, _p, _p, _i32, _i32, _p, _p, _p, _i64, _i64, _i32, _i32, _f32, _u64, _p]),
-    "mi_dense_bwd_weight_gathered": (_i32, [_p, _p, _p, _i32, _i32, _p, _i64, _p, _p, _i64, _i32, _p, _sz, _p]),
+    "mi_dense_fwd_gathered": (_i32, [_p, _p, _p, _i32, _i32, _p, _p, _p, _i64, _i64, _i32, _i32, _f32, _u64, _amax, _p]),
+    "mi_dense_bwd_weight_gathered": (_i32, [_p, _p, _p, _i32, _i32, _p, _i64, _p, _p, _i64, _i32, _p, _sz, _amax, _p]),
     "mi_sparse_catchup": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p, _f32, _f32,
                                  _f32, _p]),
     "mi_set_gemm_mode": (_i32, [_i32]),
+    "mi_absmax": (_i32, [_p, _i64, _p, _p]),
     "mi_get_gemm_mode": (_i32, []),
-    "mi_dense_fwd": (_i32, [_p, _i64, _p, _p, _p, _i64, _i64, _i32, _i32, _i32, _f32, _u64, _p]),
-    "mi_dense_bwd_data": (_i32, [_p, _i64, _p, _p, _i64, _p, _i64, _i64, _i32, _i32, _f32, _p]),
+    "mi_dense_fwd": (_i32, [_p, _i64, _p, _p, _p, _i64, _i64, _i32, _i32, _i32, _f32, _u64, _amax, _p]),
+    "mi_dense_bwd_data": (_i32, [_p, _i64, _p, _p, _i64, _p, _i64, _i64, _i32, _i32, _f32, _amax, _p]),
     "mi_dense_bwd_weight_workspace_bytes": (_sz, [_i64, _i32, _i32]),
-    "mi_dense_bwd_weight": (_i32, [_p, _i64, _p, _i64, _p, _p, _i64, _i32, _i32, _p, _sz, _p]),
+    "mi_dense_bwd_weight": (_i32, [_p, _i64, _p, _i64, _p, _p, _i64, _i32, _i32, _p, _sz, _amax, _p]),
     "mi_head_workspace_bytes": (_sz, [_i64]),
     "mi_sigmoid_ce_head": (_i32, [_p, _p, _p, _p, _p, _i64, _f32, _p, _p, _p, _p, _p, _sz, _p]),
     "mi_colsum_workspace_bytes": (_sz, [_i64, _i32]),

@@ -157,7 +157,7 @@ class DeepFM:
     def __init__(self, vocab_sizes, n_numeric=0, embedding_size=4, hidden_units=(16, 16),
                  use_linear=True, use_mf=True, use_dnn=True, dropout=0.0, optimizer=None,
                  linear_optimizer=None, reduction="mean", device="cuda", seed=0, shard=None,
-                 gemm="bf16x3", _kernels=None):
+                 gemm="f16x2", _kernels=None):
         if len(vocab_sizes) + n_numeric == 0:
             raise ValueError("At least 1 feature column of categorical_columns or numeric_columns "
                              "must be specified.")            # deep_fm.py:31-32
@@ -238,11 +238,16 @@ class DeepFM:
         # Single GPU without numeric columns: layer 1 of the MLP reads its input straight from the
         # embedding table (gathered GEMM operand) and the concat [B, F*E] is never materialised.
         self.gather_mlp = self.use_dnn and self.n_numeric == 0 and self.shard is None
-        # Matrix-pipe path of the MLP GEMMs: "bf16x3" (exact 3-way bf16 split of the fp32 operands,
-        # fp32 accumulate: fp32-level error at 2.7x the MFMA rate) or "fp32" (fp32-input MFMA).
-        if gemm not in ("bf16x3", "fp32"):
-            raise ValueError("gemm must be 'bf16x3' or 'fp32'")
+        # Matrix-pipe path of the MLP GEMMs (all: fp32 in, fp32 accumulate, fp32-level error):
+        #   "f16x2"  operands scaled by a power of two and split into fp16 high + low parts, three
+        #            products per k-step; every kernel that produces a GEMM operand also emits its
+        #            abs-max (self._amax), so the scales cost no extra pass;
+        #   "bf16x3" three bf16 parts, six products, no scales;   "fp32"  fp32-input MFMA.
+        if gemm not in ("f16x2", "bf16x3", "fp32"):
+            raise ValueError("gemm must be 'f16x2', 'bf16x3' or 'fp32'")
         self.gemm = gemm
+        self._amax = torch.zeros(_lib.AMAX_SLOTS * (2 * len(self.layers) + 4), dtype=torch.float32, device=self.device)
+        self._amax_idx = {}
 
     # ------------------------------------------------------------------ variables
     def _slots(self, like, spec):
@@ -337,6 +342,19 @@ class DeepFM:
             self._ws[name] = cur
         return cur
 
+    def _av(self, name):
+        """The abs-max vector called `name` (a slice of self._amax; zeroed by _forward each step)."""
+        i = self._amax_idx.setdefault(name, len(self._amax_idx))
+        return self._amax[i * _lib.AMAX_SLOTS:(i + 1) * _lib.AMAX_SLOTS]
+
+    def _ga(self, a, b, out):
+        """mi_gemm_amax_t for one GEMM call: names of the operands' / result's abs-max vectors.
+        None unless gemm == 'f16x2' (the library then takes the bf16x3 or fp32 path)."""
+        if self.gemm != "f16x2":
+            return None
+        p = lambda n: None if n is None else ptr(self._av(n))
+        return _lib.GemmAmax(p(a), p(b), p(out))
+
     def _layer_seed(self, layer):
         rank = 0 if self.shard is None else self.shard.rank
         return (self.seed * 0x9E3779B97F4A7C15 + (self.step + 1) * 1000003 + layer * 7919 + rank * 104729) & (2 ** 64 - 1)
@@ -366,18 +384,27 @@ class DeepFM:
             sumv = self._buf("sumv", (B, self.E)) if self.use_mf else None
             fm = self._buf("fm", (B,)) if self.use_mf else None
         lin = self._buf("lin", (B,)) if self.use_linear else None
-        if concat is not None or sumv is not None or lin is not None:
+        f16 = self.gemm == "f16x2" and self.use_dnn
+        if f16:
+            self._amax.zero_()
+        rows_amax = self._av("x0") if (f16 and gathered) else None
+        if concat is not None or sumv is not None or lin is not None or rows_amax is not None:
             k.mi_embed_fm_linear_fwd(table if self.use_emb else None, lin_w if self.use_linear else None, field_off,
-                                     rid, B, self.F, self.E, concat, ld, sumv, fm, lin)
+                                     rid, B, self.F, self.E, concat, ld, sumv, fm, lin, rows_amax)
         if self.n_numeric:
             V = self._seg(self.dense, self.num_emb_off, (self.n_numeric, self.E))
             wn = self._seg(self.dense, self.lin_num_off, (self.n_numeric,)) if self.use_linear else None
             k.mi_numeric_embed_fwd(x_num, V, wn, B, self.n_numeric, self.E, concat, ld, self.F * self.E, sumv, fm, lin)
         acts = []
         dnn = None
-        k.query("mi_set_gemm_mode", 1 if self.gemm == "bf16x3" else 0)
+        k.query("mi_set_gemm_mode", 0 if self.gemm == "fp32" else 1)
         if self.use_dnn:
             x, ldx = concat, ld
+            if f16:
+                if not gathered:
+                    k.mi_absmax(concat, B * ld, self._av("x0"))
+                # one bound for every layer's weights: the abs-max over the whole MLP parameter block
+                k.mi_absmax(self.dense, self.dnn_end, self._av("w"))
             keep = 1.0 - self.dropout if (train and self.dropout > 0) else 1.0
             nh = len(self.layers) - 1
             for i, (_, _, fan, h) in enumerate(self.layers):
@@ -385,10 +412,12 @@ class DeepFM:
                 y = self._buf("act%d" % i, (B, h))
                 if i == 0 and gathered:
                     k.mi_dense_fwd_gathered(table, field_off, rid, self.F, self.E, self.kernel(0), self.bias(0), y, h,
-                                            B, h, 0 if last else 1, 1.0 if last else keep, self._layer_seed(0))
+                                            B, h, 0 if last else 1, 1.0 if last else keep, self._layer_seed(0),
+                                            self._ga("x0", "w", "x1"))
                 else:
                     k.mi_dense_fwd(x, ldx, self.kernel(i), self.bias(i), y, h, B, h, fan, 0 if last else 1,
-                                   1.0 if last else keep, self._layer_seed(i))
+                                   1.0 if last else keep, self._layer_seed(i),
+                                   self._ga("x%d" % i, "w", "x%d" % (i + 1)))
                 acts.append(y)
                 x, ldx = y, h
             dnn = acts[-1].view(B)
@@ -527,16 +556,21 @@ class DeepFM:
                 _, _, fan, h = self.layers[i]
                 x = c["acts"][i - 1] if i else c["concat"]
                 ldx = self.layers[i - 1][3] if i else self.D
+                # abs-max of dY: known for every layer but the last (dlogit feeds the N = 1 layer,
+                # which takes the fp32 path anyway); each data gradient emits the next one
+                dyn = "dy%d" % i if i < nh else None
+                ga_w = self._ga("x%d" % i, dyn, None) if dyn else None
+                ga_d = self._ga(dyn, "w", "dy%d" % (i - 1) if i else None) if (dyn or i) else None
                 if i == 0 and c["gathered"]:
                     k.mi_dense_bwd_weight_gathered(self.table, self.field_off, c["ids"], self.F, self.E, dy, lddy,
                                                    self.kernel(0, self.d_grad), self.bias(0, self.d_grad), B, h, ws,
-                                                   ws.numel())
+                                                   ws.numel(), ga_w)
                 else:
                     k.mi_dense_bwd_weight(x, ldx, dy, lddy, self.kernel(i, self.d_grad), self.bias(i, self.d_grad), B,
-                                          h, fan, ws, ws.numel())
+                                          h, fan, ws, ws.numel(), ga_w)
                 dx = self._buf("dact%d" % i, (B, fan))
                 k.mi_dense_bwd_data(dy, lddy, self.kernel(i), x if i else None, ldx, dx, fan, B, h, fan,
-                                    keep if i else 1.0)
+                                    keep if i else 1.0, ga_d)
                 dy, lddy = dx, fan
             d_concat = dy
         if self.n_numeric:

@@ -59,7 +59,7 @@ class NumpyKernels:
         _np(num_uniq)[0] = U
 
     # ---- embedding side ------------------------------------------------------------------
-    def mi_embed_fm_linear_fwd(self, table, lin_w, field_off, ids, B, F, E, concat, ld, sumv, fm, lin):
+    def mi_embed_fm_linear_fwd(self, table, lin_w, field_off, ids, B, F, E, concat, ld, sumv, fm, lin, amax=None):
         rows = _np(ids).astype(np.int64) + _np(field_off)[None, :]
         if table is not None:
             v = _np(table)[rows]                               # [B,F,E]
@@ -117,7 +117,10 @@ class NumpyKernels:
             _np(dw)[:nd] = (_np(dll)[:, None] * _np(x)).sum(0) if dll is not None else 0
 
     # ---- MLP ----------------------------------------------------------------------------------
-    def mi_dense_fwd(self, X, ldx, W, bias, Y, ldy, M, N, K, relu, keep, seed):
+    def mi_absmax(self, x, n, out):
+        pass          # abs-max vectors only steer the HIP kernels' fp16 scales
+
+    def mi_dense_fwd(self, X, ldx, W, bias, Y, ldy, M, N, K, relu, keep, seed, amax=None):
         y = _np(X)[:, :K] @ _np(W) + _np(bias)
         if relu:
             y = np.maximum(y, 0)
@@ -125,14 +128,14 @@ class NumpyKernels:
             y = y * dropout_mask(seed, M, N, keep)
         _np(Y)[:, :N] = y
 
-    def mi_dense_bwd_data(self, dY, lddy, W, Xact, ldxa, dX, lddx, M, N, K, keep):
+    def mi_dense_bwd_data(self, dY, lddy, W, Xact, ldxa, dX, lddx, M, N, K, keep, amax=None):
         dy = _np(dY).reshape(M, -1)[:, :N]
         g = dy @ _np(W).T
         if Xact is not None:
             g = g * (_np(Xact)[:, :K] > 0) * np.float32(np.float32(1.0) / np.float32(keep))
         _np(dX)[:, :K] = g
 
-    def mi_dense_bwd_weight(self, X, ldx, dY, lddy, dW, db, M, N, K, ws, wsb):
+    def mi_dense_bwd_weight(self, X, ldx, dY, lddy, dW, db, M, N, K, ws, wsb, amax=None):
         dy = _np(dY).reshape(M, -1)[:, :N]
         _np(dW)[:] = _np(X)[:, :K].T @ dy
         if db is not None:
@@ -226,11 +229,11 @@ class NumpyKernels:
         rows = _np(ids).astype(np.int64) + _np(field_off)[None, :]
         return _np(table)[rows].reshape(len(rows), F * E)
 
-    def mi_dense_fwd_gathered(self, table, field_off, ids, F, E, W, bias, Y, ldy, M, N, relu, keep, seed):
+    def mi_dense_fwd_gathered(self, table, field_off, ids, F, E, W, bias, Y, ldy, M, N, relu, keep, seed, amax=None):
         X = torch.from_numpy(self._concat(table, field_off, ids, F, E))
         self.mi_dense_fwd(X, F * E, W, bias, Y, ldy, M, N, F * E, relu, keep, seed)
 
-    def mi_dense_bwd_weight_gathered(self, table, field_off, ids, F, E, dY, lddy, dW, db, M, N, ws, wsb):
+    def mi_dense_bwd_weight_gathered(self, table, field_off, ids, F, E, dY, lddy, dW, db, M, N, ws, wsb, amax=None):
         X = torch.from_numpy(self._concat(table, field_off, ids, F, E))
         self.mi_dense_bwd_weight(X, F * E, dY, lddy, dW, db, M, N, F * E, ws, wsb)
 

@@ -59,7 +59,7 @@ def test_embed_fm_linear_fwd(lib, E, B, F):
     fm = torch.empty(B, device="cuda")
     lin = torch.empty(B, device="cuda")
     _chk(lib.mi_embed_fm_linear_fwd(_p(t), _p(lw), _p(fo), _p(di), B, F, E, _p(concat), ld, _p(sumv), _p(fm),
-                                    _p(lin), _st()))
+                                    _p(lin), None, _st()))
     rows = off[:-1][None, :] + ids
     ref = table[rows]                                  # [B,F,E]
     got = concat.cpu().numpy()
@@ -86,7 +86,7 @@ def test_embed_fwd_linear_only_and_gather_rows(lib):
     ids = np.stack([rng.integers(0, v, B) for v in vocab], 1).astype(np.int32)
     lw, fo, di = dev(lin_w), dev(off[:-1].copy()), dev(ids)
     lin = torch.empty(B, device="cuda")
-    _chk(lib.mi_embed_fm_linear_fwd(None, _p(lw), _p(fo), _p(di), B, F, E, None, 0, None, None, _p(lin), _st()))
+    _chk(lib.mi_embed_fm_linear_fwd(None, _p(lw), _p(fo), _p(di), B, F, E, None, 0, None, None, _p(lin), None, _st()))
     rows = (off[:-1][None, :] + ids)
     ref = np.zeros(B, np.float32)
     for f in range(F):
@@ -137,7 +137,7 @@ def test_dense_fwd(lib, M, N, K, relu):
     b = rng.standard_normal(N).astype(np.float32)
     Y = torch.empty(M, N, device="cuda")
     x, w, bb = dev(X), dev(W), dev(b)
-    _chk(lib.mi_dense_fwd(_p(x), K, _p(w), _p(bb), _p(Y), N, M, N, K, relu, 1.0, 0, _st()))
+    _chk(lib.mi_dense_fwd(_p(x), K, _p(w), _p(bb), _p(Y), N, M, N, K, relu, 1.0, 0, None, _st()))
     ref = X.astype(np.float64) @ W.astype(np.float64) + b
     pre = ref.copy()
     if relu:
@@ -156,8 +156,8 @@ def test_dense_fwd_dropout_mask_matches_host_replica(lib):
     x, w, bb = dev(X), dev(W), dev(b)
     Y0 = torch.empty(M, N, device="cuda"); Y1 = torch.empty(M, N, device="cuda")
     seed, keep = 0x1234567, 0.9
-    _chk(lib.mi_dense_fwd(_p(x), K, _p(w), _p(bb), _p(Y0), N, M, N, K, 1, 1.0, seed, _st()))
-    _chk(lib.mi_dense_fwd(_p(x), K, _p(w), _p(bb), _p(Y1), N, M, N, K, 1, keep, seed, _st()))
+    _chk(lib.mi_dense_fwd(_p(x), K, _p(w), _p(bb), _p(Y0), N, M, N, K, 1, 1.0, seed, None, _st()))
+    _chk(lib.mi_dense_fwd(_p(x), K, _p(w), _p(bb), _p(Y1), N, M, N, K, 1, keep, seed, None, _st()))
     mask = dropout_mask(seed, M, N, keep)
     assert 0.85 < (mask > 0).mean() < 0.95
     assert np.array_equal(Y1.cpu().numpy(), Y0.cpu().numpy() * mask)   # bit exact: y * (1/keep) or 0
@@ -172,18 +172,18 @@ def test_dense_bwd_data_and_weight(lib, M, N, K):
     x, w, dy = dev(X), dev(W), dev(dY)
     dX = torch.empty(M, K, device="cuda")
     keep = 0.8
-    _chk(lib.mi_dense_bwd_data(_p(dy), N, _p(w), _p(x), K, _p(dX), K, M, N, K, keep, _st()))
+    _chk(lib.mi_dense_bwd_data(_p(dy), N, _p(w), _p(x), K, _p(dX), K, M, N, K, keep, None, _st()))
     full = dY.astype(np.float64) @ W.astype(np.float64).T
     ref = full * (X > 0) * np.float64(np.float32(1.0) / np.float32(keep))
     scale = np.sqrt(np.mean(full * full)) + 1e-30
     assert np.max(np.abs(dX.cpu().numpy() - ref)) / scale < 2 * TOL
-    _chk(lib.mi_dense_bwd_data(_p(dy), N, _p(w), None, K, _p(dX), K, M, N, K, 1.0, _st()))
+    _chk(lib.mi_dense_bwd_data(_p(dy), N, _p(w), None, K, _p(dX), K, M, N, K, 1.0, None, _st()))
     assert np.max(np.abs(dX.cpu().numpy() - full)) / scale < TOL
     # weight + bias gradient (split-K over M)
     nb = lib.mi_dense_bwd_weight_workspace_bytes(M, N, K)
     ws = torch.empty(nb + 256, dtype=torch.uint8, device="cuda")
     dW = torch.empty(K, N, device="cuda"); db = torch.empty(N, device="cuda")
-    _chk(lib.mi_dense_bwd_weight(_p(x), K, _p(dy), N, _p(dW), _p(db), M, N, K, _p(ws), ws.numel(), _st()))
+    _chk(lib.mi_dense_bwd_weight(_p(x), K, _p(dy), N, _p(dW), _p(db), M, N, K, _p(ws), ws.numel(), None, _st()))
     refW = X.astype(np.float64).T @ dY.astype(np.float64)
     sW = np.sqrt(np.mean(refW * refW)) + 1e-30
     assert np.max(np.abs(dW.cpu().numpy() - refW)) / sW < TOL
@@ -191,7 +191,7 @@ def test_dense_bwd_data_and_weight(lib, M, N, K):
     assert np.max(np.abs(db.cpu().numpy() - refb)) / (np.sqrt(np.mean(refb * refb)) + 1e-30) < TOL
     # reproducible: a second run gives the same bits
     dW2 = torch.empty(K, N, device="cuda")
-    _chk(lib.mi_dense_bwd_weight(_p(x), K, _p(dy), N, _p(dW2), None, M, N, K, _p(ws), ws.numel(), _st()))
+    _chk(lib.mi_dense_bwd_weight(_p(x), K, _p(dy), N, _p(dW2), None, M, N, K, _p(ws), ws.numel(), None, _st()))
     assert torch.equal(dW, dW2)
 
 
@@ -210,17 +210,17 @@ def test_gathered_layer1_matches_materialised_bitwise(lib, B, F, E, N):
     dY = rng.standard_normal((B, N)).astype(np.float32)
     t, fo, di, w, bb, dy = dev(table), dev(off[:-1].copy()), dev(ids), dev(W), dev(b), dev(dY)
     concat = torch.empty(B, K, device="cuda")
-    _chk(lib.mi_embed_fm_linear_fwd(_p(t), None, _p(fo), _p(di), B, F, E, _p(concat), K, None, None, None, _st()))
+    _chk(lib.mi_embed_fm_linear_fwd(_p(t), None, _p(fo), _p(di), B, F, E, _p(concat), K, None, None, None, None, _st()))
     Y0 = torch.empty(B, N, device="cuda"); Y1 = torch.empty(B, N, device="cuda")
-    _chk(lib.mi_dense_fwd(_p(concat), K, _p(w), _p(bb), _p(Y0), N, B, N, K, 1, 0.9, 77, _st()))
-    _chk(lib.mi_dense_fwd_gathered(_p(t), _p(fo), _p(di), F, E, _p(w), _p(bb), _p(Y1), N, B, N, 1, 0.9, 77, _st()))
+    _chk(lib.mi_dense_fwd(_p(concat), K, _p(w), _p(bb), _p(Y0), N, B, N, K, 1, 0.9, 77, None, _st()))
+    _chk(lib.mi_dense_fwd_gathered(_p(t), _p(fo), _p(di), F, E, _p(w), _p(bb), _p(Y1), N, B, N, 1, 0.9, 77, None, _st()))
     assert torch.equal(Y0, Y1)
     ws = torch.empty(lib.mi_dense_bwd_weight_workspace_bytes(B, N, K) + 256, dtype=torch.uint8, device="cuda")
     dW0 = torch.empty(K, N, device="cuda"); dW1 = torch.empty(K, N, device="cuda")
     db0 = torch.empty(N, device="cuda"); db1 = torch.empty(N, device="cuda")
-    _chk(lib.mi_dense_bwd_weight(_p(concat), K, _p(dy), N, _p(dW0), _p(db0), B, N, K, _p(ws), ws.numel(), _st()))
+    _chk(lib.mi_dense_bwd_weight(_p(concat), K, _p(dy), N, _p(dW0), _p(db0), B, N, K, _p(ws), ws.numel(), None, _st()))
     _chk(lib.mi_dense_bwd_weight_gathered(_p(t), _p(fo), _p(di), F, E, _p(dy), N, _p(dW1), _p(db1), B, N, _p(ws),
-                                          ws.numel(), _st()))
+                                          ws.numel(), None, _st()))
     assert torch.equal(dW0, dW1) and torch.equal(db0, db1)
     ref = table[off[:-1][None, :] + ids].reshape(B, K).astype(np.float64).T @ dY.astype(np.float64)
     assert np.max(np.abs(dW1.cpu().numpy() - ref)) / (np.sqrt(np.mean(ref * ref)) + 1e-30) < TOL
@@ -241,8 +241,8 @@ def test_bf16x3_and_fp32_gemm_modes_agree(lib, M, N, K):
     for tag, mode in (("bf16x3", 1), ("fp32", 0)):
         _chk(lib.mi_set_gemm_mode(mode))
         Y = torch.empty(M, N, device="cuda"); dX = torch.empty(M, K, device="cuda")
-        _chk(lib.mi_dense_fwd(_p(x), K, _p(w), _p(bb), _p(Y), N, M, N, K, 1, 0.9, 5, _st()))
-        _chk(lib.mi_dense_bwd_data(_p(dy), N, _p(w), _p(x), K, _p(dX), K, M, N, K, 0.9, _st()))
+        _chk(lib.mi_dense_fwd(_p(x), K, _p(w), _p(bb), _p(Y), N, M, N, K, 1, 0.9, 5, None, _st()))
+        _chk(lib.mi_dense_bwd_data(_p(dy), N, _p(w), _p(x), K, _p(dX), K, M, N, K, 0.9, None, _st()))
         outs[tag] = (Y.cpu(), dX.cpu())
     _chk(lib.mi_set_gemm_mode(1))
     pre = X.astype(np.float64) @ W.astype(np.float64) + b
@@ -269,11 +269,126 @@ def test_bf16x3_split_error_is_fp32_level(lib):
     for mode in (0, 1):
         _chk(lib.mi_set_gemm_mode(mode))
         Y = torch.empty(M, N, device="cuda")
-        _chk(lib.mi_dense_fwd(_p(x), K, _p(w), _p(bb), _p(Y), N, M, N, K, 0, 1.0, 0, _st()))
+        _chk(lib.mi_dense_fwd(_p(x), K, _p(w), _p(bb), _p(Y), N, M, N, K, 0, 1.0, 0, None, _st()))
         err[mode] = float(np.max(np.abs(Y.cpu().numpy() - ref) / mag))
     _chk(lib.mi_set_gemm_mode(1))
     assert err[0] < 2e-6 and err[1] < 2e-6, err            # both ~ a few fp32 ulps of sum|a||b|
     assert err[1] < 4 * err[0] + 1e-7, err
+
+
+def _amax_vec(lib, t):
+    """abs-max vector (mi_gemm_amax_t entry) of a device tensor via mi_absmax"""
+    from mi355x_rec import _lib as L
+    v = torch.zeros(L.AMAX_SLOTS, device="cuda")
+    _chk(lib.mi_absmax(_p(t), t.numel(), _p(v), _st()))
+    return v
+
+
+def _ga(a, b, out=None):
+    from mi355x_rec import _lib as L
+    return L.GemmAmax(_p(a), _p(b), None if out is None else _p(out))
+
+
+# whole-tile shapes take the predicate-free kernels, the others the any-shape ones
+F16_SHAPES = [(256, 128, 64), (1024, 512, 1664), (384, 256, 512), (300, 130, 70), (129, 128, 96), (4096, 384, 264)]
+
+
+@pytest.mark.parametrize("M,N,K", F16_SHAPES)
+def test_f16x2_gemms_against_fp64(lib, M, N, K):
+    """The scaled fp16 high/low split (three products, abs-max supplied): forward with bias, relu and
+    dropout, masked data gradient, weight + bias gradient, all against fp64; and the abs-max the
+    forward epilogue emits is exactly max |Y|."""
+    rng = np.random.default_rng(M + 7 * N + K)
+    X = np.maximum(rng.standard_normal((M, K)), 0).astype(np.float32)
+    W = (rng.standard_normal((K, N)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    dY = (rng.standard_normal((M, N)) * 1e-5).astype(np.float32)          # gradient-sized values (below fp16's normal range)
+    x, w, bb, dy = dev(X), dev(W), dev(b), dev(dY)
+    ax, aw, ady = _amax_vec(lib, x), _amax_vec(lib, w), _amax_vec(lib, dy)
+    from mi355x_rec import _lib as L
+    ay = torch.zeros(L.AMAX_SLOTS, device="cuda")
+    Y = torch.empty(M, N, device="cuda"); dX = torch.empty(M, K, device="cuda")
+    _chk(lib.mi_dense_fwd(_p(x), K, _p(w), _p(bb), _p(Y), N, M, N, K, 1, 0.9, 5, _ga(ax, aw, ay), _st()))
+    pre = X.astype(np.float64) @ W.astype(np.float64) + b
+    ref = np.maximum(pre, 0) * dropout_mask(5, M, N, 0.9)
+    assert np.max(np.abs(Y.cpu().numpy() - ref)) / np.sqrt(np.mean(pre * pre)) < TOL
+    assert float(ay.max()) == float(Y.abs().max())
+    _chk(lib.mi_dense_bwd_data(_p(dy), N, _p(w), _p(x), K, _p(dX), K, M, N, K, 0.9, _ga(ady, aw), _st()))
+    full = dY.astype(np.float64) @ W.astype(np.float64).T
+    refd = full * (X > 0) * np.float64(np.float32(1.0) / np.float32(0.9))
+    assert np.max(np.abs(dX.cpu().numpy() - refd)) / np.sqrt(np.mean(full * full)) < 2 * TOL
+    ws = torch.empty(lib.mi_dense_bwd_weight_workspace_bytes(M, N, K) + 256, dtype=torch.uint8, device="cuda")
+    dW = torch.empty(K, N, device="cuda"); db = torch.empty(N, device="cuda")
+    _chk(lib.mi_dense_bwd_weight(_p(x), K, _p(dy), N, _p(dW), _p(db), M, N, K, _p(ws), ws.numel(), _ga(ax, ady), _st()))
+    refW = X.astype(np.float64).T @ dY.astype(np.float64)
+    assert np.max(np.abs(dW.cpu().numpy() - refW)) / (np.sqrt(np.mean(refW * refW)) + 1e-30) < TOL
+    refb = dY.astype(np.float64).sum(0)
+    assert np.max(np.abs(db.cpu().numpy() - refb)) / (np.sqrt(np.mean(refb * refb)) + 1e-30) < TOL
+
+
+@pytest.mark.parametrize("sx,sw", [(1.0, 1.0), (1e-20, 1e12), (3e18, 2e-9), (1e-30, 1e-6)])
+def test_f16x2_error_is_fp32_level_at_any_magnitude(lib, sx, sw):
+    """Against fp64, relative to sum |a||b|, the f16x2 path must be as accurate as the fp32-input MFMA
+    whatever the operands' magnitudes (the power-of-two scales are exact) and with a wide dynamic
+    range inside an operand (small elements lose low bits only relative to the largest)."""
+    rng = np.random.default_rng(1)
+    M, N, K = 512, 256, 2048
+    X = (rng.standard_normal((M, K)) * np.exp(rng.uniform(-8, 8, (M, K))) * sx).astype(np.float32)
+    W = (rng.standard_normal((K, N)) * np.exp(rng.uniform(-8, 8, (K, N))) * sw).astype(np.float32)
+    x, w, bb = dev(X), dev(W), dev(np.zeros(N, np.float32))
+    ref = X.astype(np.float64) @ W.astype(np.float64)
+    mag = np.abs(X).astype(np.float64) @ np.abs(W).astype(np.float64)
+    err = {}
+    ax, aw = _amax_vec(lib, x), _amax_vec(lib, w)          # must outlive the calls: the struct holds raw pointers
+    for tag, mode, ga in (("fp32", 0, None), ("f16x2", 1, _ga(ax, aw))):
+        _chk(lib.mi_set_gemm_mode(mode))
+        Y = torch.empty(M, N, device="cuda")
+        _chk(lib.mi_dense_fwd(_p(x), K, _p(w), _p(bb), _p(Y), N, M, N, K, 0, 1.0, 0, ga, _st()))
+        assert torch.isfinite(Y).all()
+        err[tag] = float(np.max(np.abs(Y.cpu().numpy() - ref) / mag))
+    _chk(lib.mi_set_gemm_mode(1))
+    assert err["fp32"] < 2e-6 and err["f16x2"] < 2e-6, err
+    assert err["f16x2"] < 4 * err["fp32"] + 1e-7, err
+
+
+@pytest.mark.parametrize("B,F,E,N", [(256, 26, 64, 512), (384, 4, 32, 128), (300, 26, 64, 512), (129, 5, 12, 40)])
+def test_f16x2_gathered_layer1_matches_materialised_bitwise(lib, B, F, E, N):
+    """Gathered layer-1 operand in f16x2 mode (whole-tile and any-shape kernels): the abs-max comes
+    from the embedding kernel, the results equal the materialised operand's bit for bit."""
+    rng = np.random.default_rng(B + F + E)
+    vocab = rng.integers(2, 60, F)
+    off = np.concatenate([[0], np.cumsum(vocab)]).astype(np.int64)
+    table = rng.standard_normal((int(off[-1]), E)).astype(np.float32)
+    ids = np.stack([rng.integers(0, v, B) for v in vocab], 1).astype(np.int32)
+    K = F * E
+    W = (rng.standard_normal((K, N)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    dY = (rng.standard_normal((B, N)) * 1e-4).astype(np.float32)
+    t, fo, di, w, bb, dy = dev(table), dev(off[:-1].copy()), dev(ids), dev(W), dev(b), dev(dY)
+    from mi355x_rec import _lib as L
+    concat = torch.empty(B, K, device="cuda")
+    arows = torch.zeros(L.AMAX_SLOTS, device="cuda")
+    _chk(lib.mi_embed_fm_linear_fwd(_p(t), None, _p(fo), _p(di), B, F, E, _p(concat), K, None, None, None, _p(arows), _st()))
+    assert float(arows.max()) == float(concat.abs().max())
+    aw, ady = _amax_vec(lib, w), _amax_vec(lib, dy)
+    Y0 = torch.empty(B, N, device="cuda"); Y1 = torch.empty(B, N, device="cuda")
+    _chk(lib.mi_dense_fwd(_p(concat), K, _p(w), _p(bb), _p(Y0), N, B, N, K, 1, 0.9, 77, _ga(arows, aw), _st()))
+    _chk(lib.mi_dense_fwd_gathered(_p(t), _p(fo), _p(di), F, E, _p(w), _p(bb), _p(Y1), N, B, N, 1, 0.9, 77,
+                                   _ga(arows, aw), _st()))
+    assert torch.equal(Y0, Y1)
+    pre = concat.cpu().numpy().astype(np.float64) @ W.astype(np.float64) + b
+    ref = np.maximum(pre, 0) * dropout_mask(77, B, N, 0.9)
+    assert np.max(np.abs(Y1.cpu().numpy() - ref)) / np.sqrt(np.mean(pre * pre)) < TOL
+    ws = torch.empty(lib.mi_dense_bwd_weight_workspace_bytes(B, N, K) + 256, dtype=torch.uint8, device="cuda")
+    dW0 = torch.empty(K, N, device="cuda"); dW1 = torch.empty(K, N, device="cuda")
+    db0 = torch.empty(N, device="cuda"); db1 = torch.empty(N, device="cuda")
+    _chk(lib.mi_dense_bwd_weight(_p(concat), K, _p(dy), N, _p(dW0), _p(db0), B, N, K, _p(ws), ws.numel(),
+                                 _ga(arows, ady), _st()))
+    _chk(lib.mi_dense_bwd_weight_gathered(_p(t), _p(fo), _p(di), F, E, _p(dy), N, _p(dW1), _p(db1), B, N, _p(ws),
+                                          ws.numel(), _ga(arows, ady), _st()))
+    assert torch.equal(dW0, dW1) and torch.equal(db0, db1)
+    ref = concat.cpu().numpy().astype(np.float64).T @ dY.astype(np.float64)
+    assert np.max(np.abs(dW1.cpu().numpy() - ref)) / (np.sqrt(np.mean(ref * ref)) + 1e-30) < TOL
 
 
 @pytest.mark.parametrize("name", ["Adam", "Ftrl"])

@@ -89,12 +89,19 @@ def _compare_vars(m, p, atol):
         assert np.max(np.abs(g["lin_num"] - p.lin_num)) < atol
 
 
+# Multi-step Adam trajectories amplify last-bit differences: a unit whose pre-activation is 0 to within
+# rounding can have its relu mask flip between two correctly rounded fp32 GEMMs (seen: one unit at
+# 7e-9 in the config-3-shaped case), and TF-form Adam then moves the few weights whose gradient
+# is near zero by ~lr each step whichever way the sign falls.  The fp32-input MFMA path happens
+# not to flip on these seeds and pins the trajectory tightly; the default f16x2 path — equally
+# accurate against fp64, tests/test_hip_kernels.py — gets the bound such a flip implies.
+@pytest.mark.parametrize("gemm,logit_tol,var_atol", [("fp32", 5e-5, 2e-6), ("f16x2", 3e-4, 3e-3)])
 @pytest.mark.parametrize("vocab,E,hidden,B,nn", CONFIGS)
-def test_adam_training_matches_oracle(vocab, E, hidden, B, nn):
+def test_adam_training_matches_oracle(vocab, E, hidden, B, nn, gemm, logit_tol, var_atol):
     """5 train steps with fresh batches (rows sit out steps, duplicates inside a batch): the lazy
     catch-up path must reproduce TF Adam's dense-equivalent sparse update."""
     p, ids, x, y = make_problem(3, vocab, E, hidden, B, n_numeric=nn)
-    m = _engine(vocab, E, hidden, nn)
+    m = _engine(vocab, E, hidden, nn, gemm=gemm)
     m.load_oracle_params(p)
     st = O.TrainState(p, OO.Hyper("Adam", 0.001))
     rng = np.random.default_rng(0)
@@ -104,8 +111,10 @@ def test_adam_training_matches_oracle(vocab, E, hidden, B, nn):
         loss_o, logit_o = O.train_step(p, st, ids_s, y, x)
         loss_g, logit_g = m.train_step(dev(ids_s), dev(y), dev(x))
         assert abs(loss_g.item() - float(loss_o)) / abs(float(loss_o)) < 2e-5, step
-        assert max_err_scaled(logit_g.cpu().numpy(), logit_o) < 5e-5, step
-    _compare_vars(m, p, 2e-6)
+        assert max_err_scaled(logit_g.cpu().numpy(), logit_o) < logit_tol, step
+        if step == 0:                       # one step from identical parameters is not chaotic: tight in every mode
+            assert max_err_scaled(logit_g.cpu().numpy(), logit_o) < 5e-6
+    _compare_vars(m, p, var_atol)
     assert m.step == 5
 
 
@@ -170,7 +179,7 @@ def test_full_size_properties():
     sel = torch.arange(0, B, 997, device="cuda")
     # the materialising form of the gather kernel is an exact copy of the addressed rows
     concat = torch.empty(B, F * E, device="cuda")
-    m.k.mi_embed_fm_linear_fwd(m.table, None, m.field_off, ids, B, F, E, concat, F * E, None, None, None)
+    m.k.mi_embed_fm_linear_fwd(m.table, None, m.field_off, ids, B, F, E, concat, F * E, None, None, None, None)
     concat = concat.view(B, F, E)
     assert torch.equal(concat[sel], m.table[rows[sel]])
     assert "concat" not in m._ws          # the training path never materialises it (gathered layer-1 operand)

@@ -13,7 +13,7 @@ B, F, E = 65536, 26, 64
 g = torch.Generator(device="cuda"); g.manual_seed(0)
 
 
-def run(V, want_lin=True, want_sumv=True, want_concat=False, sorted_ids=False):
+def run(V, want_lin=True, want_sumv=True, want_concat=False, sorted_ids=False, want_amax=False):
     R = V * F
     table = torch.randn(R, E, device="cuda", generator=g)
     lin_w = torch.randn(R, device="cuda", generator=g)
@@ -25,8 +25,9 @@ def run(V, want_lin=True, want_sumv=True, want_concat=False, sorted_ids=False):
     fm = torch.empty(B, device="cuda") if want_sumv else None
     lin = torch.empty(B, device="cuda") if want_lin else None
     concat = torch.empty(B, F * E, device="cuda") if want_concat else None
+    amax = torch.zeros(64, device="cuda") if want_amax else None
     fn = lambda: L.mi_embed_fm_linear_fwd(p(table), p(lin_w) if want_lin else None, p(off), p(ids), B, F, E, p(concat),
-                                          F * E, p(sumv), p(fm), p(lin), st())
+                                          F * E, p(sumv), p(fm), p(lin), p(amax), st())
     assert fn() == 0, L.mi_last_error()
     torch.cuda.synchronize()
     ts = []
@@ -35,8 +36,8 @@ def run(V, want_lin=True, want_sumv=True, want_concat=False, sorted_ids=False):
         s.record(); fn(); e.record(); torch.cuda.synchronize(); ts.append(s.elapsed_time(e))
     ts.sort()
     t = ts[len(ts) // 2]
-    print("V=%8d table %6.2f GB lin=%d sumv=%d concat=%d sorted=%d : %7.1f us  %6.0f GB/s (rows only)" % (
-        V, R * E * 4 / 1e9, want_lin, want_sumv, want_concat, sorted_ids, t * 1e3, B * F * E * 4 / t / 1e6))
+    print("V=%8d table %6.2f GB lin=%d sumv=%d concat=%d sorted=%d amax=%d : %7.1f us  %6.0f GB/s (rows only)" % (
+        V, R * E * 4 / 1e9, want_lin, want_sumv, want_concat, sorted_ids, want_amax, t * 1e3, B * F * E * 4 / t / 1e6))
 
 
 for V in (10_000, 100_000, 1_000_000, 4_000_000):
@@ -45,3 +46,5 @@ run(1_000_000, want_lin=False)
 run(1_000_000, want_lin=False, want_sumv=False) if False else None
 run(1_000_000, want_lin=True, want_sumv=True, want_concat=True)
 run(1_000_000, sorted_ids=True)
+run(1_000_000, want_amax=True)
+run(1_000_000, want_lin=False, want_amax=True)
