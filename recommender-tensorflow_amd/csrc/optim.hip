@@ -193,10 +193,17 @@ __global__ __launch_bounds__(kBlock) void sparse_catchup_k(
     if (table && 4 * l < E) {
       const int64_t o = r * E + 4 * l;
       float4 w = ld4(table + o), m = ld4(tm + o), v = ld4(tv + o);
-      replay(w.x, m.x, v.x, ls + 1, step_to, lr_table, b1, b2, eps);
-      replay(w.y, m.y, v.y, ls + 1, step_to, lr_table, b1, b2, eps);
-      replay(w.z, m.z, v.z, ls + 1, step_to, lr_table, b1, b2, eps);
-      replay(w.w, m.w, v.w, ls + 1, step_to, lr_table, b1, b2, eps);
+      // one loop for the four elements: one lr_t load and one loop counter per step instead of four,
+      // four independent sqrt/divide chains in flight (the arithmetic per element is unchanged)
+      for (int s = ls + 1; s <= step_to; ++s) {
+        const float lr = lr_table[s];
+        m.x = m.x * b1; m.y = m.y * b1; m.z = m.z * b1; m.w = m.w * b1;
+        v.x = v.x * b2; v.y = v.y * b2; v.z = v.z * b2; v.w = v.w * b2;
+        w.x = w.x - (lr * m.x) / (sqrtf(v.x) + eps);
+        w.y = w.y - (lr * m.y) / (sqrtf(v.y) + eps);
+        w.z = w.z - (lr * m.z) / (sqrtf(v.z) + eps);
+        w.w = w.w - (lr * m.w) / (sqrtf(v.w) + eps);
+      }
       st4(table + o, w); st4(tm + o, m); st4(tv + o, v);
     }
     if (lin_w && l == 0) {

@@ -34,9 +34,9 @@ for mode in ("f16x2", "bf16x3"):
             e0.record(); assert fn() == 0; e1.record(); torch.cuda.synchronize()
         buf = np.zeros(64 * 64 * 8, dtype=np.int64)
         assert L.mi_gemm_stamps_read(buf.ctypes.data, buf.nbytes) == 0
-        d = buf.reshape(64, 64, 8)[:, :nk, :5]
-        ph = np.diff(d, axis=2)[:, 2:-1]                # skip the first tiles (cold) and the last
-        tot = np.diff(d[:, :, 0], axis=1)[:, 2:-1]
+        d = buf.reshape(64, 64, 8)[:, 2:nk - 2, :5]      # skip the first tiles (cold) and the peeled last one
+        ph = np.diff(d, axis=2)
+        tot = np.diff(d[:, :, 0], axis=1)
         print("%-6s %-5s kernel %7.1f us | cycles per k-tile %6.0f = main %6.0f + barrier %4.0f + frag reads %4.0f + barrier %4.0f + loop %4.0f"
               % (mode, op, e0.elapsed_time(e1) * 1e3, tot.mean(), ph[..., 0].mean(), ph[..., 1].mean(), ph[..., 2].mean(),
                  ph[..., 3].mean(), tot.mean() - ph.sum(-1).mean()))
