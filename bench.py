@@ -7,11 +7,14 @@
 
 A "step" is one pass of the whole hot path over one synthetic batch that is already resident in
 HBM: unique-row bookkeeping, lazy Adam catch-up, embedding gather + FM + wide linear, the
-[512,256,128] MLP (fp32 MFMA), sigmoid-CE head, full backward, dense + sparse TF-form Adam.
+[512,256,128] MLP (fp32 operands / accumulate / results; the matrix cores are fed a scaled fp16
+high+low split of the operands, three MFMA products per fp32 product), sigmoid-CE head, full
+backward, dense + sparse TF-form Adam.
 Workload (config.workload): trainers.deep_fm with --embedding-size 64 --hidden-units 512 256 128
 --batch-size 65536 (dropout 0.1 = the CLI default), 26 categorical fields x 1,000,000 ids each
 (Criteo-shaped), uniform ids, labels Bernoulli(0.25).  N > 1: one process per GPU, 65536 examples
-per GPU (weak scaling), embedding rows sharded row % N with all-to-all over RCCL.
+per GPU (weak scaling; --scaling strong divides 65536 over the GPUs instead), embedding rows
+sharded row % N with all-to-all over RCCL.
 
 Prints ONE JSON line on rank 0 with `roofline` (embedding gather kernel, HBM bound, timed live
 with HIP events on the launch stream) and `cpu_baseline` (the numpy oracle restating the
@@ -34,8 +37,10 @@ import torch.distributed as dist  # noqa: E402
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 HBM_MEASURED_GBS = 6290.0
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
+MFMA_F16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense f16/bf16 MFMA (no sparsity)
+SPLIT_PRODUCTS = 3            # f16x2 split: MFMA products issued per fp32 product
 
-F, V, E, HIDDEN, B = 26, 1_000_000, 64, [512, 256, 128], 65536
+F, V, E, HIDDEN, B_FULL = 26, 1_000_000, 64, [512, 256, 128], 65536
 DROPOUT = 0.1
 SEED = 20240521
 
@@ -50,10 +55,13 @@ def parse():
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="nccl = RCCL over xGMI (the measured path); gloo only rehearses the N>1 flow on one GPU")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: 65536 examples per GPU (default); strong: 65536 examples over all GPUs")
+    ap.add_argument("--gemm", choices=["f16x2", "bf16x3", "fp32"], default="f16x2", help="matrix-pipe path of the MLP GEMMs")
     return ap.parse_args()
 
 
-def make_batches(n, gen, device, zipf):
+def make_batches(n, gen, device, zipf, B):
     out = []
     for _ in range(n):
         if zipf:
@@ -78,10 +86,28 @@ def kernel_ms(timers):
     return out
 
 
+def mlp_roofline(gemm, flops, gemm_ms):
+    """All dense fwd/bwd GEMM launches of a step against the matrix-pipe peak of the path taken.
+    `achieved` counts ALGORITHMIC fp32 flops (2·M·N·K per GEMM); the split paths issue several
+    16-bit MFMA products per fp32 product, so their peak is the f16/bf16 dense peak divided by that."""
+    ach = flops / (gemm_ms * 1e-3) / 1e12
+    if gemm == "fp32":
+        peak, kern, prod = MFMA_F32_PEAK_TFLOPS, "gemm_f32_k (v_mfma_f32_32x32x2_f32)", 1
+    elif gemm == "bf16x3":
+        peak, kern, prod = MFMA_F16_PEAK_TFLOPS / 6, "gemm_split_k<bf16x3> (v_mfma_f32_32x32x16_bf16, 6 products)", 6
+    else:
+        peak, kern, prod = MFMA_F16_PEAK_TFLOPS / SPLIT_PRODUCTS, "gemm_split_k<f16x2> (v_mfma_f32_32x32x16_f16, 3 products)", SPLIT_PRODUCTS
+    return {"kernel": kern + "; all dense fwd/bwd GEMM launches incl. the N=1 logits layer on gemm_f32_k", "bound": "mfma",
+            "achieved": ach, "peak": peak, "unit": "TFLOP/s (fp32-equivalent)", "frac": ach / peak,
+            "mfma_products_per_fp32_product": prod, "executed_mfma_tflops": ach * prod,
+            "fp32_input_mfma_peak": MFMA_F32_PEAK_TFLOPS, "flops_per_step": flops, "gemm_ms_per_step": gemm_ms}
+
+
 def cpu_baseline():
     """The oracle (numpy restatement of the reference's TF graph incl. the whole-table Adam sweep)
     on this host: same B/F/E/hidden, vocabulary cut to 50k ids per field to bound the run."""
     from oracle import deepfm as O, optimizers as OO
+    B = B_FULL
     v_s, steps = 50_000, 2
     rng = np.random.default_rng(SEED)
     p = O.init_params(rng, [v_s] * F, E, HIDDEN, dtype=np.float32, lin_scale=1e-3)
@@ -121,19 +147,20 @@ def main():
             dist.init_process_group("gloo")
 
     from mi355x_rec.engine import DeepFM, OptimizerSpec
+    B = B_FULL if args.scaling == "weak" else B_FULL // world      # examples per GPU and step
     shard = None
     if world > 1:
         from mi355x_rec.parallel import RowShard
         shard = RowShard(rank, world)
     m = DeepFM([V] * F, embedding_size=E, hidden_units=HIDDEN, dropout=DROPOUT,
-               optimizer=OptimizerSpec("Adam", 0.001), device=device, seed=SEED, shard=shard)
+               optimizer=OptimizerSpec("Adam", 0.001), device=device, seed=SEED, shard=shard, gemm=args.gemm)
     gen = torch.Generator(device=device)
     gen.manual_seed(SEED + rank)
     m.init_variables(gen, lin_scale=1e-3)
     if world > 1:
         from mi355x_rec.parallel import broadcast_dense
         broadcast_dense(m)                       # replicated MLP must start identical on every rank
-    batches = make_batches(8, gen, device, args.dist == "zipf")
+    batches = make_batches(8, gen, device, args.dist == "zipf", B)
 
     def sync():
         torch.cuda.synchronize()
@@ -183,7 +210,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic (%s ids, random-init weights)" % args.dist,
@@ -191,6 +218,9 @@ def main():
                                    "--batch-size 65536 --dropout 0.1, 26 fields x 1M ids (Criteo-shaped), Adam(1e-3)",
                        "per_gpu_batch": B, "global_batch": world * B, "fields": F, "vocab_per_field": V,
                        "embedding_size": E, "hidden_units": HIDDEN,
+                       "gemm": {"f16x2": "fp32 GEMMs via scaled fp16 high+low operand split, fp32 accumulate",
+                                "bf16x3": "fp32 GEMMs via 3-way bf16 operand split, fp32 accumulate",
+                                "fp32": "fp32-input MFMA"}[args.gemm],
                        "parallelism": "dp%d + row-sharded embeddings (all-to-all)" % world if world > 1 else "single GPU"},
             "roofline": {"kernel": "embed_fm_linear_fwd_k (embedding gather + FM + wide linear; read-only form, the "
                                    "MLP gathers its own operand)", "bound": "hbm",
@@ -199,11 +229,8 @@ def main():
                          "algorithmic_bytes_per_launch": gather_bytes, "avg_launch_ms": g_ms,
                          "achieved_total_rw_GBs": total_bytes / (g_ms * 1e-3) / 1e9, "traffic": traffic,
                          "traffic_note": "HBM bytes/launch from rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE), "
-                                         "profiles/r01_pmc_hbm_traffic.md"},
-            "roofline_mlp": {"kernel": "gemm_f32_k (all dense fwd/bwd GEMMs)", "bound": "mfma",
-                             "achieved": flops / (gemm_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS,
-                             "unit": "TFLOP/s", "frac": flops / (gemm_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
-                             "flops_per_step": flops, "gemm_ms_per_step": gemm_ms},
+                                         "profiles/r01_final_pmc_hbm_traffic.md"},
+            "roofline_mlp": mlp_roofline(args.gemm, flops, gemm_ms),
             "kernel_ms_per_step": {k: v[2] / args.steps for k, v in sorted(km.items())},
             "final_loss": final_loss,
         }
