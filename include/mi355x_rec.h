@@ -40,7 +40,7 @@ enum mi_status {
 };
 
 /* ---- library ---------------------------------------------------------------------------- */
-int32_t mi_abi_version(void);       /* bumps when a signature changes (currently 6) */
+int32_t mi_abi_version(void);       /* bumps when a signature changes (currently 7) */
 const char* mi_last_error(void);    /* thread-local, never NULL */
 const char* mi_build_info(void);    /* "gfx950 hipcc <ver>" */
 
@@ -106,9 +106,11 @@ int32_t mi_numeric_embed_fwd(const float* x, const float* V, const float* w_num,
  * (gradient of deep_fm.py:54,81-87,39 w.r.t. the gathered rows; TF: IndexedSlices values).
  * pos [B*F] int32 gives the destination slot p(b,f) (NULL = identity b*F+f); the sharded path
  * uses it to write straight into all-to-all send order.  d_concat may be NULL (no DNN),
- * d_logit_fm may be NULL (no FM), d_lin/d_logit_lin may be NULL (no linear part). */
+ * d_logit_fm may be NULL (no FM), d_lin/d_logit_lin may be NULL (no linear part).  Instead of concat
+ * the gathered rows may be given in slot order (rows [n,E], row of (b,f) at slot pos[b*F+f]: the
+ * receive buffer of the row exchange, when the concat was never materialised). */
 int32_t mi_embed_fm_linear_bwd(const float* d_concat, int64_t ld_dconcat, const float* concat,
-                               int64_t ld_concat, const float* sumv, const float* d_logit_fm,
+                               int64_t ld_concat, const float* rows, const float* sumv, const float* d_logit_fm,
                                const float* d_logit_lin, const int32_t* pos, int64_t B, int32_t F,
                                int32_t E, float* d_rows, float* d_lin, mi_stream_t stream);
 
@@ -140,10 +142,11 @@ int32_t mi_sort_unique_rows(const int32_t* rows, int64_t n, int64_t num_rows_tot
 /* Routing helpers of the row-sharded multi-GPU path (row r lives on rank r % world as local row
  * r / world; the reference's own multi-worker mode is TF's parameter-server placement of whole
  * variables, distributed.md:58-82 — see DESIGN.md "Multi-GPU").
- *   mi_shard_route : owner[i] = rows[i] % world, local_row[i] = rows[i] / world
+ *   mi_shard_route : owner[i] = (i / entries_per_chunk) * world + rows[i] % world (chunk-major key of a
+ *                    pipelined step; entries_per_chunk == 0: one chunk), local_row[i] = rows[i] / world
  *   mi_invert_perm : inv[perm[i]] = i
  *   mi_gather_u32  : out[i] = src[idx[i]] for 4-byte elements (int32 ids or f32 values) */
-int32_t mi_shard_route(const int32_t* rows, int64_t n, int32_t world, int32_t* owner,
+int32_t mi_shard_route(const int32_t* rows, int64_t n, int32_t world, int64_t entries_per_chunk, int32_t* owner,
                        int32_t* local_row, mi_stream_t stream);
 int32_t mi_invert_perm(const int32_t* perm, int64_t n, int32_t* inv, mi_stream_t stream);
 int32_t mi_gather_u32(const void* src, const int32_t* idx, int64_t n, void* out, mi_stream_t stream);
@@ -179,6 +182,9 @@ typedef struct mi_opt_hparams {
  * bias live in one buffer).  slot0/slot1: Adam m,v | Adagrad accum,- | Ftrl accum,linear |
  * RMSProp ms,mom | SGD -,-.  Fused ApplyAdam / ApplyAdagrad / ApplyFtrl / ApplyRMSProp /
  * ApplyGradientDescent semantics. */
+/* y[i] += alpha * x[i]: dense-gradient accumulation over the chunks of a pipelined multi-GPU step */
+int32_t mi_axpy(float* y, const float* x, int64_t n, float alpha, mi_stream_t stream);
+
 int32_t mi_dense_apply(float* param, float* slot0, float* slot1, const float* grad, int64_t n,
                        const mi_opt_hparams* hp, mi_stream_t stream);
 

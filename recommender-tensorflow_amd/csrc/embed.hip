@@ -152,13 +152,14 @@ __global__ __launch_bounds__(kBlock) void gather_rows_k(const float* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------
-// d_rows[p(b,f),:] = d_concat[b,f,:] + dlf[b] * (sumv[b,:] - concat[b,f,:]);  d_lin[p(b,f)] = dll[b]
+// d_rows[p(b,f),:] = d_concat[b,f,:] + dlf[b] * (sumv[b,:] - v(b,f));  d_lin[p(b,f)] = dll[b]
+// v(b,f) = concat[b,f,:], or rows[p(b,f),:] when the gathered rows are held in slot order instead
 template <int LPR>
 __global__ __launch_bounds__(kBlock) void embed_fm_linear_bwd_k(
     const float* __restrict__ d_concat, int64_t lddc, const float* __restrict__ concat, int64_t ldc,
-    const float* __restrict__ sumv, const float* __restrict__ dlf, const float* __restrict__ dll,
-    const int32_t* __restrict__ pos, int64_t B, int F, int E, float* __restrict__ d_rows,
-    float* __restrict__ d_lin) {
+    const float* __restrict__ rows, const float* __restrict__ sumv, const float* __restrict__ dlf,
+    const float* __restrict__ dll, const int32_t* __restrict__ pos, int64_t B, int F, int E,
+    float* __restrict__ d_rows, float* __restrict__ d_lin) {
   const int64_t b = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) / LPR;
   const int l = threadIdx.x & (LPR - 1);
   if (b >= B) return;
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(kBlock) void embed_fm_linear_bwd_k(
       float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
       if (d_concat) g = ld4(d_concat + b * lddc + static_cast<int64_t>(f) * E + eo);
       if (dlf) {
-        const float4 v = ld4(concat + b * ldc + static_cast<int64_t>(f) * E + eo);
+        const float4 v = rows ? ld4(rows + p * E + eo) : ld4(concat + b * ldc + static_cast<int64_t>(f) * E + eo);
         g.x += gf * (sv.x - v.x); g.y += gf * (sv.y - v.y);
         g.z += gf * (sv.z - v.z); g.w += gf * (sv.w - v.w);
       }
@@ -375,7 +376,7 @@ int32_t mi_gather_rows(const float* table, const float* lin_w, const int32_t* ro
 }
 
 int32_t mi_embed_fm_linear_bwd(const float* d_concat, int64_t ld_dconcat, const float* concat,
-                               int64_t ld_concat, const float* sumv, const float* d_logit_fm,
+                               int64_t ld_concat, const float* rows, const float* sumv, const float* d_logit_fm,
                                const float* d_logit_lin, const int32_t* pos, int64_t B, int32_t F,
                                int32_t E, float* d_rows, float* d_lin, mi_stream_t stream) {
   MI_REQUIRE(B >= 0 && F > 0, "embed_fm_linear_bwd: B=%lld F=%d", (long long)B, F);
@@ -389,7 +390,8 @@ int32_t mi_embed_fm_linear_bwd(const float* d_concat, int64_t ld_dconcat, const 
   }
   if (int32_t rc = check_E("embed_fm_linear_bwd", E)) return rc;
   MI_REQUIRE(d_rows, "embed_fm_linear_bwd: d_rows is null");
-  MI_REQUIRE(!d_logit_fm || (concat && sumv), "embed_fm_linear_bwd: FM gradient needs concat and sumv");
+  MI_REQUIRE(!d_logit_fm || ((concat || rows) && sumv), "embed_fm_linear_bwd: FM gradient needs concat (or rows) and sumv");
+  MI_REQUIRE(!rows || (!concat && mi::aligned16(rows)), "embed_fm_linear_bwd: give concat or rows, not both");
   MI_REQUIRE(!d_concat || (ld_dconcat >= (int64_t)F * E && (ld_dconcat & 3) == 0 && mi::aligned16(d_concat)),
              "embed_fm_linear_bwd: d_concat leading dimension/alignment");
   MI_REQUIRE(!concat || (ld_concat >= (int64_t)F * E && (ld_concat & 3) == 0 && mi::aligned16(concat)),
@@ -400,7 +402,7 @@ int32_t mi_embed_fm_linear_bwd(const float* d_concat, int64_t ld_dconcat, const 
   const int64_t blocks = mi::ceil_div(B * lpr, kBlock);
   MI_REQUIRE(blocks <= INT32_MAX, "embed_fm_linear_bwd: grid too large");
   MI_DISPATCH_LPR(lpr, (embed_fm_linear_bwd_k<L><<<dim3((unsigned)blocks), dim3(kBlock), 0, mi::as_stream(stream)>>>(
-                           d_concat, ld_dconcat, concat, ld_concat, sumv, d_logit_fm,
+                           d_concat, ld_dconcat, concat, ld_concat, rows, sumv, d_logit_fm,
                            d_lin ? d_logit_lin : nullptr, pos, B, F, E, d_rows, d_lin)));
   MI_CHECK_LAUNCH("embed_fm_linear_bwd");
   return MI_OK;

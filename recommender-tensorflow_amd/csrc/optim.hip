@@ -247,7 +247,22 @@ static int32_t check_hp(const char* who, const mi_opt_hparams* hp) {
   return MI_OK;
 }
 
+// y += alpha * x (gradient accumulation over the chunks of a pipelined multi-GPU step)
+__global__ __launch_bounds__(kBlock) void axpy_k(float* __restrict__ y, const float* __restrict__ x, int64_t n, float alpha) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i < n) y[i] = y[i] + alpha * x[i];
+}
+
 extern "C" {
+
+int32_t mi_axpy(float* y, const float* x, int64_t n, float alpha, mi_stream_t stream) {
+  MI_REQUIRE(n >= 0 && (n == 0 || (x && y)), "axpy: n=%lld", (long long)n);
+  if (n == 0) return MI_OK;
+  axpy_k<<<dim3((unsigned)mi::ceil_div(n, kBlock)), dim3(kBlock), 0, mi::as_stream(stream)>>>(y, x, n, alpha);
+  MI_CHECK_LAUNCH("axpy");
+  return MI_OK;
+}
+
 
 int32_t mi_dense_apply(float* param, float* slot0, float* slot1, const float* grad, int64_t n,
                        const mi_opt_hparams* hp, mi_stream_t stream) {

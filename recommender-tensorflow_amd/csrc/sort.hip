@@ -312,12 +312,14 @@ int32_t mi_sort_unique_rows(const int32_t* rows, int64_t n, int64_t num_rows_tot
 namespace {
 
 __global__ __launch_bounds__(kBlock) void shard_route_k(const int32_t* __restrict__ rows, int64_t n,
-                                                        int world, int32_t* __restrict__ owner,
+                                                        int world, int64_t entries_per_chunk,
+                                                        int32_t* __restrict__ owner,
                                                         int32_t* __restrict__ local_row) {
   const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
   if (i >= n) return;
   const int32_t r = rows[i];
-  owner[i] = r % world;
+  const int32_t chunk = entries_per_chunk > 0 ? static_cast<int32_t>(i / entries_per_chunk) : 0;
+  owner[i] = chunk * world + r % world;
   local_row[i] = r / world;
 }
 
@@ -338,12 +340,12 @@ __global__ __launch_bounds__(kBlock) void gather_u32_k(const uint32_t* __restric
 
 extern "C" {
 
-int32_t mi_shard_route(const int32_t* rows, int64_t n, int32_t world, int32_t* owner,
+int32_t mi_shard_route(const int32_t* rows, int64_t n, int32_t world, int64_t entries_per_chunk, int32_t* owner,
                        int32_t* local_row, mi_stream_t stream) {
-  MI_REQUIRE(n >= 0 && world > 0, "shard_route: n=%lld world=%d", (long long)n, world);
+  MI_REQUIRE(n >= 0 && world > 0 && entries_per_chunk >= 0, "shard_route: n=%lld world=%d", (long long)n, world);
   if (n == 0) return MI_OK;
   MI_REQUIRE(rows && owner && local_row, "shard_route: null buffer");
-  shard_route_k<<<dim3((unsigned)mi::ceil_div(n, kBlock)), dim3(kBlock), 0, mi::as_stream(stream)>>>(rows, n, world, owner, local_row);
+  shard_route_k<<<dim3((unsigned)mi::ceil_div(n, kBlock)), dim3(kBlock), 0, mi::as_stream(stream)>>>(rows, n, world, entries_per_chunk, owner, local_row);
   MI_CHECK_LAUNCH("shard_route");
   return MI_OK;
 }

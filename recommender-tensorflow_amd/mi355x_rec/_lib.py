@@ -16,7 +16,7 @@ import torch  # noqa: F401  (loads the HIP runtime this library must share)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmi355x_rec.so")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class MiError(RuntimeError):
@@ -54,14 +54,15 @@ SIGNATURES = {
     "mi_embed_fm_linear_fwd": (_i32, [_p, _p, _p, _p, _i64, _i32, _i32, _p, _i64, _p, _p, _p, _p, _p]),
     "mi_gather_rows": (_i32, [_p, _p, _p, _i64, _i32, _p, _p, _p]),
     "mi_numeric_embed_fwd": (_i32, [_p, _p, _p, _i64, _i32, _i32, _p, _i64, _i64, _p, _p, _p, _p]),
-    "mi_embed_fm_linear_bwd": (_i32, [_p, _i64, _p, _i64, _p, _p, _p, _p, _i64, _i32, _i32, _p, _p, _p]),
+    "mi_embed_fm_linear_bwd": (_i32, [_p, _i64, _p, _i64, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p, _p, _p]),
     "mi_numeric_embed_bwd_workspace_bytes": (_sz, [_i64, _i32, _i32]),
     "mi_numeric_embed_bwd": (_i32, [_p, _p, _i64, _p, _i64, _i64, _p, _p, _p, _i64, _i32, _i32, _p,
                                     _p, _p, _sz, _p]),
     "mi_sort_unique_workspace_bytes": (_sz, [_i64]),
     "mi_sort_unique_rows": (_i32, [_p, _i64, _i64, _p, _p, _p, _p, _p, _sz, _p]),
     "mi_global_rows": (_i32, [_p, _p, _i64, _i32, _p, _p]),
-    "mi_shard_route": (_i32, [_p, _i64, _i32, _p, _p, _p]),
+    "mi_shard_route": (_i32, [_p, _i64, _i32, _i64, _p, _p, _p]),
+    "mi_axpy": (_i32, [_p, _p, _i64, _f32, _p]),
     "mi_invert_perm": (_i32, [_p, _i64, _p, _p]),
     "mi_gather_u32": (_i32, [_p, _p, _i64, _p, _p]),
     "mi_dense_apply": (_i32, [_p, _p, _p, _p, _i64, C.POINTER(OptHparams), _p]),

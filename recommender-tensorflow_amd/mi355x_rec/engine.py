@@ -235,9 +235,10 @@ class DeepFM:
             self.dl_s0, self.dl_s1 = self._slots(self.dense, self.lin_opt)
         self._ws = {}
         self._final_step = 0
-        # Single GPU without numeric columns: layer 1 of the MLP reads its input straight from the
-        # embedding table (gathered GEMM operand) and the concat [B, F*E] is never materialised.
-        self.gather_mlp = self.use_dnn and self.n_numeric == 0 and self.shard is None
+        # Without numeric columns layer 1 of the MLP reads its input straight from the embedding table
+        # (multi-GPU: from the receive buffer of the row exchange) as a gathered GEMM operand and the
+        # concat [B, F*E] is never materialised.
+        self.gather_mlp = self.use_dnn and self.n_numeric == 0
         # Matrix-pipe path of the MLP GEMMs (all: fp32 in, fp32 accumulate, fp32-level error):
         #   "f16x2"  operands scaled by a power of two and split into fp16 high + low parts, three
         #            products per k-step; every kernel that produces a GEMM operand also emits its
@@ -357,7 +358,9 @@ class DeepFM:
 
     def _layer_seed(self, layer):
         rank = 0 if self.shard is None else self.shard.rank
-        return (self.seed * 0x9E3779B97F4A7C15 + (self.step + 1) * 1000003 + layer * 7919 + rank * 104729) & (2 ** 64 - 1)
+        chunk = getattr(self, "_chunk", 0)              # pipelined multi-GPU step: a mask per chunk
+        return (self.seed * 0x9E3779B97F4A7C15 + (self.step + 1) * 1000003 + layer * 7919 + rank * 104729 +
+                chunk * 15485863) & (2 ** 64 - 1)
 
     @property
     def timers(self):
@@ -378,7 +381,7 @@ class DeepFM:
         table, lin_w, field_off, rid = src if src is not None else (self.table, self.lin_w, self.field_off, ids)
         concat = sumv = fm = None
         ld = self.D
-        gathered = self.gather_mlp and src is None
+        gathered = self.gather_mlp
         if self.use_emb:
             concat = None if gathered else self._buf("concat", (B, ld))
             sumv = self._buf("sumv", (B, self.E)) if self.use_mf else None
@@ -423,7 +426,7 @@ class DeepFM:
             dnn = acts[-1].view(B)
             c["keep"] = keep
         c.update(concat=concat, sumv=sumv, fm=fm, lin=lin, dnn=dnn, acts=acts, x_num=x_num, ids=rid,
-                 gathered=gathered)
+                 gathered=gathered, g_table=table, g_off=field_off)
         return c
 
     def _head(self, c, labels, want_grad, global_batch=None):
@@ -531,12 +534,18 @@ class DeepFM:
         self._apply(uniq, seg, sorted_entry, num_uniq, n, None, None, fused=(d_concat, c["sumv"], dlogit))
         return loss, logits
 
-    def _entry_grads(self, c, d_concat, dlogit, pos):
+    def _entry_grads(self, c, d_concat, dlogit, pos, d_rows=None, d_lin=None):
+        """Per-entry row gradients written at slot pos[b,f] of d_rows / d_lin (caller's buffers in the
+        sharded path: the send order of the whole step)."""
         B = c["B"]
         n = B * self.F
-        d_rows = self._buf("d_rows", (n, self.E)) if self.use_emb else None
-        d_lin = self._buf("d_lin", (n,)) if self.use_linear else None
-        self.k.mi_embed_fm_linear_bwd(d_concat, self.D, c["concat"], self.D, c["sumv"],
+        if d_rows is None and self.use_emb:
+            d_rows = self._buf("d_rows", (n, self.E))
+        if d_lin is None and self.use_linear:
+            d_lin = self._buf("d_lin", (n,))
+        # no concat (gathered layer 1): the rows sit in slot order in the exchange's receive buffer
+        rows = c["g_table"] if (c["concat"] is None and self.use_mf) else None
+        self.k.mi_embed_fm_linear_bwd(d_concat, self.D, c["concat"], self.D, rows, c["sumv"],
                                       dlogit if self.use_mf else None, dlogit if self.use_linear else None, pos,
                                       B, self.F, self.E, d_rows, d_lin)
         return d_rows, d_lin
@@ -562,7 +571,7 @@ class DeepFM:
                 ga_w = self._ga("x%d" % i, dyn, None) if dyn else None
                 ga_d = self._ga(dyn, "w", "dy%d" % (i - 1) if i else None) if (dyn or i) else None
                 if i == 0 and c["gathered"]:
-                    k.mi_dense_bwd_weight_gathered(self.table, self.field_off, c["ids"], self.F, self.E, dy, lddy,
+                    k.mi_dense_bwd_weight_gathered(c["g_table"], c["g_off"], c["ids"], self.F, self.E, dy, lddy,
                                                    self.kernel(0, self.d_grad), self.bias(0, self.d_grad), B, h, ws,
                                                    ws.numel(), ga_w)
                 else:

@@ -14,6 +14,11 @@ synchronous and mapped onto xGMI:
   backward      per-entry row gradients -> owners (all_to_all) = the sparse "reduce-scatter";
                 owners sum duplicates and apply the optimizer locally
   dense grads   one flat buffer, one all_reduce(SUM); every rank applies the same update
+  pipelining    a train step splits its local batch into chunks: while chunk c runs forward and
+                backward, the rows of chunk c+1 and the row gradients of chunk c-1 are on the
+                links (asynchronous all_to_all on RCCL's stream).  Routing, the id exchange, the
+                owners' unique/catch-up bookkeeping and the sparse apply are done once per step, so
+                the result is the unchunked step's up to fp32 summation order of the dense gradient
 
 Collectives go through torch.distributed: backend "nccl" is RCCL on ROCm and takes device tensors
 directly (point-to-point xGMI links: the all_to_all uses all 7 at once).  With the "gloo" backend
@@ -25,10 +30,12 @@ import torch.distributed as dist
 
 
 class RowShard:
-    def __init__(self, rank, world, group=None):
+    def __init__(self, rank, world, group=None, chunks=None):
+        """chunks: pipeline depth of a train step (None: 4 from 16384 examples per rank, 2 from 2048)."""
         if not (0 <= rank < world):
             raise ValueError("rank %d not in [0, %d)" % (rank, world))
         self.rank, self.world, self.group = int(rank), int(world), group
+        self.chunks = chunks
         self.comm = None
 
     def local_rows(self, R):
@@ -45,16 +52,24 @@ class Comm:
         self.direct = dist.get_backend(group) == "nccl"   # RCCL: device tensors go straight in
 
     def exchange_counts(self, send_counts, device):
-        """counts[j] entries go to rank j -> returns how many arrive from each rank (host ints)."""
-        t = torch.tensor(send_counts, dtype=torch.int64, device=device if self.direct else "cpu")
+        """send_counts[c][j] entries of chunk c go to rank j -> recv_counts[c][j] arrive from rank j
+        (host ints; one small all_to_all and one device->host copy per step)."""
+        C = len(send_counts)
+        flat = [send_counts[c][j] for j in range(self.world) for c in range(C)]      # [dest rank][chunk]
+        t = torch.tensor(flat, dtype=torch.int64, device=device if self.direct else "cpu")
         out = torch.empty_like(t)
         dist.all_to_all_single(out, t, group=self.group)
-        return [int(v) for v in out.tolist()]
+        o = out.tolist()
+        return [[int(o[j * C + c]) for j in range(self.world)] for c in range(C)]
 
-    def all_to_all(self, out, inp, out_counts, in_counts):
-        """Rows (dim 0) of `inp`, split by in_counts, go to the ranks; `out` receives out_counts rows."""
+    def all_to_all(self, out, inp, out_counts, in_counts, async_op=False):
+        """Rows (dim 0) of `inp`, split by in_counts, go to the ranks; `out` receives out_counts rows.
+        async_op (RCCL only): returns a handle whose wait() orders the current stream after the
+        exchange; the buffers must stay untouched until then."""
         if self.direct:
-            dist.all_to_all_single(out, inp, list(out_counts), list(in_counts), group=self.group)
+            return dist.all_to_all_single(out, inp, list(out_counts), list(in_counts), group=self.group,
+                                          async_op=async_op) if async_op else \
+                dist.all_to_all_single(out, inp, list(out_counts), list(in_counts), group=self.group)
         else:
             o = torch.empty(out.shape, dtype=out.dtype)
             dist.all_to_all_single(o, inp.detach().cpu().contiguous(), list(out_counts), list(in_counts),
@@ -95,9 +110,28 @@ def broadcast_dense(m, src=0):
             c.broadcast(t, src)
 
 
-def _route(m, ids):
-    """Plan the exchange for this batch.  Returns (pos, send_ids, send_counts, recv_counts, nr):
-    entry (b,f) travels in slot pos[b*F+f] of the send buffer, which is ordered by owner rank."""
+def _wait(handles):
+    for h in handles:
+        if h is not None:
+            h.wait()
+
+
+def _n_chunks(m, B, train):
+    if not train:
+        return 1
+    c = m.shard.chunks
+    if c is None:
+        c = 4 if B >= 16384 else (2 if B >= 2048 else 1)
+    c = max(1, min(int(c), B))
+    while B % c:
+        c -= 1
+    return c
+
+
+def _route(m, ids, C):
+    """Plan the exchange for this batch, C chunks of B/C examples.  Entry (b,f) travels in slot
+    pos[b*F+f] of the send buffer, which is ordered by (chunk, owner rank): chunk c owns the slots
+    [c*n/C, (c+1)*n/C).  Returns (pos, send_ids, send_counts[c][rank], recv_counts[c][rank])."""
     k, sh = m.k, m.shard
     comm = _comm(m)
     i32 = torch.int32
@@ -105,10 +139,10 @@ def _route(m, ids):
     n = B * m.F
     rows = m._buf("rows", (n,), i32)
     k.mi_global_rows(ids, m.field_off, B, m.F, rows)
-    owner = m._buf("route_owner", (n,), i32)
+    key = m._buf("route_owner", (n,), i32)
     local = m._buf("route_local", (n,), i32)
-    k.mi_shard_route(rows, n, sh.world, owner, local)
-    order, present, seg, npresent = m._sort_unique(owner, n, sh.world, "route")   # stable partition by owner
+    k.mi_shard_route(rows, n, sh.world, (n // C) if C > 1 else 0, key, local)
+    order, present, seg, npresent = m._sort_unique(key, n, sh.world * C, "route")   # stable partition by (chunk, owner)
     send_ids = m._buf("send_ids", (n,), i32)
     k.mi_gather_u32(local, order, n, send_ids)
     pos = m._buf("route_pos", (n,), i32)
@@ -117,76 +151,133 @@ def _route(m, ids):
     npres = int(npresent.item())
     pres = present[:npres].tolist()
     segs = seg[:npres + 1].tolist()
-    send_counts = [0] * sh.world
-    for j, r in enumerate(pres):
-        send_counts[r] = segs[j + 1] - segs[j]
+    send_counts = [[0] * sh.world for _ in range(C)]
+    for j, key_j in enumerate(pres):
+        send_counts[key_j // sh.world][key_j % sh.world] = segs[j + 1] - segs[j]
     recv_counts = comm.exchange_counts(send_counts, m.device)
-    return pos, send_ids, send_counts, recv_counts, sum(recv_counts)
+    return pos, send_ids, send_counts, recv_counts
 
 
-def _fetch_rows(m, ids, send_ids, pos, send_counts, recv_counts, nr, train):
-    """Owners serve the requested rows; returns (src for _forward, owner-side bookkeeping)."""
+def _zero_off(m):
+    z = m._ws.get("zero_off")
+    if z is None:
+        z = m._ws["zero_off"] = torch.zeros(m.F, dtype=torch.int64, device=m.device)
+    return z
+
+
+def _sharded_step(m, ids, labels, x_num, train):
+    """Forward (+ backward and apply when train) of one local batch on N ranks; see the module
+    docstring.  Returns (this rank's share of the loss — already divided by the global batch —,
+    local logits)."""
     k = m.k
     comm = _comm(m)
-    i32, f32 = torch.int32, torch.float32
+    i32 = torch.int32
     B = ids.shape[0]
-    n = B * m.F
+    F, E = m.F, m.E
+    n = B * F
+    C = _n_chunks(m, B, train)
+    Bc = B // C
+    nc = Bc * F                                         # entries (= send slots) per chunk
+    pos, send_ids, send_counts, recv_counts = _route(m, ids, C)
+    nrc = [sum(rc) for rc in recv_counts]
+    roff = [0]
+    for v in nrc:
+        roff.append(roff[-1] + v)
+    nr = roff[-1]
+
+    # ids to their owners (small), then the owners' bookkeeping for the WHOLE step: which rows are
+    # touched, and TF Adam's catch-up on them before any of them is read
     recv_ids = m._buf("recv_ids", (max(nr, 1),), i32)[:nr]
-    comm.all_to_all(recv_ids, send_ids, recv_counts, send_counts)
+    for c in range(C):
+        comm.all_to_all(recv_ids[roff[c]:roff[c + 1]], send_ids[c * nc:(c + 1) * nc], recv_counts[c], send_counts[c])
     book = None
     if train and nr > 0:
         book = m._sort_unique(recv_ids, nr, m.R_local, "own")     # (sorted_entry, uniq, seg, num_uniq)
         if m.adam_rows and m.step > 0:
             m._catchup(book[1], book[3], nr)
-    got_rows = got_lin = None
-    if m.use_emb:
-        own_rows = m._buf("own_rows", (max(nr, 1), m.E))[:nr]
-        own_lin = m._buf("own_lin", (max(nr, 1),))[:nr] if m.use_linear else None
-        k.mi_gather_rows(m.table, m.lin_w if m.use_linear else None, recv_ids, nr, m.E, own_rows, own_lin)
-        got_rows = m._buf("got_rows", (n, m.E))
-        comm.all_to_all(got_rows, own_rows, send_counts, recv_counts)
-    elif m.use_linear:
-        own_lin = m._buf("own_lin", (max(nr, 1),))[:nr]
-        k.mi_gather_u32(m.lin_w, recv_ids, nr, own_lin)
-    if m.use_linear:
-        got_lin = m._buf("got_lin", (n,))
-        comm.all_to_all(got_lin, own_lin, send_counts, recv_counts)
-    zero_off = m._ws.get("zero_off")
-    if zero_off is None:
-        zero_off = m._ws["zero_off"] = torch.zeros(m.F, dtype=torch.int64, device=m.device)
-    return (got_rows, got_lin, zero_off, pos.view(B, m.F)), book, recv_ids
 
+    own_rows = m._buf("own_rows", (max(nr, 1), E))[:nr] if m.use_emb else None
+    own_lin = m._buf("own_lin", (max(nr, 1),))[:nr] if m.use_linear else None
+    got_rows = m._buf("got_rows", (n, E)) if m.use_emb else None
+    got_lin = m._buf("got_lin", (n,)) if m.use_linear else None
 
-def sharded_eval_step(m, ids, labels, x_num):
-    pos, send_ids, send_counts, recv_counts, nr = _route(m, ids)
-    src, _, _ = _fetch_rows(m, ids, send_ids, pos, send_counts, recv_counts, nr, False)
-    c = m._forward(ids, x_num, False, src)
-    logits, loss, _ = m._head(c, labels, False, global_batch=ids.shape[0] * m.shard.world)
-    return loss, logits
+    def serve(c):
+        """owners gather chunk c's rows and send them back; returns the exchange handles"""
+        lo, hi = roff[c], roff[c + 1]
+        hs = []
+        if m.use_emb:
+            k.mi_gather_rows(m.table, m.lin_w if m.use_linear else None, recv_ids[lo:hi], hi - lo, E, own_rows[lo:hi],
+                             own_lin[lo:hi] if m.use_linear else None)
+            hs.append(comm.all_to_all(got_rows[c * nc:(c + 1) * nc], own_rows[lo:hi], send_counts[c], recv_counts[c], True))
+        elif m.use_linear:
+            k.mi_gather_u32(m.lin_w, recv_ids[lo:hi], hi - lo, own_lin[lo:hi])
+        if m.use_linear:
+            hs.append(comm.all_to_all(got_lin[c * nc:(c + 1) * nc], own_lin[lo:hi], send_counts[c], recv_counts[c], True))
+        return hs
 
+    d_rows = m._buf("d_rows", (n, E)) if (train and m.use_emb) else None           # send (chunk, owner) order
+    d_lin = m._buf("d_lin", (n,)) if (train and m.use_linear) else None
+    r_rows = m._buf("recv_d_rows", (max(nr, 1), E))[:nr] if (train and m.use_emb) else None
+    r_lin = m._buf("recv_d_lin", (max(nr, 1),))[:nr] if (train and m.use_linear) else None
+    logits_all = m._buf("logits_all", (B,)) if C > 1 else None
+    loss_all = m._buf("loss_all", (1,)) if C > 1 else None
+    acc = m._buf("d_grad_acc", (m.P,)) if (train and C > 1) else None
+    pos2 = pos.view(B, F)
+    zero_off = _zero_off(m)
 
-def sharded_train_step(m, ids, labels, x_num):
-    """N-rank synchronous step.  Every rank must call it with the same local batch size.  Returns
-    (this rank's share of the loss — already divided by the global batch —, local logits)."""
-    comm = _comm(m)
-    B = ids.shape[0]
-    pos, send_ids, send_counts, recv_counts, nr = _route(m, ids)
-    src, book, _ = _fetch_rows(m, ids, send_ids, pos, send_counts, recv_counts, nr, True)
-    c = m._forward(ids, x_num, True, src)
-    logits, loss, dlogit = m._head(c, labels, True, global_batch=B * m.shard.world)
-    d_concat = m._backward_dense(c, dlogit)
+    rows_h = serve(0)
+    grad_h = []
+    loss = logits = None
+    for c in range(C):
+        nxt = serve(c + 1) if c + 1 < C else []          # on the links while chunk c computes
+        _wait(rows_h)
+        rows_h = nxt
+        sl = slice(c * Bc, (c + 1) * Bc)
+        m._chunk = c
+        cc = m._forward(ids[sl], None if x_num is None else x_num[sl], train, (got_rows, got_lin, zero_off, pos2[sl]))
+        logits, loss, dlogit = m._head(cc, None if labels is None else labels[sl], train, global_batch=B * m.shard.world)
+        if C > 1:
+            logits_all[sl].copy_(logits)
+            if loss is not None:
+                if c == 0:
+                    loss_all.copy_(loss)
+                else:
+                    k.mi_axpy(loss_all, loss, 1, 1.0)
+        if not train:
+            continue
+        d_concat = m._backward_dense(cc, dlogit)
+        if C > 1:
+            if c == 0:
+                acc.copy_(m.d_grad)
+            else:
+                k.mi_axpy(acc, m.d_grad, m.P, 1.0)
+        m._entry_grads(cc, d_concat, dlogit, pos2[sl], d_rows, d_lin)      # written at their send slots
+        lo, hi = roff[c], roff[c + 1]
+        if m.use_emb:
+            grad_h.append(comm.all_to_all(r_rows[lo:hi], d_rows[c * nc:(c + 1) * nc], recv_counts[c], send_counts[c], True))
+        if m.use_linear:
+            grad_h.append(comm.all_to_all(r_lin[lo:hi], d_lin[c * nc:(c + 1) * nc], recv_counts[c], send_counts[c], True))
+    m._chunk = 0
+    if C > 1:
+        logits, loss = logits_all, (loss_all if loss is not None else None)
+    if not train:
+        return loss, logits
+    if C > 1:
+        m.d_grad.copy_(acc)
     comm.all_reduce(m.d_grad)                                   # dense gradients: SUM over ranks
-    d_rows, d_lin = m._entry_grads(c, d_concat, dlogit, pos)    # written in send (owner) order
-    r_rows = r_lin = None
-    if m.use_emb:
-        r_rows = m._buf("recv_d_rows", (max(nr, 1), m.E))[:nr]
-        comm.all_to_all(r_rows, d_rows, recv_counts, send_counts)
-    if m.use_linear:
-        r_lin = m._buf("recv_d_lin", (max(nr, 1),))[:nr]
-        comm.all_to_all(r_lin, d_lin, recv_counts, send_counts)
+    _wait(grad_h)
     if book is not None:
         sorted_entry, uniq, seg, num_uniq = book
         m._apply(uniq, seg, sorted_entry, num_uniq, nr, r_rows, r_lin)
     else:
         m._apply(None, None, None, None, 0, None, None)
     return loss, logits
+
+
+def sharded_eval_step(m, ids, labels, x_num):
+    return _sharded_step(m, ids, labels, x_num, False)
+
+
+def sharded_train_step(m, ids, labels, x_num):
+    """N-rank synchronous step.  Every rank must call it with the same local batch size."""
+    return _sharded_step(m, ids, labels, x_num, True)

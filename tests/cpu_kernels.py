@@ -35,10 +35,14 @@ class NumpyKernels:
     def mi_global_rows(self, ids, field_off, B, F, rows):
         _np(rows)[:] = (_np(ids).astype(np.int64) + _np(field_off)[None, :]).reshape(-1)
 
-    def mi_shard_route(self, rows, n, world, owner, local):
+    def mi_shard_route(self, rows, n, world, entries_per_chunk, owner, local):
         r = _np(rows)[:n]
-        _np(owner)[:n] = r % world
+        chunk = (np.arange(n) // entries_per_chunk) if entries_per_chunk > 0 else 0
+        _np(owner)[:n] = chunk * world + r % world
         _np(local)[:n] = r // world
+
+    def mi_axpy(self, y, x, n, alpha):
+        _np(y)[:n] += np.float32(alpha) * _np(x)[:n]
 
     def mi_invert_perm(self, perm, n, inv):
         _np(inv)[_np(perm)[:n]] = np.arange(n, dtype=np.int32)
@@ -92,14 +96,14 @@ class NumpyKernels:
         if lin is not None and w_num is not None:
             _np(lin)[:] += xv @ _np(w_num)
 
-    def mi_embed_fm_linear_bwd(self, d_concat, lddc, concat, ldc, sumv, dlf, dll, pos, B, F, E, d_rows, d_lin):
-        p = np.arange(B * F) if pos is None else _np(pos)[:B * F].astype(np.int64)
+    def mi_embed_fm_linear_bwd(self, d_concat, lddc, concat, ldc, rows, sumv, dlf, dll, pos, B, F, E, d_rows, d_lin):
+        p = np.arange(B * F) if pos is None else _np(pos).reshape(-1)[:B * F].astype(np.int64)
         if d_rows is not None:
             g = np.zeros((B, F, E), np.float32)
             if d_concat is not None:
                 g += _np(d_concat)[:, :F * E].reshape(B, F, E)
             if dlf is not None:
-                v = _np(concat)[:, :F * E].reshape(B, F, E)
+                v = _np(rows)[p].reshape(B, F, E) if rows is not None else _np(concat)[:, :F * E].reshape(B, F, E)
                 g += _np(dlf)[:, None, None] * (_np(sumv)[:, None, :] - v)
             _np(d_rows)[p] = g.reshape(B * F, E)
         if d_lin is not None:

@@ -47,10 +47,11 @@ def _worker(rank, world, port, cfg, out_q, device="cpu", backend="gloo"):
         if device == "cpu":
             from tests.cpu_kernels import NumpyKernels
             kernels = NumpyKernels()
-        vocab, E, hidden, B, nn, opt_name, lr, steps, flags = cfg
+        vocab, E, hidden, B, nn, opt_name, lr, steps, flags = cfg[:9]
+        chunks = cfg[9] if len(cfg) > 9 else None       # pipeline depth of the step (None: by batch size, 1 here)
         p, ids, x, y = make_problem(11, vocab, E, hidden, B * world, n_numeric=nn, use_dnn=flags[2])
         m = DeepFM(vocab, n_numeric=nn, embedding_size=E, hidden_units=hidden, use_linear=flags[0], use_mf=flags[1],
-                   use_dnn=flags[2], optimizer=OptimizerSpec(opt_name, lr), device=device, shard=RowShard(rank, world),
+                   use_dnn=flags[2], optimizer=OptimizerSpec(opt_name, lr), device=device, shard=RowShard(rank, world, chunks=chunks),
                    _kernels=kernels)
         m.load_oracle_params(p)
         rng = np.random.default_rng(5)
@@ -96,6 +97,10 @@ CASES = [
     ([11, 5, 9], 4, [12], 16, 2, "Adam", 0.001, 2, (True, True, True)),          # numeric columns
     ([7, 6, 5], 4, [8], 16, 0, "Adagrad", 0.05, 2, (True, False, True)),          # no FM, Adagrad
     ([7, 6, 5], 4, [], 16, 0, "Ftrl", 0.1, 2, (True, False, False)),              # wide part only
+    # the pipelined form: the local batch in 4 / 2 chunks, row and gradient exchanges per chunk
+    ([9, 13, 5, 6], 8, [16, 8], 32, 0, "Adam", 0.001, 3, (True, True, True), 4),
+    ([11, 5, 9], 4, [12], 16, 2, "Adam", 0.001, 2, (True, True, True), 2),
+    ([7, 6, 5], 4, [], 16, 0, "Ftrl", 0.1, 2, (True, False, False), 2),
 ]
 
 
@@ -105,7 +110,7 @@ def test_two_rank_step_equals_big_batch(cfg):
 
 
 def check_against_big_batch(cfg, res, world, tol=1.0):
-    vocab, E, hidden, B, nn, opt_name, lr, steps, flags = cfg
+    vocab, E, hidden, B, nn, opt_name, lr, steps, flags = cfg[:9]
     # 1-rank reference: the oracle on the concatenated batch
     p, ids, x, y = make_problem(11, vocab, E, hidden, B * world, n_numeric=nn, use_dnn=flags[2])
     st = O.TrainState(p, OO.Hyper(opt_name, lr))

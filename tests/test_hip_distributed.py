@@ -11,11 +11,15 @@ from tests.test_distributed_cpu import CASES, _run, check_against_big_batch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("cfg", [CASES[0], CASES[1], ([50, 30, 20, 40], 64, [64, 32], 128, 0, "Adam", 0.001, 3, (True, True, True))])
+@pytest.mark.parametrize("cfg", [CASES[0], CASES[1], ([50, 30, 20, 40], 64, [64, 32], 128, 0, "Adam", 0.001, 3, (True, True, True)),
+                                 CASES[4],                                                                        # pipelined, 4 chunks
+                                 ([50, 30, 20, 40], 64, [64, 32], 256, 0, "Adam", 0.001, 3, (True, True, True), 2)])  # 2 chunks of 128
 def test_two_ranks_one_gpu_gloo(cfg):
     check_against_big_batch(cfg, _run(cfg, 2, device="cuda", backend="gloo"), 2, tol=3.0)
 
 
-def test_single_rank_rccl_path():
-    cfg = ([50, 30, 20, 40], 16, [32, 16], 96, 0, "Adam", 0.001, 3, (True, True, True))
+@pytest.mark.parametrize("chunks", [1, 3])
+def test_single_rank_rccl_path(chunks):
+    """chunks = 3: the asynchronous all_to_all handles of the pipelined step on RCCL's own stream"""
+    cfg = ([50, 30, 20, 40], 16, [32, 16], 96, 0, "Adam", 0.001, 3, (True, True, True), chunks)
     check_against_big_batch(cfg, _run(cfg, 1, device="cuda", backend="nccl"), 1, tol=3.0)

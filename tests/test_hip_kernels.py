@@ -115,13 +115,21 @@ def test_embed_bwd_entries(lib, E, F, B):
     d_rows = torch.empty(B * F, E, device="cuda")
     d_lin = torch.empty(B * F, device="cuda")
     a = [dev(x) for x in (dc, cc, sv, dl, pos)]
-    _chk(lib.mi_embed_fm_linear_bwd(_p(a[0]), F * E, _p(a[1]), F * E, _p(a[2]), _p(a[3]), _p(a[3]), _p(a[4]), B, F,
+    _chk(lib.mi_embed_fm_linear_bwd(_p(a[0]), F * E, _p(a[1]), F * E, None, _p(a[2]), _p(a[3]), _p(a[3]), _p(a[4]), B, F,
                                     E, _p(d_rows), _p(d_lin), _st()))
     ref = dc.reshape(B, F, E).astype(np.float64) + dl[:, None, None].astype(np.float64) * (
         sv[:, None, :].astype(np.float64) - cc.reshape(B, F, E))
     g = d_rows.cpu().numpy()
     assert max_err_scaled(g[pos], ref.reshape(B * F, E)) < TOL
     assert np.array_equal(d_lin.cpu().numpy()[pos], np.repeat(dl, F))
+    # the same with the gathered rows held in slot order (multi-GPU receive buffer) instead of a concat
+    by_slot = np.empty((B * F, E), np.float32)
+    by_slot[pos] = cc.reshape(B * F, E)
+    rs = dev(by_slot)
+    d_rows2 = torch.empty(B * F, E, device="cuda")
+    _chk(lib.mi_embed_fm_linear_bwd(_p(a[0]), F * E, None, 0, _p(rs), _p(a[2]), _p(a[3]), None, _p(a[4]), B, F,
+                                    E, _p(d_rows2), None, _st()))
+    assert torch.equal(d_rows, d_rows2)
 
 
 GEMM_SHAPES = [(32, 16, 104), (300, 128, 256), (1000, 1, 128), (257, 130, 70), (128, 128, 32), (513, 64, 1),
@@ -429,7 +437,7 @@ def test_sparse_apply_fused_equals_bwd_then_apply_bitwise(lib, name):
                                            C.byref(h), _st()))
         else:
             d_rows = torch.empty(n, E, device="cuda"); d_lin = torch.empty(n, device="cuda")
-            _chk(lib.mi_embed_fm_linear_bwd(_p(d_dc), F * E, _p(d_cc), F * E, _p(d_sv), _p(d_dl), _p(d_dl), None, B, F,
+            _chk(lib.mi_embed_fm_linear_bwd(_p(d_dc), F * E, _p(d_cc), F * E, None, _p(d_sv), _p(d_dl), _p(d_dl), None, B, F,
                                             E, _p(d_rows), _p(d_lin), _st()))
             _chk(lib.mi_sparse_apply(_p(T), _p(t0), _p(t1), _p(L), _p(l0), _p(l1), None, _p(uq), _p(sg), _p(se),
                                      _p(nu), n, _p(d_rows), _p(d_lin), E, 1, C.byref(h), _st()))
