@@ -35,7 +35,7 @@ class LinearClassifier(Estimator):
             return run_batch(features, labels, mode, params, lambda plan, dev: DeepFM(
                 plan.vocab_sizes, use_linear=True, use_mf=False, use_dnn=False, optimizer=opt, reduction="sum",
                 device=dev))
-        super().__init__(model_fn, model_dir, config, {"categorical_columns": cols})
+        super().__init__(model_fn, model_dir, config, {"categorical_columns": cols, "tf_model": "linear"})
 
 
 class DNNClassifier(Estimator):
@@ -49,7 +49,7 @@ class DNNClassifier(Estimator):
             return run_batch(features, labels, mode, params, lambda plan, dev: DeepFM(
                 plan.vocab_sizes, embedding_size=E, hidden_units=hidden, use_linear=False, use_mf=False, use_dnn=True,
                 dropout=dropout or 0.0, optimizer=opt, reduction="sum", device=dev))
-        super().__init__(model_fn, model_dir, config, {"categorical_columns": cols})
+        super().__init__(model_fn, model_dir, config, {"categorical_columns": cols, "tf_model": "dnn"})
 
 
 class DNNLinearCombinedClassifier(Estimator):
@@ -73,4 +73,4 @@ class DNNLinearCombinedClassifier(Estimator):
                 plan.vocab_sizes, embedding_size=E, hidden_units=hidden, use_linear=bool(lin), use_mf=False,
                 use_dnn=bool(dnn), dropout=dnn_dropout or 0.0, optimizer=d_opt, linear_optimizer=l_opt if lin else None,
                 reduction="sum", device=dev))
-        super().__init__(model_fn, model_dir, config, {"categorical_columns": lin or dnn})
+        super().__init__(model_fn, model_dir, config, {"categorical_columns": lin or dnn, "tf_model": "dnn_linear_combined"})

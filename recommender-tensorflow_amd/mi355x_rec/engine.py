@@ -259,6 +259,22 @@ class DeepFM:
         s1 = torch.full_like(like, b) if b is not None else None
         return s0, s1
 
+    def reset_optimizer_state(self):
+        """Slots back to their TF initial values, global step 0 (after a warm start from variables only)."""
+        lin_spec = self.lin_opt or self.opt
+        for t, spec in ((self.t_s0, self.opt), (self.d_s0, self.opt), (self.l_s0, lin_spec),
+                        (getattr(self, "dl_s0", None), self.lin_opt)):
+            if t is not None:
+                t.fill_(spec.slot_init[0])
+        for t, spec in ((self.t_s1, self.opt), (self.d_s1, self.opt), (self.l_s1, lin_spec),
+                        (getattr(self, "dl_s1", None), self.lin_opt)):
+            if t is not None:
+                t.fill_(spec.slot_init[1])
+        if self.last_step is not None:
+            self.last_step.zero_()
+        self.step = 0
+        self._final_step = 0
+
     def _seg(self, buf, off, shape):
         n = int(np.prod(shape))
         return buf[off:off + n].view(*shape)

@@ -73,8 +73,12 @@ class LatestExporter:
 
 
 class Estimator:
-    def __init__(self, model_fn, model_dir=None, config=None, params=None):
+    def __init__(self, model_fn, model_dir=None, config=None, params=None, warm_start_from=None):
+        """warm_start_from: .npz of TensorFlow-named variables (mi355x_rec/tf_names.py; the dump of a
+        TF-1.12 checkpoint of the reference), applied when model_dir holds no checkpoint — the role of
+        tf.estimator.Estimator(warm_start_from=...)."""
         self.model_fn = model_fn
+        self.warm_start_from = warm_start_from
         self.config = config or RunConfig()
         self.model_dir = model_dir or self.config.model_dir or "checkpoints/model"
         self.params = dict(params or {})
@@ -107,6 +111,14 @@ class Estimator:
         if ck:
             self._engine().load_state_dict(torch.load(ck, weights_only=True))
             print("INFO: restored %s (global_step %d)" % (ck, self.global_step))
+        elif self.warm_start_from:
+            import numpy as np
+            from . import tf_names
+            plan = self.params["_store"]["plan"]
+            with np.load(self.warm_start_from, allow_pickle=False) as z:
+                names = tf_names.import_variables(self._engine(), dict(z), [c.name for c in plan.categorical],
+                                                  model=self.params.get("tf_model", "deep_fm"))
+            print("INFO: warm-started %d variables from %s" % (len(names), self.warm_start_from))
 
     def save_checkpoint(self):
         os.makedirs(self.model_dir, exist_ok=True)

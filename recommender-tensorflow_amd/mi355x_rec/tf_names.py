@@ -1,0 +1,124 @@
+"""TensorFlow-1.12 variable names for the engine's parameters.
+
+The reference's checkpoints are TF tensor bundles written by ``tf.estimator`` (conf_utils.py:6-10).
+Reading that format needs TensorFlow; naming does not.  Someone who has a TF-1.12 checkpoint dumps
+it once with TF itself
+
+    reader = tf.train.load_checkpoint(model_dir)
+    np.savez("vars.npz", **{n: reader.get_tensor(n) for n in reader.get_variable_to_shape_map()})
+
+and ``import_variables`` maps those names onto the fused table / flat dense buffer;
+``export_variables`` writes the same names back (so a run here can be inspected or resumed there
+with ``tf.train.init_from_checkpoint``-style assignment).  Names follow the scopes of
+trainers/deep_fm.py:38,48,94,99,107 for ``model="deep_fm"`` and the canned estimators' for
+``"linear" | "dnn" | "dnn_linear_combined"`` (trainers/linear.py:30, deep.py:32, linear_deep.py:32).
+Optimizer slots are not part of the mapping (a warm start re-creates them, as TF's
+``warm_start_from`` does).  Single-GPU engines only: sharded engines hold a slice of every table.
+"""
+import numpy as np
+
+_MODELS = ("deep_fm", "linear", "dnn", "dnn_linear_combined")
+
+
+def variable_names(model, column_names, n_hidden, n_numeric=0):
+    """-> dict with keys 'emb' [F names], 'lin_w' [F names], 'lin_bias', 'mlp' [(kernel, bias)] (hidden
+    layers then logits), 'num_emb', 'lin_num' (DeepFM numeric embeddings: one variable each)."""
+    if model not in _MODELS:
+        raise ValueError("model must be one of %s" % (_MODELS,))
+    cols = list(column_names)
+    if model == "deep_fm":
+        emb = ["input_layer/input_layer/%s_embedding/embedding_weights" % c for c in cols]
+        lin = ["linear/linear_model/%s/weights" % c for c in cols]
+        mlp = [("dnn/dnn/hiddenlayer_%d/dense/kernel" % i, "dnn/dnn/hiddenlayer_%d/dense/bias" % i) for i in range(n_hidden)]
+        mlp.append(("dnn/dnn/logits/dense/kernel", "dnn/dnn/logits/dense/bias"))
+    else:
+        emb = ["dnn/input_from_feature_columns/input_layer/%s_embedding/embedding_weights" % c for c in cols]
+        lin = ["linear/linear_model/%s/weights" % c for c in cols]
+        mlp = [("dnn/hiddenlayer_%d/kernel" % i, "dnn/hiddenlayer_%d/bias" % i) for i in range(n_hidden)]
+        mlp.append(("dnn/logits/kernel", "dnn/logits/bias"))
+    return {"emb": emb, "lin_w": lin, "lin_bias": "linear/linear_model/bias_weights", "mlp": mlp,
+            "num_emb": "input_layer/numeric_embeddings" if n_numeric else None,
+            "lin_num": "linear/linear_model/numeric/weights" if n_numeric else None}
+
+
+def _names_for(m, model, column_names):
+    if m.shard is not None:
+        raise ValueError("TF-named import/export works on single-GPU engines (a sharded engine holds table slices)")
+    if len(column_names) != m.F:
+        raise ValueError("%d column names for %d categorical fields" % (len(column_names), m.F))
+    return variable_names(model, column_names, len(m.layers) - 1 if m.use_dnn else 0, m.n_numeric)
+
+
+def export_variables(m, column_names, model="deep_fm"):
+    """Engine -> {TF variable name: ndarray} with TF's shapes (linear weights [vocab, 1], bias [1],
+    numeric embeddings [1, n_d, E] as deep_fm.py:64 creates them)."""
+    nm = _names_for(m, model, column_names)
+    g = m.export_numpy()
+    out = {}
+    if g.get("emb") is not None:
+        out.update({n: a for n, a in zip(nm["emb"], g["emb"])})
+    if g.get("lin_w") is not None:
+        out.update({n: a.reshape(-1, 1) for n, a in zip(nm["lin_w"], g["lin_w"])})
+        out[nm["lin_bias"]] = g["lin_bias"].reshape(1)
+    if m.use_dnn:
+        for (kn, bn), (k, b) in zip(nm["mlp"], g["mlp"]):
+            out[kn], out[bn] = k, b
+    if m.n_numeric:
+        out[nm["num_emb"]] = g["num_emb"].reshape(1, m.n_numeric, m.E)
+        if g.get("lin_w") is not None:
+            out[nm["lin_num"]] = g["lin_num"].reshape(-1, 1)
+    return out
+
+
+def import_variables(m, arrays, column_names, model="deep_fm", strict=True):
+    """{TF variable name: ndarray} (e.g. ``dict(np.load("vars.npz"))``) -> engine variables.  Every
+    variable the engine has must be present with TF's shape (strict) or keeps its value (not strict);
+    returns the list of names that were loaded.  Optimizer slots and Adam row stamps are reset."""
+    import torch
+    nm = _names_for(m, model, column_names)
+    loaded = []
+    off = m.field_off_host
+
+    def get(name, shape):
+        if name not in arrays:
+            if strict:
+                raise KeyError("variable %r not in the checkpoint dump (has: %s ...)" % (name, sorted(arrays)[:4]))
+            return None
+        a = np.asarray(arrays[name], dtype=np.float32)
+        if a.size != int(np.prod(shape)):
+            raise ValueError("variable %r has shape %s, the model needs %s" % (name, a.shape, tuple(shape)))
+        loaded.append(name)
+        return torch.from_numpy(np.ascontiguousarray(a.reshape(shape))).to(m.device)
+
+    for f in range(m.F):
+        v = int(off[f + 1] - off[f])
+        if m.table is not None:
+            a = get(nm["emb"][f], (v, m.E))
+            if a is not None:
+                m.table[off[f]:off[f + 1]].copy_(a)
+        if m.lin_w is not None:
+            a = get(nm["lin_w"][f], (v,))
+            if a is not None:
+                m.lin_w[off[f]:off[f + 1]].copy_(a)
+    if m.lin_w is not None:
+        a = get(nm["lin_bias"], (1,))
+        if a is not None:
+            m.dense[m.lin_bias_off:m.lin_bias_off + 1].copy_(a)
+    if m.use_dnn:
+        for i, (kn, bn) in enumerate(nm["mlp"]):
+            _, _, fan, h = m.layers[i]
+            a, b = get(kn, (fan, h)), get(bn, (h,))
+            if a is not None:
+                m.kernel(i).copy_(a)
+            if b is not None:
+                m.bias(i).copy_(b)
+    if m.n_numeric:
+        a = get(nm["num_emb"], (m.n_numeric, m.E))
+        if a is not None:
+            m._seg(m.dense, m.num_emb_off, (m.n_numeric, m.E)).copy_(a)
+        if m.lin_w is not None:
+            a = get(nm["lin_num"], (m.n_numeric,))
+            if a is not None:
+                m._seg(m.dense, m.lin_num_off, (m.n_numeric,)).copy_(a)
+    m.reset_optimizer_state()
+    return loaded

@@ -16,6 +16,8 @@ _COMMON = [
     ("--batch-size", dict(type=int, default=32, help="batch size (default: %(default)s)")),
     ("--train-steps", dict(type=int, default=20000, help="number of training steps (default: %(default)s)")),
     ("--device", dict(default="cuda", help="torch device of the MI355X to run on (default: %(default)s)")),
+    ("--warm-start-from", dict(default=None, help=".npz of TensorFlow-named variables (a dumped TF-1.12 checkpoint of "
+                                                   "the reference) to start from when job_dir has no checkpoint")),
 ]
 _OPTIONAL = {
     "hidden_units": ("--hidden-units", dict(type=int, nargs="+", default=[16, 16],
@@ -47,6 +49,7 @@ def run(args, make_estimator):
     config = get_run_config()
     config.device = getattr(args, "device", "cuda")
     estimator = make_estimator(columns, config)
+    estimator.warm_start_from = getattr(args, "warm_start_from", None)
     train_spec = get_train_spec(get_input_fn(args.train_csv, batch_size=args.batch_size), args.train_steps)
     eval_spec = get_eval_spec(get_input_fn(args.test_csv, ModeKeys.EVAL, batch_size=args.batch_size),
                               get_exporter(serving_input_fn))

@@ -105,3 +105,36 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     from mi355x_rec.engine import DeepFM
     with pytest.raises(_lib.MiError, match="no fallback"):
         DeepFM([3, 4], device="cpu")
+
+
+def test_tf_named_variables_round_trip():
+    """mi355x_rec/tf_names.py: engine -> {TF-1.12 variable name: array} -> a fresh engine gives the same
+    logits; names and shapes are the reference's scopes; a missing variable is an error."""
+    from mi355x_rec.engine import DeepFM, OptimizerSpec
+    from mi355x_rec import tf_names
+    from tests.cpu_kernels import NumpyKernels
+    vocab, cols = [5, 7, 3], ["age_bucketized", "gender", "item_id"]
+    p, ids, x, y = make_problem(2, vocab, 4, [8, 6], 16, n_numeric=2)
+    mk = lambda: DeepFM(vocab, n_numeric=2, embedding_size=4, hidden_units=[8, 6], optimizer=OptimizerSpec("Adam", 0.001),
+                        device="cpu", _kernels=NumpyKernels())
+    a = mk()
+    a.load_oracle_params(p)
+    t = lambda v: torch.from_numpy(np.ascontiguousarray(v))
+    a.train_step(t(ids), t(y), t(x))                       # variables move, Adam state becomes non-trivial
+    dump = tf_names.export_variables(a, cols)
+    assert dump["input_layer/input_layer/gender_embedding/embedding_weights"].shape == (7, 4)
+    assert dump["linear/linear_model/item_id/weights"].shape == (3, 1)
+    assert dump["linear/linear_model/bias_weights"].shape == (1,)
+    assert dump["dnn/dnn/hiddenlayer_1/dense/kernel"].shape == (8, 6)
+    assert dump["dnn/dnn/logits/dense/bias"].shape == (1,)
+    assert dump["input_layer/numeric_embeddings"].shape == (1, 2, 4)
+    b = mk()
+    loaded = tf_names.import_variables(b, dump, cols)
+    assert sorted(loaded) == sorted(dump)
+    assert b.step == 0
+    la, lb = a.predict_logits(t(ids), t(x)), b.predict_logits(t(ids), t(x))
+    assert np.array_equal(la.numpy(), lb.numpy())
+    del dump["dnn/dnn/logits/dense/kernel"]
+    with pytest.raises(KeyError, match="logits/dense/kernel"):
+        tf_names.import_variables(mk(), dump, cols)
+    assert "dnn/hiddenlayer_0/kernel" in str(tf_names.variable_names("dnn", cols, 2)["mlp"])

@@ -128,6 +128,30 @@ def test_train_and_evaluate_end_to_end(device, data, trainer, extra, capsys):
     assert first["probabilities"].shape == (2,)
 
 
+def test_warm_start_from_tf_named_variables(device, data, capsys):
+    """--warm-start-from: a dump of TensorFlow-named variables (the reference's checkpoint scopes) seeds a
+    fresh job; evaluating before any further step reproduces the donor's metrics."""
+    import numpy as np
+    from mi355x_rec import tf_names
+    opt = ("exclude_linear", "exclude_mf", "exclude_dnn", "hidden_units", "dropout")
+    base = ["--train-csv", str(data / "train.csv"), "--test-csv", str(data / "test.csv"), "--batch-size", "32", "--device",
+            device, "--hidden-units", "8", "--dropout", "0.0"]
+    donor = deep_fm.train_and_evaluate(_cli.make_parser("deep_fm", opt).parse_args(base + ["--job-dir", str(data / "a"), "--train-steps", "60"]))
+    store = donor.params["_store"]
+    names = [c.name for c in store["plan"].categorical]
+    dump = tf_names.export_variables(store["engine"], names)
+    assert "input_layer/input_layer/user_id_embedding/embedding_weights" in dump and "linear/linear_model/zipcode/weights" in dump
+    np.savez(str(data / "vars.npz"), **dump)
+    ev = ml_100k.get_input_fn(str(data / "test.csv"), "eval", 32)
+    ref = donor.evaluate(ev)
+    capsys.readouterr()
+    warm = deep_fm.train_and_evaluate(_cli.make_parser("deep_fm", opt).parse_args(
+        base + ["--job-dir", str(data / "b"), "--train-steps", "0", "--warm-start-from", str(data / "vars.npz")]))
+    assert "warm-started" in capsys.readouterr().out and warm.global_step == 0
+    got = warm.evaluate(ev)
+    assert abs(got["average_loss"] - ref["average_loss"]) < 1e-6 and abs(got["auc"] - ref["auc"]) < 1e-6
+
+
 def test_model_utils_helpers(device):
     if device == "cpu":
         pytest.skip("helpers bind the HIP kernels directly")
