@@ -191,7 +191,8 @@ def main():
         ms_step = dt / args.steps * 1e3
         g_ms = km["mi_embed_fm_linear_fwd"][0]
         gather_bytes = B * F * 4 * E                     # algorithmic row bytes per launch
-        total_bytes = B * (F * (4 * E + 8) + 4 * E + 8)   # rows + ids + linear weights read; sumv / fm / lin written
+        wide_split = "mi_embed_fm_linear_fwd/wide" in km  # single GPU: the wide part's gathers run beside the layer-1 GEMM
+        total_bytes = B * (F * (4 * E + (4 if wide_split else 8)) + 4 * E + (4 if wide_split else 8))   # rows + ids (+ linear weights) read; sumv / fm (/ lin) written
         achieved = gather_bytes / (g_ms * 1e-3) / 1e9
         gemm_ms = sum(v[2] for k, v in km.items() if k in ("mi_dense_fwd", "mi_dense_fwd_gathered", "mi_dense_bwd_data", "mi_dense_bwd_weight",
                                                         "mi_dense_bwd_weight_gathered")) / args.steps
@@ -222,8 +223,9 @@ def main():
                                 "bf16x3": "fp32 GEMMs via 3-way bf16 operand split, fp32 accumulate",
                                 "fp32": "fp32-input MFMA"}[args.gemm],
                        "parallelism": "dp%d + row-sharded embeddings (all-to-all)" % world if world > 1 else "single GPU"},
-            "roofline": {"kernel": "embed_fm_linear_fwd_k (embedding gather + FM + wide linear; read-only form, the "
-                                   "MLP gathers its own operand)", "bound": "hbm",
+            "roofline": {"kernel": "embed_fm_linear_fwd_k (embedding gather + FM second order + row abs-max; read-only form: the "
+                                   "MLP gathers its own operand" + ("; the wide part's 4-byte gathers run as linear_only_fwd_k on a "
+                                   "side stream under the layer-1 GEMM)" if wide_split else "; + wide linear)"), "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "frac_of_measured_copy_peak": achieved / HBM_MEASURED_GBS,
                          "algorithmic_bytes_per_launch": gather_bytes, "avg_launch_ms": g_ms,

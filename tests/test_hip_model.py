@@ -89,17 +89,21 @@ def _compare_vars(m, p, atol):
         assert np.max(np.abs(g["lin_num"] - p.lin_num)) < atol
 
 
-# Multi-step Adam trajectories amplify last-bit differences: a unit whose pre-activation is 0 to within
-# rounding can have its relu mask flip between two correctly rounded fp32 GEMMs (seen: one unit at
-# 7e-9 in the config-3-shaped case), and TF-form Adam then moves the few weights whose gradient
-# is near zero by ~lr each step whichever way the sign falls.  The fp32-input MFMA path happens
-# not to flip on these seeds and pins the trajectory tightly; the default f16x2 path — equally
-# accurate against fp64, tests/test_hip_kernels.py — gets the bound such a flip implies.
-@pytest.mark.parametrize("gemm,logit_tol,var_atol", [("fp32", 5e-5, 2e-6), ("f16x2", 3e-4, 3e-3)])
+# Multi-step Adam trajectories amplify last-bit differences.  In the config-3-shaped case one unit's
+# pre-activation is 0 to within rounding (7e-9) at step 3: its relu mask — and with it that unit's
+# whole gradient — flips under ANY change of summation order (seen with the f16x2 split, and again
+# in fp32 mode when the wide part's field sum moved to its own kernel), after which TF-form Adam moves
+# the few weights whose gradient is near zero by ~lr per step whichever way the sign falls.  That
+# case is therefore held to the bound such a flip implies from step 1 on; what is not chaotic — one
+# step from identical parameters: logits AND every updated variable — is held tight in every case,
+# and the other cases are held tight over all five steps.
+@pytest.mark.parametrize("gemm", ["f16x2", "fp32"])
 @pytest.mark.parametrize("vocab,E,hidden,B,nn", CONFIGS)
-def test_adam_training_matches_oracle(vocab, E, hidden, B, nn, gemm, logit_tol, var_atol):
+def test_adam_training_matches_oracle(vocab, E, hidden, B, nn, gemm):
     """5 train steps with fresh batches (rows sit out steps, duplicates inside a batch): the lazy
     catch-up path must reproduce TF Adam's dense-equivalent sparse update."""
+    marginal = hidden == [512, 256, 128]
+    logit_tol, var_atol = (3e-4, 3e-3) if marginal else (5e-5, 2e-6)
     p, ids, x, y = make_problem(3, vocab, E, hidden, B, n_numeric=nn)
     m = _engine(vocab, E, hidden, nn, gemm=gemm)
     m.load_oracle_params(p)
@@ -112,8 +116,9 @@ def test_adam_training_matches_oracle(vocab, E, hidden, B, nn, gemm, logit_tol, 
         loss_g, logit_g = m.train_step(dev(ids_s), dev(y), dev(x))
         assert abs(loss_g.item() - float(loss_o)) / abs(float(loss_o)) < 2e-5, step
         assert max_err_scaled(logit_g.cpu().numpy(), logit_o) < logit_tol, step
-        if step == 0:                       # one step from identical parameters is not chaotic: tight in every mode
+        if step == 0:
             assert max_err_scaled(logit_g.cpu().numpy(), logit_o) < 5e-6
+            _compare_vars(m, p, 2e-6)
     _compare_vars(m, p, var_atol)
     assert m.step == 5
 
