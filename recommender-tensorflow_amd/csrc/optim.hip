@@ -12,6 +12,7 @@
 // (oracle/optimizers.py) bit for bit given equal gradients.  HBM-bound; per unique row the
 // algorithmic traffic is 4E (grad) + 24E (w, slot0, slot1 read+write) + 8 bytes.
 #include "common.h"
+#include <algorithm>
 
 namespace {
 
@@ -96,30 +97,30 @@ struct FusedGrad {
   const float* d_concat; int64_t ldd; const float* sumv; const float* dlf; const float* dll; int F;
 };
 
-template <int LPR, bool FUSED>
-__global__ __launch_bounds__(kBlock) void sparse_apply_k(
-    float* __restrict__ table, float* __restrict__ t0, float* __restrict__ t1,
-    float* __restrict__ lin_w, float* __restrict__ l0, float* __restrict__ l1,
-    int32_t* __restrict__ last_step, const int32_t* __restrict__ uniq_rows,
-    const int32_t* __restrict__ seg_start, const int32_t* __restrict__ sorted_entry,
-    const int32_t* __restrict__ num_uniq, const float* __restrict__ d_rows,
-    const float* __restrict__ d_lin, int E, int step, const Hp h, const FusedGrad fg) {
-  const int64_t u = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) / LPR;
-  const int l = threadIdx.x & (LPR - 1);
-  if (u >= *num_uniq) return;
-  const int64_t r = uniq_rows[u];
-  const int s_beg = seg_start[u], s_end = seg_start[u + 1];
-  const bool lane_on = 4 * l < E;
-  float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-  float gl = 0.f;
-  float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (table && lane_on) w = ld4(table + r * E + 4 * l);
-  for (int k = s_beg; k < s_end; ++k) {
-    const int64_t e = sorted_entry[k];
+// Segments longer than this are left to sparse_apply_long_k (a workgroup per row instead of a lane
+// group): with skewed ids one row can own thousands of a batch's entries.
+constexpr int kLongSeg = 48;
+
+struct ApplyArgs {
+  float* table; float* t0; float* t1;
+  float* lin_w; float* l0; float* l1;
+  int32_t* last_step;
+  const int32_t* uniq_rows; const int32_t* seg_start; const int32_t* sorted_entry; const int32_t* num_uniq;
+  const float* d_rows; const float* d_lin;
+  int E, step;
+};
+
+// sum of the gradients of entries sorted_entry[k_beg..k_end) of one row, in that order
+template <bool FUSED>
+__device__ __forceinline__ void seg_accumulate(const ApplyArgs& a, const FusedGrad& fg, int k_beg, int k_end, int l,
+                                               bool lane_on, const float4& w, float4& g, float& gl) {
+  const int E = a.E;
+  for (int k = k_beg; k < k_end; ++k) {
+    const int64_t e = a.sorted_entry[k];
     if constexpr (FUSED) {
       const int64_t b = e / fg.F;
       const int f = static_cast<int>(e - b * fg.F);
-      if (table && lane_on) {
+      if (a.table && lane_on) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (fg.d_concat) v = ld4(fg.d_concat + b * fg.ldd + static_cast<int64_t>(f) * E + 4 * l);
         if (fg.dlf) {
@@ -130,36 +131,112 @@ __global__ __launch_bounds__(kBlock) void sparse_apply_k(
         }
         g.x += v.x; g.y += v.y; g.z += v.z; g.w += v.w;
       }
-      if (lin_w && l == 0) gl += fg.dll[b];
+      if (a.lin_w && l == 0) gl += fg.dll[b];
     } else {
-      if (table && lane_on) {
-        const float4 v = ld4(d_rows + e * E + 4 * l);
+      if (a.table && lane_on) {
+        const float4 v = ld4(a.d_rows + e * E + 4 * l);
         g.x += v.x; g.y += v.y; g.z += v.z; g.w += v.w;
       }
-      if (lin_w && l == 0) gl += d_lin[e];
+      if (a.lin_w && l == 0) gl += a.d_lin[e];
     }
   }
-  if (table && lane_on) {
-    const int64_t o = r * E + 4 * l;
-    float4 a = t0 ? ld4(t0 + o) : make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 b = t1 ? ld4(t1 + o) : make_float4(0.f, 0.f, 0.f, 0.f);
-    sparse_rule(h, w.x, a.x, b.x, g.x);
-    sparse_rule(h, w.y, a.y, b.y, g.y);
-    sparse_rule(h, w.z, a.z, b.z, g.z);
-    sparse_rule(h, w.w, a.w, b.w, g.w);
-    st4(table + o, w);
-    if (t0) st4(t0 + o, a);
-    if (t1) st4(t1 + o, b);
+}
+
+// optimizer rule on row r with the summed gradient (g, gl); stamps the row
+__device__ __forceinline__ void apply_row(const ApplyArgs& a, const Hp& h, int64_t r, int l, bool lane_on, float4 w,
+                                          const float4& g, float gl) {
+  if (a.table && lane_on) {
+    const int64_t o = r * a.E + 4 * l;
+    float4 s0 = a.t0 ? ld4(a.t0 + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 s1 = a.t1 ? ld4(a.t1 + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+    sparse_rule(h, w.x, s0.x, s1.x, g.x);
+    sparse_rule(h, w.y, s0.y, s1.y, g.y);
+    sparse_rule(h, w.z, s0.z, s1.z, g.z);
+    sparse_rule(h, w.w, s0.w, s1.w, g.w);
+    st4(a.table + o, w);
+    if (a.t0) st4(a.t0 + o, s0);
+    if (a.t1) st4(a.t1 + o, s1);
   }
   if (l == 0) {
-    if (lin_w) {
-      float w = lin_w[r], a = l0 ? l0[r] : 0.f, b = l1 ? l1[r] : 0.f;
-      sparse_rule(h, w, a, b, gl);
-      lin_w[r] = w;
-      if (l0) l0[r] = a;
-      if (l1) l1[r] = b;
+    if (a.lin_w) {
+      float lw = a.lin_w[r], s0 = a.l0 ? a.l0[r] : 0.f, s1 = a.l1 ? a.l1[r] : 0.f;
+      sparse_rule(h, lw, s0, s1, gl);
+      a.lin_w[r] = lw;
+      if (a.l0) a.l0[r] = s0;
+      if (a.l1) a.l1[r] = s1;
     }
-    if (last_step) last_step[r] = step;
+    if (a.last_step) a.last_step[r] = a.step;
+  }
+}
+
+// one lane group per unique row: duplicates summed in ascending entry order (TF's CPU order)
+template <int LPR, bool FUSED>
+__global__ __launch_bounds__(kBlock) void sparse_apply_k(const ApplyArgs a, const Hp h, const FusedGrad fg) {
+  const int64_t u = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) / LPR;
+  const int l = threadIdx.x & (LPR - 1);
+  if (u >= *a.num_uniq) return;
+  const int s_beg = a.seg_start[u], s_end = a.seg_start[u + 1];
+  if (s_end - s_beg > kLongSeg) return;            // sparse_apply_long_k's
+  const int64_t r = a.uniq_rows[u];
+  const bool lane_on = 4 * l < a.E;
+  float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+  float gl = 0.f;
+  float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (a.table && lane_on) w = ld4(a.table + r * a.E + 4 * l);
+  seg_accumulate<FUSED>(a, fg, s_beg, s_end, l, lane_on, w, g, gl);
+  apply_row(a, h, r, l, lane_on, w, g, gl);
+}
+
+// Rows with more than kLongSeg entries: a workgroup per row.  Workgroup j looks at the rows
+// j, j + grid, j + 2 grid, ... (hot rows have neighbouring ids: the stride spreads them), collects
+// the long ones, and for each splits the segment into kBlock/LPR contiguous slices, one per lane
+// group, summed in order; the slice sums are then added in slice order.  A fixed order, so results
+// are reproducible; it differs from the one-pass order only in fp32 association.
+template <int LPR, bool FUSED>
+__global__ __launch_bounds__(kBlock) void sparse_apply_long_k(const ApplyArgs a, const Hp h, const FusedGrad fg) {
+  constexpr int G = kBlock / LPR;
+  __shared__ int list[kBlock];
+  __shared__ int n_list;
+  __shared__ float4 part[kBlock];                  // [G][LPR]
+  __shared__ float part_l[G];
+  const int U = *a.num_uniq;
+  const int t = threadIdx.x, l = t & (LPR - 1), grp = t / LPR;
+  const bool lane_on = 4 * l < a.E;
+  const int64_t per_round = static_cast<int64_t>(kBlock) * gridDim.x;
+  for (int64_t base = 0; base < U; base += per_round) {
+    if (t == 0) n_list = 0;
+    __syncthreads();
+    const int64_t u = base + static_cast<int64_t>(t) * gridDim.x + blockIdx.x;
+    if (u < U && a.seg_start[u + 1] - a.seg_start[u] > kLongSeg) list[atomicAdd(&n_list, 1)] = static_cast<int>(u);
+    __syncthreads();
+    const int n = n_list;
+    for (int j = 0; j < n; ++j) {
+      const int uu = list[j];
+      const int64_t r = a.uniq_rows[uu];
+      const int s_beg = a.seg_start[uu], s_end = a.seg_start[uu + 1];
+      const int per = (s_end - s_beg + G - 1) / G;
+      const int k0 = min(s_end, s_beg + grp * per), k1 = min(s_end, k0 + per);
+      float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+      float gl = 0.f;
+      float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (a.table && lane_on) w = ld4(a.table + r * a.E + 4 * l);
+      seg_accumulate<FUSED>(a, fg, k0, k1, l, lane_on, w, g, gl);
+      part[t] = g;
+      if (l == 0) part_l[grp] = gl;
+      __syncthreads();
+      if (grp == 0) {
+        g = part[l];
+        gl = part_l[0];
+#pragma unroll 4
+        for (int q = 1; q < G; ++q) {
+          const float4 v = part[q * LPR + l];
+          g.x += v.x; g.y += v.y; g.z += v.z; g.w += v.w;
+          gl += part_l[q];
+        }
+        apply_row(a, h, r, l, lane_on, w, g, gl);
+      }
+      __syncthreads();
+    }
   }
 }
 
@@ -253,6 +330,12 @@ __global__ __launch_bounds__(kBlock) void axpy_k(float* __restrict__ y, const fl
   if (i < n) y[i] = y[i] + alpha * x[i];
 }
 
+// workgroups of sparse_apply_long_k: enough to spread the hot rows, few enough that a batch without
+// long segments costs one scan of seg_start
+unsigned long_grid(int64_t n_max) {
+  return static_cast<unsigned>(std::min<int64_t>(1024, mi::ceil_div(n_max, kBlock)));
+}
+
 extern "C" {
 
 int32_t mi_axpy(float* y, const float* x, int64_t n, float alpha, mi_stream_t stream) {
@@ -302,10 +385,16 @@ int32_t mi_sparse_apply(float* table, float* t_slot0, float* t_slot1, float* lin
   const int64_t blocks = mi::ceil_div(n_max * lpr, kBlock);
   MI_REQUIRE(blocks <= INT32_MAX, "sparse_apply: grid too large");
   const Hp h = make_hp(hp);
+  const ApplyArgs a{table, t_slot0, t_slot1, lin_w, l_slot0, l_slot1, last_step, uniq_rows, seg_start, sorted_entry,
+                    num_uniq, d_rows, d_lin, E, step};
   MI_DISPATCH_LPR(lpr, (sparse_apply_k<L, false><<<dim3((unsigned)blocks), dim3(kBlock), 0, mi::as_stream(stream)>>>(
-                           table, t_slot0, t_slot1, lin_w, l_slot0, l_slot1, last_step, uniq_rows, seg_start,
-                           sorted_entry, num_uniq, d_rows, d_lin, E, step, h, FusedGrad{})));
+                           a, h, FusedGrad{})));
   MI_CHECK_LAUNCH("sparse_apply");
+  if (n_max > kLongSeg) {
+    MI_DISPATCH_LPR(lpr, (sparse_apply_long_k<L, false><<<dim3(long_grid(n_max)), dim3(kBlock), 0, mi::as_stream(stream)>>>(
+                             a, h, FusedGrad{})));
+    MI_CHECK_LAUNCH("sparse_apply(long segments)");
+  }
   return MI_OK;
 }
 
@@ -336,10 +425,14 @@ int32_t mi_sparse_apply_fused(float* table, float* t_slot0, float* t_slot1, floa
   MI_REQUIRE(blocks <= INT32_MAX, "sparse_apply_fused: grid too large");
   const Hp h = make_hp(hp);
   const FusedGrad fg{d_concat, ld_dconcat, sumv, d_logit_fm, d_logit_lin, F};
-  MI_DISPATCH_LPR(lpr, (sparse_apply_k<L, true><<<dim3((unsigned)blocks), dim3(kBlock), 0, mi::as_stream(stream)>>>(
-                           table, t_slot0, t_slot1, lin_w, l_slot0, l_slot1, last_step, uniq_rows, seg_start,
-                           sorted_entry, num_uniq, nullptr, nullptr, E, step, h, fg)));
+  const ApplyArgs a{table, t_slot0, t_slot1, lin_w, l_slot0, l_slot1, last_step, uniq_rows, seg_start, sorted_entry,
+                    num_uniq, nullptr, nullptr, E, step};
+  MI_DISPATCH_LPR(lpr, (sparse_apply_k<L, true><<<dim3((unsigned)blocks), dim3(kBlock), 0, mi::as_stream(stream)>>>(a, h, fg)));
   MI_CHECK_LAUNCH("sparse_apply_fused");
+  if (n_max > kLongSeg) {
+    MI_DISPATCH_LPR(lpr, (sparse_apply_long_k<L, true><<<dim3(long_grid(n_max)), dim3(kBlock), 0, mi::as_stream(stream)>>>(a, h, fg)));
+    MI_CHECK_LAUNCH("sparse_apply_fused(long segments)");
+  }
   return MI_OK;
 }
 

@@ -448,6 +448,48 @@ def test_sparse_apply_fused_equals_bwd_then_apply_bitwise(lib, name):
     assert not torch.equal(res[0][0], torch.from_numpy(table))
 
 
+@pytest.mark.parametrize("E", [64, 4, 128])
+def test_sparse_apply_long_segments(lib, E):
+    """Skewed ids: a few rows own thousands of entries (a workgroup per row sums them in slices).
+    SGD, so row_new = row - lr * sum(grads): checked against fp64, and run twice for reproducibility;
+    rows with short segments keep the one-pass order and must match the fp32 sequential sum exactly."""
+    from mi355x_rec.engine import OptimizerSpec
+    rng = np.random.default_rng(E)
+    n, R = 20000, 300
+    p = 1.0 / np.arange(1, R + 1) ** 1.3
+    rows = rng.choice(R, size=n, p=p / p.sum()).astype(np.int32)
+    counts = np.bincount(rows, minlength=R)
+    assert counts.max() > 2000 and (counts > 48).sum() > 10 and ((counts > 0) & (counts <= 48)).sum() > 50
+    table = rng.standard_normal((R, E)).astype(np.float32)
+    lin_w = rng.standard_normal(R).astype(np.float32)
+    d_rows = rng.standard_normal((n, E)).astype(np.float32)
+    d_lin = rng.standard_normal(n).astype(np.float32)
+    r = dev(rows)
+    se = torch.empty(n, dtype=torch.int32, device="cuda"); uq = torch.empty(n, dtype=torch.int32, device="cuda")
+    sg = torch.empty(n + 1, dtype=torch.int32, device="cuda"); nu = torch.empty(1, dtype=torch.int32, device="cuda")
+    wsb = torch.empty(lib.mi_sort_unique_workspace_bytes(n) + 256, dtype=torch.uint8, device="cuda")
+    _chk(lib.mi_sort_unique_rows(_p(r), n, R, _p(se), _p(uq), _p(sg), _p(nu), _p(wsb), wsb.numel(), _st()))
+    h = OptimizerSpec("SGD", 0.01).hparams(0.0)
+    dr, dli = dev(d_rows), dev(d_lin)
+    outs = []
+    for _ in range(2):
+        T, L = dev(table), dev(lin_w)
+        _chk(lib.mi_sparse_apply(_p(T), None, None, _p(L), None, None, None, _p(uq), _p(sg), _p(se), _p(nu), n, _p(dr),
+                                 _p(dli), E, 1, C.byref(h), _st()))
+        torch.cuda.synchronize()
+        outs.append((T.cpu().numpy(), L.cpu().numpy()))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    g64 = np.zeros((R, E)); np.add.at(g64, rows, d_rows.astype(np.float64))
+    gl64 = np.zeros(R); np.add.at(gl64, rows, d_lin.astype(np.float64))
+    scale = np.sqrt(counts)[:, None] + 1.0                   # error of an fp32 sum of c terms ~ sqrt(c) ulps
+    assert np.max(np.abs(outs[0][0] - (table - 0.01 * g64)) / scale) < 1e-6
+    assert np.max(np.abs(outs[0][1] - (lin_w - 0.01 * gl64)) / scale[:, 0]) < 1e-6
+    g32 = np.zeros((R, E), np.float32); np.add.at(g32, rows, d_rows)           # sequential fp32, ascending entry
+    short = (counts > 0) & (counts <= 48)
+    expect = table - np.float32(0.01) * g32
+    assert np.array_equal(outs[0][0][short], expect[short])
+
+
 @pytest.mark.parametrize("B", [1, 37, 5000])
 def test_sigmoid_ce_head(lib, B):
     rng = np.random.default_rng(B)
