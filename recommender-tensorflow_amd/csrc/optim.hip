@@ -85,6 +85,17 @@ __global__ __launch_bounds__(kBlock) void dense_apply_k(float* __restrict__ w, f
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+// streaming forms for optimizer slots: read once and written once per step, never re-read before the
+// next step — keep them from evicting the rows the gather is about to read
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld4_nt(const float* p) {
+  const f32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(p));
+  return make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void st4_nt(float* p, float4 v) {
+  const f32x4_t x = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(x, reinterpret_cast<f32x4_t*>(p));
+}
 
 // One group of LPR lanes per unique row; lane l owns elements 4l..4l+3; lane 0 also owns the
 // row's linear weight.  Duplicates are summed in ascending entry order.
@@ -147,15 +158,15 @@ __device__ __forceinline__ void apply_row(const ApplyArgs& a, const Hp& h, int64
                                           const float4& g, float gl) {
   if (a.table && lane_on) {
     const int64_t o = r * a.E + 4 * l;
-    float4 s0 = a.t0 ? ld4(a.t0 + o) : make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 s1 = a.t1 ? ld4(a.t1 + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 s0 = a.t0 ? ld4_nt(a.t0 + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 s1 = a.t1 ? ld4_nt(a.t1 + o) : make_float4(0.f, 0.f, 0.f, 0.f);
     sparse_rule(h, w.x, s0.x, s1.x, g.x);
     sparse_rule(h, w.y, s0.y, s1.y, g.y);
     sparse_rule(h, w.z, s0.z, s1.z, g.z);
     sparse_rule(h, w.w, s0.w, s1.w, g.w);
     st4(a.table + o, w);
-    if (a.t0) st4(a.t0 + o, s0);
-    if (a.t1) st4(a.t1 + o, s1);
+    if (a.t0) st4_nt(a.t0 + o, s0);
+    if (a.t1) st4_nt(a.t1 + o, s1);
   }
   if (l == 0) {
     if (a.lin_w) {
@@ -269,7 +280,7 @@ __global__ __launch_bounds__(kBlock) void sparse_catchup_k(
   if (ls > 0) {
     if (table && 4 * l < E) {
       const int64_t o = r * E + 4 * l;
-      float4 w = ld4(table + o), m = ld4(tm + o), v = ld4(tv + o);
+      float4 w = ld4(table + o), m = ld4_nt(tm + o), v = ld4_nt(tv + o);
       // one loop for the four elements: one lr_t load and one loop counter per step instead of four,
       // four independent sqrt/divide chains in flight (the arithmetic per element is unchanged)
       for (int s = ls + 1; s <= step_to; ++s) {
@@ -281,7 +292,7 @@ __global__ __launch_bounds__(kBlock) void sparse_catchup_k(
         w.z = w.z - (lr * m.z) / (sqrtf(v.z) + eps);
         w.w = w.w - (lr * m.w) / (sqrtf(v.w) + eps);
       }
-      st4(table + o, w); st4(tm + o, m); st4(tv + o, v);
+      st4(table + o, w); st4_nt(tm + o, m); st4_nt(tv + o, v);
     }
     if (lin_w && l == 0) {
       float w = lin_w[r], m = lm[r], v = lv[r];
