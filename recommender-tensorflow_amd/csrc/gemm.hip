@@ -707,11 +707,6 @@ static int32_t bwd_weight_impl(const float* X, int64_t ldx, const float* dY, int
 
 }  // extern "C"
 
-#ifdef MI_GEMM_STAMPS
-extern "C" int32_t mi_gemm_stamps_read(void* dst, size_t nbytes) {
-  return static_cast<int32_t>(hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stamps), nbytes, 0, hipMemcpyDeviceToHost));
-}
-#endif
 
 #ifdef MI_GEMM_STAMPS
 extern "C" int32_t mi_gemm_stamps_read(void* dst, size_t nbytes) {
