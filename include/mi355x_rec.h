@@ -40,7 +40,7 @@ enum mi_status {
 };
 
 /* ---- library ---------------------------------------------------------------------------- */
-int32_t mi_abi_version(void);       /* bumps when a signature changes (currently 7) */
+int32_t mi_abi_version(void);       /* bumps when a signature changes (currently 8) */
 const char* mi_last_error(void);    /* thread-local, never NULL */
 const char* mi_build_info(void);    /* "gfx950 hipcc <ver>" */
 
@@ -217,11 +217,15 @@ int32_t mi_sparse_apply_fused(float* table, float* t_slot0, float* t_slot1, floa
  * up to date lazily: for s in (last_step[r], step_to]: m*=b1; v*=b2; w -= lr_t[s]*m/(sqrt(v)+eps)
  * — the same fp32 op sequence as the sweep, hence the same bits.  lr_table[s] (device, f32) holds
  * lr_t of step s.  Runs on the U distinct rows about to be gathered (step_to = step-1), or on all
- * rows (uniq_rows == NULL, n_max = R) before evaluation / checkpoint. */
+ * rows (uniq_rows == NULL, n_max = R) before evaluation / checkpoint.
+ * defer_slots != 0 (with uniq_rows): only w is written; m, v and last_step keep their old values and
+ * the mi_sparse_apply[_fused] of the same step — which reads and writes m, v anyway and MUST then be
+ * given last_step — decays them from the old stamp (same multiply chain, same bits).  Saves a third
+ * of this kernel's HBM traffic; every row passed here must be applied in the same step. */
 int32_t mi_sparse_catchup(float* table, float* t_m, float* t_v, float* lin_w, float* l_m, float* l_v,
                           int32_t* last_step, const int32_t* uniq_rows, const int32_t* num_uniq,
                           int64_t n_max, int32_t E, int32_t step_to, const float* lr_table,
-                          float beta1, float beta2, float epsilon, mi_stream_t stream);
+                          float beta1, float beta2, float epsilon, int32_t defer_slots, mi_stream_t stream);
 
 /* ---- (a6) the [hidden_units] MLP: fp32 GEMMs on the matrix cores with fused epilogues -----------
  * replaces tf.layers.dense / tf.layers.dropout (deep_fm.py:98-108).  Row-major everywhere.

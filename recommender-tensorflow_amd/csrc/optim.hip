@@ -153,13 +153,25 @@ __device__ __forceinline__ void seg_accumulate(const ApplyArgs& a, const FusedGr
   }
 }
 
-// optimizer rule on row r with the summed gradient (g, gl); stamps the row
+// optimizer rule on row r with the summed gradient (g, gl); stamps the row.  Adam rows whose stamp
+// is older than step - 1 (mi_sparse_catchup ran with defer_slots: it moved w only) first get the
+// decay of m and v for the steps they sat out — the same multiply chain the catch-up ran, hence
+// the same bits; a fully caught-up row (stamp == step - 1) and a never-applied one (m = v = 0) skip it.
 __device__ __forceinline__ void apply_row(const ApplyArgs& a, const Hp& h, int64_t r, int l, bool lane_on, float4 w,
                                           const float4& g, float gl) {
+  int missed = 0;
+  if (h.kind == MI_OPT_ADAM && a.last_step) {
+    const int ls = a.last_step[r];
+    missed = ls > 0 ? max(0, a.step - 1 - ls) : 0;
+  }
   if (a.table && lane_on) {
     const int64_t o = r * a.E + 4 * l;
     float4 s0 = a.t0 ? ld4_nt(a.t0 + o) : make_float4(0.f, 0.f, 0.f, 0.f);
     float4 s1 = a.t1 ? ld4_nt(a.t1 + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = 0; j < missed; ++j) {
+      s0.x = s0.x * h.beta1; s0.y = s0.y * h.beta1; s0.z = s0.z * h.beta1; s0.w = s0.w * h.beta1;
+      s1.x = s1.x * h.beta2; s1.y = s1.y * h.beta2; s1.z = s1.z * h.beta2; s1.w = s1.w * h.beta2;
+    }
     sparse_rule(h, w.x, s0.x, s1.x, g.x);
     sparse_rule(h, w.y, s0.y, s1.y, g.y);
     sparse_rule(h, w.z, s0.z, s1.z, g.z);
@@ -171,6 +183,7 @@ __device__ __forceinline__ void apply_row(const ApplyArgs& a, const Hp& h, int64
   if (l == 0) {
     if (a.lin_w) {
       float lw = a.lin_w[r], s0 = a.l0 ? a.l0[r] : 0.f, s1 = a.l1 ? a.l1[r] : 0.f;
+      for (int j = 0; j < missed; ++j) { s0 = s0 * h.beta1; s1 = s1 * h.beta2; }
       sparse_rule(h, lw, s0, s1, gl);
       a.lin_w[r] = lw;
       if (a.l0) a.l0[r] = s0;
@@ -268,7 +281,7 @@ __global__ __launch_bounds__(kBlock) void sparse_catchup_k(
     float* __restrict__ lin_w, float* __restrict__ lm, float* __restrict__ lv,
     int32_t* __restrict__ last_step, const int32_t* __restrict__ uniq_rows,
     const int32_t* __restrict__ num_uniq, int64_t n_max, int E, int step_to,
-    const float* __restrict__ lr_table, float b1, float b2, float eps) {
+    const float* __restrict__ lr_table, float b1, float b2, float eps, bool defer_slots) {
   const int64_t u = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) / LPR;
   const int l = threadIdx.x & (LPR - 1);
   const int64_t count = uniq_rows ? static_cast<int64_t>(*num_uniq) : n_max;
@@ -292,16 +305,21 @@ __global__ __launch_bounds__(kBlock) void sparse_catchup_k(
         w.z = w.z - (lr * m.z) / (sqrtf(v.z) + eps);
         w.w = w.w - (lr * m.w) / (sqrtf(v.w) + eps);
       }
-      st4(table + o, w); st4_nt(tm + o, m); st4_nt(tv + o, v);
+      st4(table + o, w);
+      if (!defer_slots) { st4_nt(tm + o, m); st4_nt(tv + o, v); }
     }
     if (lin_w && l == 0) {
       float w = lin_w[r], m = lm[r], v = lv[r];
       replay(w, m, v, ls + 1, step_to, lr_table, b1, b2, eps);
-      lin_w[r] = w; lm[r] = m; lv[r] = v;
+      lin_w[r] = w;
+      if (!defer_slots) { lm[r] = m; lv[r] = v; }
     }
   }
+  // defer_slots: the sparse apply that follows in the same step decays m and v itself (it reads and
+  // writes them anyway) from the old stamp, so neither they nor the stamp are written here — a third
+  // of this kernel's HBM traffic.
   // every lane of the group has read last_step[r] above (same wave, program order) before lane 0 writes
-  if (l == 0) last_step[r] = step_to;
+  if (l == 0 && !defer_slots) last_step[r] = step_to;
 }
 
 int lanes_per_row(int E) {
@@ -450,7 +468,7 @@ int32_t mi_sparse_apply_fused(float* table, float* t_slot0, float* t_slot1, floa
 int32_t mi_sparse_catchup(float* table, float* t_m, float* t_v, float* lin_w, float* l_m, float* l_v,
                           int32_t* last_step, const int32_t* uniq_rows, const int32_t* num_uniq,
                           int64_t n_max, int32_t E, int32_t step_to, const float* lr_table,
-                          float beta1, float beta2, float epsilon, mi_stream_t stream) {
+                          float beta1, float beta2, float epsilon, int32_t defer_slots, mi_stream_t stream) {
   MI_REQUIRE(n_max >= 0 && step_to >= 0, "sparse_catchup: n_max=%lld step_to=%d", (long long)n_max, step_to);
   if (n_max == 0 || step_to == 0) return MI_OK;
   MI_REQUIRE(last_step && lr_table, "sparse_catchup: null buffer");
@@ -464,7 +482,7 @@ int32_t mi_sparse_catchup(float* table, float* t_m, float* t_v, float* lin_w, fl
   MI_REQUIRE(blocks <= INT32_MAX, "sparse_catchup: grid too large");
   MI_DISPATCH_LPR(lpr, (sparse_catchup_k<L><<<dim3((unsigned)blocks), dim3(kBlock), 0, mi::as_stream(stream)>>>(
                            table, t_m, t_v, lin_w, l_m, l_v, last_step, uniq_rows, num_uniq, n_max, E, step_to,
-                           lr_table, beta1, beta2, epsilon)));
+                           lr_table, beta1, beta2, epsilon, defer_slots != 0 && uniq_rows != nullptr)));
   MI_CHECK_LAUNCH("sparse_catchup");
   return MI_OK;
 }

@@ -530,9 +530,13 @@ class DeepFM:
         self._catchup(None, None, self.R_local)
         self._final_step = self.step
 
-    def _catchup(self, uniq, num_uniq, n_max):
+    def _catchup(self, uniq, num_uniq, n_max, defer=False):
+        """defer: the rows are about to be applied in this same step by ONE mi_sparse_apply call, which
+        then decays m and v itself from the old stamps — the catch-up moves w only (a third less HBM
+        traffic).  Not with a separate linear optimizer (two apply calls would see each other's stamps)."""
         if self.sched is None or n_max == 0:
             return
+        defer = bool(defer and uniq is not None and self.lin_opt is None)
         s = self.sched.spec
         t_adam = self.opt.name == "Adam" and self.table is not None
         l_adam = (self.lin_opt or self.opt).name == "Adam" and self.lin_w is not None
@@ -541,7 +545,7 @@ class DeepFM:
                                  self.t_s1 if t_adam else None, self.lin_w if l_adam else None,
                                  self.l_s0 if l_adam else None, self.l_s1 if l_adam else None, self.last_step,
                                  uniq, num_uniq, n_max, self.E, self.step, self.sched.table, s.beta1, s.beta2,
-                                 s.epsilon)
+                                 s.epsilon, 1 if defer else 0)
 
     def _sort_unique(self, keys, n, key_range, tag):
         """mi_sort_unique_rows into persistent buffers named after `tag`."""
@@ -569,7 +573,7 @@ class DeepFM:
         sorted_entry, uniq, seg, num_uniq = self._sort_unique(rows, n, self.R, "own")
         # (2) TF Adam moved these rows on every step they sat out: replay that now
         if self.adam_rows and self.step > 0:
-            self._catchup(uniq, num_uniq, n)
+            self._catchup(uniq, num_uniq, n, defer=True)
         # (3) forward + head
         c = self._forward(ids, x_num, True)
         logits, loss, dlogit = self._head(c, labels, True)

@@ -194,7 +194,7 @@ def _sharded_step(m, ids, labels, x_num, train):
     if train and nr > 0:
         book = m._sort_unique(recv_ids, nr, m.R_local, "own")     # (sorted_entry, uniq, seg, num_uniq)
         if m.adam_rows and m.step > 0:
-            m._catchup(book[1], book[3], nr)
+            m._catchup(book[1], book[3], nr, defer=True)
 
     own_rows = m._buf("own_rows", (max(nr, 1), E))[:nr] if m.use_emb else None
     own_lin = m._buf("own_lin", (max(nr, 1),))[:nr] if m.use_linear else None

@@ -175,7 +175,8 @@ class NumpyKernels:
                        _np(grad)[:n], np.float32(hp.lr_t))
 
     def mi_sparse_catchup(self, table, tm, tv, lin_w, lm, lv, last_step, uniq, num_uniq, n_max, E, step_to, lr_table,
-                          b1, b2, eps):
+                          b1, b2, eps, defer_slots=0):
+        defer = bool(defer_slots) and uniq is not None
         rows = np.arange(n_max) if uniq is None else _np(uniq)[:int(_np(num_uniq)[0])]
         ls = _np(last_step)
         lr = _np(lr_table)
@@ -188,11 +189,15 @@ class NumpyKernels:
                     if w is None:
                         continue
                     W, M, V = _np(w), _np(m), _np(v)
+                    mr, vr = M[r].copy(), V[r].copy()
                     for s in range(ls[r] + 1, step_to + 1):
-                        M[r] = M[r] * b1
-                        V[r] = V[r] * b2
-                        W[r] = W[r] - (lr[s] * M[r]) / (np.sqrt(V[r]) + eps)
-            ls[r] = step_to
+                        mr = mr * b1
+                        vr = vr * b2
+                        W[r] = W[r] - (lr[s] * mr) / (np.sqrt(vr) + eps)
+                    if not defer:
+                        M[r], V[r] = mr, vr
+            if not defer:
+                ls[r] = step_to
 
     def mi_sparse_apply(self, table, t0, t1, lin_w, l0, l1, last_step, uniq, seg, sorted_entry, num_uniq, n_max,
                         d_rows, d_lin, E, step, hp):
@@ -215,6 +220,13 @@ class NumpyKernels:
             wv, av, bv = W[rows], A[rows], Bm[rows]
             if h.name == "Adam":
                 b1, b2, eps = np.float32(h.beta1), np.float32(h.beta2), np.float32(h.epsilon)
+                if last_step is not None:                       # deferred decay of the steps the row sat out
+                    ls = _np(last_step)[rows]
+                    missed = np.where(ls > 0, np.maximum(0, step - 1 - ls), 0)
+                    for j in range(int(missed.max()) if len(missed) else 0):
+                        on = (missed > j)[:, None]
+                        av = np.where(on, av * b1, av)
+                        bv = np.where(on, bv * b2, bv)
                 av = av * b1 + gsum * (np.float32(1) - b1)
                 bv = bv * b2 + (gsum * gsum) * (np.float32(1) - b2)
                 wv = wv - (np.float32(hp.lr_t) * av) / (np.sqrt(bv) + eps)

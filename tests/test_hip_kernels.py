@@ -633,7 +633,7 @@ def test_sparse_apply_and_catchup_bit_exact(lib, name, E):
         if name == "Adam" and step > 1:
             assert abs(sched.lr_t(step) - float(lr_t)) == 0.0
             _chk(lib.mi_sparse_catchup(_p(dW), _p(d_ws0), _p(d_ws1), _p(dL), _p(d_ls0), _p(d_ls1), _p(last), _p(uq),
-                                       _p(nu), n, E, step - 1, _p(sched.table), hp.beta1, hp.beta2, hp.epsilon, _st()))
+                                       _p(nu), n, E, step - 1, _p(sched.table), hp.beta1, hp.beta2, hp.epsilon, 0, _st()))
         h = spec.hparams(float(lr_t))
         dg, dgl = dev(g), dev(gl[:, 0].copy())      # keep references: launches are asynchronous
         _chk(lib.mi_sparse_apply(_p(dW), _p(d_ws0) if need0 else None, _p(d_ws1) if need1 else None, _p(dL),
@@ -643,7 +643,7 @@ def test_sparse_apply_and_catchup_bit_exact(lib, name, E):
         torch.cuda.synchronize()
     if name == "Adam":   # bring the rows that sat out the last steps up to date: all-rows catch-up
         _chk(lib.mi_sparse_catchup(_p(dW), _p(d_ws0), _p(d_ws1), _p(dL), _p(d_ls0), _p(d_ls1), _p(last), None, None,
-                                   R, E, steps, _p(sched.table), hp.beta1, hp.beta2, hp.epsilon, _st()))
+                                   R, E, steps, _p(sched.table), hp.beta1, hp.beta2, hp.epsilon, 0, _st()))
         assert np.all(last.cpu().numpy() == steps)
     assert np.array_equal(dW.cpu().numpy(), W)
     assert np.array_equal(dL.cpu().numpy(), L[:, 0])
