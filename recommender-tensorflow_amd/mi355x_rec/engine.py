@@ -403,6 +403,7 @@ class DeepFM:
         rows received from their owners, addressed by slot)."""
         k = self.k
         B = ids.shape[0]
+        self._last_B = B
         c = {"B": B}
         table, lin_w, field_off, rid = src if src is not None else (self.table, self.lin_w, self.field_off, ids)
         concat = sumv = fm = None
@@ -679,6 +680,34 @@ class DeepFM:
                                       d_rows if tb is not None else None, d_lin if lw is not None else None, self.E,
                                       step, h)
         self.step = step
+
+    def layer_summaries(self):
+        """What the reference's layer_summary calls record (model_utils.py:4-6 at deep_fm.py:43,89,105,
+        110,115): fraction of zeros (+ min / max / mean) of the linear, mf and dnn logits, of every hidden
+        layer's output and of the summed logits — computed on the activations the last step left in the
+        workspace (mi_layer_stats), one small host copy.  Keys follow the reference's scopes."""
+        k = self.k
+        B = getattr(self, "_last_B", 0)
+        if not B:
+            return {}
+        named = []
+        if self.use_linear and "lin" in self._ws:
+            named.append(("linear/logits", self._ws["lin"][:B]))
+        if self.use_mf and "fm" in self._ws:
+            named.append(("mf/logits", self._ws["fm"][:B]))
+        if self.use_dnn:
+            for i, (_, _, _, h) in enumerate(self.layers):
+                a = self._ws.get("act%d" % i)
+                if a is not None:
+                    named.append(("dnn/hiddenlayer_%d" % i if i < len(self.layers) - 1 else "dnn/logits", a[:B * h]))
+        if "logits" in self._ws:
+            named.append(("logits", self._ws["logits"][:B]))
+        out = self._buf("layer_stats", (len(named), 4))
+        for j, (_, x) in enumerate(named):
+            ws = self._bytes("layer_stats_ws", k.query("mi_layer_stats_workspace_bytes", x.numel()))
+            k.mi_layer_stats(x, x.numel(), out[j], ws, ws.numel())
+        vals = out.cpu().tolist()
+        return {n: dict(zip(("fraction_of_zero_values", "min", "max", "mean"), v)) for (n, _), v in zip(named, vals)}
 
     # ------------------------------------------------------------------ checkpoint
     _STATE_KEYS = ("dense", "d_s0", "d_s1", "table", "lin_w", "t_s0", "t_s1", "l_s0", "l_s1", "last_step",

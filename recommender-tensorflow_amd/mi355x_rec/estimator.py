@@ -139,6 +139,17 @@ class Estimator:
             json.dump({"model_checkpoint_path": name, "all_model_checkpoint_paths": files}, f)
         return os.path.join(self.model_dir, name)
 
+    def _write_summaries(self, loss):
+        """Every save_summary_steps: loss + the layer_summary statistics (model_utils.py:4-6; TensorBoard
+        events in the reference) appended as one JSON line to <model_dir>/summaries.jsonl."""
+        eng = self._engine()
+        if eng is None or not hasattr(eng, "layer_summaries"):
+            return
+        os.makedirs(self.model_dir, exist_ok=True)
+        rec = {"global_step": self.global_step, "loss": loss, "layers": eng.layer_summaries()}
+        with open(os.path.join(self.model_dir, "summaries.jsonl"), "a") as f:
+            f.write(json.dumps(rec) + "\n")
+
     # -- modes ----------------------------------------------------------------------------
     def _first_call(self, features, labels, mode):
         """Build the variables (first model_fn call) and restore the latest checkpoint before any step."""
@@ -166,6 +177,8 @@ class Estimator:
                 print("INFO: loss = %.6f, step = %d (%.1f global_step/sec)" %
                       (float(loss), self.global_step, n_log / max(now - t_log, 1e-9)))
                 t_log, n_log = now, 0
+            if self.config.save_summary_steps and self.global_step % self.config.save_summary_steps == 0:
+                self._write_summaries(float(loss))
             if self.config.save_checkpoints_secs and time.time() - t_ckpt >= self.config.save_checkpoints_secs:
                 self.save_checkpoint()
                 t_ckpt = time.time()

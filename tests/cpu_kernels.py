@@ -278,6 +278,10 @@ class NumpyKernels:
                              d_rows, d_lin, E, step, hp)
 
     # ---- eval counters --------------------------------------------------------------------------
+    def mi_layer_stats(self, x, n, out4, ws, wsb):
+        v = _np(x).reshape(-1)[:n]
+        _np(out4)[:4] = [np.mean(v == 0), v.min(), v.max(), v.mean()]
+
     def mi_eval_accumulate(self, logits, labels, B, hist, counts, sums):
         from oracle.metrics import auc_thresholds
         x = _np(logits)[:B].astype(np.float32)

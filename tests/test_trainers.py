@@ -117,6 +117,12 @@ def test_train_and_evaluate_end_to_end(device, data, trainer, extra, capsys):
     out = capsys.readouterr().out
     assert "Saving dict for global step 120" in out and "auc = " in out and "average_loss = " in out
     assert os.path.exists(os.path.join(job, "model.ckpt-120.pt")) and os.listdir(os.path.join(job, "export", "exporter"))
+    import json as _json                                   # layer_summary records every save_summary_steps (100)
+    recs = [_json.loads(l) for l in open(os.path.join(job, "summaries.jsonl"))]
+    assert recs and recs[0]["global_step"] == 100 and "logits" in recs[0]["layers"]
+    if name == "deep_fm":
+        assert {"linear/logits", "mf/logits", "dnn/hiddenlayer_0", "dnn/logits"} <= set(recs[0]["layers"])
+        assert 0.0 <= recs[0]["layers"]["dnn/hiddenlayer_0"]["fraction_of_zero_values"] <= 1.0
     # --restore continues from the checkpoint; without it the job dir is wiped (deep_fm.py:147-148)
     est2 = trainer.train_and_evaluate(_cli.make_parser(name, opt).parse_args(argv[:-len(extra) or None] + extra + ["--restore", "--train-steps", "150"]))
     assert est2.global_step == 150 and "restored" in capsys.readouterr().out
