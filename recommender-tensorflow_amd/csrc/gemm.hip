@@ -470,6 +470,131 @@ __global__ __launch_bounds__(kThreads) void colsum_final_k(const float* __restri
   out[c] = acc;
 }
 
+// ---- the N = 1 logits layer (deep_fm.py:108): matrix-vector forms -----------------------------
+// A 128x128 MFMA tile for one output column wastes 127/128 of the matrix pipe; these are plain
+// HBM-bound kernels instead (read X once / write dX once).  16 lanes per example.
+constexpr int kGvLanes = 16;
+
+__global__ __launch_bounds__(kThreads) void gemv_fwd_k(const float* __restrict__ X, int64_t ldx,
+                                                       const float* __restrict__ W, const float* __restrict__ bias,
+                                                       float* __restrict__ Y, int64_t ldy, int64_t M, int K, int relu,
+                                                       float keep_prob, float inv_keep, uint64_t seed,
+                                                       float* __restrict__ amax_out) {
+  const int l = threadIdx.x & (kGvLanes - 1);
+  const int64_t groups = static_cast<int64_t>(gridDim.x) * (kThreads / kGvLanes);
+  const uint32_t thresh = static_cast<uint32_t>(keep_prob * 16777216.0f);
+  const float b0 = bias ? bias[0] : 0.f;
+  float mx = 0.f;
+  for (int64_t m0 = (static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x) / kGvLanes; m0 < M; m0 += 2 * groups) {
+    float acc[2] = {0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {                  // two rows in flight per lane group
+      const int64_t m = min(m0 + j * groups, M - 1);
+      const float* x = X + m * ldx;
+      for (int k = 4 * l; k < K; k += 4 * kGvLanes) {
+        const float4 a = *reinterpret_cast<const float4*>(x + k);
+        const float4 w = *reinterpret_cast<const float4*>(W + k);
+        acc[j] += (a.x * w.x + a.y * w.y) + (a.z * w.z + a.w * w.w);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+      for (int o = kGvLanes / 2; o > 0; o >>= 1) acc[j] += __shfl_xor(acc[j], o, kGvLanes);
+      const int64_t m = m0 + j * groups;
+      if (m < M && l == 0) {
+        float v = acc[j] + b0;
+        if (relu) v = fmaxf(v, 0.f);
+        if (keep_prob < 1.f) v = dropout_keep(seed, static_cast<uint32_t>(m), 0u, thresh) ? v * inv_keep : 0.f;
+        Y[m * ldy] = v;
+        mx = fmaxf(mx, fabsf(v));
+      }
+    }
+  }
+  const float v = mx;
+  if (amax_out) mi_amax_publish(amax_out, fabsf(v));
+}
+
+// dX[m,k] = dY[m] * W[k], masked by the stored activation (see mi_dense_bwd_data)
+__global__ __launch_bounds__(kThreads) void gemv_dgrad_k(const float* __restrict__ dY, int64_t lddy,
+                                                         const float* __restrict__ W, const float* __restrict__ Xact,
+                                                         int64_t ldxa, float* __restrict__ dX, int64_t lddx, int64_t M,
+                                                         int K, float inv_keep, float* __restrict__ amax_out) {
+  const int kq = K >> 2;
+  const int64_t total = M * kq, stride = static_cast<int64_t>(gridDim.x) * kThreads;
+  float mx = 0.f;
+  for (int64_t base = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; base < total; base += 4 * stride) {
+    float4 xv[4], wv[4];
+    float gv[4];
+    int64_t mm[4];
+    int kk[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {                  // loads of four elements first, then the arithmetic
+      const int64_t idx = min(base + j * stride, total - 1);
+      mm[j] = idx / kq;
+      kk[j] = static_cast<int>(idx - mm[j] * kq) * 4;
+      gv[j] = dY[mm[j] * lddy];
+      wv[j] = *reinterpret_cast<const float4*>(W + kk[j]);
+      if (Xact) xv[j] = *reinterpret_cast<const float4*>(Xact + mm[j] * ldxa + kk[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (base + j * stride >= total) break;
+      float4 v = make_float4(gv[j] * wv[j].x, gv[j] * wv[j].y, gv[j] * wv[j].z, gv[j] * wv[j].w);
+      if (Xact) {
+        v.x = xv[j].x > 0.f ? v.x * inv_keep : 0.f; v.y = xv[j].y > 0.f ? v.y * inv_keep : 0.f;
+        v.z = xv[j].z > 0.f ? v.z * inv_keep : 0.f; v.w = xv[j].w > 0.f ? v.w * inv_keep : 0.f;
+      }
+      *reinterpret_cast<float4*>(dX + mm[j] * lddx + kk[j]) = v;
+      mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    }
+  }
+  if (amax_out) mi_amax_publish(amax_out, mx);
+}
+
+// slab s of rows: part[s][k] = sum_m X[m,k] dY[m], bpart[s] = sum_m dY[m]; rows in ascending order per
+// thread column, the 64 row-lanes of a column folded in a fixed tree: reproducible.  slab_reduce_k adds
+// the slabs.  Block = 4 column-float4 x 64 row lanes.
+__global__ __launch_bounds__(kThreads) void gemv_wgrad_k(const float* __restrict__ X, int64_t ldx,
+                                                         const float* __restrict__ dY, int64_t lddy, int64_t M, int K,
+                                                         int64_t rows_per_slab, float* __restrict__ part,
+                                                         float* __restrict__ bpart) {
+  __shared__ float4 red[kThreads];
+  __shared__ float redb[64];
+  const int c = threadIdx.x & 3, rl = threadIdx.x >> 2;            // column group inside the block, row lane
+  const int k = (blockIdx.x * 4 + c) * 4;
+  const int64_t r0 = static_cast<int64_t>(blockIdx.y) * rows_per_slab, r1 = min(M, r0 + rows_per_slab);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  float accb = 0.f;
+  for (int64_t m = r0 + rl; m < r1; m += 64) {
+    const float g = dY[m * lddy];
+    if (k < K) {
+      const float4 x = *reinterpret_cast<const float4*>(X + m * ldx + k);
+      acc.x += x.x * g; acc.y += x.y * g; acc.z += x.z * g; acc.w += x.w * g;
+    }
+    if (c == 0) accb += g;
+  }
+  red[threadIdx.x] = acc;
+  if (c == 0) redb[rl] = accb;
+  __syncthreads();
+  for (int o = 32; o > 0; o >>= 1) {
+    if (rl < o) {
+      const float4 b = red[threadIdx.x + 4 * o];
+      float4 a = red[threadIdx.x];
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+      red[threadIdx.x] = a;
+      if (c == 0) redb[rl] += redb[rl + o];
+    }
+    __syncthreads();
+  }
+  if (rl == 0 && k < K) *reinterpret_cast<float4*>(part + static_cast<int64_t>(blockIdx.y) * K + k) = red[c];
+  if (threadIdx.x == 0 && blockIdx.x == 0 && bpart) bpart[blockIdx.y] = redb[0];
+}
+
+bool gemv_ok(const float* X, int64_t ldx, const float* W, int K) {
+  return mi::aligned16(X) && mi::aligned16(W) && (ldx & 3) == 0 && (K & 3) == 0;
+}
+
 bool vec_ok(const float* p, int64_t ld, int contiguous_extent) {
   return mi::aligned16(p) && (ld & 3) == 0 && (contiguous_extent & 3) == 0;
 }
@@ -561,6 +686,13 @@ int32_t mi_dense_fwd(const float* X, int64_t ldx, const float* W, const float* b
   MI_REQUIRE(X && W && Y, "dense_fwd: null buffer");
   MI_REQUIRE(ldx >= K && ldy >= N, "dense_fwd: ldx=%lld ldy=%lld", (long long)ldx, (long long)ldy);
   MI_REQUIRE(keep_prob > 0.f && keep_prob <= 1.f, "dense_fwd: keep_prob=%f", keep_prob);
+  if (N == 1 && gemv_ok(X, ldx, W, K)) {
+    const int64_t blocks = std::min<int64_t>(mi::ceil_div(M * kGvLanes, 2 * kThreads), 2048);
+    gemv_fwd_k<<<dim3((unsigned)blocks), dim3(kThreads), 0, mi::as_stream(stream)>>>(
+        X, ldx, W, bias, Y, ldy, M, K, relu, keep_prob, 1.f / keep_prob, seed, amax ? amax->out : nullptr);
+    MI_CHECK_LAUNCH("dense_fwd(N = 1)");
+    return MI_OK;
+  }
   GemmArgs a{};
   a.A = X; a.lda = ldx; a.B = W; a.ldb = N; a.C = Y; a.ldc = ldy;
   a.M = (int)M; a.N = N; a.K = K; a.k_per_split = ((K + BK - 1) / BK) * BK;
@@ -579,6 +711,14 @@ int32_t mi_dense_bwd_data(const float* dY, int64_t lddy, const float* W, const f
   MI_REQUIRE(dY && W && dX, "dense_bwd_data: null buffer");
   MI_REQUIRE(lddy >= N && lddx >= K && (!Xact || ldxa >= K), "dense_bwd_data: leading dimensions");
   MI_REQUIRE(keep_prob > 0.f && keep_prob <= 1.f, "dense_bwd_data: keep_prob=%f", keep_prob);
+  if (N == 1 && mi::aligned16(W) && mi::aligned16(dX) && (lddx & 3) == 0 && (K & 3) == 0 &&
+      (!Xact || (mi::aligned16(Xact) && (ldxa & 3) == 0))) {
+    const int64_t blocks = std::min<int64_t>(mi::ceil_div(M * (K >> 2), 4 * kThreads), 4096);
+    gemv_dgrad_k<<<dim3((unsigned)blocks), dim3(kThreads), 0, mi::as_stream(stream)>>>(
+        dY, lddy, W, Xact, ldxa, dX, lddx, M, K, Xact ? 1.f / keep_prob : 1.f, amax ? amax->out : nullptr);
+    MI_CHECK_LAUNCH("dense_bwd_data(N = 1)");
+    return MI_OK;
+  }
   GemmArgs a{};                       // dX[M,K] = dY[M,N] * W[K,N]^T : gemm M x K x (reduce N)
   a.A = dY; a.lda = lddy; a.B = W; a.ldb = N; a.C = dX; a.ldc = lddx;
   a.M = (int)M; a.N = K; a.K = N; a.k_per_split = ((N + BK - 1) / BK) * BK;
@@ -684,6 +824,19 @@ static int32_t bwd_weight_impl(const float* X, int64_t ldx, const float* dY, int
   const int64_t n = static_cast<int64_t>(K) * N;
   float* slab = static_cast<float*>(workspace);
   float* cpart = slab + static_cast<int64_t>(splits) * n;   // [splits][N] bias-gradient partials
+  if (N == 1 && !g_ids && gemv_ok(X, ldx, X, K)) {          // logits layer: slabs of rows, then the same reduce
+    const int64_t rows = mi::ceil_div(M, splits);
+    gemv_wgrad_k<<<dim3((unsigned)mi::ceil_div(K, 16), (unsigned)splits), dim3(kThreads), 0, st>>>(
+        X, ldx, dY, lddy, M, K, rows, slab, db ? cpart : nullptr);
+    MI_CHECK_LAUNCH("dense_bwd_weight(N = 1)");
+    slab_reduce_k<<<dim3((unsigned)mi::ceil_div(n, 64)), dim3(kThreads), 0, st>>>(slab, splits, n, dW);
+    MI_CHECK_LAUNCH("dense_bwd_weight(reduce)");
+    if (db) {
+      slab_reduce_k<<<dim3(1), dim3(kThreads), 0, st>>>(cpart, splits, 1, db);
+      MI_CHECK_LAUNCH("dense_bwd_weight(reduce bias)");
+    }
+    return MI_OK;
+  }
   GemmArgs a{};                       // dW[K,N] = X[M,K]^T * dY[M,N] : gemm K x N x (reduce M)
   a.A = X; a.lda = ldx; a.B = dY; a.ldb = lddy;
   a.M = K; a.N = N; a.K = (int)M; a.k_per_split = (int)wgrad_k_per_split(M, splits);
