@@ -1,0 +1,20 @@
+#!/usr/bin/env python3
+"""global_step/sec of `python -m trainers.deep_fm` at the reference's defaults (E=4, [16,16], B=32) on a
+synthetic MovieLens-shaped CSV: the end-to-end loop a user of the reference runs first (input_fn in
+Python + id transforms + the launch-bound step)."""
+import os, sys, tempfile, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "recommender-tensorflow_amd"))
+from tests.test_trainers import _write_csv
+from trainers import _cli, deep_fm
+import pathlib
+d = pathlib.Path(tempfile.mkdtemp())
+_write_csv(d / "train.csv", 20000, 1); _write_csv(d / "test.csv", 2000, 2)
+opt = ("exclude_linear", "exclude_mf", "exclude_dnn", "hidden_units", "dropout")
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
+args = _cli.make_parser("deep_fm", opt).parse_args(["--train-csv", str(d / "train.csv"), "--test-csv", str(d / "test.csv"),
+                                                     "--job-dir", str(d / "job"), "--train-steps", str(steps)])
+t0 = time.time()
+est = deep_fm.train_and_evaluate(args)
+dt = time.time() - t0
+print("RESULT: %d steps in %.1f s incl. input parsing, final eval and export: %.0f global_step/sec" % (est.global_step, dt, est.global_step / dt))
