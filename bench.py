@@ -98,7 +98,7 @@ def mlp_roofline(gemm, flops, gemm_ms):
         peak, kern, prod = MFMA_F16_PEAK_TFLOPS / 6, "gemm_split_k<bf16x3> (v_mfma_f32_32x32x16_bf16, 6 products)", 6
     else:
         peak, kern, prod = MFMA_F16_PEAK_TFLOPS / SPLIT_PRODUCTS, "gemm_split_k<f16x2> (v_mfma_f32_32x32x16_f16, 3 products)", SPLIT_PRODUCTS
-    return {"kernel": kern + "; all dense fwd/bwd GEMM launches incl. the N=1 logits layer on gemm_f32_k", "bound": "mfma",
+    return {"kernel": kern + "; all dense fwd/bwd launches incl. the N=1 logits layer (matrix-vector kernels)", "bound": "mfma",
             "achieved": ach, "peak": peak, "unit": "TFLOP/s (fp32-equivalent)", "frac": ach / peak,
             "mfma_products_per_fp32_product": prod, "executed_mfma_tflops": ach * prod,
             "fp32_input_mfma_peak": MFMA_F32_PEAK_TFLOPS, "flops_per_step": flops, "gemm_ms_per_step": gemm_ms}
