@@ -32,6 +32,7 @@ CONFIGS = [
     ([50, 30, 20, 40], 64, [512, 256, 128], 300, 0),  # config-3 shaped, small vocab
     ([11, 5, 9], 8, [32], 257, 2),                    # numeric columns (deep_fm.py:62-73)
     ([7] * 40, 128, [64, 32], 65, 0),                 # config-5 shaped
+    ([6, 5, 4], 12, [10, 7], 5, 1),                   # nothing a multiple of 4 or of a tile: scalar-load GEMM paths
 ]
 
 
