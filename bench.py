@@ -42,6 +42,7 @@ SPLIT_PRODUCTS = 3            # f16x2 split: MFMA products issued per fp32 produ
 
 F, V, E, HIDDEN, B_FULL = 26, 1_000_000, 64, [512, 256, 128], 65536
 DROPOUT = 0.1
+POOL = 256                    # distinct synthetic batches at most
 SEED = 20240521
 
 
@@ -165,7 +166,12 @@ def main():
     if world > 1:
         from mi355x_rec.parallel import broadcast_dense
         broadcast_dense(m)                       # replicated MLP must start identical on every rank
-    batches = make_batches(8, gen, device, args.dist == "zipf", B)
+    # A fresh batch every step, as in training on a real dataset: which rows sit out how many steps
+    # (the gap TF Adam's dense-equivalent sparse update is replayed over) then follows the id
+    # distribution — uniform ids: geometric with mean 1M/65536 = 15 steps — instead of being pinned
+    # to the period of a small rotating pool.  All batches are generated before the timed region
+    # (256 at most: 1.7 GB of ids; a longer run cycles through them).
+    batches = make_batches(min(args.warmup + args.steps, POOL), gen, device, args.dist == "zipf", B)
 
     def sync():
         torch.cuda.synchronize()
@@ -196,7 +202,7 @@ def main():
     other = None
     if not args.no_second_dist:
         o_zipf = args.dist != "zipf"
-        ob = make_batches(4, gen, device, o_zipf, B)
+        ob = make_batches(35, gen, device, o_zipf, B)
         ow, os_ = 5, 30
         for i in range(ow):
             m.train_step(*ob[i % len(ob)])
@@ -241,7 +247,7 @@ def main():
             "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic (%s ids, random-init weights)" % args.dist,
+            "data": "synthetic (%s ids, a fresh batch every step from a pool of %d, random-init weights)" % (args.dist, len(batches)),
             "config": {"workload": "config 3: trainers.deep_fm --embedding-size 64 --hidden-units 512 256 128 "
                                    "--batch-size 65536 --dropout 0.1, 26 fields x 1M ids (Criteo-shaped), Adam(1e-3)",
                        "per_gpu_batch": B, "global_batch": world * B, "fields": F, "vocab_per_field": V,
