@@ -40,7 +40,7 @@ enum mi_status {
 };
 
 /* ---- library ---------------------------------------------------------------------------- */
-int32_t mi_abi_version(void);       /* bumps when a signature changes (currently 8) */
+int32_t mi_abi_version(void);       /* bumps when a signature changes (currently 9) */
 const char* mi_last_error(void);    /* thread-local, never NULL */
 const char* mi_build_info(void);    /* "gfx950 hipcc <ver>" */
 
@@ -222,6 +222,13 @@ int32_t mi_sparse_apply_fused(float* table, float* t_slot0, float* t_slot1, floa
  * the mi_sparse_apply[_fused] of the same step — which reads and writes m, v anyway and MUST then be
  * given last_step — decays them from the old stamp (same multiply chain, same bits).  Saves a third
  * of this kernel's HBM traffic; every row passed here must be applied in the same step. */
+/* keys[u] = how many steps row uniq_rows[u] will be replayed over by mi_sparse_catchup(step_to) (0..62,
+ * clamped), 63 for the slots u >= *num_uniq.  Sorting the rows by it (mi_sort_unique_rows with
+ * key_range 64, then mi_gather_u32 of uniq_rows through the permutation) groups rows of equal
+ * staleness, which halves the catch-up's divergence; the valid rows stay in front. */
+int32_t mi_catchup_gap_keys(const int32_t* uniq_rows, const int32_t* num_uniq, const int32_t* last_step, int64_t n_max,
+                            int32_t step_to, int32_t* keys, mi_stream_t stream);
+
 int32_t mi_sparse_catchup(float* table, float* t_m, float* t_v, float* lin_w, float* l_m, float* l_v,
                           int32_t* last_step, const int32_t* uniq_rows, const int32_t* num_uniq,
                           int64_t n_max, int32_t E, int32_t step_to, const float* lr_table,

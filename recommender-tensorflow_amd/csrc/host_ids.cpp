@@ -164,7 +164,7 @@ static uint64_t hash64(const uint8_t* s, size_t len) {
 
 extern "C" {
 
-int32_t mi_abi_version(void) { return 8; }
+int32_t mi_abi_version(void) { return 9; }
 
 const char* mi_last_error(void) { return mi::g_err; }
 

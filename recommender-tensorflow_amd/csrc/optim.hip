@@ -322,6 +322,24 @@ __global__ __launch_bounds__(kBlock) void sparse_catchup_k(
   if (l == 0 && !defer_slots) last_step[r] = step_to;
 }
 
+// key[u] = number of steps row uniq_rows[u] has to be replayed over (clamped to 62), 63 for the slots past
+// num_uniq: sorting the rows by it (one 6-bit radix pass) puts rows of equal staleness into the same
+// wave of sparse_catchup_k, whose lane groups otherwise all run as long as the stalest of their rows
+// (4 rows per wave at E = 64: twice the average gap with geometric gaps).
+__global__ __launch_bounds__(kBlock) void gap_keys_k(const int32_t* __restrict__ uniq_rows,
+                                                     const int32_t* __restrict__ num_uniq,
+                                                     const int32_t* __restrict__ last_step, int64_t n_max, int step_to,
+                                                     int32_t* __restrict__ keys) {
+  const int64_t u = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (u >= n_max) return;
+  int32_t key = 63;
+  if (u < *num_uniq) {
+    const int ls = last_step[uniq_rows[u]];
+    key = (ls > 0 && ls < step_to) ? min(step_to - ls, 62) : 0;
+  }
+  keys[u] = key;
+}
+
 int lanes_per_row(int E) {
   int q = (E + 3) / 4, l = 1;
   while (l < q) l <<= 1;
@@ -462,6 +480,17 @@ int32_t mi_sparse_apply_fused(float* table, float* t_slot0, float* t_slot1, floa
     MI_DISPATCH_LPR(lpr, (sparse_apply_long_k<L, true><<<dim3(long_grid(n_max)), dim3(kBlock), 0, mi::as_stream(stream)>>>(a, h, fg)));
     MI_CHECK_LAUNCH("sparse_apply_fused(long segments)");
   }
+  return MI_OK;
+}
+
+int32_t mi_catchup_gap_keys(const int32_t* uniq_rows, const int32_t* num_uniq, const int32_t* last_step, int64_t n_max,
+                            int32_t step_to, int32_t* keys, mi_stream_t stream) {
+  MI_REQUIRE(n_max >= 0 && step_to >= 0, "catchup_gap_keys: n_max=%lld", (long long)n_max);
+  if (n_max == 0) return MI_OK;
+  MI_REQUIRE(uniq_rows && num_uniq && last_step && keys, "catchup_gap_keys: null buffer");
+  gap_keys_k<<<dim3((unsigned)mi::ceil_div(n_max, kBlock)), dim3(kBlock), 0, mi::as_stream(stream)>>>(
+      uniq_rows, num_uniq, last_step, n_max, step_to, keys);
+  MI_CHECK_LAUNCH("catchup_gap_keys");
   return MI_OK;
 }
 

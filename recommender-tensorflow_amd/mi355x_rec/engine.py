@@ -531,6 +531,8 @@ class DeepFM:
         self._catchup(None, None, self.R_local)
         self._final_step = self.step
 
+    GAP_SORT_MIN = 16384      # entries from which sorting the touched rows by staleness pays for itself
+
     def _catchup(self, uniq, num_uniq, n_max, defer=False):
         """defer: the rows are about to be applied in this same step by ONE mi_sparse_apply call, which
         then decays m and v itself from the old stamps — the catch-up moves w only (a third less HBM
@@ -542,6 +544,14 @@ class DeepFM:
         t_adam = self.opt.name == "Adam" and self.table is not None
         l_adam = (self.lin_opt or self.opt).name == "Adam" and self.lin_w is not None
         self.sched.lr_t(self.step)  # make sure the table covers step
+        if uniq is not None and n_max >= self.GAP_SORT_MIN:
+            # rows of equal staleness into the same wave (the replay runs as long as a wave's stalest row)
+            keys = self._buf("gap_keys", (n_max,), torch.int32)
+            self.k.mi_catchup_gap_keys(uniq, num_uniq, self.last_step, n_max, self.step, keys)
+            perm = self._sort_unique(keys, n_max, 64, "gap")[0]
+            by_gap = self._buf("uniq_by_gap", (n_max,), torch.int32)
+            self.k.mi_gather_u32(uniq, perm, n_max, by_gap)
+            uniq = by_gap
         self.k.mi_sparse_catchup(self.table if t_adam else None, self.t_s0 if t_adam else None,
                                  self.t_s1 if t_adam else None, self.lin_w if l_adam else None,
                                  self.l_s0 if l_adam else None, self.l_s1 if l_adam else None, self.last_step,

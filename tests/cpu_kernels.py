@@ -174,6 +174,13 @@ class NumpyKernels:
         OO.dense_apply(h, _np(param)[:n], _np(s0)[:n] if s0 is not None else z, _np(s1)[:n] if s1 is not None else z,
                        _np(grad)[:n], np.float32(hp.lr_t))
 
+    def mi_catchup_gap_keys(self, uniq, num_uniq, last_step, n_max, step_to, keys):
+        U = int(_np(num_uniq)[0])
+        k = np.full(n_max, 63, np.int32)
+        ls = _np(last_step)[_np(uniq)[:U]]
+        k[:U] = np.where((ls > 0) & (ls < step_to), np.minimum(step_to - ls, 62), 0)
+        _np(keys)[:n_max] = k
+
     def mi_sparse_catchup(self, table, tm, tv, lin_w, lm, lv, last_step, uniq, num_uniq, n_max, E, step_to, lr_table,
                           b1, b2, eps, defer_slots=0):
         defer = bool(defer_slots) and uniq is not None

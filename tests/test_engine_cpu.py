@@ -37,6 +37,7 @@ def _check_vars(m, p, atol):
 def test_engine_orchestration_matches_oracle(vocab, E, hidden, B, nn):
     p, ids, x, y = make_problem(7, vocab, E, hidden, B, n_numeric=nn)
     m = _engine(vocab, E, hidden, nn)
+    m.GAP_SORT_MIN = 1 if nn else m.GAP_SORT_MIN      # one case goes through the sort-rows-by-staleness path
     m.load_oracle_params(p)
     st = O.TrainState(p, OO.Hyper("Adam", 0.001))
     rng = np.random.default_rng(1)

@@ -107,6 +107,8 @@ def test_adam_training_matches_oracle(vocab, E, hidden, B, nn, gemm):
     logit_tol, var_atol = (3e-4, 3e-3) if marginal else (5e-5, 2e-6)
     p, ids, x, y = make_problem(3, vocab, E, hidden, B, n_numeric=nn)
     m = _engine(vocab, E, hidden, nn, gemm=gemm)
+    if gemm == "fp32":
+        m.GAP_SORT_MIN = 1               # also exercise the sort-rows-by-staleness path of the catch-up
     m.load_oracle_params(p)
     st = O.TrainState(p, OO.Hyper("Adam", 0.001))
     rng = np.random.default_rng(0)
