@@ -275,10 +275,77 @@ __device__ __forceinline__ void replay(float& w, float& m, float& v, int s_from,
   }
 }
 
+// With the rows sorted by staleness the replay is bound by VALU issue.  hipcc's correctly rounded sqrtf
+// and '/' carry range scaling (v_div_scale x2, v_div_fmas, v_div_fixup; the 2^32 pre-scale, un-scale
+// and class test of sqrt) that only matters at the ends of the exponent range.  These are the same
+// two algorithms without it — v_sqrt_f32 + the one-ulp residual test, v_rcp_f32 + Newton + two
+// residual corrections — hence the same bits wherever no intermediate leaves the normal range;
+// catchup_in_range() is the (generous) condition under which a WAVE takes them (all its lanes in
+// range: a wave never runs both loops); otherwise it runs sqrtf and '/'.
+__device__ __forceinline__ float sqrt_rn_inrange(float x) {            // x == 0 or x >= 2^-96
+  float s = __builtin_amdgcn_sqrtf(x);
+  const float sm = __uint_as_float(__float_as_uint(s) - 1u), sp = __uint_as_float(__float_as_uint(s) + 1u);
+  const float rm = fmaf(-sm, s, x), rp = fmaf(-sp, s, x);
+  s = (rm <= 0.f) ? sm : s;
+  s = (rp > 0.f) ? sp : s;
+  return s;
+}
+__device__ __forceinline__ float div_rn_inrange(float n, float d) {     // n == 0 or |n| >= 2^-100; d, n/d normal
+  float r = __builtin_amdgcn_rcpf(d);
+  const float e = fmaf(-d, r, 1.0f);
+  r = fmaf(e, r, r);
+  float q = n * r;
+  const float e2 = fmaf(-d, q, n);
+  q = fmaf(e2, r, q);
+  const float e3 = fmaf(-d, q, n);
+  return fmaf(e3, r, q);
+}
+// m and v only shrink during the replay (by b1^k, b2^k <= 1): in range at the start and after k steps
+// means in range throughout.  |m| >= 2^-41 and k <= 200 keep lr_t*m above 2^-92 (lr_t >= 2^-20) and
+// its residuals (2^-24 below) normal; v in [2^-80, 2^20] keeps sqrt(v)+eps within [eps, 2^10] and
+// v*b2^k above 2^-96.
+__device__ __forceinline__ bool catchup_in_range(float m, float v) {
+  const float am = fabsf(m);
+  return (am == 0.f || (am >= 0x1p-41f && am <= 0x1p60f)) && (v == 0.f || (v >= 0x1p-80f && v <= 0x1p20f));
+}
+__device__ __forceinline__ bool catchup_params_in_range(int steps, float lr_last, float eps) {
+  return steps <= 200 && lr_last >= 0x1p-17f && eps >= 0x1p-40f && eps <= 1.f;   // lr_t >= 0.14 lr for every t
+}
+
+// The wide part: one thread per row (1/E of the work).  Its own kernel, run BEFORE the row kernel (it
+// reads the stamps the row kernel writes), so that lane 0 of a row's lane group does not drag a fifth
+// chain through a second loop of the same length.
+__global__ __launch_bounds__(kBlock) void catchup_lin_k(
+    float* __restrict__ lin_w, float* __restrict__ lm, float* __restrict__ lv, const int32_t* __restrict__ last_step,
+    const int32_t* __restrict__ uniq_rows, const int32_t* __restrict__ num_uniq, int64_t n_max, int step_to,
+    const float* __restrict__ lr_table, float b1, float b2, float eps, bool defer_slots) {
+  const int64_t u = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  const int64_t count = uniq_rows ? static_cast<int64_t>(*num_uniq) : n_max;
+  const bool on = u < count;
+  const int64_t r = on ? (uniq_rows ? static_cast<int64_t>(uniq_rows[u]) : u) : 0;
+  const int ls = on ? last_step[r] : step_to;
+  const bool work = on && ls > 0 && ls < step_to;
+  float w = 0.f, m = 0.f, v = 0.f;
+  if (work) { w = lin_w[r]; m = lm[r]; v = lv[r]; }
+  const bool ok = !work || (catchup_params_in_range(step_to - ls, lr_table[step_to], eps) && catchup_in_range(m, v));
+  if (__ballot(!ok) == 0) {
+    if (work)
+      for (int s = ls + 1; s <= step_to; ++s) {
+        m = m * b1; v = v * b2;
+        w = w - div_rn_inrange(lr_table[s] * m, sqrt_rn_inrange(v) + eps);
+      }
+  } else if (work) {
+    replay(w, m, v, ls + 1, step_to, lr_table, b1, b2, eps);
+  }
+  if (work) {
+    lin_w[r] = w;
+    if (!defer_slots) { lm[r] = m; lv[r] = v; }
+  }
+}
+
 template <int LPR>
 __global__ __launch_bounds__(kBlock) void sparse_catchup_k(
     float* __restrict__ table, float* __restrict__ tm, float* __restrict__ tv,
-    float* __restrict__ lin_w, float* __restrict__ lm, float* __restrict__ lv,
     int32_t* __restrict__ last_step, const int32_t* __restrict__ uniq_rows,
     const int32_t* __restrict__ num_uniq, int64_t n_max, int E, int step_to,
     const float* __restrict__ lr_table, float b1, float b2, float eps, bool defer_slots) {
@@ -296,6 +363,19 @@ __global__ __launch_bounds__(kBlock) void sparse_catchup_k(
       float4 w = ld4(table + o), m = ld4_nt(tm + o), v = ld4_nt(tv + o);
       // one loop for the four elements: one lr_t load and one loop counter per step instead of four,
       // four independent sqrt/divide chains in flight (the arithmetic per element is unchanged)
+      const bool ok = catchup_params_in_range(step_to - ls, lr_table[step_to], eps) && catchup_in_range(m.x, v.x) &&
+                      catchup_in_range(m.y, v.y) && catchup_in_range(m.z, v.z) && catchup_in_range(m.w, v.w);
+      if (__ballot(!ok) == 0) {                    // over the wave's active lanes
+        for (int s = ls + 1; s <= step_to; ++s) {
+          const float lr = lr_table[s];
+          m.x = m.x * b1; m.y = m.y * b1; m.z = m.z * b1; m.w = m.w * b1;
+          v.x = v.x * b2; v.y = v.y * b2; v.z = v.z * b2; v.w = v.w * b2;
+          w.x = w.x - div_rn_inrange(lr * m.x, sqrt_rn_inrange(v.x) + eps);
+          w.y = w.y - div_rn_inrange(lr * m.y, sqrt_rn_inrange(v.y) + eps);
+          w.z = w.z - div_rn_inrange(lr * m.z, sqrt_rn_inrange(v.z) + eps);
+          w.w = w.w - div_rn_inrange(lr * m.w, sqrt_rn_inrange(v.w) + eps);
+        }
+      } else
       for (int s = ls + 1; s <= step_to; ++s) {
         const float lr = lr_table[s];
         m.x = m.x * b1; m.y = m.y * b1; m.z = m.z * b1; m.w = m.w * b1;
@@ -308,13 +388,8 @@ __global__ __launch_bounds__(kBlock) void sparse_catchup_k(
       st4(table + o, w);
       if (!defer_slots) { st4_nt(tm + o, m); st4_nt(tv + o, v); }
     }
-    if (lin_w && l == 0) {
-      float w = lin_w[r], m = lm[r], v = lv[r];
-      replay(w, m, v, ls + 1, step_to, lr_table, b1, b2, eps);
-      lin_w[r] = w;
-      if (!defer_slots) { lm[r] = m; lv[r] = v; }
-    }
   }
+  // (the wide part's scalar per row: catchup_lin_k)
   // defer_slots: the sparse apply that follows in the same step decays m and v itself (it reads and
   // writes them anyway) from the old stamp, so neither they nor the stamp are written here — a third
   // of this kernel's HBM traffic.
@@ -506,12 +581,18 @@ int32_t mi_sparse_catchup(float* table, float* t_m, float* t_v, float* lin_w, fl
              "sparse_catchup: table needs m, v, E multiple of 4 in [4,256]");
   MI_REQUIRE(!lin_w || (l_m && l_v), "sparse_catchup: lin_w needs m, v");
   MI_REQUIRE(!uniq_rows || num_uniq, "sparse_catchup: uniq_rows without num_uniq");
+  const bool defer = defer_slots != 0 && uniq_rows != nullptr;
+  if (lin_w) {
+    catchup_lin_k<<<dim3((unsigned)mi::ceil_div(n_max, kBlock)), dim3(kBlock), 0, mi::as_stream(stream)>>>(
+        lin_w, l_m, l_v, last_step, uniq_rows, num_uniq, n_max, step_to, lr_table, beta1, beta2, epsilon, defer);
+    MI_CHECK_LAUNCH("sparse_catchup(wide part)");
+  }
   const int lpr = table ? lanes_per_row(E) : 1;
   const int64_t blocks = mi::ceil_div(n_max * lpr, kBlock);
   MI_REQUIRE(blocks <= INT32_MAX, "sparse_catchup: grid too large");
   MI_DISPATCH_LPR(lpr, (sparse_catchup_k<L><<<dim3((unsigned)blocks), dim3(kBlock), 0, mi::as_stream(stream)>>>(
-                           table, t_m, t_v, lin_w, l_m, l_v, last_step, uniq_rows, num_uniq, n_max, E, step_to,
-                           lr_table, beta1, beta2, epsilon, defer_slots != 0 && uniq_rows != nullptr)));
+                           table, t_m, t_v, last_step, uniq_rows, num_uniq, n_max, E, step_to, lr_table, beta1, beta2,
+                           epsilon, defer)));
   MI_CHECK_LAUNCH("sparse_catchup");
   return MI_OK;
 }
