@@ -308,8 +308,10 @@ __device__ __forceinline__ bool catchup_in_range(float m, float v) {
   const float am = fabsf(m);
   return (am == 0.f || (am >= 0x1p-41f && am <= 0x1p60f)) && (v == 0.f || (v >= 0x1p-80f && v <= 0x1p20f));
 }
-__device__ __forceinline__ bool catchup_params_in_range(int steps, float lr_last, float eps) {
-  return steps <= 200 && lr_last >= 0x1p-17f && eps >= 0x1p-40f && eps <= 1.f;   // lr_t >= 0.14 lr for every t
+// (the bounds above assume the decays of 200 steps stay above 2^-31 and 2^-3: beta1 >= 0.9, beta2 >= 0.99)
+__device__ __forceinline__ bool catchup_params_in_range(int steps, float lr_last, float eps, float b1, float b2) {
+  return steps <= 200 && lr_last >= 0x1p-17f && eps >= 0x1p-40f && eps <= 1.f &&   // lr_t >= 0.14 lr for every t
+         b1 >= 0.9f && b1 <= 1.f && b2 >= 0.99f && b2 <= 1.f;
 }
 
 // The wide part: one thread per row (1/E of the work).  Its own kernel, run BEFORE the row kernel (it
@@ -327,7 +329,7 @@ __global__ __launch_bounds__(kBlock) void catchup_lin_k(
   const bool work = on && ls > 0 && ls < step_to;
   float w = 0.f, m = 0.f, v = 0.f;
   if (work) { w = lin_w[r]; m = lm[r]; v = lv[r]; }
-  const bool ok = !work || (catchup_params_in_range(step_to - ls, lr_table[step_to], eps) && catchup_in_range(m, v));
+  const bool ok = !work || (catchup_params_in_range(step_to - ls, lr_table[step_to], eps, b1, b2) && catchup_in_range(m, v));
   if (__ballot(!ok) == 0) {
     if (work)
       for (int s = ls + 1; s <= step_to; ++s) {
@@ -363,7 +365,7 @@ __global__ __launch_bounds__(kBlock) void sparse_catchup_k(
       float4 w = ld4(table + o), m = ld4_nt(tm + o), v = ld4_nt(tv + o);
       // one loop for the four elements: one lr_t load and one loop counter per step instead of four,
       // four independent sqrt/divide chains in flight (the arithmetic per element is unchanged)
-      const bool ok = catchup_params_in_range(step_to - ls, lr_table[step_to], eps) && catchup_in_range(m.x, v.x) &&
+      const bool ok = catchup_params_in_range(step_to - ls, lr_table[step_to], eps, b1, b2) && catchup_in_range(m.x, v.x) &&
                       catchup_in_range(m.y, v.y) && catchup_in_range(m.z, v.z) && catchup_in_range(m.w, v.w);
       if (__ballot(!ok) == 0) {                    // over the wave's active lanes
         for (int s = ls + 1; s <= step_to; ++s) {

@@ -490,6 +490,47 @@ def test_sparse_apply_long_segments(lib, E):
     assert np.array_equal(outs[0][0][short], expect[short])
 
 
+def test_catchup_exact_at_range_edges(lib):
+    """mi_sparse_catchup takes an exactly rounded sqrt/divide without range scaling when a whole wave's
+    values are in a safe range, hipcc's sqrtf and '/' otherwise: both must give the bits of the
+    sequential fp32 sweep (numpy: IEEE sqrt and divide), for values from denormal to huge, zeros, gaps
+    beyond the fast path's limit, and waves that mix both kinds of rows."""
+    rng = np.random.default_rng(12)
+    R, E, step_to = 4096, 64, 300
+    b1, b2, eps = np.float32(0.9), np.float32(0.999), np.float32(1e-8)
+    w = rng.standard_normal((R, E)).astype(np.float32)
+    m = (rng.choice([-1.0, 1.0], (R, E)) * 10.0 ** rng.uniform(-30, 1, (R, E))).astype(np.float32)
+    v = (10.0 ** rng.uniform(-42, 2, (R, E))).astype(np.float32)
+    calm = rng.random(R) < 0.6                                   # rows well inside the fast range
+    m[calm] = (rng.standard_normal((int(calm.sum()), E)) * 1e-6).astype(np.float32)
+    v[calm] = (10.0 ** rng.uniform(-14, -8, (int(calm.sum()), E))).astype(np.float32)
+    m[rng.random((R, E)) < 0.05] = 0.0
+    v[rng.random((R, E)) < 0.05] = 0.0
+    lw = rng.standard_normal(R).astype(np.float32)
+    lmm = (rng.standard_normal(R) * 1e-5).astype(np.float32); lvv = (10.0 ** rng.uniform(-12, -6, R)).astype(np.float32)
+    last = rng.integers(1, step_to, R).astype(np.int32)          # gaps 1 .. 299 (> 200: generic path)
+    last[rng.random(R) < 0.1] = 0                                # never applied: untouched
+    lr = (1e-3 * np.sqrt(1 - 0.999 ** np.arange(step_to + 1)) / np.maximum(1 - 0.9 ** np.arange(step_to + 1), 1e-30)).astype(np.float32)
+    ew, em, ev = w.copy(), m.copy(), v.copy()
+    elw, elm, elv = lw.copy(), lmm.copy(), lvv.copy()
+    with np.errstate(all="ignore"):
+        for r in range(R):
+            if last[r] == 0:
+                continue
+            for s in range(last[r] + 1, step_to + 1):
+                em[r] = em[r] * b1; ev[r] = ev[r] * b2
+                ew[r] = ew[r] - (lr[s] * em[r]) / (np.sqrt(ev[r]) + eps)
+                elm[r] = elm[r] * b1; elv[r] = elv[r] * b2
+                elw[r] = elw[r] - (lr[s] * elm[r]) / (np.sqrt(elv[r]) + eps)
+    dW, dM, dV, dL, dLm, dLv, dlast, dlr = dev(w), dev(m), dev(v), dev(lw), dev(lmm), dev(lvv), dev(last), dev(lr)
+    _chk(lib.mi_sparse_catchup(_p(dW), _p(dM), _p(dV), _p(dL), _p(dLm), _p(dLv), _p(dlast), None, None, R, E, step_to,
+                               _p(dlr), float(b1), float(b2), float(eps), 0, _st()))
+    torch.cuda.synchronize()
+    for got, exp in ((dW, ew), (dM, em), (dV, ev), (dL, elw), (dLm, elm), (dLv, elv)):
+        assert np.array_equal(got.cpu().numpy().view(np.uint32), exp.view(np.uint32))
+    assert np.array_equal(dlast.cpu().numpy(), np.where(last < step_to, step_to, last))
+
+
 @pytest.mark.parametrize("B", [1, 37, 5000])
 def test_sigmoid_ce_head(lib, B):
     rng = np.random.default_rng(B)
