@@ -132,7 +132,9 @@ int32_t mi_numeric_embed_bwd(const float* x, const float* d_concat, int64_t ld_d
  *   uniq_rows    [n]   first U slots hold the distinct rows in ascending order
  *   seg_start    [n+1] segment u covers sorted_entry[seg_start[u] .. seg_start[u+1])
  *   num_uniq     [1]   U (int32) — stays on the device; later kernels read it there
- * num_rows_total bounds the key range (picks the number of radix passes). */
+ * num_rows_total bounds the key range (picks the number of radix passes).
+ * With uniq_rows == NULL only the stable sort permutation is produced (sorted_entry); seg_start and
+ * num_uniq are then ignored. */
 size_t mi_sort_unique_workspace_bytes(int64_t n);
 int32_t mi_sort_unique_rows(const int32_t* rows, int64_t n, int64_t num_rows_total,
                             int32_t* sorted_entry, int32_t* uniq_rows, int32_t* seg_start,

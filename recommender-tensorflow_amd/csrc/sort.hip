@@ -255,7 +255,9 @@ int32_t mi_sort_unique_rows(const int32_t* rows, int64_t n, int64_t num_rows_tot
   MI_REQUIRE(n > 0 && n < (int64_t)INT32_MAX - kTile, "sort_unique_rows: n=%lld", (long long)n);
   MI_REQUIRE(num_rows_total > 0 && num_rows_total <= (int64_t)INT32_MAX, "sort_unique_rows: num_rows_total=%lld",
              (long long)num_rows_total);
-  MI_REQUIRE(rows && sorted_entry && uniq_rows && seg_start && num_uniq && workspace, "sort_unique_rows: null buffer");
+  MI_REQUIRE(rows && sorted_entry && workspace, "sort_unique_rows: null buffer");
+  const bool perm_only = uniq_rows == nullptr;       // just the stable sort permutation, no unique / segment pass
+  MI_REQUIRE(perm_only || (seg_start && num_uniq), "sort_unique_rows: uniq_rows needs seg_start and num_uniq");
   MI_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255u) == 0, "sort_unique_rows: workspace must be 256-byte aligned");
   const Layout L = layout_for(n);
   if (workspace_bytes < static_cast<size_t>(L.bytes)) {
@@ -286,7 +288,7 @@ int32_t mi_sort_unique_rows(const int32_t* rows, int64_t n, int64_t num_rows_tot
   const int32_t* vin = nullptr;  // pass 0: value = position
   for (int p = 0; p < passes; ++p) {
     int32_t* kout = kbuf[p & 1];
-    int32_t* vout = vbuf[p & 1];
+    int32_t* vout = (perm_only && p == passes - 1) ? sorted_entry : vbuf[p & 1];
     int32_t* bt = bin_total + p * kMaxBins;
     hist_k<<<dim3(ntiles), dim3(kBlock), 0, st>>>(kin, n, nbits * p, nbins, ntiles, hist, bt);
     MI_CHECK_LAUNCH("sort_unique_rows(hist)");
@@ -297,6 +299,7 @@ int32_t mi_sort_unique_rows(const int32_t* rows, int64_t n, int64_t num_rows_tot
     kin = kout;
     vin = vout;
   }
+  if (perm_only) return MI_OK;
   head_count_k<<<dim3(ntiles), dim3(kBlock), 0, st>>>(kin, n, heads);
   MI_CHECK_LAUNCH("sort_unique_rows(heads)");
   scan_small_k<<<dim3(1), dim3(1024), 0, st>>>(heads, ntiles, total);

@@ -548,7 +548,9 @@ class DeepFM:
             # rows of equal staleness into the same wave (the replay runs as long as a wave's stalest row)
             keys = self._buf("gap_keys", (n_max,), torch.int32)
             self.k.mi_catchup_gap_keys(uniq, num_uniq, self.last_step, n_max, self.step, keys)
-            perm = self._sort_unique(keys, n_max, 64, "gap")[0]
+            perm = self._buf("gap_perm", (n_max,), torch.int32)
+            ws = self._bytes("sort_ws", self.k.query("mi_sort_unique_workspace_bytes", n_max))
+            self.k.mi_sort_unique_rows(keys, n_max, 64, perm, None, None, None, ws, ws.numel())   # permutation only
             by_gap = self._buf("uniq_by_gap", (n_max,), torch.int32)
             self.k.mi_gather_u32(uniq, perm, n_max, by_gap)
             uniq = by_gap

@@ -57,6 +57,8 @@ class NumpyKernels:
         starts = np.flatnonzero(np.r_[True, sr[1:] != sr[:-1]]).astype(np.int32)
         U = len(starts)
         _np(sorted_entry)[:n] = order
+        if uniq is None:
+            return
         _np(uniq)[:U] = sr[starts]
         _np(seg)[:U] = starts
         _np(seg)[U] = n
