@@ -109,6 +109,12 @@ def test_two_rank_step_equals_big_batch(cfg):
     check_against_big_batch(cfg, _run(cfg, 2), 2)
 
 
+def test_four_rank_pipelined_step_equals_big_batch():
+    """world 4 (keys chunk * 4 + owner, 4-way splits, some empty): the pipelined step in 2 chunks"""
+    cfg = ([9, 13, 5, 6], 8, [16, 8], 16, 0, "Adam", 0.001, 3, (True, True, True), 2)
+    check_against_big_batch(cfg, _run(cfg, 4), 4)
+
+
 def check_against_big_batch(cfg, res, world, tol=1.0):
     vocab, E, hidden, B, nn, opt_name, lr, steps, flags = cfg[:9]
     # 1-rank reference: the oracle on the concatenated batch
