@@ -100,6 +100,18 @@ int32_t mi_numeric_embed_fwd(const float* x, const float* V, const float* w_num,
                              int32_t n_d, int32_t E, float* concat, int64_t ld_concat, int64_t col0,
                              float* sumv, float* fm, float* lin, mi_stream_t stream);
 
+/* Numeric columns of the canned estimators (tf.feature_column.numeric_column handed to
+ * DNNLinearCombinedClassifier, trainers/linear_deep.py:32-39): input_layer takes
+ * the VALUE as a column of the concat, linear_model multiplies it by a [1,1] weight.
+ *   concat[b, col0 + j] = x[b,j] for j < n_d, 0 for n_d <= j < n_cols   (zero pad: whole k-tiles for layer 1)
+ *   lin[b] += sum_j x[b,j] * w_num[j]        (ascending j, after the categorical sum; bias added by the head)
+ * concat or lin may be NULL.  Backward: dw_num[j] = sum_b d_logit_lin[b] * x[b,j] (two-stage, fixed order). */
+int32_t mi_numeric_raw_fwd(const float* x, const float* w_num, int64_t B, int32_t n_d, float* concat,
+                           int64_t ld_concat, int64_t col0, int32_t n_cols, float* lin, mi_stream_t stream);
+size_t mi_numeric_raw_bwd_workspace_bytes(int64_t B, int32_t n_d);
+int32_t mi_numeric_raw_bwd(const float* x, const float* d_logit_lin, int64_t B, int32_t n_d, float* dw_num,
+                           void* workspace, size_t workspace_bytes, mi_stream_t stream);
+
 /* ---- (a2,a3,a5) backward: per-entry row gradients -------------------------------------------
  * d_rows[p(b,f), :] = d_concat[b,f,:] + d_logit_fm[b] * (sumv[b,:] - concat[b,f,:])
  * d_lin [p(b,f)]    = d_logit_lin[b]

@@ -37,18 +37,30 @@ class Params:
                       [(c(k), c(b)) for k, b in self.mlp], c(self.num_emb), c(self.lin_num))
 
     def dense_list(self):
-        """Dense variables in the order the HIP host packs its flat buffer."""
+        """Dense variables: MLP kernels / biases, linear bias, [numeric_embeddings], numeric linear
+        weights (num_emb is None for the canned estimators' raw numeric columns)."""
         out = []
         for k, b in self.mlp:
             out += [k, b]
         out.append(self.lin_bias)
         if self.num_emb is not None:
-            out += [self.num_emb, self.lin_num]
+            out.append(self.num_emb)
+        if self.lin_num is not None:
+            out.append(self.lin_num)
+        return out
+
+    def wide_flags(self):
+        """Per entry of dense_list(): True for the variables under TF's ``linear`` scope."""
+        out = [False] * (2 * len(self.mlp)) + [True]
+        if self.num_emb is not None:
+            out.append(False)
+        if self.lin_num is not None:
+            out.append(True)
         return out
 
 
 def init_params(rng, vocab_sizes, E, hidden_units, n_numeric=0, dtype=np.float32, lin_scale=0.0,
-                use_dnn=True):
+                use_dnn=True, numeric="embed"):
     """TF initialisers: embeddings truncated_normal(0, 1/sqrt(E)) at 2 sigma,
     linear weights / biases zero, dense kernels glorot-uniform.  ``lin_scale`` > 0 replaces the
     zero linear init by N(0, lin_scale) so parity tests exercise that path with non-trivial data.
@@ -68,25 +80,34 @@ def init_params(rng, vocab_sizes, E, hidden_units, n_numeric=0, dtype=np.float32
     emb = [trunc_normal((v, E), 1.0 / np.sqrt(E)) for v in vocab_sizes]
     lin_w = [(rng.standard_normal(v) * lin_scale).astype(dtype) for v in vocab_sizes]
     lin_bias = np.zeros(1, dtype)
-    d = len(vocab_sizes) + n_numeric
+    d = len(vocab_sizes) + (n_numeric if numeric == "embed" else 0)
     mlp = []
     if use_dnn:
-        fan = d * E
+        fan = d * E + (n_numeric if numeric == "raw" else 0)
         for h in list(hidden_units) + [1]:
             mlp.append((glorot(fan, h, (fan, h)), np.zeros(h, dtype)))
             fan = h
-    num_emb = glorot(n_numeric, E, (n_numeric, E)) if n_numeric else None  # deep_fm.py:64
+    num_emb = glorot(n_numeric, E, (n_numeric, E)) if (n_numeric and numeric == "embed") else None  # deep_fm.py:64
     lin_num = (rng.standard_normal(n_numeric) * lin_scale).astype(dtype) if n_numeric else None
     return Params(emb, lin_w, lin_bias, mlp, num_emb, lin_num)
 
 
-def forward(p, ids, x_num=None, use_linear=True, use_mf=True, use_dnn=True, dropout_masks=None):
+def forward(p, ids, x_num=None, use_linear=True, use_mf=True, use_dnn=True, dropout_masks=None, numeric="embed",
+            keep_prob=1.0):
     """model_fn forward (deep_fm.py:36-115).  ids [B,F] per-field local ids; x_num [B,n_d].
-    dropout_masks: per hidden layer, a [B,h] array of {0, 1/keep} multipliers (TRAIN) or None.
+    dropout_masks: per hidden layer, a [B,h] array of {0, 1} keep flags (TRAIN) or None; tf.layers.dropout
+    (deep_fm.py:102-103) is tf.nn.dropout: div(x, keep_prob) * mask — a division, not a multiplication by 1/keep.
+    numeric: "embed" = DeepFM's numeric_embeddings (deep_fm.py:62-73: x[B,n_d,1] * V[1,n_d,E]);
+    "raw" = the canned estimators' input_layer, where a numeric_column contributes its value itself to
+    the concat (trainers/linear_deep.py:32-39 with numeric columns in dnn_feature_columns) —
+    no FM term exists there.  The engine keeps numeric columns after the categorical block in both
+    forms; TF's input_layer interleaves them by column name, which only permutes kernel_0's rows.
     Returns a cache with logits [B] and every intermediate the backward needs."""
     dt = p.dtype
     B, F = ids.shape
-    c = {"ids": ids, "x_num": x_num, "flags": (use_linear, use_mf, use_dnn)}
+    if numeric == "raw" and use_mf:
+        raise ValueError("raw numeric columns belong to the canned estimators, which have no FM term")
+    c = {"ids": ids, "x_num": x_num, "flags": (use_linear, use_mf, use_dnn), "numeric": numeric, "keep_prob": keep_prob}
     logits = np.zeros(B, dt)                                      # deep_fm.py:36
     if use_linear:                                                # deep_fm.py:37-44 linear_model
         lin = np.zeros(B, dt)
@@ -100,13 +121,14 @@ def forward(p, ids, x_num=None, use_linear=True, use_mf=True, use_dnn=True, drop
         logits = logits + lin
     if use_mf or use_dnn:                                         # deep_fm.py:47-73 input layer
         parts = [p.emb[f][ids[:, f]] for f in range(F)]           # mean of one id = the row
-        if x_num is not None:                                     # deep_fm.py:62-70
-            E = p.num_emb.shape[1]
+        E = parts[0].shape[1] if parts else p.num_emb.shape[1]    # numeric columns only: deep_fm.py:57-70
+        if x_num is not None and numeric == "embed":              # deep_fm.py:62-70
             parts += [x_num[:, j:j + 1] * p.num_emb[j][None, :] for j in range(x_num.shape[1])]
-        concat = np.concatenate(parts, 1)                         # [B, d*E]
-        c["concat"] = concat
-        E = parts[0].shape[1]
         d = len(parts)
+        if x_num is not None and numeric == "raw":                # canned input_layer: the value itself
+            parts.append(x_num.astype(dt))
+        concat = np.concatenate(parts, 1)                         # [B, d*E (+ n_d raw)]
+        c["concat"] = concat
     if use_mf:                                                    # deep_fm.py:76-90
         mat = concat.reshape(B, d, E)                             # :79
         s = mat.sum(1)
@@ -123,7 +145,7 @@ def forward(p, ids, x_num=None, use_linear=True, use_mf=True, use_dnn=True, drop
             k, b = p.mlp[i]
             net = np.maximum(net @ k + b, 0)                      # tf.layers.dense(relu) :100
             if dropout_masks is not None and dropout_masks[i] is not None:
-                net = net * dropout_masks[i]                      # tf.layers.dropout :102-103
+                net = (net / dt.type(keep_prob)) * dropout_masks[i].astype(dt)   # tf.layers.dropout :102-103
             acts.append(net)
         k, b = p.mlp[nh]
         dnn = (net @ k + b)[:, 0]                                 # :108
@@ -162,6 +184,7 @@ def backward(p, c, d_logits, dropout_masks=None):
     per-entry sparse grads: d_rows [B,F,E] for the embedding rows, d_lin [B,F] for linear rows)."""
     use_linear, use_mf, use_dnn = c["flags"]
     ids, x_num = c["ids"], c["x_num"]
+    raw = c.get("numeric", "embed") == "raw" and x_num is not None
     B, F = ids.shape
     dt = p.dtype
     g_mlp = []
@@ -176,7 +199,7 @@ def backward(p, c, d_logits, dropout_masks=None):
         for i in range(nh - 1, -1, -1):
             a = c["acts"][i]                 # post-relu, post-dropout activation
             if dropout_masks is not None and dropout_masks[i] is not None:
-                d_net = d_net * dropout_masks[i]
+                d_net = (d_net * dropout_masks[i].astype(dt)) / dt.type(c["keep_prob"])
             # a > 0  <=>  (pre-activation > 0 and the unit was kept); dropped units already got 0
             d_pre = d_net * (a > 0)
             inp = c["acts"][i - 1] if i else c["concat"]
@@ -185,13 +208,14 @@ def backward(p, c, d_logits, dropout_masks=None):
             d_net = d_pre @ k_i.T
         g_mlp = list(reversed(g_hidden)) + [g_last]
         d_concat = d_net
-    E = c["concat"].shape[1] // (F + (0 if x_num is None else x_num.shape[1])) if (use_mf or use_dnn) else 0
-    d = F + (0 if x_num is None else x_num.shape[1])
+    n_emb_num = 0 if (x_num is None or raw) else x_num.shape[1]    # numeric columns that own an embedding
+    d = F + n_emb_num
+    E = (c["concat"].shape[1] - (x_num.shape[1] if raw else 0)) // d if (use_mf or use_dnn) else 0
     g_v = None
     if use_mf or use_dnn:
         g_v = np.zeros((B, d, E), dt)
         if d_concat is not None:
-            g_v += d_concat.reshape(B, d, E)
+            g_v += d_concat[:, :d * E].reshape(B, d, E)
         if use_mf:                            # d fm / d v_j = S - v_j
             mat = c["concat"].reshape(B, d, E)
             g_v += d_logits[:, None, None] * (c["sumv"][:, None, :] - mat)
@@ -200,32 +224,48 @@ def backward(p, c, d_logits, dropout_masks=None):
         dense += [gk, gb]
     dense.append(d_logits.sum(keepdims=True) if use_linear else np.zeros(1, dt))
     if x_num is not None:
-        g_num = np.einsum("bj,bje->je", x_num, g_v[:, F:, :]) if g_v is not None else np.zeros_like(p.num_emb)
+        if raw:
+            g_num = None                      # a raw numeric column has no variable of its own in the deep part
+        else:
+            g_num = np.einsum("bj,bje->je", x_num, g_v[:, F:, :]) if g_v is not None else np.zeros_like(p.num_emb)
         g_lnum = (d_logits[:, None] * x_num).sum(0) if use_linear else np.zeros_like(p.lin_num)
-        dense += [g_num.astype(dt), g_lnum.astype(dt)]
+        dense += ([] if raw else [g_num.astype(dt)]) + [g_lnum.astype(dt)]
     d_rows = g_v[:, :F, :] if g_v is not None else None
     d_lin = np.broadcast_to(d_logits[:, None], (B, F)).copy() if use_linear else None
     return dense, d_rows, d_lin
 
 
 class TrainState:
-    """Optimizer slots for every variable + global step."""
+    """Optimizer slots for every variable + global step.
 
-    def __init__(self, p, hp):
+    lin_hp: the canned DNNLinearCombinedClassifier's second optimizer (reference
+    trainers/linear_deep.py:32-39).  TF 1.12's ``_dnn_linear_combined_model_fn`` builds ONE forward
+    and ONE loss, then ``dnn_optimizer.minimize(loss, var_list=<variables under the dnn scope>)`` and
+    ``linear_optimizer.minimize(loss, var_list=<variables under the linear scope>)``, groups the two
+    and increments global_step once.  Linear scope = linear_model weights of every column (categorical
+    [vocab,1] tables, numeric [1,1] weights) + bias_weights; dnn scope = embeddings, hidden layers,
+    logits layer (and, for a DeepFM given two optimizers, numeric_embeddings: an input-layer variable).
+    Both gradients are taken at the same pre-update variables."""
+
+    def __init__(self, p, hp, lin_hp=None):
         self.hp = hp
+        self.lin_hp = lin_hp if lin_hp is not None else hp
         self.step = 0
         self.emb = [opt.slot_init(hp, a) for a in p.emb]
-        self.lin = [opt.slot_init(hp, a) for a in p.lin_w]
-        self.dense = [opt.slot_init(hp, a) for a in p.dense_list()]
+        self.lin = [opt.slot_init(self.lin_hp, a) for a in p.lin_w]
+        self.wide = p.wide_flags()           # per dense variable: does it belong to the linear scope
+        self.dense = [opt.slot_init(self.lin_hp if w else hp, a) for a, w in zip(p.dense_list(), self.wide)]
         self.powers = opt.AdamPowers(hp, p.dtype) if hp.name == opt.ADAM else None
+        self.lin_powers = self.powers if lin_hp is None else (
+            opt.AdamPowers(lin_hp, p.dtype) if lin_hp.name == opt.ADAM else None)
 
 
 def train_step(p, st, ids, labels, x_num=None, use_linear=True, use_mf=True, use_dnn=True,
-               reduction="mean", dropout_masks=None, global_batch=None):
+               reduction="mean", dropout_masks=None, global_batch=None, numeric="embed", keep_prob=1.0):
     """One optimizer.minimize(loss) (deep_fm.py:119-125 TRAIN branch): forward, head, backward,
     apply_gradients (dense vars: fused Apply*, embedding / linear tables: sparse apply with
     duplicate-summing), beta powers / global_step update.  Returns (loss, logits)."""
-    c = forward(p, ids, x_num, use_linear, use_mf, use_dnn, dropout_masks)
+    c = forward(p, ids, x_num, use_linear, use_mf, use_dnn, dropout_masks, numeric, keep_prob)
     loss, d_logits, _, _ = head(c["logits"], labels, reduction, global_batch)
     dense_g, d_rows, d_lin = backward(p, c, d_logits, dropout_masks)
     apply_gradients(p, st, ids, dense_g, d_rows, d_lin)
@@ -233,20 +273,26 @@ def train_step(p, st, ids, labels, x_num=None, use_linear=True, use_mf=True, use
 
 
 def apply_gradients(p, st, ids, dense_g, d_rows, d_lin):
-    hp = st.hp
+    hp, lhp = st.hp, st.lin_hp
     lr_t = st.powers.lr_t(hp.lr) if st.powers else None
+    lin_lr_t = st.lin_powers.lr_t(lhp.lr) if st.lin_powers else None
     F = ids.shape[1]
-    for var, (s0, s1), g in zip(p.dense_list(), st.dense, dense_g):
-        opt.dense_apply(hp, var, s0, s1, g.reshape(var.shape).astype(var.dtype), lr_t)
+    for var, (s0, s1), g, wide in zip(p.dense_list(), st.dense, dense_g, st.wide):
+        if wide:
+            opt.dense_apply(lhp, var, s0, s1, g.reshape(var.shape).astype(var.dtype), lin_lr_t)
+        else:
+            opt.dense_apply(hp, var, s0, s1, g.reshape(var.shape).astype(var.dtype), lr_t)
     for f in range(F):
         if d_rows is not None:
             opt.sparse_apply(hp, p.emb[f], st.emb[f][0], st.emb[f][1], ids[:, f], d_rows[:, f, :], lr_t)
         if d_lin is not None:
             w = p.lin_w[f][:, None]
             s0, s1 = st.lin[f][0][:, None], st.lin[f][1][:, None]
-            opt.sparse_apply(hp, w, s0, s1, ids[:, f], d_lin[:, f:f + 1], lr_t)
+            opt.sparse_apply(lhp, w, s0, s1, ids[:, f], d_lin[:, f:f + 1], lin_lr_t)
     if st.powers:
         st.powers.finish()
+    if st.lin_powers is not None and st.lin_powers is not st.powers:
+        st.lin_powers.finish()
     st.step += 1
 
 

@@ -285,6 +285,40 @@ __global__ __launch_bounds__(kBlock) void numeric_embed_bwd_part_k(
   }
 }
 
+// Canned estimators' numeric columns (tf.feature_column.numeric_column in dnn_feature_columns /
+// linear_feature_columns of trainers/linear_deep.py:32-39): the value itself is a column of the
+// input_layer concat, and linear_model multiplies it by a [1,1] weight.  One thread per example;
+// the linear terms are added in column order after the categorical sum (products rounded on their own).
+__global__ __launch_bounds__(kBlock) void numeric_raw_fwd_k(const float* __restrict__ x, const float* __restrict__ w_num,
+                                                            int64_t B, int nd, float* __restrict__ concat, int64_t ldc,
+                                                            int64_t col0, int ncols, float* __restrict__ lin) {
+  const int64_t b = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (b >= B) return;
+  const float* xr = x + b * nd;
+  if (concat) {
+    float* cr = concat + b * ldc + col0;
+    for (int j = 0; j < ncols; ++j) cr[j] = j < nd ? xr[j] : 0.f;
+  }
+  if (lin && w_num) {
+    float acc = lin[b];
+    for (int j = 0; j < nd; ++j) acc = acc + xr[j] * w_num[j];
+    lin[b] = acc;
+  }
+}
+
+// partw[blk, j] = sum_{b in slice} dll[b] * x[b,j]  (reduce_parts_k adds the slices in order)
+__global__ __launch_bounds__(kBlock) void numeric_raw_bwd_part_k(const float* __restrict__ x, const float* __restrict__ dll,
+                                                                 int64_t B, int nd, int64_t rows_per_block,
+                                                                 float* __restrict__ partw) {
+  const int64_t b0 = static_cast<int64_t>(blockIdx.x) * rows_per_block;
+  const int64_t b1 = min(B, b0 + rows_per_block);
+  for (int j = threadIdx.x; j < nd; j += kBlock) {
+    float acc = 0.f;
+    for (int64_t b = b0; b < b1; ++b) acc += dll[b] * x[b * nd + j];
+    partw[static_cast<int64_t>(blockIdx.x) * nd + j] = acc;
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void reduce_parts_k(const float* __restrict__ part, int nparts,
                                                          int width, float* __restrict__ out) {
   const int c = blockIdx.x * kBlock + threadIdx.x;
@@ -474,6 +508,44 @@ int32_t mi_numeric_embed_bwd(const float* x, const float* d_concat, int64_t ld_d
     reduce_parts_k<<<dim3((unsigned)mi::ceil_div(n_d, kBlock)), dim3(kBlock), 0, st>>>(partw, (int)nb, n_d, dw_num);
     MI_CHECK_LAUNCH("numeric_embed_bwd(reduce w)");
   }
+  return MI_OK;
+}
+
+int32_t mi_numeric_raw_fwd(const float* x, const float* w_num, int64_t B, int32_t n_d, float* concat,
+                           int64_t ld_concat, int64_t col0, int32_t n_cols, float* lin, mi_stream_t stream) {
+  MI_REQUIRE(B >= 0 && n_d > 0, "numeric_raw_fwd: B=%lld n_d=%d", (long long)B, n_d);
+  if (B == 0) return MI_OK;
+  MI_REQUIRE(x && (concat || lin), "numeric_raw_fwd: null buffer");
+  MI_REQUIRE(!concat || (col0 >= 0 && n_cols >= n_d && ld_concat >= col0 + n_cols),
+             "numeric_raw_fwd: col0=%lld n_cols=%d ld=%lld", (long long)col0, n_cols, (long long)ld_concat);
+  MI_REQUIRE(!lin || w_num, "numeric_raw_fwd: lin needs w_num");
+  const int64_t blocks = mi::ceil_div(B, kBlock);
+  MI_REQUIRE(blocks <= INT32_MAX, "numeric_raw_fwd: grid too large");
+  numeric_raw_fwd_k<<<dim3((unsigned)blocks), dim3(kBlock), 0, mi::as_stream(stream)>>>(x, lin ? w_num : nullptr, B, n_d, concat,
+                                                                                        ld_concat, col0, n_cols, lin);
+  MI_CHECK_LAUNCH("numeric_raw_fwd");
+  return MI_OK;
+}
+
+size_t mi_numeric_raw_bwd_workspace_bytes(int64_t B, int32_t n_d) {
+  return static_cast<size_t>(mi::ceil_div(B > 0 ? B : 1, kNumericRowsPerBlock)) * static_cast<size_t>(n_d) * sizeof(float);
+}
+
+int32_t mi_numeric_raw_bwd(const float* x, const float* d_logit_lin, int64_t B, int32_t n_d, float* dw_num,
+                           void* workspace, size_t workspace_bytes, mi_stream_t stream) {
+  MI_REQUIRE(B > 0 && n_d > 0, "numeric_raw_bwd: B=%lld n_d=%d", (long long)B, n_d);
+  MI_REQUIRE(x && d_logit_lin && dw_num && workspace, "numeric_raw_bwd: null buffer");
+  if (workspace_bytes < mi_numeric_raw_bwd_workspace_bytes(B, n_d)) {
+    mi::set_error("numeric_raw_bwd: workspace %zu < %zu", workspace_bytes, mi_numeric_raw_bwd_workspace_bytes(B, n_d));
+    return MI_ERR_WORKSPACE;
+  }
+  const int64_t nb = mi::ceil_div(B, kNumericRowsPerBlock);
+  float* partw = static_cast<float*>(workspace);
+  hipStream_t st = mi::as_stream(stream);
+  numeric_raw_bwd_part_k<<<dim3((unsigned)nb), dim3(kBlock), 0, st>>>(x, d_logit_lin, B, n_d, kNumericRowsPerBlock, partw);
+  MI_CHECK_LAUNCH("numeric_raw_bwd(part)");
+  reduce_parts_k<<<dim3((unsigned)mi::ceil_div(n_d, kBlock)), dim3(kBlock), 0, st>>>(partw, (int)nb, n_d, dw_num);
+  MI_CHECK_LAUNCH("numeric_raw_bwd(reduce)");
   return MI_OK;
 }
 

@@ -39,7 +39,7 @@ struct GemmArgs {
   int vecA, vecB;
   int epi;
   const float* bias; int relu;
-  float keep_prob; float inv_keep; uint64_t seed;
+  float keep_prob; float keep_div; uint64_t seed;   // keep_div: what kept values are DIVIDED by (tf.nn.dropout: div(x, keep_prob) * mask)
   const float* mask_src; int64_t ldm;
   float* colsum_part;   // TN only: [splits][N] partial column sums of B (bias gradient), or NULL
   // Gathered A operand (layer 1 of the MLP): A is the embedding table and logical element
@@ -236,11 +236,11 @@ __device__ __forceinline__ void store_tile_c(const GemmArgs& a, const f32x16 (&a
         if (a.epi == EPI_BIAS_ACT) {
           v += bv;
           if (a.relu) v = fmaxf(v, 0.f);
-          if (a.keep_prob < 1.f) v = dropout_keep(a.seed, row, col, thresh) ? v * a.inv_keep : 0.f;
+          if (a.keep_prob < 1.f) v = dropout_keep(a.seed, row, col, thresh) ? v / a.keep_div : 0.f;
         } else if (a.epi == EPI_MASK) {
           if (a.mask_src) {
             const float x = a.mask_src[static_cast<int64_t>(row) * a.ldm + col];
-            v = (x > 0.f) ? v * a.inv_keep : 0.f;
+            v = (x > 0.f) ? v / a.keep_div : 0.f;
           }
         }
         Cb[static_cast<int64_t>(row) * a.ldc + col] = v;
@@ -478,7 +478,7 @@ constexpr int kGvLanes = 16;
 __global__ __launch_bounds__(kThreads) void gemv_fwd_k(const float* __restrict__ X, int64_t ldx,
                                                        const float* __restrict__ W, const float* __restrict__ bias,
                                                        float* __restrict__ Y, int64_t ldy, int64_t M, int K, int relu,
-                                                       float keep_prob, float inv_keep, uint64_t seed,
+                                                       float keep_prob, float keep_div, uint64_t seed,
                                                        float* __restrict__ amax_out) {
   const int l = threadIdx.x & (kGvLanes - 1);
   const int64_t groups = static_cast<int64_t>(gridDim.x) * (kThreads / kGvLanes);
@@ -505,7 +505,7 @@ __global__ __launch_bounds__(kThreads) void gemv_fwd_k(const float* __restrict__
       if (m < M && l == 0) {
         float v = acc[j] + b0;
         if (relu) v = fmaxf(v, 0.f);
-        if (keep_prob < 1.f) v = dropout_keep(seed, static_cast<uint32_t>(m), 0u, thresh) ? v * inv_keep : 0.f;
+        if (keep_prob < 1.f) v = dropout_keep(seed, static_cast<uint32_t>(m), 0u, thresh) ? v / keep_div : 0.f;
         Y[m * ldy] = v;
         mx = fmaxf(mx, fabsf(v));
       }
@@ -519,7 +519,7 @@ __global__ __launch_bounds__(kThreads) void gemv_fwd_k(const float* __restrict__
 __global__ __launch_bounds__(kThreads) void gemv_dgrad_k(const float* __restrict__ dY, int64_t lddy,
                                                          const float* __restrict__ W, const float* __restrict__ Xact,
                                                          int64_t ldxa, float* __restrict__ dX, int64_t lddx, int64_t M,
-                                                         int K, float inv_keep, float* __restrict__ amax_out) {
+                                                         int K, float keep_div, float* __restrict__ amax_out) {
   const int kq = K >> 2;
   const int64_t total = M * kq, stride = static_cast<int64_t>(gridDim.x) * kThreads;
   float mx = 0.f;
@@ -542,8 +542,8 @@ __global__ __launch_bounds__(kThreads) void gemv_dgrad_k(const float* __restrict
       if (base + j * stride >= total) break;
       float4 v = make_float4(gv[j] * wv[j].x, gv[j] * wv[j].y, gv[j] * wv[j].z, gv[j] * wv[j].w);
       if (Xact) {
-        v.x = xv[j].x > 0.f ? v.x * inv_keep : 0.f; v.y = xv[j].y > 0.f ? v.y * inv_keep : 0.f;
-        v.z = xv[j].z > 0.f ? v.z * inv_keep : 0.f; v.w = xv[j].w > 0.f ? v.w * inv_keep : 0.f;
+        v.x = xv[j].x > 0.f ? v.x / keep_div : 0.f; v.y = xv[j].y > 0.f ? v.y / keep_div : 0.f;
+        v.z = xv[j].z > 0.f ? v.z / keep_div : 0.f; v.w = xv[j].w > 0.f ? v.w / keep_div : 0.f;
       }
       *reinterpret_cast<float4*>(dX + mm[j] * lddx + kk[j]) = v;
       mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
@@ -689,7 +689,7 @@ int32_t mi_dense_fwd(const float* X, int64_t ldx, const float* W, const float* b
   if (N == 1 && gemv_ok(X, ldx, W, K)) {
     const int64_t blocks = std::min<int64_t>(mi::ceil_div(M * kGvLanes, 2 * kThreads), 2048);
     gemv_fwd_k<<<dim3((unsigned)blocks), dim3(kThreads), 0, mi::as_stream(stream)>>>(
-        X, ldx, W, bias, Y, ldy, M, K, relu, keep_prob, 1.f / keep_prob, seed, amax ? amax->out : nullptr);
+        X, ldx, W, bias, Y, ldy, M, K, relu, keep_prob, keep_prob, seed, amax ? amax->out : nullptr);
     MI_CHECK_LAUNCH("dense_fwd(N = 1)");
     return MI_OK;
   }
@@ -698,7 +698,7 @@ int32_t mi_dense_fwd(const float* X, int64_t ldx, const float* W, const float* b
   a.M = (int)M; a.N = N; a.K = K; a.k_per_split = ((K + BK - 1) / BK) * BK;
   a.vecA = vec_ok(X, ldx, K); a.vecB = vec_ok(W, N, N);
   a.epi = EPI_BIAS_ACT; a.bias = bias; a.relu = relu;
-  a.keep_prob = keep_prob; a.inv_keep = 1.f / keep_prob; a.seed = seed;
+  a.keep_prob = keep_prob; a.keep_div = keep_prob; a.seed = seed;
   set_amax(a, amax);
   return launch<KC, MC>(a, 1, mi::as_stream(stream), "dense_fwd");
 }
@@ -715,7 +715,7 @@ int32_t mi_dense_bwd_data(const float* dY, int64_t lddy, const float* W, const f
       (!Xact || (mi::aligned16(Xact) && (ldxa & 3) == 0))) {
     const int64_t blocks = std::min<int64_t>(mi::ceil_div(M * (K >> 2), 4 * kThreads), 4096);
     gemv_dgrad_k<<<dim3((unsigned)blocks), dim3(kThreads), 0, mi::as_stream(stream)>>>(
-        dY, lddy, W, Xact, ldxa, dX, lddx, M, K, Xact ? 1.f / keep_prob : 1.f, amax ? amax->out : nullptr);
+        dY, lddy, W, Xact, ldxa, dX, lddx, M, K, Xact ? keep_prob : 1.f, amax ? amax->out : nullptr);
     MI_CHECK_LAUNCH("dense_bwd_data(N = 1)");
     return MI_OK;
   }
@@ -724,7 +724,7 @@ int32_t mi_dense_bwd_data(const float* dY, int64_t lddy, const float* W, const f
   a.M = (int)M; a.N = K; a.K = N; a.k_per_split = ((N + BK - 1) / BK) * BK;
   a.vecA = vec_ok(dY, lddy, N); a.vecB = vec_ok(W, N, N);
   a.epi = EPI_MASK; a.mask_src = Xact; a.ldm = ldxa;
-  a.keep_prob = keep_prob; a.inv_keep = Xact ? 1.f / keep_prob : 1.f;
+  a.keep_prob = keep_prob; a.keep_div = Xact ? keep_prob : 1.f;
   set_amax(a, amax);
   return launch<KC, KC>(a, 1, mi::as_stream(stream), "dense_bwd_data");
 }
@@ -751,7 +751,7 @@ int32_t mi_dense_fwd_gathered(const float* table, const int64_t* field_off, cons
   a.M = (int)M; a.N = N; a.K = K; a.k_per_split = ((K + BK - 1) / BK) * BK;
   a.vecA = 1; a.vecB = vec_ok(W, N, N);
   a.epi = EPI_BIAS_ACT; a.bias = bias; a.relu = relu;
-  a.keep_prob = keep_prob; a.inv_keep = 1.f / keep_prob; a.seed = seed;
+  a.keep_prob = keep_prob; a.keep_div = keep_prob; a.seed = seed;
   a.g_ids = ids; a.g_off = field_off; a.g_F = F; a.g_E = E;
   set_amax(a, amax);
   return launch<KC, MC, false, true>(a, 1, mi::as_stream(stream), "dense_fwd_gathered");
@@ -841,7 +841,7 @@ static int32_t bwd_weight_impl(const float* X, int64_t ldx, const float* dY, int
   a.A = X; a.lda = ldx; a.B = dY; a.ldb = lddy;
   a.M = K; a.N = N; a.K = (int)M; a.k_per_split = (int)wgrad_k_per_split(M, splits);
   a.vecA = vec_ok(X, ldx, K); a.vecB = vec_ok(dY, lddy, N);
-  a.C = slab; a.ldc = N; a.epi = EPI_SLAB; a.keep_prob = 1.f; a.inv_keep = 1.f;
+  a.C = slab; a.ldc = N; a.epi = EPI_SLAB; a.keep_prob = 1.f; a.keep_div = 1.f;
   a.colsum_part = db ? cpart : nullptr;
   set_amax(a, amax);
   a.amax_c = nullptr;                 // the slabs are partial sums; dW is nobody's matrix operand

@@ -54,6 +54,9 @@ SIGNATURES = {
     "mi_embed_fm_linear_fwd": (_i32, [_p, _p, _p, _p, _i64, _i32, _i32, _p, _i64, _p, _p, _p, _p, _p]),
     "mi_gather_rows": (_i32, [_p, _p, _p, _i64, _i32, _p, _p, _p]),
     "mi_numeric_embed_fwd": (_i32, [_p, _p, _p, _i64, _i32, _i32, _p, _i64, _i64, _p, _p, _p, _p]),
+    "mi_numeric_raw_fwd": (_i32, [_p, _p, _i64, _i32, _p, _i64, _i64, _i32, _p, _p]),
+    "mi_numeric_raw_bwd_workspace_bytes": (_sz, [_i64, _i32]),
+    "mi_numeric_raw_bwd": (_i32, [_p, _p, _i64, _i32, _p, _p, _sz, _p]),
     "mi_embed_fm_linear_bwd": (_i32, [_p, _i64, _p, _i64, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p, _p, _p]),
     "mi_numeric_embed_bwd_workspace_bytes": (_sz, [_i64, _i32, _i32]),
     "mi_numeric_embed_bwd": (_i32, [_p, _p, _i64, _p, _i64, _i64, _p, _p, _p, _i64, _i32, _i32, _p,

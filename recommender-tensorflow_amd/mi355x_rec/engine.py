@@ -14,9 +14,10 @@ Variable layout in HBM
   lin_w   [R]    f32   linear_model weights, same row numbering
   t_s0/t_s1, l_s0/l_s1 optimizer slots shaped like table / lin_w
   last_step [R]  i32   Adam only: step at which a row was last brought up to date
-  dense   [P]    f32   every dense variable back to back (16-float aligned segments):
-                       kernel_0, bias_0, ..., kernel_logits, bias_logits, linear bias,
-                       numeric_embeddings, numeric linear weights; d_s0/d_s1/d_grad mirror it
+  dense   [P]    f32   every dense variable back to back (16-float aligned segments): first TF's
+                       "dnn" scope — kernel_0, bias_0, ..., kernel_logits, bias_logits,
+                       numeric_embeddings — then, from wide_off on, the dense part of its "linear" scope —
+                       linear bias, numeric linear weights; d_s0/d_s1/d_grad mirror it
 With a RowShard (N > 1 GPUs) table / lin_w / slots / last_step hold only the rows r with
 r % world == rank, stored at r // world; the dense buffer is replicated.
 """
@@ -150,8 +151,8 @@ class AdamSchedule:
         self.table = torch.from_numpy(self.host.copy()).to(self.device)
 
     def lr_t(self, step):
-        if step >= len(self.host):
-            self._extend(2 * len(self.host))
+        while step >= len(self.host):                     # also after restoring a checkpoint far into a run
+            self._extend(max(2 * len(self.host), step + 1))
         return float(self.host[step])
 
 
@@ -162,24 +163,33 @@ class DeepFM:
     reduction: "mean" (contrib head, DeepFM) or "sum" (canned estimators), SURVEY A.5.
     linear_optimizer: if given, the wide part (lin_w + linear bias [+ numeric linear weights]) uses
     it and everything else uses ``optimizer`` (DNNLinearCombinedClassifier).
+    numeric: what a numeric column feeds the deep part with — "embed": DeepFM's numeric_embeddings
+    (deep_fm.py:62-73, x[b,j] * V[j,:], also seen by the FM term); "raw": the value itself, appended
+    to the concat after the embedding columns, as the canned estimators' input_layer does (TF orders
+    the concat by column name; here numeric columns follow the categorical block, which permutes
+    kernel_0's rows only — tf_names maps them).
     shard: parallel.RowShard for N > 1 GPUs (row-sharded tables, data-parallel MLP)."""
 
     def __init__(self, vocab_sizes, n_numeric=0, embedding_size=4, hidden_units=(16, 16),
                  use_linear=True, use_mf=True, use_dnn=True, dropout=0.0, optimizer=None,
                  linear_optimizer=None, reduction="mean", device="cuda", seed=0, shard=None,
-                 gemm="f16x2", _kernels=None):
+                 gemm="f16x2", numeric="embed", _kernels=None):
         if len(vocab_sizes) + n_numeric == 0:
             raise ValueError("At least 1 feature column of categorical_columns or numeric_columns "
                              "must be specified.")            # deep_fm.py:31-32
         if not (use_linear or use_mf or use_dnn):
             raise ValueError("At least 1 of linear, mf or dnn component must be used.")  # :33-34
-        if len(vocab_sizes) == 0:
-            raise NotImplementedError("numeric-only models are not supported by the HIP path")
+        if numeric not in ("embed", "raw"):
+            raise ValueError("numeric must be 'embed' or 'raw'")
+        if numeric == "raw" and use_mf:
+            raise ValueError("raw numeric columns belong to the canned estimators, which have no FM term")
         self.k = _kernels if _kernels is not None else HipKernels()
         self.device = torch.device(device)
         self.vocab_sizes = [int(v) for v in vocab_sizes]
         self.F = len(self.vocab_sizes)
         self.n_numeric = int(n_numeric)
+        self.numeric = numeric if self.n_numeric else "embed"
+        self.raw_numeric = self.numeric == "raw"
         self.E = int(embedding_size)
         self.hidden = [int(h) for h in hidden_units] if use_dnn else []
         self.use_linear, self.use_mf, self.use_dnn = bool(use_linear), bool(use_mf), bool(use_dnn)
@@ -193,8 +203,8 @@ class DeepFM:
         self.step = 0
         if self.use_emb and (self.E % 4 or not 4 <= self.E <= 256):
             raise ValueError("embedding_size must be a multiple of 4 in [4, 256] on the HIP path")
-        if self.n_numeric and not self.use_emb:
-            raise NotImplementedError("numeric columns need the embedding path (use_mf or use_dnn)")
+        if self.n_numeric and not self.raw_numeric and not self.use_emb:
+            raise NotImplementedError("numeric embeddings need the embedding path (use_mf or use_dnn)")
 
         off = np.zeros(self.F + 1, np.int64)
         off[1:] = np.cumsum(self.vocab_sizes)
@@ -207,8 +217,8 @@ class DeepFM:
         self.R_local = self.R if shard is None else shard.local_rows(self.R)
 
         f32 = dict(dtype=torch.float32, device=dev)
-        self.table = torch.zeros(self.R_local, self.E, **f32) if self.use_emb else None
-        self.lin_w = torch.zeros(self.R_local, **f32) if self.use_linear else None
+        self.table = torch.zeros(self.R_local, self.E, **f32) if (self.use_emb and self.F) else None
+        self.lin_w = torch.zeros(self.R_local, **f32) if (self.use_linear and self.F) else None
         sparse_lin_opt = self.lin_opt or self.opt
         self.t_s0, self.t_s1 = self._slots(self.table, self.opt)
         self.l_s0, self.l_s1 = self._slots(self.lin_w, sparse_lin_opt)
@@ -217,11 +227,23 @@ class DeepFM:
         self.adam_rows = t_adam or l_adam
         self.last_step = torch.zeros(self.R_local, dtype=torch.int32, device=dev) if self.adam_rows else None
         adam_spec = self.opt if self.opt.name == "Adam" else (sparse_lin_opt if sparse_lin_opt.name == "Adam" else None)
+        if self.lin_opt is not None and self.lin_opt.name == "Adam" and self.opt.name == "Adam" and \
+                (self.lin_opt.lr, self.lin_opt.beta1, self.lin_opt.beta2, self.lin_opt.epsilon) != \
+                (self.opt.lr, self.opt.beta1, self.opt.beta2, self.opt.epsilon):
+            raise NotImplementedError("two different Adam optimizers would need two lr_t schedules")
+        if shard is not None and self.F == 0:
+            raise NotImplementedError("a model without categorical columns has nothing to shard")
         self.sched = AdamSchedule(adam_spec, dev) if adam_spec is not None else None
 
         # dense variables: one flat buffer
-        self.D = (self.F + self.n_numeric) * self.E if self.use_emb else 0
-        self.layers = []                         # (kernel_off, bias_off, fan_in, fan_out)
+        # D_in: logical width of the MLP input; D: its width in memory (raw numeric columns: padded with
+        # zero columns to a multiple of 32, so that layer 1 keeps whole k-tiles; the matching rows of
+        # kernel_0 are zero, get zero gradients and stay zero under every optimizer here)
+        n_emb = self.F + (0 if self.raw_numeric else self.n_numeric)
+        self.D_emb = n_emb * self.E if self.use_emb else 0
+        self.D_in = self.D_emb + (self.n_numeric if (self.raw_numeric and self.use_dnn) else 0)
+        self.D = _align(self.D_in, 32) if (self.raw_numeric and self.use_dnn) else self.D_in
+        self.layers = []                         # (kernel_off, bias_off, fan_in as stored, fan_out)
         o = 0
         if self.use_dnn:
             fan = self.D
@@ -230,11 +252,13 @@ class DeepFM:
                 b_off = o; o = _align(o + h)
                 self.layers.append((k_off, b_off, fan, h))
                 fan = h
-        self.dnn_end = o
-        self.lin_bias_off = o; o = _align(o + 1)
+        self.dnn_end = o                         # end of the MLP parameter block
         self.num_emb_off = self.lin_num_off = None
-        if self.n_numeric:
+        if self.n_numeric and not self.raw_numeric:
             self.num_emb_off = o; o = _align(o + self.n_numeric * self.E)
+        self.wide_off = o                        # [0, wide_off): TF's "dnn" scope; [wide_off, P): "linear" scope
+        self.lin_bias_off = o; o = _align(o + 1)
+        if self.n_numeric and self.use_linear:
             self.lin_num_off = o; o = _align(o + self.n_numeric)
         self.P = o
         self.dense = torch.zeros(self.P, **f32)
@@ -248,7 +272,7 @@ class DeepFM:
         # Without numeric columns layer 1 of the MLP reads its input straight from the embedding table
         # (multi-GPU: from the receive buffer of the row exchange) as a gathered GEMM operand and the
         # concat [B, F*E] is never materialised.
-        self.gather_mlp = self.use_dnn and self.n_numeric == 0
+        self.gather_mlp = self.use_dnn and self.n_numeric == 0 and self.F > 0
         # Matrix-pipe path of the MLP GEMMs (all: fp32 in, fp32 accumulate, fp32-level error):
         #   "f16x2"  operands scaled by a power of two and split into fp16 high + low parts, three
         #            products per k-step; every kernel that produces a GEMM operand also emits its
@@ -309,9 +333,12 @@ class DeepFM:
         if self.lin_w is not None and lin_scale:
             self.lin_w.normal_(0.0, lin_scale, generator=g)
         for i, (_, _, fan, h) in enumerate(self.layers):
-            lim = math.sqrt(6.0 / (fan + h))
+            fan_in = self.D_in if i == 0 else fan
+            lim = math.sqrt(6.0 / (fan_in + h))
             self.kernel(i).uniform_(-lim, lim, generator=g)
-        if self.n_numeric:
+            if i == 0 and fan_in < fan:
+                self.kernel(0)[fan_in:].zero_()            # rows of the zero pad columns
+        if self.num_emb_off is not None:
             lim = math.sqrt(6.0 / (self.n_numeric + self.E))
             self._seg(self.dense, self.num_emb_off, (self.n_numeric, self.E)).uniform_(-lim, lim, generator=g)
 
@@ -327,18 +354,22 @@ class DeepFM:
         if self.lin_w is not None:
             self.lin_w.copy_(t(self._my_rows(np.concatenate(p.lin_w, 0))))
         for i in range(len(self.layers)):
-            self.kernel(i).copy_(t(p.mlp[i][0]))
+            k = self.kernel(i)
+            k.zero_()
+            k[:p.mlp[i][0].shape[0]].copy_(t(p.mlp[i][0]))
             self.bias(i).copy_(t(p.mlp[i][1]))
         self.dense[self.lin_bias_off] = float(p.lin_bias[0])
-        if self.n_numeric:
+        if self.num_emb_off is not None:
             self._seg(self.dense, self.num_emb_off, (self.n_numeric, self.E)).copy_(t(p.num_emb))
+        if self.lin_num_off is not None:
             self._seg(self.dense, self.lin_num_off, (self.n_numeric,)).copy_(t(p.lin_num))
 
     def export_numpy(self):
         """Variables as numpy arrays (after bringing Adam rows up to date).  Sparse variables are
         returned per field for a single GPU, as the local shard ("table", "lin_w_local") otherwise."""
         self.finalize_rows()
-        out = {"mlp": [(self.kernel(i).cpu().numpy(), self.bias(i).cpu().numpy()) for i in range(len(self.layers))],
+        rows = lambda i: self.D_in if i == 0 else self.layers[i][2]          # without the zero pad rows
+        out = {"mlp": [(self.kernel(i)[:rows(i)].cpu().numpy(), self.bias(i).cpu().numpy()) for i in range(len(self.layers))],
                "lin_bias": self.dense[self.lin_bias_off:self.lin_bias_off + 1].cpu().numpy()}
         if self.shard is None:
             off = self.field_off_host
@@ -347,8 +378,9 @@ class DeepFM:
         else:
             out.update(table=None if self.table is None else self.table.cpu().numpy(),
                        lin_w_local=None if self.lin_w is None else self.lin_w.cpu().numpy())
-        if self.n_numeric:
+        if self.num_emb_off is not None:
             out["num_emb"] = self._seg(self.dense, self.num_emb_off, (self.n_numeric, self.E)).cpu().numpy()
+        if self.lin_num_off is not None:
             out["lin_num"] = self._seg(self.dense, self.lin_num_off, (self.n_numeric,)).cpu().numpy()
         return out
 
@@ -409,10 +441,13 @@ class DeepFM:
         concat = sumv = fm = None
         ld = self.D
         gathered = self.gather_mlp
+        F = self.F
         if self.use_emb:
             concat = None if gathered else self._buf("concat", (B, ld))
             sumv = self._buf("sumv", (B, self.E)) if self.use_mf else None
             fm = self._buf("fm", (B,)) if self.use_mf else None
+        elif self.raw_numeric and self.use_dnn:
+            concat = self._buf("concat", (B, ld))
         lin = self._buf("lin", (B,)) if self.use_linear else None
         f16 = self.gemm == "f16x2" and self.use_dnn
         if f16:
@@ -422,27 +457,37 @@ class DeepFM:
         # (3.9 vs 4.9 TB/s of row bytes).  On a single GPU they run as their own kernel on a side stream
         # under the matrix-bound layer-1 GEMM instead; the head joins the two streams.
         side_lin = (src is None and self.device.type == "cuda" and self.use_emb and self.use_linear and self.use_dnn
-                    and self.n_numeric == 0)
+                    and self.n_numeric == 0 and F > 0)
         c["lin_join"] = None
-        if side_lin:
+        if F == 0:
+            # numeric columns only (deep_fm.py:57-70 allows it): the sums start from zero (memsets)
+            for t in (sumv, fm, lin):
+                if t is not None:
+                    t.zero_()
+        elif side_lin:
             if concat is not None or sumv is not None or rows_amax is not None:
-                k.mi_embed_fm_linear_fwd(table, None, field_off, rid, B, self.F, self.E, concat, ld, sumv, fm, None,
+                k.mi_embed_fm_linear_fwd(table, None, field_off, rid, B, F, self.E, concat, ld, sumv, fm, None,
                                          rows_amax)
             side = self._ws.get("side_stream")
             if side is None:
                 side = self._ws["side_stream"] = torch.cuda.Stream(device=self.device)
             side.wait_stream(torch.cuda.current_stream())        # the catch-up of these rows ran on the main stream
             with torch.cuda.stream(side):
-                k.tagged("mi_embed_fm_linear_fwd", "/wide")(None, lin_w, field_off, rid, B, self.F, self.E, None, 0, None,
+                k.tagged("mi_embed_fm_linear_fwd", "/wide")(None, lin_w, field_off, rid, B, F, self.E, None, 0, None,
                                                             None, lin, None)
             c["lin_join"] = side
         elif concat is not None or sumv is not None or lin is not None or rows_amax is not None:
-            k.mi_embed_fm_linear_fwd(table if self.use_emb else None, lin_w if self.use_linear else None, field_off,
-                                     rid, B, self.F, self.E, concat, ld, sumv, fm, lin, rows_amax)
+            emb_on = self.use_emb
+            k.mi_embed_fm_linear_fwd(table if emb_on else None, lin_w if self.use_linear else None, field_off,
+                                     rid, B, F, self.E, concat if emb_on else None, ld, sumv, fm, lin, rows_amax)
         if self.n_numeric:
-            V = self._seg(self.dense, self.num_emb_off, (self.n_numeric, self.E))
             wn = self._seg(self.dense, self.lin_num_off, (self.n_numeric,)) if self.use_linear else None
-            k.mi_numeric_embed_fwd(x_num, V, wn, B, self.n_numeric, self.E, concat, ld, self.F * self.E, sumv, fm, lin)
+            if self.raw_numeric:
+                # canned input_layer: the values themselves (+ zero pad) follow the embedding columns
+                k.mi_numeric_raw_fwd(x_num, wn, B, self.n_numeric, concat, ld, self.D_emb, ld - self.D_emb, lin)
+            else:
+                V = self._seg(self.dense, self.num_emb_off, (self.n_numeric, self.E))
+                k.mi_numeric_embed_fwd(x_num, V, wn, B, self.n_numeric, self.E, concat, ld, F * self.E, sumv, fm, lin)
         acts = []
         dnn = None
         k.query("mi_set_gemm_mode", 0 if self.gemm == "fp32" else 1)
@@ -459,7 +504,7 @@ class DeepFM:
                 last = i == nh
                 y = self._buf("act%d" % i, (B, h))
                 if i == 0 and gathered:
-                    k.mi_dense_fwd_gathered(table, field_off, rid, self.F, self.E, self.kernel(0), self.bias(0), y, h,
+                    k.mi_dense_fwd_gathered(table, field_off, rid, F, self.E, self.kernel(0), self.bias(0), y, h,
                                             B, h, 0 if last else 1, 1.0 if last else keep, self._layer_seed(0),
                                             self._ga("x0", "w", "x1"))
                 else:
@@ -580,6 +625,12 @@ class DeepFM:
         k = self.k
         B = ids.shape[0]
         n = B * self.F
+        if n == 0:                       # numeric columns only: no sparse variable exists
+            c = self._forward(ids, x_num, True)
+            logits, loss, dlogit = self._head(c, labels, True)
+            self._backward_dense(c, dlogit)
+            self._apply(None, None, None, None, 0, None, None)
+            return loss, logits
         # (1) which rows does this batch touch: sort + unique (TF: unique/unsorted_segment_sum)
         rows = self._buf("rows", (n,), torch.int32)
         k.mi_global_rows(ids, self.field_off, B, self.F, rows)
@@ -645,7 +696,11 @@ class DeepFM:
                                     keep if i else 1.0, ga_d)
                 dy, lddy = dx, fan
             d_concat = dy
-        if self.n_numeric:
+        if self.n_numeric and self.raw_numeric:
+            if self.use_linear:       # a raw numeric column owns no deep variable: only its linear_model weight
+                ws = self._bytes("num_ws", k.query("mi_numeric_raw_bwd_workspace_bytes", B, self.n_numeric))
+                k.mi_numeric_raw_bwd(c["x_num"], dlogit, B, self.n_numeric, self.d_grad[self.lin_num_off:], ws, ws.numel())
+        elif self.n_numeric:
             ws = self._bytes("num_ws", k.query("mi_numeric_embed_bwd_workspace_bytes", B, self.n_numeric, self.E))
             k.mi_numeric_embed_bwd(c["x_num"], d_concat, self.D, c["concat"], self.D, self.F * self.E, c["sumv"],
                                    dlogit if self.use_mf else None, dlogit if self.use_linear else None, B,
@@ -666,9 +721,9 @@ class DeepFM:
             sparse_hp = [(True, True, hp)]
         else:
             lhp = self.lin_opt.hparams(lr_t)
-            if self.dnn_end:
-                k.mi_dense_apply(self.dense, self.d_s0, self.d_s1, self.d_grad, self.dnn_end, hp)
-            o = self.dnn_end
+            if self.wide_off:
+                k.mi_dense_apply(self.dense, self.d_s0, self.d_s1, self.d_grad, self.wide_off, hp)
+            o = self.wide_off
             sl = lambda t: t[o:] if t is not None else None
             k.mi_dense_apply(self.dense[o:], sl(self.dl_s0), sl(self.dl_s1), self.d_grad[o:], self.P - o, lhp)
             sparse_hp = [(True, False, hp), (False, True, lhp)]

@@ -117,7 +117,8 @@ class Estimator:
             plan = self.params["_store"]["plan"]
             with np.load(self.warm_start_from, allow_pickle=False) as z:
                 names = tf_names.import_variables(self._engine(), dict(z), [c.name for c in plan.categorical],
-                                                  model=self.params.get("tf_model", "deep_fm"))
+                                                  model=self.params.get("tf_model", "deep_fm"),
+                                                  numeric_names=[c.name for c in plan.numeric])
             print("INFO: warm-started %d variables from %s" % (len(names), self.warm_start_from))
 
     def save_checkpoint(self):
@@ -220,11 +221,27 @@ class Estimator:
 def train_and_evaluate(estimator, train_spec, eval_spec):
     """Local-mode tf.estimator.train_and_evaluate: train to max_steps; after every checkpoint
     (every save_checkpoints_secs and at the end) evaluate on the whole eval input and export."""
-    def after_checkpoint():
+    t_start = time.time()
+    state = {"last_eval": None, "evaluated_step": None}
+
+    def after_checkpoint(final=False):
+        # EvalSpec.start_delay_secs / throttle_secs (conf_utils.py:27-34): no evaluation before
+        # start_delay_secs of training, none sooner than throttle_secs after the previous one started;
+        # the checkpoint written when training ends is always evaluated (as TF's local loop does).
+        now = time.time()
+        if not final:
+            if now - t_start < (eval_spec.start_delay_secs or 0):
+                return
+            if state["last_eval"] is not None and now - state["last_eval"] < (eval_spec.throttle_secs or 0):
+                return
+        if state["evaluated_step"] == estimator.global_step:
+            return
+        state["last_eval"], state["evaluated_step"] = now, estimator.global_step
         estimator.evaluate(eval_spec.input_fn, steps=eval_spec.steps)
         exporters = eval_spec.exporters
         if exporters is not None:
             for ex in (exporters if isinstance(exporters, (list, tuple)) else [exporters]):
                 ex.export(estimator, os.path.join(estimator.model_dir, "export"))
     estimator.train(train_spec.input_fn, max_steps=train_spec.max_steps, on_checkpoint=after_checkpoint)
+    after_checkpoint(final=True)
     return estimator

@@ -168,7 +168,14 @@ def embedding_column(categorical_column, dimension, combiner="mean"):
 
 class FieldPlan:
     """Lowering of (categorical_columns, numeric_columns) to the fused-table layout.
-    input_layer / linear_model iterate columns sorted by name: so do we."""
+
+    Field order: TF's input_layer iterates the EMBEDDING columns sorted by their name, which is
+    ``<categorical name>_embedding`` — that order fixes the row blocks of the first MLP
+    kernel, so it is the order of the fused table.  It differs from sorting by the categorical name
+    only when one name is a prefix of another followed by a character below '_' ('war' < 'war2' but
+    'war2_embedding' < 'war_embedding'); linear_model sorts by the categorical name, which for such a
+    pair changes nothing but the fp32 association of the wide sum (the kernels add the fields of an
+    example as a lane tree, not sequentially, in either order)."""
 
     def __init__(self, categorical_columns, numeric_columns=()):
         cats = [c.categorical_column if isinstance(c, EmbeddingColumn) else c for c in categorical_columns]
@@ -178,7 +185,7 @@ class FieldPlan:
         for c in numeric_columns:
             if not isinstance(c, NumericColumn):
                 raise ValueError("not a numeric column: %r" % (c,))
-        self.categorical = sorted(cats, key=lambda c: c.name)
+        self.categorical = sorted(cats, key=lambda c: c.name + "_embedding")
         self.numeric = sorted(numeric_columns, key=lambda c: c.name)
         names = [c.name for c in self.categorical]
         if len(set(names)) != len(names):
@@ -187,8 +194,25 @@ class FieldPlan:
 
     def transform(self, features):
         """features: dict key -> sequence of B raw values.  Returns (ids int32 [B,F], x float32 [B,n_d] or None)."""
-        ids = np.stack([c.transform(features) for c in self.categorical], 1).astype(np.int32)
+        cols = []
+        for c in self.categorical:
+            v = np.asarray(c.transform(features))
+            # The kernels index table[field_off[f] + id] unchecked.  TF drops ids < 0 (an out-of-vocabulary
+            # value of a vocabulary column without OOV buckets: zero embedding, zero linear term) and fails
+            # on ids >= num_buckets; neither may reach the device here.
+            if v.size and (v.min() < 0 or v.max() >= c.num_buckets):
+                bad = v[(v < 0) | (v >= c.num_buckets)][0]
+                raise ValueError("column %r produced id %d outside [0, %d): give the column num_oov_buckets (or a "
+                                 "default_value inside the vocabulary); the HIP path has no dropped-id row"
+                                 % (c.name, int(bad), c.num_buckets))
+            cols.append(v)
+        ids = (np.stack(cols, 1) if cols else np.zeros((self._batch_size(features), 0))).astype(np.int32)
         x = None
         if self.numeric:
             x = np.stack([c.values(features) for c in self.numeric], 1).astype(np.float32)
         return np.ascontiguousarray(ids), x
+
+    def _batch_size(self, features):
+        for c in self.numeric:
+            return len(c.values(features))
+        return len(next(iter(features.values())))

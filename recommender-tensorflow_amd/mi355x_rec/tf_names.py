@@ -20,9 +20,10 @@ import numpy as np
 _MODELS = ("deep_fm", "linear", "dnn", "dnn_linear_combined")
 
 
-def variable_names(model, column_names, n_hidden, n_numeric=0):
+def variable_names(model, column_names, n_hidden, n_numeric=0, numeric_names=None):
     """-> dict with keys 'emb' [F names], 'lin_w' [F names], 'lin_bias', 'mlp' [(kernel, bias)] (hidden
-    layers then logits), 'num_emb', 'lin_num' (DeepFM numeric embeddings: one variable each)."""
+    layers then logits), 'num_emb' (DeepFM's numeric_embeddings), 'lin_num' (one name for all numeric
+    linear weights, or — with numeric_names — a list of per-column linear_model weights [1,1])."""
     if model not in _MODELS:
         raise ValueError("model must be one of %s" % (_MODELS,))
     cols = list(column_names)
@@ -36,23 +37,43 @@ def variable_names(model, column_names, n_hidden, n_numeric=0):
         lin = ["linear/linear_model/%s/weights" % c for c in cols]
         mlp = [("dnn/hiddenlayer_%d/kernel" % i, "dnn/hiddenlayer_%d/bias" % i) for i in range(n_hidden)]
         mlp.append(("dnn/logits/kernel", "dnn/logits/bias"))
+    lin_num = None
+    if n_numeric:
+        lin_num = (["linear/linear_model/%s/weights" % c for c in numeric_names] if numeric_names
+                   else "linear/linear_model/numeric/weights")
     return {"emb": emb, "lin_w": lin, "lin_bias": "linear/linear_model/bias_weights", "mlp": mlp,
-            "num_emb": "input_layer/numeric_embeddings" if n_numeric else None,
-            "lin_num": "linear/linear_model/numeric/weights" if n_numeric else None}
+            "num_emb": "input_layer/numeric_embeddings" if (n_numeric and model == "deep_fm") else None,
+            "lin_num": lin_num}
 
 
-def _names_for(m, model, column_names):
+def kernel0_rows(column_names, numeric_names, E):
+    """Canned estimators with raw numeric columns: TF's input_layer orders the concat by column name over
+    ``<categorical>_embedding`` (E columns each) and the numeric keys (1 column each); the engine keeps
+    the numeric columns after the categorical block.  Returns perm with
+    tf_kernel0[i] == engine_kernel0[perm[i]]."""
+    items = [(c + "_embedding", f * E, E) for f, c in enumerate(column_names)]
+    items += [(n, len(column_names) * E + j, 1) for j, n in enumerate(numeric_names)]
+    perm = []
+    for _, start, width in sorted(items):
+        perm.extend(range(start, start + width))
+    return np.asarray(perm, np.int64)
+
+
+def _names_for(m, model, column_names, numeric_names=None):
     if m.shard is not None:
         raise ValueError("TF-named import/export works on single-GPU engines (a sharded engine holds table slices)")
     if len(column_names) != m.F:
         raise ValueError("%d column names for %d categorical fields" % (len(column_names), m.F))
-    return variable_names(model, column_names, len(m.layers) - 1 if m.use_dnn else 0, m.n_numeric)
+    if m.raw_numeric and (numeric_names is None or len(numeric_names) != m.n_numeric):
+        raise ValueError("raw numeric columns need their %d names (kernel row order, linear_model weights)" % m.n_numeric)
+    return variable_names(model, column_names, len(m.layers) - 1 if m.use_dnn else 0, m.n_numeric,
+                          numeric_names if m.raw_numeric else None)
 
 
-def export_variables(m, column_names, model="deep_fm"):
+def export_variables(m, column_names, model="deep_fm", numeric_names=None):
     """Engine -> {TF variable name: ndarray} with TF's shapes (linear weights [vocab, 1], bias [1],
     numeric embeddings [1, n_d, E] as deep_fm.py:64 creates them)."""
-    nm = _names_for(m, model, column_names)
+    nm = _names_for(m, model, column_names, numeric_names)
     g = m.export_numpy()
     out = {}
     if g.get("emb") is not None:
@@ -61,21 +82,27 @@ def export_variables(m, column_names, model="deep_fm"):
         out.update({n: a.reshape(-1, 1) for n, a in zip(nm["lin_w"], g["lin_w"])})
         out[nm["lin_bias"]] = g["lin_bias"].reshape(1)
     if m.use_dnn:
-        for (kn, bn), (k, b) in zip(nm["mlp"], g["mlp"]):
+        for i, ((kn, bn), (k, b)) in enumerate(zip(nm["mlp"], g["mlp"])):
+            if i == 0 and m.raw_numeric:
+                k = k[kernel0_rows(column_names, numeric_names, m.E)]
             out[kn], out[bn] = k, b
     if m.n_numeric:
-        out[nm["num_emb"]] = g["num_emb"].reshape(1, m.n_numeric, m.E)
-        if g.get("lin_w") is not None:
-            out[nm["lin_num"]] = g["lin_num"].reshape(-1, 1)
+        if nm["num_emb"] is not None:
+            out[nm["num_emb"]] = g["num_emb"].reshape(1, m.n_numeric, m.E)
+        if "lin_num" in g:
+            if isinstance(nm["lin_num"], list):
+                out.update({n: g["lin_num"][j].reshape(1, 1) for j, n in enumerate(nm["lin_num"])})
+            else:
+                out[nm["lin_num"]] = g["lin_num"].reshape(-1, 1)
     return out
 
 
-def import_variables(m, arrays, column_names, model="deep_fm", strict=True):
+def import_variables(m, arrays, column_names, model="deep_fm", strict=True, numeric_names=None):
     """{TF variable name: ndarray} (e.g. ``dict(np.load("vars.npz"))``) -> engine variables.  Every
     variable the engine has must be present with TF's shape (strict) or keeps its value (not strict);
     returns the list of names that were loaded.  Optimizer slots and Adam row stamps are reset."""
     import torch
-    nm = _names_for(m, model, column_names)
+    nm = _names_for(m, model, column_names, numeric_names)
     loaded = []
     off = m.field_off_host
 
@@ -107,18 +134,30 @@ def import_variables(m, arrays, column_names, model="deep_fm", strict=True):
     if m.use_dnn:
         for i, (kn, bn) in enumerate(nm["mlp"]):
             _, _, fan, h = m.layers[i]
-            a, b = get(kn, (fan, h)), get(bn, (h,))
+            rows = m.D_in if i == 0 else fan
+            a, b = get(kn, (rows, h)), get(bn, (h,))
             if a is not None:
-                m.kernel(i).copy_(a)
+                if i == 0 and m.raw_numeric:
+                    inv = torch.from_numpy(np.argsort(kernel0_rows(column_names, numeric_names, m.E))).to(m.device)
+                    a = a[inv]
+                m.kernel(i)[:rows].copy_(a)
             if b is not None:
                 m.bias(i).copy_(b)
     if m.n_numeric:
-        a = get(nm["num_emb"], (m.n_numeric, m.E))
-        if a is not None:
-            m._seg(m.dense, m.num_emb_off, (m.n_numeric, m.E)).copy_(a)
-        if m.lin_w is not None:
-            a = get(nm["lin_num"], (m.n_numeric,))
+        if nm["num_emb"] is not None:
+            a = get(nm["num_emb"], (m.n_numeric, m.E))
             if a is not None:
-                m._seg(m.dense, m.lin_num_off, (m.n_numeric,)).copy_(a)
+                m._seg(m.dense, m.num_emb_off, (m.n_numeric, m.E)).copy_(a)
+        if m.lin_num_off is not None:
+            seg = m._seg(m.dense, m.lin_num_off, (m.n_numeric,))
+            if isinstance(nm["lin_num"], list):
+                for j, n in enumerate(nm["lin_num"]):
+                    a = get(n, (1,))
+                    if a is not None:
+                        seg[j:j + 1].copy_(a)
+            else:
+                a = get(nm["lin_num"], (m.n_numeric,))
+                if a is not None:
+                    seg.copy_(a)
     m.reset_optimizer_state()
     return loaded

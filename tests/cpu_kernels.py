@@ -98,6 +98,21 @@ class NumpyKernels:
         if lin is not None and w_num is not None:
             _np(lin)[:] += xv @ _np(w_num)
 
+    def mi_numeric_raw_fwd(self, x, w_num, B, nd, concat, ld, col0, ncols, lin):
+        xv = _np(x)
+        if concat is not None:
+            cc = _np(concat)
+            cc[:, col0:col0 + ncols] = 0
+            cc[:, col0:col0 + nd] = xv
+        if lin is not None and w_num is not None:
+            acc = _np(lin).copy()
+            for j in range(nd):
+                acc = acc + xv[:, j] * _np(w_num)[j]
+            _np(lin)[:] = acc
+
+    def mi_numeric_raw_bwd(self, x, dll, B, nd, dw, ws, wsb):
+        _np(dw)[:nd] = (_np(dll)[:, None] * _np(x)).sum(0)
+
     def mi_embed_fm_linear_bwd(self, d_concat, lddc, concat, ldc, rows, sumv, dlf, dll, pos, B, F, E, d_rows, d_lin):
         p = np.arange(B * F) if pos is None else _np(pos).reshape(-1)[:B * F].astype(np.int64)
         if d_rows is not None:
@@ -131,14 +146,14 @@ class NumpyKernels:
         if relu:
             y = np.maximum(y, 0)
         if keep < 1.0:
-            y = y * dropout_mask(seed, M, N, keep)
+            y = (y / np.float32(keep)) * dropout_mask(seed, M, N, keep)
         _np(Y)[:, :N] = y
 
     def mi_dense_bwd_data(self, dY, lddy, W, Xact, ldxa, dX, lddx, M, N, K, keep, amax=None):
         dy = _np(dY).reshape(M, -1)[:, :N]
         g = dy @ _np(W).T
         if Xact is not None:
-            g = g * (_np(Xact)[:, :K] > 0) * np.float32(np.float32(1.0) / np.float32(keep))
+            g = (g * (_np(Xact)[:, :K] > 0)) / np.float32(keep)
         _np(dX)[:, :K] = g
 
     def mi_dense_bwd_weight(self, X, ldx, dY, lddy, dW, db, M, N, K, ws, wsb, amax=None):

@@ -49,9 +49,12 @@ def _worker(rank, world, port, cfg, out_q, device="cpu", backend="gloo"):
             kernels = NumpyKernels()
         vocab, E, hidden, B, nn, opt_name, lr, steps, flags = cfg[:9]
         chunks = cfg[9] if len(cfg) > 9 else None       # pipeline depth of the step (None: by batch size, 1 here)
-        p, ids, x, y = make_problem(11, vocab, E, hidden, B * world, n_numeric=nn, use_dnn=flags[2])
+        extra = cfg[10] if len(cfg) > 10 else {}        # numeric="raw", lin_opt=(name, lr), reduction="sum": the canned W&D
+        p, ids, x, y = _problem(cfg, world)
+        lin_opt = OptimizerSpec(*extra["lin_opt"]) if "lin_opt" in extra else None
         m = DeepFM(vocab, n_numeric=nn, embedding_size=E, hidden_units=hidden, use_linear=flags[0], use_mf=flags[1],
                    use_dnn=flags[2], optimizer=OptimizerSpec(opt_name, lr), device=device, shard=RowShard(rank, world, chunks=chunks),
+                   numeric=extra.get("numeric", "embed"), linear_optimizer=lin_opt, reduction=extra.get("reduction", "mean"),
                    _kernels=kernels)
         m.load_oracle_params(p)
         rng = np.random.default_rng(5)
@@ -73,6 +76,19 @@ def _worker(rank, world, port, cfg, out_q, device="cpu", backend="gloo"):
         dist.destroy_process_group()
     except Exception:                                  # surface the traceback in the parent
         out_q.put((rank, "error", traceback.format_exc(), None, None))
+
+
+def _problem(cfg, world):
+    vocab, E, hidden, B, nn, opt_name, lr, steps, flags = cfg[:9]
+    extra = cfg[10] if len(cfg) > 10 else {}
+    if extra.get("numeric") == "raw":
+        rng = np.random.default_rng(11)
+        p = O.init_params(rng, vocab, E, hidden, n_numeric=nn, dtype=np.float32, lin_scale=0.05, use_dnn=flags[2], numeric="raw")
+        ids = np.stack([rng.integers(0, v, B * world) for v in vocab], 1).astype(np.int32)
+        x = rng.standard_normal((B * world, nn)).astype(np.float32)
+        y = (rng.random(B * world) < 0.3).astype(np.uint8)
+        return p, ids, x, y
+    return make_problem(11, vocab, E, hidden, B * world, n_numeric=nn, use_dnn=flags[2])
 
 
 def _run(cfg, world=2, device="cpu", backend="gloo"):
@@ -101,6 +117,10 @@ CASES = [
     ([9, 13, 5, 6], 8, [16, 8], 32, 0, "Adam", 0.001, 3, (True, True, True), 4),
     ([11, 5, 9], 4, [12], 16, 2, "Adam", 0.001, 2, (True, True, True), 2),
     ([7, 6, 5], 4, [], 16, 0, "Ftrl", 0.1, 2, (True, False, False), 2),
+    # BASELINE config 4's model: Wide&Deep with raw numeric columns, Adagrad on the deep part + Ftrl on the
+    # wide part, SUM loss (trainers/linear_deep.py:32-39), data-parallel over 2 ranks, 2 chunks
+    ([9, 13, 5, 6], 8, [16, 8], 16, 3, "Adagrad", 0.05, 2, (True, False, True), 2,
+     dict(numeric="raw", lin_opt=("Ftrl", 0.2), reduction="sum")),
 ]
 
 
@@ -117,15 +137,17 @@ def test_four_rank_pipelined_step_equals_big_batch():
 
 def check_against_big_batch(cfg, res, world, tol=1.0):
     vocab, E, hidden, B, nn, opt_name, lr, steps, flags = cfg[:9]
+    extra = cfg[10] if len(cfg) > 10 else {}
+    numeric, red = extra.get("numeric", "embed"), extra.get("reduction", "mean")
     # 1-rank reference: the oracle on the concatenated batch
-    p, ids, x, y = make_problem(11, vocab, E, hidden, B * world, n_numeric=nn, use_dnn=flags[2])
-    st = O.TrainState(p, OO.Hyper(opt_name, lr))
+    p, ids, x, y = _problem(cfg, world)
+    st = O.TrainState(p, OO.Hyper(opt_name, lr), OO.Hyper(*extra["lin_opt"]) if "lin_opt" in extra else None)
     rng = np.random.default_rng(5)
     for s in range(steps):
         ids_s = np.stack([rng.integers(0, v, B * world) for v in vocab], 1).astype(np.int32)
         ids_s[1] = ids_s[0]
         ids_s[B % len(ids_s)] = ids_s[0]
-        lo, logit_o = O.train_step(p, st, ids_s, y, x, *flags)
+        lo, logit_o = O.train_step(p, st, ids_s, y, x, *flags, reduction=red, numeric=numeric)
         for r in range(world):
             tot, logits = res[r][0][s]
             assert abs(tot - float(lo)) < tol * (1e-5 * abs(float(lo)) + 1e-7)
@@ -146,7 +168,7 @@ def check_against_big_batch(cfg, res, world, tol=1.0):
         for r in range(1, world):
             assert np.array_equal(res[0][1]["mlp"][i][0], res[r][1]["mlp"][i][0])
     # sharded eval forward agrees with the oracle forward on the updated variables
-    c = O.forward(p, ids, x, *flags)
+    c = O.forward(p, ids, x, *flags, numeric=numeric)
     for r in range(world):
         assert np.allclose(res[r][2], c["logits"][r * B:(r + 1) * B], rtol=1e-4 * tol, atol=2e-6 * tol)
 

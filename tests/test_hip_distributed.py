@@ -13,7 +13,11 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("cfg", [CASES[0], CASES[1], ([50, 30, 20, 40], 64, [64, 32], 128, 0, "Adam", 0.001, 3, (True, True, True)),
                                  CASES[4],                                                                        # pipelined, 4 chunks
-                                 ([50, 30, 20, 40], 64, [64, 32], 256, 0, "Adam", 0.001, 3, (True, True, True), 2)])  # 2 chunks of 128
+                                 ([50, 30, 20, 40], 64, [64, 32], 256, 0, "Adam", 0.001, 3, (True, True, True), 2),   # 2 chunks of 128
+                                 # BASELINE config 5's model shape: 40 fields, E=128, [512,256,128], row-sharded, pipelined
+                                 ([13] * 40, 128, [512, 256, 128], 128, 0, "Adam", 0.001, 2, (True, True, True), 2),
+                                 # BASELINE config 4's model: Wide&Deep + raw numeric columns, Ftrl + Adagrad, SUM loss
+                                 CASES[7]])
 def test_two_ranks_one_gpu_gloo(cfg):
     check_against_big_batch(cfg, _run(cfg, 2, device="cuda", backend="gloo"), 2, tol=3.0)
 

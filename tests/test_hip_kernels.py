@@ -168,7 +168,7 @@ def test_dense_fwd_dropout_mask_matches_host_replica(lib):
     _chk(lib.mi_dense_fwd(_p(x), K, _p(w), _p(bb), _p(Y1), N, M, N, K, 1, keep, seed, None, _st()))
     mask = dropout_mask(seed, M, N, keep)
     assert 0.85 < (mask > 0).mean() < 0.95
-    assert np.array_equal(Y1.cpu().numpy(), Y0.cpu().numpy() * mask)   # bit exact: y * (1/keep) or 0
+    assert np.array_equal(Y1.cpu().numpy(), (Y0.cpu().numpy() / np.float32(keep)) * mask)   # bit exact: y / keep or 0
 
 
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
@@ -182,7 +182,7 @@ def test_dense_bwd_data_and_weight(lib, M, N, K):
     keep = 0.8
     _chk(lib.mi_dense_bwd_data(_p(dy), N, _p(w), _p(x), K, _p(dX), K, M, N, K, keep, None, _st()))
     full = dY.astype(np.float64) @ W.astype(np.float64).T
-    ref = full * (X > 0) * np.float64(np.float32(1.0) / np.float32(keep))
+    ref = full * (X > 0) / np.float64(np.float32(keep))
     scale = np.sqrt(np.mean(full * full)) + 1e-30
     assert np.max(np.abs(dX.cpu().numpy() - ref)) / scale < 2 * TOL
     _chk(lib.mi_dense_bwd_data(_p(dy), N, _p(w), None, K, _p(dX), K, M, N, K, 1.0, None, _st()))
@@ -254,10 +254,10 @@ def test_bf16x3_and_fp32_gemm_modes_agree(lib, M, N, K):
         outs[tag] = (Y.cpu(), dX.cpu())
     _chk(lib.mi_set_gemm_mode(1))
     pre = X.astype(np.float64) @ W.astype(np.float64) + b
-    ref = np.maximum(pre, 0) * dropout_mask(5, M, N, 0.9)
+    ref = np.maximum(pre, 0) / np.float64(np.float32(0.9)) * dropout_mask(5, M, N, 0.9)
     sc = np.sqrt(np.mean(pre * pre))
     full = dY.astype(np.float64) @ W.astype(np.float64).T
-    refd = full * (X > 0) * np.float64(np.float32(1.0) / np.float32(0.9))
+    refd = full * (X > 0) / np.float64(np.float32(0.9))
     for tag in ("bf16x3", "fp32"):
         assert np.max(np.abs(outs[tag][0].numpy() - ref)) / sc < TOL, tag
         assert np.max(np.abs(outs[tag][1].numpy() - refd)) / np.sqrt(np.mean(full * full)) < 2 * TOL, tag
@@ -318,12 +318,12 @@ def test_f16x2_gemms_against_fp64(lib, M, N, K):
     Y = torch.empty(M, N, device="cuda"); dX = torch.empty(M, K, device="cuda")
     _chk(lib.mi_dense_fwd(_p(x), K, _p(w), _p(bb), _p(Y), N, M, N, K, 1, 0.9, 5, _ga(ax, aw, ay), _st()))
     pre = X.astype(np.float64) @ W.astype(np.float64) + b
-    ref = np.maximum(pre, 0) * dropout_mask(5, M, N, 0.9)
+    ref = np.maximum(pre, 0) / np.float64(np.float32(0.9)) * dropout_mask(5, M, N, 0.9)
     assert np.max(np.abs(Y.cpu().numpy() - ref)) / np.sqrt(np.mean(pre * pre)) < TOL
     assert float(ay.max()) == float(Y.abs().max())
     _chk(lib.mi_dense_bwd_data(_p(dy), N, _p(w), _p(x), K, _p(dX), K, M, N, K, 0.9, _ga(ady, aw), _st()))
     full = dY.astype(np.float64) @ W.astype(np.float64).T
-    refd = full * (X > 0) * np.float64(np.float32(1.0) / np.float32(0.9))
+    refd = full * (X > 0) / np.float64(np.float32(0.9))
     assert np.max(np.abs(dX.cpu().numpy() - refd)) / np.sqrt(np.mean(full * full)) < 2 * TOL
     ws = torch.empty(lib.mi_dense_bwd_weight_workspace_bytes(M, N, K) + 256, dtype=torch.uint8, device="cuda")
     dW = torch.empty(K, N, device="cuda"); db = torch.empty(N, device="cuda")
@@ -385,7 +385,7 @@ def test_f16x2_gathered_layer1_matches_materialised_bitwise(lib, B, F, E, N):
                                    _ga(arows, aw), _st()))
     assert torch.equal(Y0, Y1)
     pre = concat.cpu().numpy().astype(np.float64) @ W.astype(np.float64) + b
-    ref = np.maximum(pre, 0) * dropout_mask(77, B, N, 0.9)
+    ref = np.maximum(pre, 0) / np.float64(np.float32(0.9)) * dropout_mask(77, B, N, 0.9)
     assert np.max(np.abs(Y1.cpu().numpy() - ref)) / np.sqrt(np.mean(pre * pre)) < TOL
     ws = torch.empty(lib.mi_dense_bwd_weight_workspace_bytes(B, N, K) + 256, dtype=torch.uint8, device="cuda")
     dW0 = torch.empty(K, N, device="cuda"); dW1 = torch.empty(K, N, device="cuda")

@@ -152,7 +152,7 @@ def test_dropout_training_step_matches_oracle_with_same_mask():
     st = O.TrainState(p, OO.Hyper("Adam", 0.001))
     for _ in range(2):
         masks = [dropout_mask(m._layer_seed(i), B, h, 0.75) for i, h in enumerate(hidden)]
-        loss_o, _ = O.train_step(p, st, ids, y, dropout_masks=masks)
+        loss_o, _ = O.train_step(p, st, ids, y, dropout_masks=masks, keep_prob=0.75)
         loss_g, _ = m.train_step(dev(ids), dev(y))
         assert abs(loss_g.item() - float(loss_o)) / abs(float(loss_o)) < 2e-5
     _compare_vars(m, p, 2e-6)
@@ -214,3 +214,105 @@ def test_full_size_properties():
     m.step = step
     b = m.train_step(ids, y)[1]
     assert torch.equal(a, b) and torch.equal(ta, m.table)
+
+
+def _props_after_steps(m, ids, y, x, table0, rows, steps=3, replay=True):
+    """loss falls, only touched rows change, a replay from the same state gives the same bits"""
+    losses = [m.train_step(ids, y, x)[0].item() for _ in range(steps)]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+    changed = (m.table != table0).any(1)
+    touched = torch.zeros(m.R, dtype=torch.bool, device="cuda"); touched[rows.reshape(-1)] = True
+    assert not bool((changed & ~touched).any())
+    assert int(changed.sum()) > 0.9 * int(touched.sum())
+    if not replay:
+        return losses
+    keys = [k for k in ("table", "t_s0", "t_s1", "lin_w", "l_s0", "l_s1", "last_step", "dense", "d_s0", "d_s1", "dl_s0",
+                        "dl_s1") if getattr(m, k, None) is not None]
+    snap = {k: getattr(m, k).clone() for k in keys}
+    step = m.step
+    a = m.train_step(ids, y, x)[1].clone(); ta = m.table.clone(); da = m.dense.clone()
+    for k in keys:
+        getattr(m, k).copy_(snap[k])
+    m.step = step
+    b = m.train_step(ids, y, x)[1]
+    assert torch.equal(a, b) and torch.equal(ta, m.table) and torch.equal(da, m.dense)
+    return losses
+
+
+def test_config4_full_size_properties():
+    """BASELINE config 4 at full size on one GPU: Wide&Deep (trainers/linear_deep.py:32-39) with 26 x 1M-row
+    categorical columns + 13 dense columns, E=64, [512,256,128], B=65536, Ftrl on the wide part + Adagrad on
+    the deep part, SUM loss, dropout 0.1 — through size-independent properties (the oracle comparison at this
+    model shape with small vocabularies is tests/test_canned_parity.py::test_config4_shape_small_vocab)."""
+    from mi355x_rec.engine import OptimizerSpec
+    F, V, E, B, ND = 26, 1_000_000, 64, 65536, 13
+    m = _engine([V] * F, E, [512, 256, 128], ND, numeric="raw", use_mf=False, dropout=0.1, reduction="sum",
+                optimizer=OptimizerSpec("Adagrad", 0.05), linear_optimizer=OptimizerSpec("Ftrl", min(0.2, 1 / np.sqrt(F + ND))))
+    g = torch.Generator(device="cuda"); g.manual_seed(4)
+    m.init_variables(g, lin_scale=1e-3)
+    ids = torch.randint(0, V, (B, F), device="cuda", dtype=torch.int32, generator=g)
+    x = torch.log1p(-torch.log(torch.rand(B, ND, device="cuda", generator=g).clamp_min(1e-12)))   # log1p(Exp(1)), SURVEY 8d
+    y = (torch.rand(B, device="cuda", generator=g) < 0.25).to(torch.uint8)
+    assert m.D_in == F * E + ND and m.D == 1696 and m.lin_opt.name == "Ftrl"
+    table0, lin0 = m.table.clone(), m.lin_w.clone()
+    rows = ids.long() + m.field_off[None, :]
+    loss0, _ = m.loss(ids, y, x)
+    concat = m._ws["concat"][:B * m.D].view(B, m.D)
+    sel = torch.arange(0, B, 1009, device="cuda")
+    assert torch.equal(concat[sel, :F * E].reshape(-1, F, E), m.table[rows[sel]])      # exact-copy gather
+    assert torch.equal(concat[sel, F * E:F * E + ND], x[sel])                            # the values themselves
+    assert float(concat[:, F * E + ND:].abs().max()) == 0.0                             # zero pad
+    losses = _props_after_steps(m, ids, y, x, table0, rows)
+    assert losses[0] == pytest.approx(loss0.item(), rel=1e-5)
+    assert float(m.kernel(0)[m.D_in:].abs().max()) == 0.0                               # pad rows stay zero
+    lin_changed = m.lin_w != lin0
+    touched = torch.zeros(m.R, dtype=torch.bool, device="cuda"); touched[rows.reshape(-1)] = True
+    assert not bool((lin_changed & ~touched).any()) and int(lin_changed.sum()) > 0.9 * int(touched.sum())
+    # the two optimizers' slots: Adagrad accumulators only grow from 0.1, Ftrl's second slot is in use
+    assert float(m.t_s0.min()) >= 0.1 and float(m.l_s1.abs().max()) > 0 and m.t_s1 is None
+
+
+def test_config5_one_rank_share_properties():
+    """One rank's share of BASELINE config 5 (8 GPUs: 40 fields x 10M rows / 8 = 1.25M rows per field and rank,
+    E=128, B=131072/8 = 16384): a 25.6 GB table (76.8 GB with Adam's slots) whose byte offsets pass 2^32 and
+    whose element offsets pass 2^31.  Exact-copy gather across the whole table, then the training
+    properties."""
+    F, V, E, B = 40, 1_250_000, 128, 16384
+    m = _engine([V] * F, E, [512, 256, 128])
+    assert m.table.numel() * 4 > 2 ** 34 and m.table.numel() > 2 ** 32
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    # row-dependent contents without a 25 GB random fill: value = hash-like function of (row, col)
+    c = torch.arange(E, device="cuda", dtype=torch.float32).unsqueeze(0)
+    for r0 in range(0, m.R, 1 << 22):
+        r = torch.arange(r0, min(m.R, r0 + (1 << 22)), device="cuda", dtype=torch.float32).unsqueeze(1)
+        m.table[r0:r0 + (1 << 22)] = torch.sin(r * 0.37 + c * 1.3) * 0.09
+    del r, c
+    m.lin_w.normal_(0, 1e-3, generator=g)
+    for i, (_, _, fan, h) in enumerate(m.layers):
+        lim = (6.0 / (fan + h)) ** 0.5
+        m.kernel(i).uniform_(-lim, lim, generator=g)
+    ids = torch.randint(0, V, (B, F), device="cuda", dtype=torch.int32, generator=g)
+    ids[:, -1] = torch.randint(V - 1000, V, (B,), device="cuda", dtype=torch.int32, generator=g)   # the table's last rows
+    y = (torch.rand(B, device="cuda", generator=g) < 0.25).to(torch.uint8)
+    rows = ids.long() + m.field_off[None, :]
+    assert int(rows.max()) * E * 4 > 2 ** 34
+    concat = torch.empty(B, F * E, device="cuda")
+    m.k.mi_embed_fm_linear_fwd(m.table, None, m.field_off, ids, B, F, E, concat, F * E, None, None, None, None)
+    sel = torch.arange(0, B, 331, device="cuda")
+    assert torch.equal(concat[sel].view(-1, F, E), m.table[rows[sel]])
+    del concat
+    # the gathered layer-1 operand reads the same rows: eval logits vs a torch fp64 forward on sampled examples
+    loss0, logits = m.loss(ids, y)
+    v = m.table[rows[sel]].double()
+    lin = m.lin_w[rows[sel]].double().sum(1) + m.dense[m.lin_bias_off].double()
+    fm = 0.5 * ((v.sum(1) ** 2).sum(1) - (v * v).sum((1, 2)))
+    net = v.reshape(len(sel), -1)
+    for i in range(len(m.layers)):
+        net = net @ m.kernel(i).double() + m.bias(i).double()
+        if i < len(m.layers) - 1:
+            net = net.clamp_min(0)
+    ref = lin + fm + net[:, 0]
+    err = (logits[sel].double() - ref).abs() / ref.abs().clamp_min(ref.abs().mean())
+    assert float(err.max()) < 1e-5
+    table0 = m.table.clone()
+    _props_after_steps(m, ids, y, None, table0, rows, replay=False)    # (the replay check would hold 200 GB of clones)

@@ -179,9 +179,9 @@ def test_layer_summary_and_dropout_backward_rule():
     # dropout: backward through (relu -> mask) only needs the stored post-dropout activation
     p, ids, x, y = _problem(nn=0)
     rng = np.random.default_rng(3)
-    masks = [(rng.random((6, 8)) < 0.7) / 0.7, (rng.random((6, 6)) < 0.7) / 0.7]
-    loss_of = lambda: O.head(O.forward(p, ids, None, dropout_masks=masks)["logits"], y)[0]
-    c = O.forward(p, ids, None, dropout_masks=masks); _, dl, _, _ = O.head(c["logits"], y)
+    masks = [(rng.random((6, 8)) < 0.7).astype(np.float64), (rng.random((6, 6)) < 0.7).astype(np.float64)]
+    loss_of = lambda: O.head(O.forward(p, ids, None, dropout_masks=masks, keep_prob=0.7)["logits"], y)[0]
+    c = O.forward(p, ids, None, dropout_masks=masks, keep_prob=0.7); _, dl, _, _ = O.head(c["logits"], y)
     dense, _, _ = O.backward(p, c, dl, masks)
     k0 = p.mlp[0][0]; eps = 1e-6
     for i in [(0, 0), (3, 5), (11, 7)]:

@@ -15,7 +15,8 @@ def _mix32(x):
 
 
 def dropout_mask(seed, M, N, keep):
-    """Host replica of gemm.hip's counter-based dropout mask: multiplier {0, 1/keep} per element."""
+    """Host replica of gemm.hip's counter-based dropout mask: keep flag {0, 1} per element (kept values
+    are divided by keep, as tf.nn.dropout does)."""
     row = np.arange(M, dtype=np.uint32)[:, None]
     col = np.arange(N, dtype=np.uint32)[None, :]
     with np.errstate(over="ignore"):
@@ -23,7 +24,7 @@ def dropout_mask(seed, M, N, keep):
         h = _mix32((row * np.uint32(0x9E3779B1)) ^ (col * np.uint32(0x85EBCA77)) ^ s)
     thresh = np.uint32(np.float32(keep) * np.float32(16777216.0))
     kept = (h >> np.uint32(8)) < thresh
-    return kept.astype(np.float32) * np.float32(np.float32(1.0) / np.float32(keep))
+    return kept.astype(np.float32)
 
 
 def make_problem(seed, vocab, E, hidden, B, n_numeric=0, lin_scale=0.05, dup=True, use_dnn=True):
