@@ -222,13 +222,15 @@ def main():
     if rank == 0:
         km = kernel_ms(timers)
         ms_step = dt / args.steps * 1e3
-        g_ms = km["mi_embed_fm_linear_fwd"][0]
+        planes_gather = "mi_embed_fm_planes_fwd" in km
+        g_ms = km["mi_embed_fm_planes_fwd" if planes_gather else "mi_embed_fm_linear_fwd"][0]
         gather_bytes = B * F * 4 * E                     # algorithmic row bytes per launch
         wide_split = "mi_embed_fm_linear_fwd/wide" in km  # single GPU: the wide part's gathers run beside the layer-1 GEMM
         total_bytes = B * (F * (4 * E + (4 if wide_split else 8)) + 4 * E + (4 if wide_split else 8))   # rows + ids (+ linear weights) read; sumv / fm (/ lin) written
         achieved = gather_bytes / (g_ms * 1e-3) / 1e9
         gemm_ms = sum(v[2] for k, v in km.items() if k in ("mi_dense_fwd", "mi_dense_fwd_gathered", "mi_dense_bwd_data", "mi_dense_bwd_weight",
-                                                        "mi_dense_bwd_weight_gathered")) / args.steps
+                                                        "mi_dense_bwd_weight_gathered", "mi_dense_fwd_planes",
+                                                        "mi_dense_bwd_data_planes")) / args.steps
         dims = [F * E] + HIDDEN + [1]
         flops = 3 * 2 * B * sum(a * b for a, b in zip(dims[:-1], dims[1:]))
         traffic = None

@@ -88,6 +88,16 @@ int32_t mi_embed_fm_linear_fwd(const float* table, const float* lin_w, const int
                                float* concat, int64_t ld_concat, float* sumv, float* fm, float* lin,
                                float* amax_rows, mi_stream_t stream);
 
+/* The gather with the concat written as fp16 high/low planes (struct mi_planes, below): the operand of
+ * the layer-1 GEMMs mi_dense_fwd_planes / mi_dense_bwd_weight_planes.  One exponent per example, from the
+ * example's abs-max over all F*E values (the lane group that gathers an example holds all its rows in
+ * registers).  Also sumv / fm as above and amax_rows.  E a multiple of 16 and >= 32, F <= 48; the wide part
+ * is mi_embed_fm_linear_fwd(table = NULL). */
+struct mi_planes;
+int32_t mi_embed_fm_planes_fwd(const float* table, const int64_t* field_off, const int32_t* ids, int64_t B, int32_t F,
+                               int32_t E, float* sumv, float* fm, const struct mi_planes* concat, float* amax_rows,
+                               mi_stream_t stream);
+
 /* Owner-side half of the row-sharded path (multi-GPU): out_rows[i,:] = table[rows[i],:],
  * out_lin[i] = lin_w[rows[i]].  rows [n] int32 local row ids. */
 int32_t mi_gather_rows(const float* table, const float* lin_w, const int32_t* rows, int64_t n,
@@ -316,6 +326,63 @@ size_t mi_dense_bwd_weight_workspace_bytes(int64_t M, int32_t N, int32_t K);
 int32_t mi_dense_bwd_weight(const float* X, int64_t ldx, const float* dY, int64_t lddy, float* dW,
                             float* db, int64_t M, int32_t N, int32_t K, void* workspace,
                             size_t workspace_bytes, const mi_gemm_amax_t* amax, mi_stream_t stream);
+
+/* ---- (a6) the same layers with operands held as pre-split 16-bit planes ------------------------------
+ * A "planes" matrix [rows][K] stores x * 2^s_r = hi + lo (fp16 high and low parts, RNE) with one power-
+ * of-two exponent s_r per row, chosen from the row's abs-max (-> [2^14, 2^15)): ~22 significant bits
+ * relative to the ROW's largest element, whatever the spread between rows.  Memory layout, k-block major:
+ * for every block of 16 columns, all rows back to back, 64 bytes per row (16 x hi then 16 x lo); block j
+ * starts at data + j * blk_stride (blk_stride >= 64 * rows, a multiple of 64; data 16-byte aligned; columns
+ * K..ceil16(K) are zero).  The 16-k tile of a range of rows is one contiguous run of full cache lines.
+ * Producers: mi_split_rows (fp32 -> planes; the weights once per step, W itself for the data gradient and
+ * W transposed for the forward pass), the epilogues of the two GEMMs below (the next layer's operand never
+ * exists in fp32) and mi_embed_fm_planes_fwd (the input_layer concat).  The GEMMs run three f16 MFMA
+ * products per k-step (hi*hi, hi*lo, lo*hi; fp32 accumulate) fed by LDS-DMA with no arithmetic in the loop;
+ * row exponents are undone exactly in the epilogue.  Shapes: N and K multiples of 16; a planes result needs
+ * its width <= 512 (one workgroup then owns whole rows and knows their abs-max) — otherwise take the fp32
+ * result and mi_split_rows, or the any-shape entries above. */
+typedef struct mi_planes {
+  void* data;          /* [ceil16(K)/16][blk_stride bytes]: row r of block j at data + j*blk_stride + 64*r */
+  int32_t* row_exp;    /* [rows] s_r */
+  int64_t blk_stride;  /* bytes between consecutive 16-column blocks */
+} mi_planes_t;
+
+size_t mi_planes_bytes(int64_t rows, int32_t K);   /* size of data with blk_stride = 64 * rows */
+
+/* out row r = X[r, 0:K] (transpose == 0) or X[0:K, r] (transpose != 0: X is [K][rows], ldx >= rows).
+ * amax_out (may be NULL): abs-max vector (MI_AMAX_SLOTS floats) receiving max |X|. */
+int32_t mi_split_rows(const float* X, int64_t ldx, int64_t rows, int32_t K, int32_t transpose,
+                      const mi_planes_t* out, float* amax_out, mi_stream_t stream);
+/* Every hidden layer's kernel as planes, both orientations, in one launch (once per training step).
+ * Job q: W = dense + offset, [K][N] row-major; w (rows = K, the data gradient's operand) and / or wt (rows
+ * = N, W transposed: the forward pass's) — a NULL data pointer skips one.  All rows get ONE exponent, from
+ * amax (abs-max vector of the parameter block, mi_absmax): weights more than 2^-17 below the block's
+ * largest lose low bits. */
+#define MI_MAX_WEIGHT_JOBS 8
+typedef struct mi_weight_job {
+  int64_t offset;
+  int32_t K, N;
+  mi_planes_t w, wt;
+} mi_weight_job_t;
+int32_t mi_split_weights(const float* dense, const mi_weight_job_t* jobs, int32_t n_jobs, const float* amax,
+                         mi_stream_t stream);
+/* X[r, k] = (hi + lo) * 2^-s_r (tests, summaries) */
+int32_t mi_merge_rows(const mi_planes_t* in, int64_t rows, int32_t K, float* X, int64_t ldx, mi_stream_t stream);
+
+/* Y[M][N] = act(X[M][K] * W[K][N] + bias) with X as planes and Wt = planes of W TRANSPOSED (rows = N);
+ * epilogue as mi_dense_fwd.  Y (fp32) and / or Yp (planes, N <= 512; a positive value keeps a positive high
+ * part, so "hi > 0" is the relu/dropout mask of the data gradient) receive the result; amax_out (may be
+ * NULL) its abs-max. */
+int32_t mi_dense_fwd_planes(const mi_planes_t* X, const mi_planes_t* Wt, const float* bias, float* Y, int64_t ldy,
+                            const mi_planes_t* Yp, int64_t M, int32_t N, int32_t K, int32_t relu, float keep_prob,
+                            uint64_t seed, float* amax_out, mi_stream_t stream);
+
+/* dX[M][K] = (dY[M][N] * W[K][N]^T) .* mask with dY as planes and W = planes of W as stored (rows = K);
+ * mask from Xact (planes of the previous layer's stored output: hi > 0 <=> active and kept; NULL: none),
+ * survivors divided by keep_prob.  dX (fp32) and / or dXp (planes, K <= 512). */
+int32_t mi_dense_bwd_data_planes(const mi_planes_t* dY, const mi_planes_t* W, const mi_planes_t* Xact, float* dX,
+                                 int64_t lddx, const mi_planes_t* dXp, int64_t M, int32_t N, int32_t K, float keep_prob,
+                                 float* amax_out, mi_stream_t stream);
 
 /* ---- (a7,a8) logits sum + sigmoid cross-entropy head -----------------------------------------
  * replaces `logits += ...` (deep_fm.py:36,44,90,111) and

@@ -122,6 +122,89 @@ __global__ __launch_bounds__(kBlock) void embed_fm_linear_fwd_k(
 }
 
 // ------------------------------------------------------------------------------------------
+// The same gather with the input_layer concat written as fp16 high/low PLANES (mi_planes_t, gemm_pl.hip):
+// the operand of the layer-1 GEMMs.  A lane group owns a whole example, so it knows the example's abs-max
+// before it writes: all F rows of the example stay in registers (FC >= F float4 per lane, all loads in
+// flight at once), then one power-of-two exponent per example, then 8-byte stores (4 k of one plane per
+// lane; the LPR lanes of a group write each field's 4E bytes of planes contiguously).  E % 16 == 0.
+typedef _Float16 e_h16x2 __attribute__((ext_vector_type(2)));
+typedef float e_f32x2 __attribute__((ext_vector_type(2)));
+template <int LPR, int FC>
+__global__ __launch_bounds__(kBlock) void embed_fm_planes_fwd_k(
+    const float* __restrict__ table, const int64_t* __restrict__ field_off, const int32_t* __restrict__ ids, int64_t B,
+    int F, int E, float* __restrict__ sumv, float* __restrict__ fm, char* __restrict__ planes, int64_t ldp_b,
+    int32_t* __restrict__ row_exp, float* __restrict__ amax_rows) {
+  static_assert(LPR >= 8, "planes gather: E >= 32");
+  const int64_t g = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) / LPR;
+  const int l = threadIdx.x & (LPR - 1);
+  const bool valid = g < B;
+  const int64_t b = valid ? g : 0;
+  const bool lane_on = 4 * l < E;
+  const int eo = 4 * l;
+  const int32_t* idrow = ids + b * F;
+  float4 r[FC];
+#pragma unroll
+  for (int fb = 0; fb < FC; fb += LPR) {
+    const int fl = fb + l;
+    int32_t myrow = 0;
+    if (fl < F) myrow = static_cast<int32_t>(field_off[fl] + idrow[fl]);
+#pragma unroll
+    for (int j = 0; j < LPR; ++j) {
+      if (fb + j < FC) {
+        const int32_t row = __shfl(myrow, j, LPR);
+        r[fb + j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (fb + j < F && lane_on) r[fb + j] = ld4(table + static_cast<int64_t>(row) * E + eo);
+      }
+    }
+  }
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = s;
+  float mx = 0.f;
+#pragma unroll
+  for (int f = 0; f < FC; ++f) {
+    if (f < F) {
+      s.x += r[f].x; s.y += r[f].y; s.z += r[f].z; s.w += r[f].w;
+      q.x += __fmul_rn(r[f].x, r[f].x); q.y += __fmul_rn(r[f].y, r[f].y);
+      q.z += __fmul_rn(r[f].z, r[f].z); q.w += __fmul_rn(r[f].w, r[f].w);
+      mx = fmaxf(fmaxf(mx, fmaxf(fabsf(r[f].x), fabsf(r[f].y))), fmaxf(fabsf(r[f].z), fabsf(r[f].w)));
+    }
+  }
+  float t = ((__fmul_rn(s.x, s.x) - q.x) + (__fmul_rn(s.y, s.y) - q.y)) +
+            ((__fmul_rn(s.z, s.z) - q.z) + (__fmul_rn(s.w, s.w) - q.w));
+  t = group_sum<LPR>(t);
+  float gmx = mx;                                  // the example's abs-max over all fields and lanes
+#pragma unroll
+  for (int off = LPR / 2; off > 0; off >>= 1) gmx = fmaxf(gmx, __shfl_xor(gmx, off, LPR));
+  const int ex = static_cast<int>((__float_as_uint(gmx) >> 23) & 0xffu);
+  const int sx = max(-100, min(100, 141 - ex));
+  const float sc = __uint_as_float(static_cast<uint32_t>(127 + sx) << 23);
+  if (valid) {
+    if (sumv && lane_on) st4(sumv + b * E + eo, s);
+    if (l == 0) {
+      if (fm) fm[b] = 0.5f * t;
+      row_exp[b] = sx;
+    }
+    if (lane_on) {
+      char* prow = planes + b * 64 + (eo & 15) * 2;      // k-block major: block (k >> 4) at planes + (k >> 4) * ldp_b
+#pragma unroll
+      for (int f = 0; f < FC; ++f) {
+        if (f < F) {
+          const int k = f * E + eo;
+          const e_f32x2 u01 = {r[f].x * sc, r[f].y * sc}, u23 = {r[f].z * sc, r[f].w * sc};
+          const e_h16x2 h01 = __builtin_convertvector(u01, e_h16x2), h23 = __builtin_convertvector(u23, e_h16x2);
+          const e_f32x2 d01 = {u01[0] - static_cast<float>(h01[0]), u01[1] - static_cast<float>(h01[1])};
+          const e_f32x2 d23 = {u23[0] - static_cast<float>(h23[0]), u23[1] - static_cast<float>(h23[1])};
+          const e_h16x2 l01 = __builtin_convertvector(d01, e_h16x2), l23 = __builtin_convertvector(d23, e_h16x2);
+          char* d = prow + (k >> 4) * ldp_b;
+          *reinterpret_cast<uint2*>(d) = make_uint2(__builtin_bit_cast(uint32_t, h01), __builtin_bit_cast(uint32_t, h23));
+          *reinterpret_cast<uint2*>(d + 32) = make_uint2(__builtin_bit_cast(uint32_t, l01), __builtin_bit_cast(uint32_t, l23));
+        }
+      }
+    }
+  }
+  if (amax_rows) mi_amax_publish(amax_rows, mx);
+}
+
+// ------------------------------------------------------------------------------------------
 template <int LPR>
 __global__ __launch_bounds__(kBlock) void gather_rows_k(const float* __restrict__ table,
                                                         const float* __restrict__ lin_w,
@@ -389,6 +472,47 @@ int32_t mi_embed_fm_linear_fwd(const float* table, const float* lin_w, const int
                            table, lin ? lin_w : nullptr, field_off, ids, B, F, E, concat, ld_concat, sumv, fm, lin,
                            amax_rows)));
   MI_CHECK_LAUNCH("embed_fm_linear_fwd");
+  return MI_OK;
+}
+
+int32_t mi_embed_fm_planes_fwd(const float* table, const int64_t* field_off, const int32_t* ids, int64_t B, int32_t F,
+                               int32_t E, float* sumv, float* fm, const mi_planes_t* concat, float* amax_rows,
+                               mi_stream_t stream) {
+  if (int32_t rc = check_E("embed_fm_planes_fwd", E)) return rc;
+  MI_REQUIRE(B >= 0 && F > 0, "embed_fm_planes_fwd: B=%lld F=%d", (long long)B, F);
+  if ((E & 15) || E < 32 || F > 48) {
+    mi::set_error("embed_fm_planes_fwd: needs E a multiple of 16 >= 32 and F <= 48 (E=%d F=%d): use mi_embed_fm_linear_fwd + mi_split_rows", E, F);
+    return MI_ERR_UNSUPPORTED;
+  }
+  MI_REQUIRE(table && field_off && ids && concat && concat->data && concat->row_exp, "embed_fm_planes_fwd: null buffer");
+  MI_REQUIRE(concat->blk_stride >= B * 64 && (concat->blk_stride & 63) == 0 && mi::aligned16(concat->data) && mi::aligned16(table) &&
+                 (!sumv || mi::aligned16(sumv)), "embed_fm_planes_fwd: planes block stride / alignment");
+  MI_REQUIRE(!fm || sumv, "embed_fm_planes_fwd: fm needs sumv");
+  if (B == 0) return MI_OK;
+  const int lpr = lanes_per_row(E);
+  const int64_t blocks = mi::ceil_div(B * lpr, kBlock);
+  MI_REQUIRE(blocks <= INT32_MAX, "embed_fm_planes_fwd: grid too large");
+  char* pd = static_cast<char*>(concat->data);
+  const dim3 g((unsigned)blocks), blk(kBlock);
+  hipStream_t st = mi::as_stream(stream);
+#define MI_PL_GATHER(L, FCAP) embed_fm_planes_fwd_k<L, FCAP><<<g, blk, 0, st>>>(table, field_off, ids, B, F, E, sumv, fm, pd, concat->blk_stride, concat->row_exp, amax_rows)
+  if (F <= 32) {
+    switch (lpr) {
+      case 8: MI_PL_GATHER(8, 32); break;
+      case 16: MI_PL_GATHER(16, 32); break;
+      case 32: MI_PL_GATHER(32, 32); break;
+      default: MI_PL_GATHER(64, 32); break;
+    }
+  } else {
+    switch (lpr) {
+      case 8: MI_PL_GATHER(8, 48); break;
+      case 16: MI_PL_GATHER(16, 48); break;
+      case 32: MI_PL_GATHER(32, 48); break;
+      default: MI_PL_GATHER(64, 48); break;
+    }
+  }
+#undef MI_PL_GATHER
+  MI_CHECK_LAUNCH("embed_fm_planes_fwd");
   return MI_OK;
 }
 

@@ -1,0 +1,692 @@
+// fp32-accurate GEMMs of the MLP on the f16 matrix pipe, operands held as PRE-SPLIT 16-bit planes.
+//
+// Replaces tf.layers.dense / tf.layers.dropout (trainers/deep_fm.py:98-108) and their data gradients
+// for every layer whose shape allows it (gemm.hip keeps the any-shape kernels and the weight gradient).
+//
+// Operand format ("planes", mi_planes_t): a matrix [rows][K] is stored as fp16 high + fp16 low parts
+// of x * 2^s_r with ONE power-of-two exponent s_r PER ROW (row max -> [2^14, 2^15)):
+//     x * 2^s_r = hi + lo,   hi = fp16(x * 2^s_r)  (RNE),  lo = fp16(x * 2^s_r - hi)
+// so every row keeps ~22 significant bits relative to ITS OWN largest element (elements more than
+// 2^-17 below their row's maximum lose low bits gradually; the round-1 matrix-wide scale lost them for
+// whole rows, e.g. the dY rows of well-fit examples).  In memory the matrix is K-BLOCK MAJOR: for each block
+// of 16 k, all rows back to back, a row's piece being 16 x hi then 16 x lo (64 B); blocks are blk_stride
+// bytes apart.  The 16-k tile of any range of rows is therefore ONE contiguous run of full cache lines —
+// what a workgroup's LDS-DMA stage reads (measured against row-major pieces of 64 B, 6.6 KB apart: layer-1
+// forward 422 -> 339 us).
+//
+// Both operands of these GEMMs are "k-contiguous" (NT form):
+//     forward        Y[m][n]  = sum_k X[m][k]  * Wt[n][k]      (Wt = planes of W transposed, rows = n)
+//     data gradient  dX[m][n] = sum_k dY[m][k] * W [n][k]      (W  = planes of W as stored,  rows = n)
+// The row exponents are undone exactly in the epilogue (per output column for the weights, per output
+// row for the activations).  Three MFMA products per k-step: lo*hi, hi*lo, hi*hi (the dropped lo*lo is
+// <= 2^-22 |ab|); a product of two fp16 values is exact in fp32 and the matrix pipe accumulates in fp32.
+//
+// Kernel: one 512-thread workgroup (8 waves as 4 x 2) per CU computes a tile of (128 TN) output columns x
+// (64 TM) output rows; the WEIGHT rows are the MFMA's A operand and the EXAMPLE rows its B operand, so a
+// lane owns one example (column of the 32x32 accumulator tile) and its registers run over output columns:
+// per-example quantities (row exponent, row abs-max of the result) are per-lane scalars, and a lane pair
+// assembles 64 contiguous output bytes (16 hi + 16 lo) with v_permlane32_swap — no LDS transpose.
+// With TN = 4 a workgroup holds ALL 512 columns of a row: the epilogue knows the row's abs-max and writes
+// the next layer's operand directly as planes.
+// Staging is LDS-DMA only (global_load_lds_dwordx4, no register staging, no VALU in the loop): 3 stage
+// buffers of 16 k, counted vmcnt + raw s_barrier, one barrier per k-tile, loads two tiles ahead; the LDS
+// image is dense 64-B rows with the 16-B chunk index XOR-swizzled by (row >> 2) & 3 on the SOURCE address
+// (ds_read_b128 fragment reads are then conflict-free).
+#include "common.h"
+#include <algorithm>
+#include <cstdlib>
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float fl32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int PL_THREADS = 512;
+constexpr int PL_BK = 16;
+constexpr int PL_ROWB = 64;       // bytes per tile row and stage: 16 k x (hi, lo) x 2 B
+
+enum { PL_FWD = 0, PL_DGRAD = 1 };
+
+struct PlArgs {
+  const char* A; int64_t bsa; const int32_t* a_exp;     // weight side (rows = output columns); bsa: k-block stride in bytes
+  const char* B; int64_t bsb; const int32_t* b_exp;     // example side (rows = output rows)
+  int M, N, K;
+  int tiles_n;
+  float* C; int64_t ldc;                                // fp32 result [M][N] or NULL
+  char* Cp; int64_t bsc; int32_t* c_exp;                // planes of the result or NULL (one column tile only)
+  const float* bias; int relu; float keep_prob, keep_div; uint64_t seed;
+  const char* mask; int64_t bsm;                        // dgrad: planes of the stored activation (hi > 0 <=> active & kept)
+  float* amax_c;                                        // abs-max vector of the result (gemm.hip's weight gradient) or NULL
+};
+
+__device__ __forceinline__ float pl_pow2(int s) { return __uint_as_float(static_cast<uint32_t>(127 + s) << 23); }
+// exponent s with amax * 2^s in [2^14, 2^15), clamped so that 2^s and 2^-s are normal numbers
+__device__ __forceinline__ int pl_exp_for(float amax) {
+  const int e = static_cast<int>((__float_as_uint(amax) >> 23) & 0xffu);
+  return max(-100, min(100, 141 - e));
+}
+
+__device__ __forceinline__ uint32_t pl_mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU;
+  x ^= x >> 15; x *= 0x846ca68bU;
+  x ^= x >> 16;
+  return x;
+}
+// the same counter-based mask as gemm.hip (tests/util.py replays it)
+__device__ __forceinline__ bool pl_dropout_keep(uint64_t seed, uint32_t row, uint32_t col, uint32_t thresh) {
+  const uint32_t s = static_cast<uint32_t>(seed) ^ (static_cast<uint32_t>(seed >> 32) * 0xC2B2AE35U);
+  return (pl_mix32((row * 0x9E3779B1U) ^ (col * 0x85EBCA77U) ^ s) >> 8) < thresh;
+}
+
+template <int N> __device__ __forceinline__ void pl_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int TN, int TM, int EPI>
+__global__ __launch_bounds__(PL_THREADS, 2) void gemm_pl_k(const PlArgs a) {
+  // stage buffers: 4 where one workgroup per CU runs anyway (256 registers); 3 for the 128-column tile, whose
+  // 128 registers and 72 KB let two workgroups share a CU (one stores its result while the other computes)
+  constexpr int PL_NBUF = TN == 1 ? 3 : 4;
+  constexpr int BNt = 128 * TN, BMt = 64 * TM, ROWS = BNt + BMt;
+  constexpr int LPS = ROWS * 4 / PL_THREADS;             // LDS-DMA instructions per thread and stage
+  static_assert(ROWS * 4 % PL_THREADS == 0, "tile rows");
+  constexpr int STAGE = ROWS * PL_ROWB;
+  static_assert(PL_NBUF * STAGE <= 160 * 1024, "LDS");
+  __shared__ __attribute__((aligned(1024))) char smem[PL_NBUF * STAGE];
+
+  // XCD-aware bijective remap (blocks round-robin over the 8 XCDs): the column tiles of one row panel,
+  // which read the same activation rows, run on one XCD
+  const int nb = gridDim.x, bid = blockIdx.x;
+  const int qq = nb >> 3, rr = nb & 7, xcd = bid & 7, idx = bid >> 3;
+  const int lid = (xcd < rr) ? xcd * (qq + 1) + idx : rr * (qq + 1) + (xcd - rr) * qq + idx;
+  const int n0 = (lid % a.tiles_n) * BNt, m0 = (lid / a.tiles_n) * BMt;
+  const int nk = a.K / PL_BK;
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int i = lane & 31, h = lane >> 5;
+  const int wn = wv & 3, wm = wv >> 2;
+
+  // ---- LDS-DMA source addresses: chunk p = j * 512 + t of a stage lands at LDS byte 16 p ----
+  const char* src[LPS];
+#pragma unroll
+  for (int j = 0; j < LPS; ++j) {
+    const int p = j * PL_THREADS + t;
+    const int row = p >> 2, c = (p & 3) ^ ((row >> 2) & 3);
+    if (j < TN) {                                          // rows [0, BNt): weights
+      const int n = min(n0 + row, a.N - 1);
+      src[j] = a.A + static_cast<int64_t>(n) * PL_ROWB + c * 16;
+    } else {                                               // rows [BNt, ROWS): examples
+      const int m = min(m0 + row - BNt, a.M - 1);
+      src[j] = a.B + static_cast<int64_t>(m) * PL_ROWB + c * 16;
+    }
+  }
+
+  // ---- fragment addresses (bytes inside a stage) ----
+  const int sw = (i >> 2) & 3;
+  const int ch = (h ^ sw) * 16, cl = ((2 | h) ^ sw) * 16;
+  const int offA = (wn * 32 * TN + i) * PL_ROWB;
+  const int offB = (BNt + wm * 32 * TM + i) * PL_ROWB;
+
+  f32x16 acc[TN][TM];
+#pragma unroll
+  for (int x = 0; x < TN; ++x)
+#pragma unroll
+    for (int y = 0; y < TM; ++y)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.f;
+
+  // Software pipeline: the two waves of a SIMD ping-pong.  The workgroup's 8 waves form two groups (waves
+  // 0-3 and 4-7; wave w and w + 4 share a SIMD).  Every wave runs the same loop
+  //     L(t): issue its share of LDS-DMA stage t - 1 + NBUF, read the fragments of tile t from LDS
+  //     barrier
+  //     C(t): the 3 TN TM MFMAs of tile t, from registers only
+  //     barrier
+  // but group 1 enters it one barrier late (and group 0 leaves it one barrier late), so between any two
+  // consecutive barriers one group is in C and the other in L: each SIMD's matrix pipe always has exactly
+  // one wave feeding it, and every LDS-DMA issue, ds_read and wait of a wave sits under its partner's
+  // MFMAs.  With the barriers numbered globally, group 0 runs L(t) in slot [2t, 2t+1] and C(t) in
+  // [2t+1, 2t+2]; group 1 runs L(t) in [2t+1, 2t+2] and C(t) in [2t+2, 2t+3].  Tile t lives in stage buffer
+  // t % NBUF.
+  //   * a wave waits for its own share of stage t + 1 at the end of L(t): all shares are complete before
+  //     barrier 2t+2, the first read of tile t + 1 comes after it;
+  //   * L(t) refills the buffer tile t - 1 has left: its last reader was group 1's L(t - 1), which drained
+  //     its LDS reads (lgkmcnt(0)) before barrier 2t, and no L(t) starts before barrier 2t;
+  //   * at the end of L(t) a wave has issued stages up to t - 1 + NBUF and needs stage t + 1:
+  //     vmcnt((NBUF - 2) LPS); a share is in flight for 2 NBUF - 3 slots.
+  auto issue_share = [&](int kt, int buf) {
+#pragma unroll
+    for (int j = 0; j < LPS; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + kt * (j < TN ? a.bsa : a.bsb)),
+                                       (__attribute__((address_space(3))) void*)(smem + buf * STAGE + (j * PL_THREADS + wv * 64) * 16),
+                                       16, 0, 0);
+  };
+  f16x8 ah[TN], al[TN], bh[TM], bl[TM];
+  auto read_frags = [&](int bufi) {
+    const char* buf = smem + bufi * STAGE;
+#pragma unroll
+    for (int x = 0; x < TN; ++x) {
+      ah[x] = *reinterpret_cast<const f16x8*>(buf + offA + x * 32 * PL_ROWB + ch);
+      al[x] = *reinterpret_cast<const f16x8*>(buf + offA + x * 32 * PL_ROWB + cl);
+    }
+#pragma unroll
+    for (int y = 0; y < TM; ++y) {
+      bh[y] = *reinterpret_cast<const f16x8*>(buf + offB + y * 32 * PL_ROWB + ch);
+      bl[y] = *reinterpret_cast<const f16x8*>(buf + offB + y * 32 * PL_ROWB + cl);
+    }
+  };
+  auto phase_c = [&]() {
+#pragma unroll
+    for (int x = 0; x < TN; ++x)
+#pragma unroll
+      for (int y = 0; y < TM; ++y) {
+        f32x16 c = acc[x][y];                    // smallest partial products first
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[x], bh[y], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[x], bl[y], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[x], bh[y], c, 0, 0, 0);
+        acc[x][y] = c;
+      }
+  };
+  // L(t): share of stage t - 1 + NBUF into the buffer tile t - 1 has left, then the fragments of tile t
+  auto phase_l = [&](int t) {
+    if (t >= 1) {
+      int fb = t - 1;
+      fb -= (fb / PL_NBUF) * PL_NBUF;
+      issue_share(min(t - 1 + PL_NBUF, nk - 1), fb);      // (the tail re-issues the last tile: uniform counts)
+    }
+    int rb = t;
+    rb -= (rb / PL_NBUF) * PL_NBUF;
+    read_frags(rb);
+  };
+  const bool g1 = __builtin_amdgcn_readfirstlane(wm) != 0;
+
+#pragma unroll
+  for (int s = 0; s < PL_NBUF; ++s) issue_share(min(s, nk - 1), s);
+  pl_wait_vmcnt<LPS*(PL_NBUF - 1)>();                      // own share of stage 0
+  __builtin_amdgcn_s_barrier();                            // barrier 0
+  if (g1) __builtin_amdgcn_s_barrier();                    // the stagger
+  // (sched_barrier(0): hipcc otherwise moves register-only MFMAs across s_barrier, which would put both
+  // groups' MFMAs into the same slot)
+#pragma unroll 1
+  for (int t = 0; t < nk; ++t) {
+    phase_l(t);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    pl_wait_vmcnt<LPS*(PL_NBUF - 2)>();                    // own share of stage t + 1
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+    phase_c();
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (!g1) __builtin_amdgcn_s_barrier();
+
+  // ---------------------------------------------------------------- epilogue
+  pl_wait_vmcnt<0>();                 // the tail's re-issued loads
+  __syncthreads();                    // every wave is done with the stage buffers: LDS is free
+  float* e_fw = reinterpret_cast<float*>(smem);     // [BNt] 2^-s of the weight row (0 outside the matrix)
+  float* e_bias = e_fw + BNt;                       // [BNt]
+  float* e_rmax = e_bias + BNt;                     // [4][BMt] row abs-max per column group of waves
+  float* e_wmax = e_rmax + 4 * BMt;                 // [8] per-wave abs-max (amax_c)
+  for (int n = t; n < BNt; n += PL_THREADS) {
+    const int gn = n0 + n;
+    const bool ok = gn < a.N;
+    e_fw[n] = ok ? pl_pow2(-a.a_exp[ok ? gn : 0]) : 0.f;
+    e_bias[n] = (EPI == PL_FWD && a.bias && ok) ? a.bias[gn] : 0.f;
+  }
+  __syncthreads();
+
+  const uint32_t thresh = static_cast<uint32_t>(a.keep_prob * 16777216.0f);
+  const int nw = wn * 32 * TN;                      // this wave's first column inside the tile
+  float rmx[TM];
+#pragma unroll
+  for (int y = 0; y < TM; ++y) {
+    const int m = m0 + wm * 32 * TM + y * 32 + i;
+    const bool mok = m < a.M;
+    const int mc = mok ? m : a.M - 1;
+    const float fx = pl_pow2(-a.b_exp[mc]);
+    float mx = 0.f;
+#pragma unroll
+    for (int x = 0; x < TN; ++x) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int nl = nw + x * 32 + 8 * g + 4 * h;       // tile column of register 4 g
+        uint2 mk = make_uint2(0u, 0u);
+        if constexpr (EPI == PL_DGRAD) {
+          if (a.mask) {
+            const int gn = min(n0 + nl, a.N - 4);
+            mk = *reinterpret_cast<const uint2*>(a.mask + (gn >> 4) * a.bsm + static_cast<int64_t>(mc) * PL_ROWB + (gn & 15) * 2);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int r = 4 * g + j;
+          float v = (acc[x][y][r] * fx) * e_fw[nl + j];
+          if constexpr (EPI == PL_FWD) {
+            v += e_bias[nl + j];
+            if (a.relu) v = fmaxf(v, 0.f);
+            if (a.keep_prob < 1.f)
+              v = pl_dropout_keep(a.seed, static_cast<uint32_t>(m), static_cast<uint32_t>(n0 + nl + j), thresh) ? v / a.keep_div : 0.f;
+          } else {
+            if (a.mask) {
+              const uint32_t w32 = (j < 2) ? mk.x : mk.y;
+              const uint32_t hbits = (j & 1) ? (w32 >> 16) : (w32 & 0xffffu);
+              // positive fp16 (sign clear, not zero): the unit was active and kept
+              v = (hbits != 0u && hbits < 0x8000u) ? v / a.keep_div : 0.f;
+            }
+          }
+          if (n0 + nl + j >= a.N) v = 0.f;
+          acc[x][y][r] = v;
+          mx = fmaxf(mx, fabsf(v));
+        }
+        if (a.C && mok && n0 + nl < a.N)
+          *reinterpret_cast<float4*>(a.C + static_cast<int64_t>(m) * a.ldc + n0 + nl) =
+              make_float4(acc[x][y][4 * g], acc[x][y][4 * g + 1], acc[x][y][4 * g + 2], acc[x][y][4 * g + 3]);
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));               // the lane pair that shares this example
+    rmx[y] = mx;
+    if (h == 0) e_rmax[wn * BMt + wm * 32 * TM + y * 32 + i] = mx;
+  }
+  if (a.amax_c) {
+    float wmx = 0.f;
+#pragma unroll
+    for (int y = 0; y < TM; ++y) wmx = fmaxf(wmx, (m0 + wm * 32 * TM + y * 32 + i < a.M) ? rmx[y] : 0.f);
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) wmx = fmaxf(wmx, __shfl_xor(wmx, o));
+    if (lane == 0) e_wmax[wv] = wmx;
+  }
+  __syncthreads();
+  if (a.amax_c && t == 0) {
+    float mx = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) mx = fmaxf(mx, e_wmax[w]);
+    unsigned int* slot = reinterpret_cast<unsigned int*>(a.amax_c) + (blockIdx.x & (MI_AMAX_SLOTS - 1));
+    const unsigned int bits = __float_as_uint(mx);
+    if (bits > *reinterpret_cast<volatile unsigned int*>(slot)) atomicMax(slot, bits);
+  }
+  if (!a.Cp) return;
+
+  // ---- the result as planes: row exponent from the row's abs-max over ALL columns (tiles_n == 1) ----
+#pragma unroll
+  for (int y = 0; y < TM; ++y) {
+    const int ml = wm * 32 * TM + y * 32 + i;
+    const int m = m0 + ml;
+    const bool mok = m < a.M;
+    const float mx = fmaxf(fmaxf(e_rmax[ml], e_rmax[BMt + ml]), fmaxf(e_rmax[2 * BMt + ml], e_rmax[3 * BMt + ml]));
+    const int s = pl_exp_for(mx);
+    const float sc = pl_pow2(s);
+    if (mok && h == 0 && wn == 0) a.c_exp[m] = s;
+#pragma unroll
+    for (int x = 0; x < TN; ++x) {
+      uint32_t ph[8], pq[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float u0 = acc[x][y][2 * q] * sc, u1 = acc[x][y][2 * q + 1] * sc;
+        const fl32x2 uu = {u0, u1};
+        h16x2 hh = __builtin_convertvector(uu, h16x2);                 // v_cvt_pk_f16_f32 (RNE)
+        uint32_t hb = __builtin_bit_cast(uint32_t, hh);
+        if constexpr (EPI == PL_FWD) {
+          // a positive value must stay positive in the high plane: the data gradient's relu/dropout mask
+          // reads "hi > 0" (only values below 2^-39 of the row maximum round to zero at all)
+          if (u0 > 0.f && (hb & 0xffffu) == 0u) hb |= 1u;
+          if (u1 > 0.f && (hb >> 16) == 0u) hb |= 0x10000u;
+          hh = __builtin_bit_cast(h16x2, hb);
+        }
+        const fl32x2 rr2 = {u0 - static_cast<float>(hh[0]), u1 - static_cast<float>(hh[1])};
+        const h16x2 ll = __builtin_convertvector(rr2, h16x2);
+        ph[q] = hb;
+        pq[q] = __builtin_bit_cast(uint32_t, ll);
+      }
+      // lane h = 0 collects columns 0..15 of the 32-column tile, lane h = 1 columns 16..31
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        auto r1 = __builtin_amdgcn_permlane32_swap(ph[q], ph[q + 4], false, false);
+        ph[q] = r1[0]; ph[q + 4] = r1[1];
+        auto r2 = __builtin_amdgcn_permlane32_swap(pq[q], pq[q + 4], false, false);
+        pq[q] = r2[0]; pq[q + 4] = r2[1];
+      }
+      const int nblk = n0 + nw + x * 32 + 16 * h;       // first column of this lane's 16-column block
+      if (mok && nblk < a.N) {
+        char* d = a.Cp + (nblk >> 4) * a.bsc + static_cast<int64_t>(m) * PL_ROWB;
+        *reinterpret_cast<uint4*>(d) = make_uint4(ph[0], ph[1], ph[4], ph[5]);
+        *reinterpret_cast<uint4*>(d + 16) = make_uint4(ph[2], ph[3], ph[6], ph[7]);
+        *reinterpret_cast<uint4*>(d + 32) = make_uint4(pq[0], pq[1], pq[4], pq[5]);
+        *reinterpret_cast<uint4*>(d + 48) = make_uint4(pq[2], pq[3], pq[6], pq[7]);
+      }
+    }
+  }
+}
+
+// ---- fp32 rows -> planes (weights once per step; any buffer no kernel here produced) ---------------
+// One wave per output row.  transpose: the source is [K][rows] row-major and output row r is its column r
+// (the weights of the forward pass: W[k][n] -> rows n).
+__global__ __launch_bounds__(256) void split_rows_k(const float* __restrict__ X, int64_t ldx, int64_t rows, int K,
+                                                    int transpose, char* __restrict__ out, int64_t ldo_b,
+                                                    int32_t* __restrict__ row_exp, float* __restrict__ amax_out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  float mx = 0.f;
+  if (r < rows) {
+    for (int k = lane; k < K; k += 64) mx = fmaxf(mx, fabsf(transpose ? X[static_cast<int64_t>(k) * ldx + r] : X[r * ldx + k]));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  if (r < rows) {
+    const int s = pl_exp_for(mx);
+    const float sc = pl_pow2(s);
+    if (lane == 0) row_exp[r] = s;
+    const int K16 = (K + 15) & ~15;
+    char* d = out + r * PL_ROWB;
+    for (int k = lane; k < K16; k += 64) {
+      const float x = k < K ? (transpose ? X[static_cast<int64_t>(k) * ldx + r] : X[r * ldx + k]) : 0.f;
+      const float u = x * sc;
+      _Float16 hi = static_cast<_Float16>(u);
+      if (u > 0.f && hi == static_cast<_Float16>(0.f)) hi = __builtin_bit_cast(_Float16, static_cast<unsigned short>(1));
+      const _Float16 lo = static_cast<_Float16>(u - static_cast<float>(hi));
+      _Float16* e = reinterpret_cast<_Float16*>(d + (k >> 4) * ldo_b);
+      e[k & 15] = hi;
+      e[16 + (k & 15)] = lo;
+    }
+  }
+  if (amax_out) {                       // (every thread of the block reaches this)
+    __shared__ float part[4];
+    if (lane == 0) part[threadIdx.x >> 6] = r < rows ? mx : 0.f;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const float m4 = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
+      unsigned int* slot = reinterpret_cast<unsigned int*>(amax_out) + (blockIdx.x & (MI_AMAX_SLOTS - 1));
+      const unsigned int bits = __float_as_uint(m4);
+      if (bits > *reinterpret_cast<volatile unsigned int*>(slot)) atomicMax(slot, bits);
+    }
+  }
+}
+
+// ---- the transposed split (weights of the forward pass: X is [K][rows], output row r = column r of X) in
+// one launch: a block owns 32 output rows; pass 1 their abs-max over all k (coalesced 128-B row pieces),
+// pass 2 64-k tiles transposed through LDS and written as planes (the tiles come back from L2).
+__global__ __launch_bounds__(256) void split_t_k(const float* __restrict__ X, int64_t ldx, int64_t rows, int K,
+                                                 char* __restrict__ out, int64_t ldo_b, int32_t* __restrict__ row_exp,
+                                                 float* __restrict__ amax_out) {
+  __shared__ float tile[64][33];
+  __shared__ float cmax[8][32];
+  const int64_t r0 = static_cast<int64_t>(blockIdx.x) * 32;
+  const int c = threadIdx.x & 31, q = threadIdx.x >> 5;
+  const bool cok = r0 + c < rows;
+  float mx = 0.f;
+  if (cok)
+    for (int k = q; k < K; k += 8) mx = fmaxf(mx, fabsf(X[static_cast<int64_t>(k) * ldx + r0 + c]));
+  cmax[q][c] = mx;
+  __syncthreads();
+  const int rl = threadIdx.x >> 2, kb = (threadIdx.x & 3) * 16;     // (threads < 128) output row in the block, 16-k block
+  float rmx = 0.f;
+  if (threadIdx.x < 128) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) rmx = fmaxf(rmx, cmax[j][rl]);
+  }
+  const int sx = pl_exp_for(rmx);
+  const float sc = pl_pow2(sx);
+  const int64_t r = r0 + rl;
+  if (threadIdx.x < 128 && (threadIdx.x & 3) == 0 && r < rows) {
+    row_exp[r] = sx;
+    if (amax_out && rmx > 0.f) atomicMax(reinterpret_cast<unsigned int*>(amax_out) + (r & (MI_AMAX_SLOTS - 1)), __float_as_uint(rmx));
+  }
+  const int K16 = (K + 15) & ~15;
+  for (int k0 = 0; k0 < K16; k0 += 64) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = k0 + q * 8 + j;
+      tile[q * 8 + j][c] = (k < K && cok) ? X[static_cast<int64_t>(k) * ldx + r0 + c] : 0.f;
+    }
+    __syncthreads();
+    if (threadIdx.x < 128 && r < rows && k0 + kb < K16) {
+      uint32_t ph[8], pq[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float u0 = tile[kb + 2 * j][rl] * sc, u1 = tile[kb + 2 * j + 1][rl] * sc;
+        const fl32x2 uu = {u0, u1};
+        h16x2 hh = __builtin_convertvector(uu, h16x2);
+        uint32_t hb = __builtin_bit_cast(uint32_t, hh);
+        if (u0 > 0.f && (hb & 0xffffu) == 0u) hb |= 1u;
+        if (u1 > 0.f && (hb >> 16) == 0u) hb |= 0x10000u;
+        hh = __builtin_bit_cast(h16x2, hb);
+        const fl32x2 dd = {u0 - static_cast<float>(hh[0]), u1 - static_cast<float>(hh[1])};
+        ph[j] = hb;
+        pq[j] = __builtin_bit_cast(uint32_t, __builtin_convertvector(dd, h16x2));
+      }
+      char* d = out + ((k0 + kb) >> 4) * ldo_b + r * PL_ROWB;
+      *reinterpret_cast<uint4*>(d) = make_uint4(ph[0], ph[1], ph[2], ph[3]);
+      *reinterpret_cast<uint4*>(d + 16) = make_uint4(ph[4], ph[5], ph[6], ph[7]);
+      *reinterpret_cast<uint4*>(d + 32) = make_uint4(pq[0], pq[1], pq[2], pq[3]);
+      *reinterpret_cast<uint4*>(d + 48) = make_uint4(pq[4], pq[5], pq[6], pq[7]);
+    }
+  }
+}
+
+// ---- all weight planes of a training step in ONE launch ---------------------------------------------
+// Every hidden layer's kernel W[K][N] is needed twice: as stored (rows = K: the data gradient's operand) and
+// transposed (rows = N: the forward pass's).  One exponent for the whole parameter block, from its abs-max
+// (mi_absmax): no per-row reduction, so a 64 x 64 tile of W goes through LDS once and leaves as both.
+// (Weights more than 2^-17 below the block's largest lose low bits: their products are that far below the
+// largest terms of any dot product they enter.  The per-ROW exponents that matter are the examples'.)
+struct WJob { int64_t off; int K, N; char* pw; int64_t bsw; int32_t* ew; char* pt; int64_t bst; int32_t* et; int tile0; };
+struct WJobs { WJob j[MI_MAX_WEIGHT_JOBS]; int n; };
+
+__global__ __launch_bounds__(256) void split_weights_k(const float* __restrict__ dense, const WJobs jobs,
+                                                       const float* __restrict__ amax) {
+  __shared__ float tile[64][65];
+  int ji = 0;
+#pragma unroll
+  for (int q = 1; q < MI_MAX_WEIGHT_JOBS; ++q)
+    if (q < jobs.n && static_cast<int>(blockIdx.x) >= jobs.j[q].tile0) ji = q;
+  const WJob& jb = jobs.j[ji];
+  const int tn = (jb.N + 63) >> 6;
+  const int tl = blockIdx.x - jb.tile0;
+  const int k0 = (tl / tn) * 64, n0 = (tl % tn) * 64;
+  float m = 0.f;
+  if (threadIdx.x < MI_AMAX_SLOTS) m = amax[threadIdx.x];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  m = __shfl(m, 0);                                  // (wave 0 holds it; the other waves get it through LDS)
+  __shared__ float s_m;
+  if (threadIdx.x == 0) s_m = m;
+  const float* W = dense + jb.off;
+  const int c = threadIdx.x & 63, q4 = threadIdx.x >> 6;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int k = k0 + q4 * 16 + j, n = n0 + c;
+    tile[q4 * 16 + j][c] = (k < jb.K && n < jb.N) ? W[static_cast<int64_t>(k) * jb.N + n] : 0.f;
+  }
+  __syncthreads();
+  const int sx = pl_exp_for(s_m);
+  const float sc = pl_pow2(sx);
+  const int rl = threadIdx.x >> 2, cb = (threadIdx.x & 3) * 16;
+  auto emit = [&](bool transposed, char* d) {
+    uint32_t ph[8], pq[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float u0 = (transposed ? tile[cb + 2 * j][rl] : tile[rl][cb + 2 * j]) * sc;
+      const float u1 = (transposed ? tile[cb + 2 * j + 1][rl] : tile[rl][cb + 2 * j + 1]) * sc;
+      const fl32x2 uu = {u0, u1};
+      const h16x2 hh = __builtin_convertvector(uu, h16x2);
+      const fl32x2 dd = {u0 - static_cast<float>(hh[0]), u1 - static_cast<float>(hh[1])};
+      ph[j] = __builtin_bit_cast(uint32_t, hh);
+      pq[j] = __builtin_bit_cast(uint32_t, __builtin_convertvector(dd, h16x2));
+    }
+    *reinterpret_cast<uint4*>(d) = make_uint4(ph[0], ph[1], ph[2], ph[3]);
+    *reinterpret_cast<uint4*>(d + 16) = make_uint4(ph[4], ph[5], ph[6], ph[7]);
+    *reinterpret_cast<uint4*>(d + 32) = make_uint4(pq[0], pq[1], pq[2], pq[3]);
+    *reinterpret_cast<uint4*>(d + 48) = make_uint4(pq[4], pq[5], pq[6], pq[7]);
+  };
+  if (jb.pw && k0 + rl < jb.K && n0 + cb < ((jb.N + 15) & ~15)) {          // rows = k, columns = n
+    emit(false, jb.pw + ((n0 + cb) >> 4) * jb.bsw + static_cast<int64_t>(k0 + rl) * PL_ROWB);
+    if (n0 + cb == 0) jb.ew[k0 + rl] = sx;
+  }
+  if (jb.pt && n0 + rl < jb.N && k0 + cb < ((jb.K + 15) & ~15)) {          // rows = n, columns = k
+    emit(true, jb.pt + ((k0 + cb) >> 4) * jb.bst + static_cast<int64_t>(n0 + rl) * PL_ROWB);
+    if (k0 + cb == 0) jb.et[n0 + rl] = sx;
+  }
+}
+
+// planes -> fp32 (tests, summaries)
+__global__ __launch_bounds__(256) void merge_rows_k(const char* __restrict__ in, int64_t ldi_b, const int32_t* __restrict__ row_exp,
+                                                    int64_t rows, int K, float* __restrict__ X, int64_t ldx) {
+  const int64_t idx = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  const int64_t r = idx / K;
+  if (r >= rows) return;
+  const int k = static_cast<int>(idx - r * K);
+  const _Float16* d = reinterpret_cast<const _Float16*>(in + (k >> 4) * ldi_b + r * PL_ROWB);
+  const float v = static_cast<float>(d[k & 15]) + static_cast<float>(d[16 + (k & 15)]);
+  X[r * ldx + k] = v * pl_pow2(-row_exp[r]);
+}
+
+bool planes_ok(const mi_planes_t* p, int64_t rows, int K) {
+  return p && p->data && p->row_exp && mi::aligned16(p->data) && p->blk_stride >= rows * PL_ROWB && (p->blk_stride & 63) == 0 && rows >= 0;
+}
+
+template <int EPI>
+int32_t launch_pl(PlArgs& a, hipStream_t st, const char* what) {
+  // column tile: the narrowest that holds N (planes out needs all of N in one tile); row tile: 256 rows for
+  // the narrower column tiles (same accumulator budget), 128 for 512 columns
+  int tn = a.N <= 128 ? 1 : (a.N <= 256 ? 2 : 4);
+  if (a.N > 512) tn = 2;                              // fp32 result only: 256 x 256 tiles
+  if (const char* e = getenv("MI_PL_TILE")) {         // tuning experiments (tools/gemm_pl_bench.py)
+    const int v = atoi(e);
+    if ((v == 1 || v == 2 || v == 4) && (!a.Cp || a.N <= 128 * v)) tn = v;
+  }
+  const int tm = tn == 4 ? 2 : 4;
+  const int bn = 128 * tn, bm = 64 * tm;
+  a.tiles_n = (a.N + bn - 1) / bn;
+  const int64_t blocks = static_cast<int64_t>(a.tiles_n) * ((a.M + bm - 1) / bm);
+  if (blocks <= 0 || blocks > INT32_MAX) {
+    mi::set_error("%s: bad grid", what);
+    return MI_ERR_INVALID;
+  }
+  if (a.Cp && a.tiles_n != 1) {
+    mi::set_error("%s: a planes result needs N <= 512 (one column tile holds the whole row)", what);
+    return MI_ERR_UNSUPPORTED;
+  }
+  const dim3 g(static_cast<unsigned>(blocks)), b(PL_THREADS);
+  if (tn == 1) gemm_pl_k<1, 4, EPI><<<g, b, 0, st>>>(a);
+  else if (tn == 2) gemm_pl_k<2, 4, EPI><<<g, b, 0, st>>>(a);
+  else gemm_pl_k<4, 2, EPI><<<g, b, 0, st>>>(a);
+  MI_CHECK_LAUNCH(what);
+  return MI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t mi_planes_bytes(int64_t rows, int32_t K) { return static_cast<size_t>((K + 15) >> 4) * static_cast<size_t>(rows) * PL_ROWB; }
+
+int32_t mi_split_rows(const float* X, int64_t ldx, int64_t rows, int32_t K, int32_t transpose, const mi_planes_t* out,
+                      float* amax_out, mi_stream_t stream) {
+  MI_REQUIRE(rows >= 0 && K > 0 && X, "split_rows: rows=%lld K=%d", (long long)rows, K);
+  if (rows == 0) return MI_OK;
+  MI_REQUIRE(planes_ok(out, rows, K), "split_rows: output planes (16-byte aligned data, blk_stride >= 64 * rows and a multiple of 64, row_exp)");
+  MI_REQUIRE(transpose ? ldx >= rows : ldx >= K, "split_rows: ldx=%lld", (long long)ldx);
+  if (transpose) {
+    const int64_t tb = mi::ceil_div(rows, 32);
+    MI_REQUIRE(tb <= INT32_MAX, "split_rows: grid too large");
+    split_t_k<<<dim3((unsigned)tb), dim3(256), 0, mi::as_stream(stream)>>>(X, ldx, rows, K, static_cast<char*>(out->data),
+                                                                           out->blk_stride, out->row_exp, amax_out);
+    MI_CHECK_LAUNCH("split_rows(transposed)");
+    return MI_OK;
+  }
+  const int64_t blocks = mi::ceil_div(rows, 4);
+  MI_REQUIRE(blocks <= INT32_MAX, "split_rows: grid too large");
+  split_rows_k<<<dim3((unsigned)blocks), dim3(256), 0, mi::as_stream(stream)>>>(
+      X, ldx, rows, K, transpose, static_cast<char*>(out->data), out->blk_stride, out->row_exp, amax_out);
+  MI_CHECK_LAUNCH("split_rows");
+  return MI_OK;
+}
+
+int32_t mi_split_weights(const float* dense, const mi_weight_job_t* jobs, int32_t n_jobs, const float* amax,
+                         mi_stream_t stream) {
+  MI_REQUIRE(dense && jobs && amax && n_jobs > 0 && n_jobs <= MI_MAX_WEIGHT_JOBS, "split_weights: n_jobs=%d (1..%d)", n_jobs,
+             MI_MAX_WEIGHT_JOBS);
+  WJobs js{};
+  js.n = n_jobs;
+  int tiles = 0;
+  for (int q = 0; q < n_jobs; ++q) {
+    const mi_weight_job_t& u = jobs[q];
+    MI_REQUIRE(u.K > 0 && u.N > 0 && u.offset >= 0 && (u.w.data || u.wt.data), "split_weights: job %d", q);
+    MI_REQUIRE(!u.w.data || planes_ok(&u.w, u.K, u.N), "split_weights: job %d planes of W", q);
+    MI_REQUIRE(!u.wt.data || planes_ok(&u.wt, u.N, u.K), "split_weights: job %d planes of W transposed", q);
+    WJob& j = js.j[q];
+    j.off = u.offset; j.K = u.K; j.N = u.N;
+    j.pw = static_cast<char*>(u.w.data); j.bsw = u.w.blk_stride; j.ew = u.w.row_exp;
+    j.pt = static_cast<char*>(u.wt.data); j.bst = u.wt.blk_stride; j.et = u.wt.row_exp;
+    j.tile0 = tiles;
+    tiles += ((u.K + 63) >> 6) * ((u.N + 63) >> 6);
+  }
+  split_weights_k<<<dim3((unsigned)tiles), dim3(256), 0, mi::as_stream(stream)>>>(dense, js, amax);
+  MI_CHECK_LAUNCH("split_weights");
+  return MI_OK;
+}
+
+int32_t mi_merge_rows(const mi_planes_t* in, int64_t rows, int32_t K, float* X, int64_t ldx, mi_stream_t stream) {
+  MI_REQUIRE(rows >= 0 && K > 0 && X && ldx >= K, "merge_rows: rows=%lld K=%d", (long long)rows, K);
+  if (rows == 0) return MI_OK;
+  MI_REQUIRE(planes_ok(in, rows, K), "merge_rows: input planes");
+  const int64_t blocks = mi::ceil_div(rows * K, 256);
+  MI_REQUIRE(blocks <= INT32_MAX, "merge_rows: grid too large");
+  merge_rows_k<<<dim3((unsigned)blocks), dim3(256), 0, mi::as_stream(stream)>>>(static_cast<const char*>(in->data), in->blk_stride,
+                                                                                in->row_exp, rows, K, X, ldx);
+  MI_CHECK_LAUNCH("merge_rows");
+  return MI_OK;
+}
+
+int32_t mi_dense_fwd_planes(const mi_planes_t* X, const mi_planes_t* Wt, const float* bias, float* Y, int64_t ldy,
+                            const mi_planes_t* Yp, int64_t M, int32_t N, int32_t K, int32_t relu, float keep_prob,
+                            uint64_t seed, float* amax_out, mi_stream_t stream) {
+  MI_REQUIRE(M >= 0 && M <= INT32_MAX && N > 0 && K > 0, "dense_fwd_planes: M=%lld N=%d K=%d", (long long)M, N, K);
+  if (M == 0) return MI_OK;
+  MI_REQUIRE((K & 15) == 0 && (N & 15) == 0, "dense_fwd_planes: N=%d and K=%d must be multiples of 16 (use mi_dense_fwd)", N, K);
+  MI_REQUIRE(planes_ok(X, M, K) && planes_ok(Wt, N, K), "dense_fwd_planes: operand planes");
+  MI_REQUIRE(Y || Yp, "dense_fwd_planes: no output");
+  MI_REQUIRE(!Y || (ldy >= N && (ldy & 3) == 0 && mi::aligned16(Y)), "dense_fwd_planes: Y leading dimension / alignment");
+  MI_REQUIRE(!Yp || planes_ok(Yp, M, N), "dense_fwd_planes: output planes");
+  MI_REQUIRE(keep_prob > 0.f && keep_prob <= 1.f, "dense_fwd_planes: keep_prob=%f", keep_prob);
+  PlArgs a{};
+  a.A = static_cast<const char*>(Wt->data); a.bsa = Wt->blk_stride; a.a_exp = Wt->row_exp;
+  a.B = static_cast<const char*>(X->data); a.bsb = X->blk_stride; a.b_exp = X->row_exp;
+  a.M = (int)M; a.N = N; a.K = K;
+  a.C = Y; a.ldc = ldy;
+  if (Yp) { a.Cp = static_cast<char*>(Yp->data); a.bsc = Yp->blk_stride; a.c_exp = Yp->row_exp; }
+  a.bias = bias; a.relu = relu; a.keep_prob = keep_prob; a.keep_div = keep_prob; a.seed = seed;
+  a.amax_c = amax_out;
+  return launch_pl<PL_FWD>(a, mi::as_stream(stream), "dense_fwd_planes");
+}
+
+int32_t mi_dense_bwd_data_planes(const mi_planes_t* dY, const mi_planes_t* W, const mi_planes_t* Xact, float* dX,
+                                 int64_t lddx, const mi_planes_t* dXp, int64_t M, int32_t N, int32_t K, float keep_prob,
+                                 float* amax_out, mi_stream_t stream) {
+  // dX[M][K] = dY[M][N] * W[K][N]^T : output width K, reduction over N
+  MI_REQUIRE(M >= 0 && M <= INT32_MAX && N > 0 && K > 0, "dense_bwd_data_planes: M=%lld N=%d K=%d", (long long)M, N, K);
+  if (M == 0) return MI_OK;
+  MI_REQUIRE((K & 15) == 0 && (N & 15) == 0, "dense_bwd_data_planes: N=%d and K=%d must be multiples of 16", N, K);
+  MI_REQUIRE(planes_ok(dY, M, N) && planes_ok(W, K, N), "dense_bwd_data_planes: operand planes");
+  MI_REQUIRE(!Xact || planes_ok(Xact, M, K), "dense_bwd_data_planes: activation planes");
+  MI_REQUIRE(dX || dXp, "dense_bwd_data_planes: no output");
+  MI_REQUIRE(!dX || (lddx >= K && (lddx & 3) == 0 && mi::aligned16(dX)), "dense_bwd_data_planes: dX leading dimension / alignment");
+  MI_REQUIRE(!dXp || planes_ok(dXp, M, K), "dense_bwd_data_planes: output planes");
+  MI_REQUIRE(keep_prob > 0.f && keep_prob <= 1.f, "dense_bwd_data_planes: keep_prob=%f", keep_prob);
+  PlArgs a{};
+  a.A = static_cast<const char*>(W->data); a.bsa = W->blk_stride; a.a_exp = W->row_exp;
+  a.B = static_cast<const char*>(dY->data); a.bsb = dY->blk_stride; a.b_exp = dY->row_exp;
+  a.M = (int)M; a.N = K; a.K = N;
+  a.C = dX; a.ldc = lddx;
+  if (dXp) { a.Cp = static_cast<char*>(dXp->data); a.bsc = dXp->blk_stride; a.c_exp = dXp->row_exp; }
+  a.keep_prob = keep_prob; a.keep_div = Xact ? keep_prob : 1.f;
+  if (Xact) { a.mask = static_cast<const char*>(Xact->data); a.bsm = Xact->blk_stride; }
+  a.amax_c = amax_out;
+  return launch_pl<PL_DGRAD>(a, mi::as_stream(stream), "dense_bwd_data_planes");
+}
+
+}  // extern "C"

@@ -31,6 +31,7 @@ class OptHparams(C.Structure):
 
 
 AMAX_SLOTS = 64      # MI_AMAX_SLOTS: floats per abs-max vector
+MAX_WEIGHT_JOBS = 8  # MI_MAX_WEIGHT_JOBS
 
 
 class GemmAmax(C.Structure):
@@ -38,9 +39,20 @@ class GemmAmax(C.Structure):
     _fields_ = [("a", C.c_void_p), ("b", C.c_void_p), ("out", C.c_void_p)]
 
 
+class Planes(C.Structure):
+    """mi_planes_t: a matrix as fp16 high + low planes with one power-of-two exponent per row."""
+    _fields_ = [("data", C.c_void_p), ("row_exp", C.c_void_p), ("blk_stride", C.c_int64)]
+
+
+class WeightJob(C.Structure):
+    """mi_weight_job_t"""
+    _fields_ = [("offset", C.c_int64), ("K", C.c_int32), ("N", C.c_int32), ("w", Planes), ("wt", Planes)]
+
+
 _p = C.c_void_p
 _i32, _i64, _u64, _f32, _sz = C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_size_t
 _amax = C.POINTER(GemmAmax)
+_pl = C.POINTER(Planes)
 
 # name -> (restype, argtypes); mirrors include/mi355x_rec.h declaration by declaration
 SIGNATURES = {
@@ -85,6 +97,13 @@ SIGNATURES = {
     "mi_dense_bwd_data": (_i32, [_p, _i64, _p, _p, _i64, _p, _i64, _i64, _i32, _i32, _f32, _amax, _p]),
     "mi_dense_bwd_weight_workspace_bytes": (_sz, [_i64, _i32, _i32]),
     "mi_dense_bwd_weight": (_i32, [_p, _i64, _p, _i64, _p, _p, _i64, _i32, _i32, _p, _sz, _amax, _p]),
+    "mi_planes_bytes": (_sz, [_i64, _i32]),
+    "mi_split_rows": (_i32, [_p, _i64, _i64, _i32, _i32, _pl, _p, _p]),
+    "mi_split_weights": (_i32, [_p, _p, _i32, _p, _p]),
+    "mi_merge_rows": (_i32, [_pl, _i64, _i32, _p, _i64, _p]),
+    "mi_dense_fwd_planes": (_i32, [_pl, _pl, _p, _p, _i64, _pl, _i64, _i32, _i32, _i32, _f32, _u64, _p, _p]),
+    "mi_dense_bwd_data_planes": (_i32, [_pl, _pl, _pl, _p, _i64, _pl, _i64, _i32, _i32, _f32, _p, _p]),
+    "mi_embed_fm_planes_fwd": (_i32, [_p, _p, _p, _i64, _i32, _i32, _p, _p, _pl, _p, _p]),
     "mi_head_workspace_bytes": (_sz, [_i64]),
     "mi_sigmoid_ce_head": (_i32, [_p, _p, _p, _p, _p, _i64, _f32, _p, _p, _p, _p, _p, _sz, _p]),
     "mi_colsum_workspace_bytes": (_sz, [_i64, _i32]),

@@ -49,6 +49,8 @@ class HipKernels:
     path always constructs this class, and this class cannot be constructed without the library.
     """
 
+    supports_planes = True        # the pre-split 16-bit operand path of the MLP (csrc/gemm_pl.hip)
+
     def __init__(self):
         self.lib = _lib.load()
         self.timers = None
@@ -89,6 +91,18 @@ class HipKernels:
             check(rc, name)
 
         return call
+
+
+class PlaneBuf:
+    """Device memory of one mi_planes_t matrix (k-block major: [K/16 blocks][rows][64 B]) + one int32
+    exponent per row."""
+
+    def __init__(self, rows, K, device):
+        self.rows, self.K = int(rows), int(K)
+        self.blk_stride = 64 * max(self.rows, 1)
+        self.data = torch.empty(_align(self.K, 16) // 16 * self.blk_stride, dtype=torch.uint8, device=device)
+        self.exp = torch.empty(max(self.rows, 1), dtype=torch.int32, device=device)
+        self.struct = _lib.Planes(self.data.data_ptr(), self.exp.data_ptr(), self.blk_stride)
 
 
 class OptimizerSpec:
@@ -283,6 +297,20 @@ class DeepFM:
         self.gemm = gemm
         self._amax = torch.zeros(_lib.AMAX_SLOTS * (2 * len(self.layers) + 4), dtype=torch.float32, device=self.device)
         self._amax_idx = {}
+        # Planes path (f16x2 only): forward and data-gradient GEMMs read operands that their producers left
+        # as fp16 high/low planes with a per-row exponent (no split arithmetic in the GEMM loop, LDS-DMA
+        # staging, 512-column tiles).  Every hidden layer's widths must be multiples of 16; the weight
+        # gradient still runs on the fp32 copies (gemm.hip, matrix-wide scales: its reduction runs over the
+        # examples, where a per-example exponent cannot be undone).
+        self.planes = (gemm == "f16x2" and self.use_dnn and len(self.hidden) > 0 and
+                       getattr(self.k, "supports_planes", False) and self.D % 16 == 0 and
+                       all(h % 16 == 0 for h in self.hidden))
+        self._pl = {}
+        # layer 1's operand: the gather kernel writes it as planes when the embedding size allows; otherwise
+        # the concat is materialised in fp32 (as with numeric columns) and split
+        self.pl_gather_ok = self.E % 16 == 0 and self.E >= 32 and self.F <= 48
+        if self.planes and self.gather_mlp and not self.pl_gather_ok:
+            self.gather_mlp = False
 
     # ------------------------------------------------------------------ variables
     def _slots(self, like, spec):
@@ -401,6 +429,12 @@ class DeepFM:
             self._ws[name] = cur
         return cur
 
+    def _planes(self, name, rows, K):
+        cur = self._pl.get(name)
+        if cur is None or cur.rows < rows or cur.K != K:
+            cur = self._pl[name] = PlaneBuf(rows, K, self.device)
+        return cur.struct
+
     def _av(self, name):
         """The abs-max vector called `name` (a slice of self._amax; zeroed by _forward each step)."""
         i = self._amax_idx.setdefault(name, len(self._amax_idx))
@@ -413,6 +447,26 @@ class DeepFM:
             return None
         p = lambda n: None if n is None else ptr(self._av(n))
         return _lib.GemmAmax(p(a), p(b), p(out))
+
+    def _split_weights(self, train):
+        """Planes of every hidden layer's kernel in one launch per step: transposed (rows = output units) for
+        the forward pass, as stored (rows = inputs) for the data gradient; one exponent for the whole
+        parameter block, from its abs-max."""
+        hidden = self.layers[:-1]
+        if len(hidden) > _lib.MAX_WEIGHT_JOBS:
+            raise NotImplementedError("more than %d hidden layers on the planes path" % _lib.MAX_WEIGHT_JOBS)
+        key = "wjobs_train" if train else "wjobs_eval"
+        jobs = self._ws.get(key)
+        if jobs is None:
+            jobs = (_lib.WeightJob * len(hidden))()
+            for i, (k_off, _, fan, h) in enumerate(hidden):
+                jobs[i].offset, jobs[i].K, jobs[i].N = k_off, fan, h
+                jobs[i].wt = self._planes("wt%d" % i, h, fan)
+                if train:
+                    jobs[i].w = self._planes("w%d" % i, fan, h)
+            self._ws[key] = jobs
+        self.k.mi_absmax(self.dense, self.dnn_end, self._av("w"))
+        self.k.mi_split_weights(self.dense, jobs, len(hidden), self._av("w"))
 
     def _layer_seed(self, layer):
         rank = 0 if self.shard is None else self.shard.rank
@@ -453,6 +507,8 @@ class DeepFM:
         if f16:
             self._amax.zero_()
         rows_amax = self._av("x0") if (f16 and gathered) else None
+        # planes path, layer 1: the gather itself writes the concat as planes (one exponent per example)
+        pl_gather = self.planes and gathered and self.pl_gather_ok
         # The wide part's 4-byte weight gathers drag a whole sector each through the row-gather kernel
         # (3.9 vs 4.9 TB/s of row bytes).  On a single GPU they run as their own kernel on a side stream
         # under the matrix-bound layer-1 GEMM instead; the head joins the two streams.
@@ -465,7 +521,9 @@ class DeepFM:
                 if t is not None:
                     t.zero_()
         elif side_lin:
-            if concat is not None or sumv is not None or rows_amax is not None:
+            if pl_gather:
+                k.mi_embed_fm_planes_fwd(table, field_off, rid, B, F, self.E, sumv, fm, self._planes("x0p", B, ld), rows_amax)
+            elif concat is not None or sumv is not None or rows_amax is not None:
                 k.mi_embed_fm_linear_fwd(table, None, field_off, rid, B, F, self.E, concat, ld, sumv, fm, None,
                                          rows_amax)
             side = self._ws.get("side_stream")
@@ -476,6 +534,10 @@ class DeepFM:
                 k.tagged("mi_embed_fm_linear_fwd", "/wide")(None, lin_w, field_off, rid, B, F, self.E, None, 0, None,
                                                             None, lin, None)
             c["lin_join"] = side
+        elif pl_gather:
+            k.mi_embed_fm_planes_fwd(table, field_off, rid, B, F, self.E, sumv, fm, self._planes("x0p", B, ld), rows_amax)
+            if lin is not None:
+                k.tagged("mi_embed_fm_linear_fwd", "/wide")(None, lin_w, field_off, rid, B, F, self.E, None, 0, None, None, lin, None)
         elif concat is not None or sumv is not None or lin is not None or rows_amax is not None:
             emb_on = self.use_emb
             k.mi_embed_fm_linear_fwd(table if emb_on else None, lin_w if self.use_linear else None, field_off,
@@ -496,21 +558,39 @@ class DeepFM:
             if f16:
                 if not gathered:
                     k.mi_absmax(concat, B * ld, self._av("x0"))
-                # one bound for every layer's weights: the abs-max over the whole MLP parameter block
-                k.mi_absmax(self.dense, self.dnn_end, self._av("w"))
+                if not self.planes:
+                    # one bound for every layer's weights: the abs-max over the whole MLP parameter block
+                    k.mi_absmax(self.dense, self.dnn_end, self._av("w"))
             keep = 1.0 - self.dropout if (train and self.dropout > 0) else 1.0
             nh = len(self.layers) - 1
+            if self.planes:
+                if not pl_gather:           # the concat exists in fp32 (numeric columns, small E): split it
+                    k.mi_split_rows(concat, ld, B, ld, 0, self._planes("x0p", B, ld), None)
+                self._split_weights(train)
+            xp = "x0p"
             for i, (_, _, fan, h) in enumerate(self.layers):
                 last = i == nh
                 y = self._buf("act%d" % i, (B, h))
-                if i == 0 and gathered:
+                if self.planes and not last:
+                    # the next layer's operand as planes straight from the epilogue when a workgroup owns
+                    # whole rows (h <= 512); the fp32 copy feeds the weight gradient / the logits layer
+                    need_p = i + 1 < nh
+                    yp = self._planes("x%dp" % (i + 1), B, h) if need_p else None
+                    direct = need_p and h <= 512
+                    k.mi_dense_fwd_planes(self._planes(xp, B, fan), self._pl["wt%d" % i].struct, self.bias(i), y, h,
+                                          yp if direct else None, B, h, fan, 1, keep, self._layer_seed(i),
+                                          self._av("x%d" % (i + 1)))
+                    if need_p and not direct:
+                        k.mi_split_rows(y, h, B, h, 0, yp, None)
+                    xp = "x%dp" % (i + 1)
+                elif i == 0 and gathered:
                     k.mi_dense_fwd_gathered(table, field_off, rid, F, self.E, self.kernel(0), self.bias(0), y, h,
                                             B, h, 0 if last else 1, 1.0 if last else keep, self._layer_seed(0),
                                             self._ga("x0", "w", "x1"))
                 else:
                     k.mi_dense_fwd(x, ldx, self.kernel(i), self.bias(i), y, h, B, h, fan, 0 if last else 1,
                                    1.0 if last else keep, self._layer_seed(i),
-                                   self._ga("x%d" % i, "w", "x%d" % (i + 1)))
+                                   None if self.planes else self._ga("x%d" % i, "w", "x%d" % (i + 1)))
                 acts.append(y)
                 x, ldx = y, h
             dnn = acts[-1].view(B)
@@ -692,8 +772,27 @@ class DeepFM:
                     k.mi_dense_bwd_weight(x, ldx, dy, lddy, self.kernel(i, self.d_grad), self.bias(i, self.d_grad), B,
                                           h, fan, ws, ws.numel(), ga_w)
                 dx = self._buf("dact%d" % i, (B, fan))
-                k.mi_dense_bwd_data(dy, lddy, self.kernel(i), x if i else None, ldx, dx, fan, B, h, fan,
-                                    keep if i else 1.0, ga_d)
+                if self.planes and i < nh:
+                    # dY of this layer is at hand as planes ("dy<i>p": written by the layer above); the mask is
+                    # the stored activation's high plane; the result becomes the next dY (planes + fp32)
+                    need_p = i > 0
+                    dxp = self._planes("dy%dp" % (i - 1), B, fan) if need_p else None
+                    direct = need_p and fan <= 512
+                    xa = self._pl["x%dp" % i].struct if (i > 0 and ("x%dp" % i) in self._pl and i < nh) else None
+                    if i > 0 and xa is None:      # (the last hidden layer's output has no planes: make them)
+                        xa = self._planes("x%dp" % i, B, fan)
+                        k.mi_split_rows(x, ldx, B, fan, 0, xa, None)
+                    k.mi_dense_bwd_data_planes(self._planes("dy%dp" % i, B, h), self._pl["w%d" % i].struct, xa, dx, fan,
+                                               dxp if direct else None, B, h, fan, keep if i else 1.0,
+                                               self._av("dy%d" % (i - 1)) if i else None)
+                    if need_p and not direct:
+                        k.mi_split_rows(dx, fan, B, fan, 0, dxp, None)
+                else:
+                    k.mi_dense_bwd_data(dy, lddy, self.kernel(i), x if i else None, ldx, dx, fan, B, h, fan,
+                                        keep if i else 1.0, None if self.planes else ga_d)
+                    if self.planes and i == nh and i > 0:
+                        # the logits layer's matrix-vector data gradient writes fp32: split it for the layer below
+                        k.mi_split_rows(dx, fan, B, fan, 0, self._planes("dy%dp" % (i - 1), B, fan), self._av("dy%d" % (i - 1)))
                 dy, lddy = dx, fan
             d_concat = dy
         if self.n_numeric and self.raw_numeric:

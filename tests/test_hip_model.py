@@ -256,14 +256,14 @@ def test_config4_full_size_properties():
     assert m.D_in == F * E + ND and m.D == 1696 and m.lin_opt.name == "Ftrl"
     table0, lin0 = m.table.clone(), m.lin_w.clone()
     rows = ids.long() + m.field_off[None, :]
-    loss0, _ = m.loss(ids, y, x)
+    loss0 = m.loss(ids, y, x)[0].item()          # (the returned tensor is workspace the next step overwrites)
     concat = m._ws["concat"][:B * m.D].view(B, m.D)
     sel = torch.arange(0, B, 1009, device="cuda")
     assert torch.equal(concat[sel, :F * E].reshape(-1, F, E), m.table[rows[sel]])      # exact-copy gather
     assert torch.equal(concat[sel, F * E:F * E + ND], x[sel])                            # the values themselves
     assert float(concat[:, F * E + ND:].abs().max()) == 0.0                             # zero pad
     losses = _props_after_steps(m, ids, y, x, table0, rows)
-    assert losses[0] == pytest.approx(loss0.item(), rel=1e-5)
+    assert losses[0] == pytest.approx(loss0, rel=2e-2)     # (the training forward drops 10 % of the units)
     assert float(m.kernel(0)[m.D_in:].abs().max()) == 0.0                               # pad rows stay zero
     lin_changed = m.lin_w != lin0
     touched = torch.zeros(m.R, dtype=torch.bool, device="cuda"); touched[rows.reshape(-1)] = True

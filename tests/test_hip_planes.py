@@ -1,0 +1,299 @@
+"""-m gpu: the planes GEMM path (csrc/gemm_pl.hip) through the C ABI.
+
+Operands are fp16 high + low planes with one power-of-two exponent PER ROW (mi_planes_t).  The point of
+the per-row exponent is that every example keeps fp32-level accuracy relative to ITS OWN magnitude — the
+round-1 matrix-wide scale lost it for rows far below the matrix abs-max (VERDICT r1, weak point 2: dY rows
+of well-fit examples) — so the error here is measured PER OUTPUT ROW, relative to that row's own norm, on
+operands whose rows span 2^30.  Bars: row-relative error < 1e-5 against fp64 (north_star's bar); exact
+equality on small-integer data (layout / index errors cannot hide behind a tolerance); the planes a kernel
+writes equal, bit for bit, mi_split_rows of its fp32 result."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from tests.util import dev, dropout_mask
+
+pytestmark = pytest.mark.gpu
+
+
+def _st():
+    from mi355x_rec import _lib
+    return _lib.cur_stream()
+
+
+def _chk(rc, what="call"):
+    from mi355x_rec import _lib
+    _lib.check(rc, what)
+
+
+class PB:
+    """planes buffer on the device + its mi_planes_t"""
+
+    def __init__(self, lib, rows, K, pad=0):
+        from mi355x_rec import _lib
+        self.rows, self.K = rows, K
+        self.nblk = (K + 15) // 16
+        self.rows_alloc = max(rows, 1) + pad                    # pad: a block stride larger than 64 * rows
+        assert int(lib.mi_planes_bytes(self.rows_alloc, K)) == self.nblk * self.rows_alloc * 64
+        self.data = torch.zeros(self.nblk, self.rows_alloc, 32, dtype=torch.int16, device="cuda")
+        self.exp = torch.zeros(max(rows, 1), dtype=torch.int32, device="cuda")
+        self.s = _lib.Planes(self.data.data_ptr(), self.exp.data_ptr(), 64 * self.rows_alloc)
+
+    def bits(self):
+        """[rows][nblk][32] int16: per row, its 64-byte pieces in k order (-0.0 folded into +0.0)"""
+        a = self.data.cpu().numpy()[:, :self.rows, :].transpose(1, 0, 2).reshape(self.rows, -1)
+        return np.where(a == -32768, 0, a)
+
+    @property
+    def ref(self):
+        return C.byref(self.s)
+
+    def merged(self, lib):
+        out = torch.empty(self.rows, self.K, device="cuda")
+        _chk(lib.mi_merge_rows(self.ref, self.rows, self.K, out.data_ptr(), self.K, _st()))
+        return out.cpu().numpy()
+
+
+def split(lib, X, transpose=False, pad=0):
+    x = dev(np.ascontiguousarray(X))
+    rows, K = (X.shape[1], X.shape[0]) if transpose else X.shape
+    pb = PB(lib, rows, K, pad)
+    _chk(lib.mi_split_rows(x.data_ptr(), X.shape[1], rows, K, 1 if transpose else 0, pb.ref, None, _st()))
+    return pb
+
+
+def host_planes(X):
+    """numpy restatement of the format: per-row exponent, fp16 hi / lo (RNE), blocks of 16 k"""
+    rows, K = X.shape
+    K16 = (K + 15) // 16 * 16
+    mx = np.abs(X).max(1) if K else np.zeros(rows)
+    e = (mx.astype(np.float32).view(np.uint32) >> 23) & 0xff
+    s = np.clip(141 - e.astype(np.int64), -100, 100).astype(np.int32)
+    u = np.zeros((rows, K16), np.float32)
+    u[:, :K] = X.astype(np.float32) * np.exp2(s.astype(np.float32))[:, None]
+    hi = u.astype(np.float16)
+    lo = (u - hi.astype(np.float32)).astype(np.float16)
+    out = np.zeros((rows, K16 // 16, 2, 16), np.float16)
+    out[:, :, 0, :] = hi.reshape(rows, -1, 16)
+    out[:, :, 1, :] = lo.reshape(rows, -1, 16)
+    bits = out.reshape(rows, 2 * K16).view(np.int16)
+    return np.where(bits == -32768, 0, bits), s
+
+
+def row_rel_err(got, ref):
+    """max over rows of max|got - ref| / rms(ref row)  (rows that are exactly zero must match exactly)"""
+    got = np.asarray(got, np.float64); ref = np.asarray(ref, np.float64)
+    rms = np.sqrt(np.mean(ref * ref, 1))
+    err = np.abs(got - ref).max(1)
+    z = rms == 0
+    assert np.all(err[z] == 0)
+    return float((err[~z] / rms[~z]).max()) if (~z).any() else 0.0
+
+
+def rows_spread(rng, M, K, lo_exp=-30):
+    """rows whose magnitudes span 2^lo_exp .. 1"""
+    X = rng.standard_normal((M, K)).astype(np.float32)
+    X *= np.exp2(rng.integers(lo_exp, 1, M)).astype(np.float32)[:, None]
+    return X
+
+
+@pytest.mark.parametrize("rows,K", [(1, 16), (5, 104), (300, 1664), (64, 48)])
+def test_split_rows_format_and_round_trip(lib, rows, K):
+    rng = np.random.default_rng(rows + K)
+    X = rows_spread(rng, rows, K)
+    X[0, :] *= 0 if rows > 3 else 1                       # an all-zero row
+    pb = split(lib, X, pad=1)
+    ref_bits, ref_exp = host_planes(X)
+    assert np.array_equal(pb.exp.cpu().numpy()[:rows], ref_exp)
+    got_bits = pb.bits()
+    assert float(pb.data[:, rows:, :].abs().max()) == 0 if pb.rows_alloc > rows else True     # nothing written past the rows
+    bad = np.argwhere(got_bits != ref_bits)
+    assert len(bad) == 0, (len(bad), bad[:8].tolist(), [(hex(int(got_bits[i, j]) & 0xffff), hex(int(ref_bits[i, j]) & 0xffff), float(X[i, (j // 32) * 16 + j % 16])) for i, j in bad[:8]])
+    back = pb.merged(lib)
+    assert row_rel_err(back, X) < 2 ** -20
+    # transposed source: rows of the output are columns of the input (the forward pass's weights)
+    pt = split(lib, np.ascontiguousarray(X.T), transpose=True)
+    assert np.array_equal(pt.bits(), ref_bits)
+    assert np.array_equal(pt.exp.cpu().numpy()[:rows], ref_exp)
+
+
+SHAPES = [  # M, N, K
+    (256, 512, 1664),     # config-3 layer 1: one column tile of 512 (planes out)
+    (300, 256, 512),      # layer 2, ragged M
+    (128, 128, 256),      # layer 3
+    (70, 64, 32),         # N below the narrowest tile, two k-tiles
+    (257, 1664, 512),     # layer-1 data gradient shape: 7 column tiles (fp32 result only), ragged M and N
+    (64, 16, 16),         # the smallest legal shape: one k-tile
+    (192, 384, 48),       # N between tile widths, K = 3 k-tiles
+]
+
+
+@pytest.mark.parametrize("M,N,K", SHAPES)
+def test_dense_fwd_planes_exact_on_integers(lib, M, N, K):
+    """small integers: every product and partial sum is exact in fp16 / fp32 -> the result must be EXACT"""
+    rng = np.random.default_rng(M + N + K)
+    X = rng.integers(-8, 9, (M, K)).astype(np.float32)
+    W = rng.integers(-8, 9, (K, N)).astype(np.float32)      # asymmetric, no structure
+    b = rng.integers(-3, 4, N).astype(np.float32)
+    xp, wt = split(lib, X), split(lib, W, transpose=True)
+    Y = torch.full((M, N + 4), -7.0, device="cuda")
+    yp = PB(lib, M, N) if N <= 512 else None
+    _chk(lib.mi_dense_fwd_planes(xp.ref, wt.ref, dev(b).data_ptr(), Y.data_ptr(), N + 4, yp.ref if yp else None, M, N, K, 0, 1.0,
+                                 0, None, _st()))
+    ref = X.astype(np.float64) @ W.astype(np.float64) + b
+    got = Y.cpu().numpy()
+    assert np.array_equal(got[:, :N], ref.astype(np.float32))
+    assert np.all(got[:, N:] == -7.0)                        # nothing written outside [M, N]
+    if yp is not None:
+        hb, he = host_planes(ref.astype(np.float32))
+        assert np.array_equal(yp.exp.cpu().numpy(), he)
+        assert np.array_equal(yp.bits(), hb)
+
+
+@pytest.mark.parametrize("M,N,K", SHAPES)
+def test_dense_fwd_planes_row_relative_error(lib, M, N, K):
+    rng = np.random.default_rng(M * 3 + N + K)
+    X = rows_spread(rng, M, K)
+    W = (rng.standard_normal((K, N)) / np.sqrt(K)).astype(np.float32)
+    W[:, : N // 4] *= np.float32(2.0 ** -12)                 # output columns of very different weight scale
+    b = np.zeros(N, np.float32)
+    xp, wt = split(lib, X), split(lib, W, transpose=True)
+    Y = torch.empty(M, N, device="cuda")
+    yp = PB(lib, M, N) if N <= 512 else None
+    amax = torch.zeros(64, device="cuda")
+    _chk(lib.mi_dense_fwd_planes(xp.ref, wt.ref, dev(b).data_ptr(), Y.data_ptr(), N, yp.ref if yp else None, M, N, K, 0, 1.0, 0,
+                                 amax.data_ptr(), _st()))
+    ref = X.astype(np.float64) @ W.astype(np.float64)
+    got = Y.cpu().numpy()
+    assert row_rel_err(got, ref) < 1e-5
+    assert float(amax.max()) == float(np.abs(got).max())
+    if yp is not None:
+        assert row_rel_err(yp.merged(lib), ref) < 1e-5
+        hb, he = host_planes(got)                           # the planes written == split of the fp32 result
+        assert np.array_equal(yp.exp.cpu().numpy(), he)
+        assert np.array_equal(yp.bits(), hb)
+
+
+def test_dense_fwd_planes_bias_relu_dropout(lib):
+    M, N, K = 200, 256, 64
+    rng = np.random.default_rng(3)
+    X = rng.standard_normal((M, K)).astype(np.float32)
+    W = rng.standard_normal((K, N)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    xp, wt = split(lib, X), split(lib, W, transpose=True)
+    Y0 = torch.empty(M, N, device="cuda"); Y1 = torch.empty(M, N, device="cuda")
+    yp = PB(lib, M, N)
+    seed, keep = 0x1234567, 0.9
+    _chk(lib.mi_dense_fwd_planes(xp.ref, wt.ref, dev(b).data_ptr(), Y0.data_ptr(), N, None, M, N, K, 1, 1.0, seed, None, _st()))
+    _chk(lib.mi_dense_fwd_planes(xp.ref, wt.ref, dev(b).data_ptr(), Y1.data_ptr(), N, yp.ref, M, N, K, 1, keep, seed, None, _st()))
+    ref = np.maximum(X.astype(np.float64) @ W.astype(np.float64) + b, 0)
+    y0 = Y0.cpu().numpy()
+    assert np.max(np.abs(y0 - ref)) / np.sqrt(np.mean(ref * ref)) < 1e-5
+    assert (y0 == 0).mean() > 0.3                                               # relu did something
+    mask = dropout_mask(seed, M, N, keep)
+    assert np.array_equal(Y1.cpu().numpy(), (y0 / np.float32(keep)) * mask)      # tf.nn.dropout: div(x, keep) * mask
+    hi = yp.data.cpu().numpy()[:, :M, :16].transpose(1, 0, 2).reshape(M, N).view(np.float16)
+    assert np.array_equal(hi > 0, Y1.cpu().numpy() > 0)                          # "hi > 0" is the backward's mask
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 128, 256), (300, 256, 512), (257, 512, 1664), (130, 64, 48)])
+def test_dense_bwd_data_planes(lib, M, N, K):
+    """dX[M][K] = (dY[M][N] W[K][N]^T) .* (Xact > 0) / keep with dY rows spanning 2^30 (the rows of well-fit
+    examples): per-row error against fp64."""
+    rng = np.random.default_rng(M + N + K)
+    dY = rows_spread(rng, M, N)
+    W = (rng.standard_normal((K, N)) / np.sqrt(N)).astype(np.float32)
+    Xact = np.maximum(rng.standard_normal((M, K)), 0).astype(np.float32) * np.float32(3.0)
+    keep = 0.9
+    dyp, wp, xap = split(lib, dY), split(lib, W), split(lib, Xact)
+    dX = torch.empty(M, K, device="cuda")
+    dxp = PB(lib, M, K) if K <= 512 else None
+    _chk(lib.mi_dense_bwd_data_planes(dyp.ref, wp.ref, xap.ref, dX.data_ptr(), K, dxp.ref if dxp else None, M, N, K, keep, None,
+                                      _st()))
+    ref = (dY.astype(np.float64) @ W.astype(np.float64).T) * (Xact > 0) / np.float64(np.float32(keep))
+    got = dX.cpu().numpy()
+    assert row_rel_err(got, ref) < 1e-5
+    assert np.array_equal(got == 0, ref == 0) or np.mean((got == 0) != (ref == 0)) < 1e-4
+    if dxp is not None:
+        hb, he = host_planes(got)
+        assert np.array_equal(dxp.exp.cpu().numpy(), he)
+        assert np.array_equal(dxp.bits(), hb)
+    # without a mask (the layer-1 data gradient: the concat has no activation)
+    _chk(lib.mi_dense_bwd_data_planes(dyp.ref, wp.ref, None, dX.data_ptr(), K, None, M, N, K, 1.0, None, _st()))
+    assert row_rel_err(dX.cpu().numpy(), dY.astype(np.float64) @ W.astype(np.float64).T) < 1e-5
+
+
+def test_planes_entries_refuse_bad_shapes(lib):
+    from mi355x_rec._lib import MiError
+    X = np.ones((64, 24), np.float32)
+    xp = split(lib, X)
+    wt = split(lib, np.ones((24, 16), np.float32), transpose=True)
+    Y = torch.empty(64, 16, device="cuda")
+    with pytest.raises(MiError, match="multiples of 16"):
+        _chk(lib.mi_dense_fwd_planes(xp.ref, wt.ref, None, Y.data_ptr(), 16, None, 64, 16, 24, 0, 1.0, 0, None, _st()))
+    xp2 = split(lib, np.ones((64, 32), np.float32))
+    w2 = split(lib, np.ones((32, 1024), np.float32), transpose=True)
+    yp = PB(lib, 64, 1024)
+    with pytest.raises(MiError, match="N <= 512"):
+        _chk(lib.mi_dense_fwd_planes(xp2.ref, w2.ref, None, None, 0, yp.ref, 64, 1024, 32, 0, 1.0, 0, None, _st()))
+
+
+@pytest.mark.parametrize("E,F,B", [(64, 26, 300), (128, 40, 65), (32, 5, 129), (48, 3, 17)])
+def test_embed_fm_planes_fwd(lib, E, F, B):
+    """the gather that writes the concat as planes: same bits as mi_split_rows of the materialised concat;
+    sumv / fm equal to the fp32 gather kernel's."""
+    rng = np.random.default_rng(E + F + B)
+    vocab = rng.integers(2, 50, F)
+    off = np.concatenate([[0], np.cumsum(vocab)]).astype(np.int64)
+    table = rng.standard_normal((int(off[-1]), E)).astype(np.float32)
+    table[:3] *= np.float32(2.0 ** -20)
+    ids = np.stack([rng.integers(0, v, B) for v in vocab], 1).astype(np.int32)
+    t, fo, di = dev(table), dev(off[:-1].copy()), dev(ids)
+    cp = PB(lib, B, F * E, pad=1)
+    sumv = torch.empty(B, E, device="cuda"); fm = torch.empty(B, device="cuda"); amax = torch.zeros(64, device="cuda")
+    _chk(lib.mi_embed_fm_planes_fwd(t.data_ptr(), fo.data_ptr(), di.data_ptr(), B, F, E, sumv.data_ptr(), fm.data_ptr(), cp.ref,
+                                    amax.data_ptr(), _st()))
+    concat = torch.empty(B, F * E, device="cuda"); sumv2 = torch.empty(B, E, device="cuda"); fm2 = torch.empty(B, device="cuda")
+    _chk(lib.mi_embed_fm_linear_fwd(t.data_ptr(), None, fo.data_ptr(), di.data_ptr(), B, F, E, concat.data_ptr(), F * E,
+                                    sumv2.data_ptr(), fm2.data_ptr(), None, None, _st()))
+    rows = ids.astype(np.int64) + off[:-1][None, :]
+    assert np.array_equal(concat.cpu().numpy(), table[rows].reshape(B, F * E))
+    hb, he = host_planes(concat.cpu().numpy())
+    assert np.array_equal(cp.exp.cpu().numpy(), he)
+    assert np.array_equal(cp.bits(), hb)
+    assert torch.equal(sumv, sumv2) and torch.equal(fm, fm2)
+    assert float(amax.max()) == float(np.abs(table[rows]).max())
+
+
+def test_split_weights_one_launch(lib):
+    """all weight planes of a step in one launch: both orientations, one exponent from the block's abs-max"""
+    from mi355x_rec import _lib
+    rng = np.random.default_rng(5)
+    shapes = [(1664, 512), (512, 256), (256, 128), (48, 16)]
+    offs, o = [], 0
+    for k, n in shapes:
+        offs.append(o); o += (k * n + 15) // 16 * 16
+    dense = (rng.standard_normal(o) * 0.1).astype(np.float32)
+    d = dev(dense)
+    amax = torch.zeros(64, device="cuda")
+    _chk(lib.mi_absmax(d.data_ptr(), o, amax.data_ptr(), _st()))
+    jobs = (_lib.WeightJob * len(shapes))()
+    bufs = []
+    for q, ((k, n), off) in enumerate(zip(shapes, offs)):
+        pw, pt = PB(lib, k, n), PB(lib, n, k, pad=3)
+        jobs[q].offset, jobs[q].K, jobs[q].N, jobs[q].w, jobs[q].wt = off, k, n, pw.s, pt.s
+        bufs.append((pw, pt))
+    _chk(lib.mi_split_weights(d.data_ptr(), jobs, len(shapes), amax.data_ptr(), _st()))
+    e = (np.float32(np.abs(dense).max()).view(np.uint32) >> 23) & 0xff
+    sx = int(np.clip(141 - int(e), -100, 100))
+    for (k, n), off, (pw, pt) in zip(shapes, offs, bufs):
+        W = dense[off:off + k * n].reshape(k, n)
+        assert np.all(pw.exp.cpu().numpy() == sx) and np.all(pt.exp.cpu().numpy() == sx)
+        assert np.max(np.abs(pw.merged(lib) - W)) <= 2.0 ** -21 * np.abs(dense).max()
+        assert np.max(np.abs(pt.merged(lib) - W.T)) <= 2.0 ** -21 * np.abs(dense).max()
+        # same bits as the format's restatement with the common exponent
+        u = W * np.float32(2.0) ** sx
+        hi = u.astype(np.float16)
+        assert np.array_equal(pw.data.cpu().numpy()[:, :k, :16].transpose(1, 0, 2).reshape(k, -1)[:, :n].view(np.float16), hi)
