@@ -7,9 +7,12 @@
 
 A "step" is one pass of the whole hot path over one synthetic batch that is already resident in
 HBM: unique-row bookkeeping, lazy Adam catch-up, embedding gather + FM + wide linear, the
-[512,256,128] MLP (fp32 operands / accumulate / results; the matrix cores are fed a scaled fp16
-high+low split of the operands, three MFMA products per fp32 product), sigmoid-CE head, full
-backward, dense + sparse TF-form Adam.
+[512,256,128] MLP (fp32 accumulate / results; the matrix cores are fed fp16 high+low parts of the
+operands with one power-of-two exponent per row, three MFMA products per fp32 product), sigmoid-CE
+head, full backward, dense + sparse TF-form Adam.
+`value` is the STEADY-STATE rate (timed after enough steps that >= 99 % of the rows have optimizer state
+to catch up on); `cold_start` is the same K steps from a fresh model; `gemm_fp32` and
+`lazy_adam_off_semantics` price the matrix-pipe path and the exact-Adam catch-up.
 Workload (config.workload): trainers.deep_fm with --embedding-size 64 --hidden-units 512 256 128
 --batch-size 65536 (dropout 0.1 = the CLI default), 26 categorical fields x 1,000,000 ids each
 (Criteo-shaped), uniform ids, labels Bernoulli(0.25).  N > 1: one process per GPU, 65536 examples
@@ -22,6 +25,7 @@ reference's TF graph, timed on this host on a bounded sample).
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -53,6 +57,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-second-dist", action="store_true", help="skip the short run on the other id distribution")
+    ap.add_argument("--no-extras", action="store_true", help="skip the fp32-MFMA and LazyAdam-semantics legs")
     ap.add_argument("--dist", choices=["uniform", "zipf"], default="uniform", help="id distribution")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="nccl = RCCL over xGMI (the measured path); gloo only rehearses the N>1 flow on one GPU")
@@ -98,39 +103,52 @@ def mlp_roofline(gemm, flops, gemm_ms):
     elif gemm == "bf16x3":
         peak, kern, prod = MFMA_F16_PEAK_TFLOPS / 6, "gemm_split_k<bf16x3> (v_mfma_f32_32x32x16_bf16, 6 products)", 6
     else:
-        peak, kern, prod = MFMA_F16_PEAK_TFLOPS / SPLIT_PRODUCTS, "gemm_split_k<f16x2> (v_mfma_f32_32x32x16_f16, 3 products)", SPLIT_PRODUCTS
+        peak, kern, prod = MFMA_F16_PEAK_TFLOPS / SPLIT_PRODUCTS, ("gemm_pl_k (forward, data gradient: pre-split fp16 high/low planes, per-row exponents) + "
+                                                                   "gemm_split_k<f16x2> (weight gradient); v_mfma_f32_32x32x16_f16, 3 products"), SPLIT_PRODUCTS
     return {"kernel": kern + "; all dense fwd/bwd launches incl. the N=1 logits layer (matrix-vector kernels)", "bound": "mfma",
             "achieved": ach, "peak": peak, "unit": "TFLOP/s (fp32-equivalent)", "frac": ach / peak,
             "mfma_products_per_fp32_product": prod, "executed_mfma_tflops": ach * prod,
             "fp32_input_mfma_peak": MFMA_F32_PEAK_TFLOPS, "flops_per_step": flops, "gemm_ms_per_step": gemm_ms}
 
 
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline():
-    """The oracle (numpy restatement of the reference's TF graph incl. the whole-table Adam sweep)
-    on this host: same B/F/E/hidden, vocabulary cut to 50k ids per field to bound the run."""
-    from oracle import deepfm as O, optimizers as OO
-    B = B_FULL
-    v_s, steps = 50_000, 5
-    rng = np.random.default_rng(SEED)
-    p = O.init_params(rng, [v_s] * F, E, HIDDEN, dtype=np.float32, lin_scale=1e-3)
-    st = O.TrainState(p, OO.Hyper("Adam", 0.001))
-    ids = rng.integers(0, v_s, (B, F)).astype(np.int32)
-    y = (rng.random(B) < 0.25).astype(np.uint8)
-    O.train_step(p, st, ids, y)                       # warm-up (page faults, BLAS threads)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        O.train_step(p, st, ids, y)
-    dt = time.perf_counter() - t0
+    """The reference graph restated on PyTorch-CPU (oracle/cpu_torch.py: one table per field, materialised
+    [B,d,E], un-fused layers, TF Adam's whole-table sweep) on this host, ALL threads, FULL vocabulary
+    (26 x 1M rows: 20 GB of variables + slots), same B / F / E / hidden as the GPU run."""
+    from oracle import cpu_torch as T
     try:
         cores = len(os.sched_getaffinity(0))             # the CPUs this process may run on (the box's share)
     except AttributeError:
         cores = os.cpu_count()
+    torch.set_num_threads(cores)
+    B = B_FULL
+    st = T.State([V] * F, E, HIDDEN, seed=SEED)
+    g = torch.Generator().manual_seed(SEED)
+    draw = lambda: (torch.randint(0, V, (B, F), generator=g), (torch.rand(B, generator=g) < 0.25).float())
+    T.train_step(st, *draw())                         # warm-up (page faults, thread pools)
+    steps, t0 = 0, time.perf_counter()
+    while steps < 8 and (steps < 2 or time.perf_counter() - t0 < 20.0):
+        ids, y = draw()
+        T.train_step(st, ids, y)
+        steps += 1
+    dt = time.perf_counter() - t0
     return {"value": B * steps / dt, "unit": "examples/sec", "cores": cores, "kind": "port",
-            "sample": "numpy fp32 oracle (CPU restatement of the reference TF graph; TensorFlow 1.12 "
-                      "unavailable), B=%d F=%d E=%d hidden=%s, vocab cut to %d ids/field (1/20 of the rows "
-                      "the Adam sweep visits), %d steps after 1 warm-up, no dropout; OpenBLAS threads = host "
-                      "cores for the GEMMs, elementwise numpy single-threaded" % (B, F, E, HIDDEN, v_s, steps),
-            "ms_per_step": dt / steps * 1e3}
+            "cpu_model": cpu_model(), "torch_threads": torch.get_num_threads(), "ms_per_step": dt / steps * 1e3,
+            "sample": "CPU restatement of the reference graph (TensorFlow 1.12 unavailable): oracle/cpu_torch.py on PyTorch-CPU fp32, "
+                      "B=%d F=%d E=%d hidden=%s, FULL vocabulary %d ids/field, TF Adam's whole-table sweep, fresh uniform batch "
+                      "per step, %d steps after 1 warm-up (batch generation inside the timed loop: <1 %%), no dropout" %
+                      (B, F, E, HIDDEN, V, steps)}
 
 
 def main():
@@ -169,9 +187,18 @@ def main():
     # A fresh batch every step, as in training on a real dataset: which rows sit out how many steps
     # (the gap TF Adam's dense-equivalent sparse update is replayed over) then follows the id
     # distribution — uniform ids: geometric with mean 1M/65536 = 15 steps — instead of being pinned
-    # to the period of a small rotating pool.  All batches are generated before the timed region
+    # to the period of a small rotating pool.  All batches are generated before any timed region
     # (256 at most: 1.7 GB of ids; a longer run cycles through them).
-    batches = make_batches(min(args.warmup + args.steps, POOL), gen, device, args.dist == "zipf", B)
+    # STEADY STATE: a step costs most once every row it touches has optimizer state to catch up on, so the
+    # headline is timed only after a state-preparation phase of plain train steps that has given >= 99 % of
+    # the rows of a field their first update (ln(100) / -ln(1 - B_global/V) = 68 steps at B = 65536).  The
+    # same K steps timed from the freshly initialised model are reported as `cold_start` (round 1's headline).
+    B_glob = B * world
+    prep_total = int(math.ceil(math.log(100.0) / -math.log(1.0 - min(B_glob / V, 0.999))))
+    n_cold = args.warmup + args.steps
+    n_prep = max(0, prep_total - n_cold)
+    batches = make_batches(min(2 * n_cold + n_prep, POOL), gen, device, args.dist == "zipf", B)
+    cursor = [0]
 
     def sync():
         torch.cuda.synchronize()
@@ -179,54 +206,95 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        ids, y = batches[i % len(batches)]
-        m.train_step(ids, y)
+    def run(nsteps):
+        out = None
+        for _ in range(nsteps):
+            ids, y = batches[cursor[0] % len(batches)]
+            cursor[0] += 1
+            out = m.train_step(ids, y)
+        return out
+
+    def timed(nsteps):
+        """barrier + synchronize, nsteps steps, barrier + synchronize; max over ranks"""
+        sync()
+        t0 = time.perf_counter()
+        out = run(nsteps)
+        sync()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([dt], device=device if args.backend == "nccl" else "cpu", dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        return dt, out
+
+    run(args.warmup)
+    cold_dt, _ = timed(args.steps)
+    cold = {"value": world * B * args.steps / cold_dt, "unit": "examples/sec", "ms_per_step": cold_dt / args.steps * 1e3,
+            "note": "the same %d steps after %d warm-up steps from a freshly initialised model (few rows have optimizer "
+                    "state to catch up on yet)" % (args.steps, args.warmup)}
+    run(n_prep)
+    run(args.warmup)
     m.timers = {}
-    sync()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        ids, y = batches[(args.warmup + i) % len(batches)]
-        loss, _ = m.train_step(ids, y)
-    sync()
-    dt = time.perf_counter() - t0
+    dt, (loss, _) = timed(args.steps)
     timers, m.timers = m.timers, None
-    if world > 1:
-        tmax = torch.tensor([dt], device=device if args.backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
     final_loss = float(loss.item())
+    steps_before = cursor[0] - args.steps
 
     # second distribution of SURVEY 8d (Criteo-like skew), a short run after the headline one: same
     # protocol (barrier + synchronize on both sides, max over ranks); reported beside `value`
     other = None
     if not args.no_second_dist:
         o_zipf = args.dist != "zipf"
-        ob = make_batches(35, gen, device, o_zipf, B)
+        batches = make_batches(35, gen, device, o_zipf, B)
+        cursor[0] = 0
         ow, os_ = 5, 30
-        for i in range(ow):
-            m.train_step(*ob[i % len(ob)])
-        sync()
-        t1 = time.perf_counter()
-        for i in range(os_):
-            m.train_step(*ob[(ow + i) % len(ob)])
-        sync()
-        odt = time.perf_counter() - t1
-        if world > 1:
-            tmax = torch.tensor([odt], device=device if args.backend == "nccl" else "cpu", dtype=torch.float64)
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            odt = float(tmax.item())
+        run(ow)
+        odt, _ = timed(os_)
         other = {"data": "zipf s=1.05 ids" if o_zipf else "uniform ids", "value": world * B * os_ / odt,
                  "unit": "examples/sec", "ms_per_step": odt / os_ * 1e3, "steps": os_, "warmup": ow}
+        batches = make_batches(24, gen, device, args.dist == "zipf", B)
+        cursor[0] = 0
+
+    # what the matrix-pipe path and the exact-Adam semantics cost (single GPU, short legs after the headline)
+    extras = {}
+    if world == 1 and not args.no_extras:
+        if args.gemm != "fp32":
+            keep = (m.gemm, m.planes, m.gather_mlp)
+            m.gemm, m.planes, m.gather_mlp = "fp32", False, True
+            run(3)
+            fdt, _ = timed(10)
+            extras["gemm_fp32"] = {"value": B * 10 / fdt, "unit": "examples/sec", "ms_per_step": fdt / 10 * 1e3,
+                                   "note": "same steps with every MLP GEMM on the fp32-input MFMA (v_mfma_f32_32x32x2_f32, exact "
+                                           "products): the un-emulated number beside the headline's fp16 high/low operand split"}
+            m.gemm, m.planes, m.gather_mlp = keep
+        # LazyAdam semantics: rows that sat out are NOT replayed (no catch-up, no deferred slot decay).  NOT the
+        # reference's tf.train.AdamOptimizer (SURVEY A.6) — here only to put a price on exactness.  Last leg: it
+        # leaves the model's stamps stale.
+        m.adam_rows, stamps, m.last_step = False, m.last_step, None
+        run(3)
+        ldt, _ = timed(10)
+        extras["lazy_adam_off_semantics"] = {"value": B * 10 / ldt, "unit": "examples/sec", "ms_per_step": ldt / 10 * 1e3,
+                                             "note": "LazyAdam semantics (touched rows only; NOT the reference's dense-equivalent "
+                                                     "AdamOptimizer): the step without the catch-up replay"}
+        m.adam_rows, m.last_step = True, stamps
 
     if rank == 0:
         km = kernel_ms(timers)
         ms_step = dt / args.steps * 1e3
         planes_gather = "mi_embed_fm_planes_fwd" in km
         g_ms = km["mi_embed_fm_planes_fwd" if planes_gather else "mi_embed_fm_linear_fwd"][0]
-        gather_bytes = B * F * 4 * E                     # algorithmic row bytes per launch
-        wide_split = "mi_embed_fm_linear_fwd/wide" in km  # single GPU: the wide part's gathers run beside the layer-1 GEMM
-        total_bytes = B * (F * (4 * E + (4 if wide_split else 8)) + 4 * E + (4 if wide_split else 8))   # rows + ids (+ linear weights) read; sumv / fm (/ lin) written
+        # Algorithmic bytes per launch (SURVEY 8d, per example): the kernel READS F rows of 4E bytes + F ids and
+        # WRITES the input_layer concat (as fp16 high/low planes: 4 bytes per element, the bytes of the fp32
+        # concat SURVEY counts) + sumv + fm + the example's exponent.  `achieved` counts both directions — the
+        # kernel is HBM bound on their sum; `row_read_GBs` is the read side alone (what round 1's read-only
+        # kernel reported: that form never wrote the concat, each of the layer-1 GEMMs re-gathered the rows).
+        row_bytes = B * F * 4 * E
+        wide_split = "mi_embed_fm_linear_fwd/wide" in km  # the wide part's 4-byte gathers run as their own kernel
+        if planes_gather:
+            gather_bytes = B * (F * (4 * E + 4) + F * 4 * E + 4 * E + 8)
+        else:
+            gather_bytes = row_bytes
+        total_bytes = gather_bytes if planes_gather else B * (F * (4 * E + (4 if wide_split else 8)) + 4 * E + (4 if wide_split else 8))
         achieved = gather_bytes / (g_ms * 1e-3) / 1e9
         gemm_ms = sum(v[2] for k, v in km.items() if k in ("mi_dense_fwd", "mi_dense_fwd_gathered", "mi_dense_bwd_data", "mi_dense_bwd_weight",
                                                         "mi_dense_bwd_weight_gathered", "mi_dense_fwd_planes",
@@ -236,7 +304,7 @@ def main():
         traffic = None
         try:
             with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-                traffic = json.load(f)["embed_fm_linear_fwd_k"]["bytes_per_launch"] if world == 1 else None
+                traffic = json.load(f)["embed_fm_planes_fwd_k" if planes_gather else "embed_fm_linear_fwd_k"]["bytes_per_launch"] if world == 1 else None
         except (OSError, KeyError, ValueError):
             pass
         out = {
@@ -249,7 +317,7 @@ def main():
             "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic (%s ids, a fresh batch every step from a pool of %d, random-init weights)" % (args.dist, len(batches)),
+            "data": "synthetic (%s ids, a fresh batch every step from a pool of up to %d, random-init weights)" % (args.dist, POOL),
             "config": {"workload": "config 3: trainers.deep_fm --embedding-size 64 --hidden-units 512 256 128 "
                                    "--batch-size 65536 --dropout 0.1, 26 fields x 1M ids (Criteo-shaped), Adam(1e-3)",
                        "per_gpu_batch": B, "global_batch": world * B, "fields": F, "vocab_per_field": V,
@@ -258,19 +326,25 @@ def main():
                                 "bf16x3": "fp32 GEMMs via 3-way bf16 operand split, fp32 accumulate",
                                 "fp32": "fp32-input MFMA"}[args.gemm],
                        "parallelism": "dp%d + row-sharded embeddings (all-to-all)" % world if world > 1 else "single GPU"},
-            "roofline": {"kernel": "embed_fm_linear_fwd_k (embedding gather + FM second order + row abs-max; read-only form: the "
-                                   "MLP gathers its own operand" + ("; the wide part's 4-byte gathers run as linear_only_fwd_k on a "
-                                   "side stream under the layer-1 GEMM)" if wide_split else "; + wide linear)"), "bound": "hbm",
+            "roofline": {"kernel": ("embed_fm_planes_fwd_k: embedding gather + FM second order, writes the input_layer concat as fp16 "
+                                    "high/low planes with one exponent per example (the operand of the layer-1 GEMMs); the wide part's "
+                                    "4-byte gathers run as linear_only_fwd_k on a side stream" if planes_gather else
+                                    "embed_fm_linear_fwd_k (embedding gather + FM second order; read-only form)"), "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "frac_of_measured_copy_peak": achieved / HBM_MEASURED_GBS,
                          "algorithmic_bytes_per_launch": gather_bytes, "avg_launch_ms": g_ms,
-                         "achieved_total_rw_GBs": total_bytes / (g_ms * 1e-3) / 1e9, "traffic": traffic,
-                         "traffic_note": "HBM bytes/launch from rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE), "
-                                         "profiles/r01_final_pmc_hbm_traffic.md"},
+                         "row_read_GBs": row_bytes / (g_ms * 1e-3) / 1e9, "row_read_frac": row_bytes / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "traffic": traffic,
+                         "traffic_note": "HBM bytes/launch from rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE), profiles/"},
             "roofline_mlp": mlp_roofline(args.gemm, flops, gemm_ms),
             "kernel_ms_per_step": {k: v[2] / args.steps for k, v in sorted(km.items())},
             "final_loss": final_loss,
+            "state": {"steps_before_timed_region": steps_before, "state_prep_steps": n_prep,
+                      "rows_with_optimizer_state": 1.0 - (1.0 - min(B_glob / V, 0.999)) ** steps_before,
+                      "note": "value = steady state (>= 99 % of a field's rows have Adam state and a stamp to catch up from)"},
+            "cold_start": cold,
         }
+        out.update(extras)
         if other is not None:
             out["other_distribution"] = other
         if world == 1 and not args.no_cpu_baseline:

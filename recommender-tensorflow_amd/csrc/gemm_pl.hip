@@ -231,6 +231,11 @@ __global__ __launch_bounds__(PL_THREADS, 2) void gemm_pl_k(const PlArgs a) {
   float* e_bias = e_fw + BNt;                       // [BNt]
   float* e_rmax = e_bias + BNt;                     // [4][BMt] row abs-max per column group of waves
   float* e_wmax = e_rmax + 4 * BMt;                 // [8] per-wave abs-max (amax_c)
+  // one private LDS region per wave for the result's way out (row-contiguous stores, below)
+  constexpr int FS = TN * 128 + 16;                 // bytes per fp32 row of the wave's 32 x 32 TN sub-tile (+ pad: banks)
+  constexpr int WREG = 32 * FS > TN * 4096 ? 32 * FS : TN * 4096;
+  static_assert(8192 + 8 * WREG <= PL_NBUF * STAGE, "epilogue LDS");
+  char* wreg = smem + 8192 + wv * WREG;
   for (int n = t; n < BNt; n += PL_THREADS) {
     const int gn = n0 + n;
     const bool ok = gn < a.N;
@@ -282,10 +287,24 @@ __global__ __launch_bounds__(PL_THREADS, 2) void gemm_pl_k(const PlArgs a) {
           acc[x][y][r] = v;
           mx = fmaxf(mx, fabsf(v));
         }
-        if (a.C && mok && n0 + nl < a.N)
-          *reinterpret_cast<float4*>(a.C + static_cast<int64_t>(m) * a.ldc + n0 + nl) =
+        if (a.C)
+          *reinterpret_cast<float4*>(wreg + i * FS + (x * 32 + 8 * g + 4 * h) * 4) =
               make_float4(acc[x][y][4 * g], acc[x][y][4 * g + 1], acc[x][y][4 * g + 2], acc[x][y][4 * g + 3]);
       }
+    }
+    if (a.C) {
+      // the wave's 32 rows x 32 TN columns went through its own LDS region: read them back row by row, so that
+      // a store instruction writes whole 128 TN-byte row segments instead of 64 scattered 16-byte pieces
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      constexpr int LPR_ = TN * 8, RPI = 64 / LPR_;                  // lanes per row, rows per instruction
+#pragma unroll
+      for (int it = 0; it < 32 / RPI; ++it) {
+        const int row = it * RPI + lane / LPR_, c16 = lane % LPR_;
+        const float4 v4 = *reinterpret_cast<const float4*>(wreg + row * FS + c16 * 16);
+        const int mm = m0 + wm * 32 * TM + y * 32 + row, nn = n0 + nw + c16 * 4;
+        if (mm < a.M && nn < a.N) *reinterpret_cast<float4*>(a.C + static_cast<int64_t>(mm) * a.ldc + nn) = v4;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     mx = fmaxf(mx, __shfl_xor(mx, 32));               // the lane pair that shares this example
     rmx[y] = mx;
@@ -349,15 +368,28 @@ __global__ __launch_bounds__(PL_THREADS, 2) void gemm_pl_k(const PlArgs a) {
         auto r2 = __builtin_amdgcn_permlane32_swap(pq[q], pq[q + 4], false, false);
         pq[q] = r2[0]; pq[q + 4] = r2[1];
       }
-      const int nblk = n0 + nw + x * 32 + 16 * h;       // first column of this lane's 16-column block
-      if (mok && nblk < a.N) {
-        char* d = a.Cp + (nblk >> 4) * a.bsc + static_cast<int64_t>(m) * PL_ROWB;
-        *reinterpret_cast<uint4*>(d) = make_uint4(ph[0], ph[1], ph[4], ph[5]);
-        *reinterpret_cast<uint4*>(d + 16) = make_uint4(ph[2], ph[3], ph[6], ph[7]);
-        *reinterpret_cast<uint4*>(d + 32) = make_uint4(pq[0], pq[1], pq[4], pq[5]);
-        *reinterpret_cast<uint4*>(d + 48) = make_uint4(pq[2], pq[3], pq[6], pq[7]);
-      }
+      // this lane's 64 bytes (row i of 16-column block 2 x + h) into the wave's LDS region as [block][row][64 B],
+      // the four 16-byte pieces rotated by the row so that the 8 lanes of a write group spread over the banks
+      char* d = wreg + ((2 * x + h) * 32 + i) * 64;
+      const int rot = (i >> 1) & 3;
+      *reinterpret_cast<uint4*>(d + ((0 ^ rot) << 4)) = make_uint4(ph[0], ph[1], ph[4], ph[5]);
+      *reinterpret_cast<uint4*>(d + ((1 ^ rot) << 4)) = make_uint4(ph[2], ph[3], ph[6], ph[7]);
+      *reinterpret_cast<uint4*>(d + ((2 ^ rot) << 4)) = make_uint4(pq[0], pq[1], pq[4], pq[5]);
+      *reinterpret_cast<uint4*>(d + ((3 ^ rot) << 4)) = make_uint4(pq[2], pq[3], pq[6], pq[7]);
     }
+    // read the region back linearly: one instruction = 16 rows x 64 B of one block = 1 KiB contiguous in the
+    // k-block-major result
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int q = 0; q < TN * 4; ++q) {
+      const int off = q * 1024 + lane * 16;
+      const int blk = off >> 11, row = (off >> 6) & 31, slot = (off >> 4) & 3;
+      const uint4 v4 = *reinterpret_cast<const uint4*>(wreg + off);
+      const int mm = m0 + wm * 32 * TM + y * 32 + row, ncol = n0 + nw + blk * 16;
+      if (mm < a.M && ncol < a.N)
+        *reinterpret_cast<uint4*>(a.Cp + (ncol >> 4) * a.bsc + static_cast<int64_t>(mm) * PL_ROWB + ((slot ^ ((row >> 1) & 3)) << 4)) = v4;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
 }
 
@@ -553,7 +585,8 @@ int32_t launch_pl(PlArgs& a, hipStream_t st, const char* what) {
   // column tile: the narrowest that holds N (planes out needs all of N in one tile); row tile: 256 rows for
   // the narrower column tiles (same accumulator budget), 128 for 512 columns
   int tn = a.N <= 128 ? 1 : (a.N <= 256 ? 2 : 4);
-  if (a.N > 512) tn = 2;                              // fp32 result only: 256 x 256 tiles
+  if (a.N > 512) tn = 1;                              // fp32 result only: 128-column tiles, two workgroups per CU (measured:
+                                                      // layer-1 data gradient 426 us, 256 columns 467, 512 columns 520)
   if (const char* e = getenv("MI_PL_TILE")) {         // tuning experiments (tools/gemm_pl_bench.py)
     const int v = atoi(e);
     if ((v == 1 || v == 2 || v == 4) && (!a.Cp || a.N <= 128 * v)) tn = v;

@@ -187,3 +187,28 @@ def test_layer_summary_and_dropout_backward_rule():
     for i in [(0, 0), (3, 5), (11, 7)]:
         old = k0[i]; k0[i] = old + eps; lp = loss_of(); k0[i] = old - eps; lm = loss_of(); k0[i] = old
         assert abs((lp - lm) / (2 * eps) - dense[0][i]) < 1e-8
+
+
+def test_torch_cpu_restatement_matches_numpy_oracle():
+    """oracle/cpu_torch.py (bench.py's multi-threaded cpu_baseline) == oracle/deepfm.py over 3 Adam steps"""
+    import torch
+    from oracle import cpu_torch as T
+    vocab, E, hidden, B = [9, 13, 5, 6], 8, [16, 8], 64
+    rng = np.random.default_rng(4)
+    p = O.init_params(rng, vocab, E, hidden, dtype=np.float32, lin_scale=0.05)
+    st_t = T.State(vocab, E, hidden)
+    st_t.load_numpy(p)
+    st = O.TrainState(p, OO.Hyper("Adam", 0.001))
+    for _ in range(3):
+        ids = np.stack([rng.integers(0, v, B) for v in vocab], 1).astype(np.int32)
+        ids[1] = ids[0]
+        y = (rng.random(B) < 0.3).astype(np.uint8)
+        lo, logit_o = O.train_step(p, st, ids, y)
+        lt, logit_t = T.train_step(st_t, torch.from_numpy(ids.astype(np.int64)), torch.from_numpy(y.astype(np.float32)))
+        assert abs(float(lt) - float(lo)) < 1e-6 * abs(float(lo)) + 1e-7
+        assert np.allclose(logit_t.numpy(), logit_o, rtol=1e-5, atol=1e-6)
+    for f in range(len(vocab)):
+        assert np.max(np.abs(st_t.emb[f].numpy() - p.emb[f])) < 1e-6
+        assert np.max(np.abs(st_t.lin_w[f].numpy() - p.lin_w[f])) < 1e-6
+    for (k, b), (ko, bo) in zip(st_t.mlp, p.mlp):
+        assert np.max(np.abs(k.numpy() - ko)) < 1e-6 and np.max(np.abs(b.numpy() - bo)) < 1e-6
