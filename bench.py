@@ -122,23 +122,53 @@ def cpu_model():
     return "unknown"
 
 
+def host_threads():
+    """CPUs this process may really use: the affinity mask capped by the cgroup CPU quota (a GPU box hands a
+    job a share of the node, e.g. 16 of 256 CPUs: more threads than that only fight over the quota)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, int(int(parts[0]) / int(parts[1]))))
+            else:
+                q = int(parts[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                        n = min(n, max(1, q // int(f.read())))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
+def log(msg):
+    print("[bench] " + msg, file=sys.stderr, flush=True)
+
+
 def cpu_baseline():
     """The reference graph restated on PyTorch-CPU (oracle/cpu_torch.py: one table per field, materialised
     [B,d,E], un-fused layers, TF Adam's whole-table sweep) on this host, ALL threads, FULL vocabulary
     (26 x 1M rows: 20 GB of variables + slots), same B / F / E / hidden as the GPU run."""
     from oracle import cpu_torch as T
-    try:
-        cores = len(os.sched_getaffinity(0))             # the CPUs this process may run on (the box's share)
-    except AttributeError:
-        cores = os.cpu_count()
+    cores = host_threads()
     torch.set_num_threads(cores)
     B = B_FULL
+    t_init = time.perf_counter()
     st = T.State([V] * F, E, HIDDEN, seed=SEED)
     g = torch.Generator().manual_seed(SEED)
     draw = lambda: (torch.randint(0, V, (B, F), generator=g), (torch.rand(B, generator=g) < 0.25).float())
+    log("cpu baseline: %d threads, variables built in %.1f s" % (cores, time.perf_counter() - t_init))
+    tw = time.perf_counter()
     T.train_step(st, *draw())                         # warm-up (page faults, thread pools)
+    log("cpu baseline: warm-up step %.1f s" % (time.perf_counter() - tw))
     steps, t0 = 0, time.perf_counter()
-    while steps < 8 and (steps < 2 or time.perf_counter() - t0 < 20.0):
+    while steps < 8 and (steps < 1 or time.perf_counter() - t0 < 15.0):
         ids, y = draw()
         T.train_step(st, ids, y)
         steps += 1
@@ -227,8 +257,10 @@ def main():
             dt = float(tmax.item())
         return dt, out
 
+    log("model and %d batches ready" % len(batches))
     run(args.warmup)
     cold_dt, _ = timed(args.steps)
+    log("cold start: %.3f ms/step" % (cold_dt / args.steps * 1e3))
     cold = {"value": world * B * args.steps / cold_dt, "unit": "examples/sec", "ms_per_step": cold_dt / args.steps * 1e3,
             "note": "the same %d steps after %d warm-up steps from a freshly initialised model (few rows have optimizer "
                     "state to catch up on yet)" % (args.steps, args.warmup)}
@@ -238,6 +270,7 @@ def main():
     dt, (loss, _) = timed(args.steps)
     timers, m.timers = m.timers, None
     final_loss = float(loss.item())
+    log("steady state: %.3f ms/step" % (dt / args.steps * 1e3))
     steps_before = cursor[0] - args.steps
 
     # second distribution of SURVEY 8d (Criteo-like skew), a short run after the headline one: same
@@ -348,6 +381,7 @@ def main():
         if other is not None:
             out["other_distribution"] = other
         if world == 1 and not args.no_cpu_baseline:
+            log("extras done; cpu baseline")
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
     if world > 1:

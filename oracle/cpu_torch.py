@@ -17,9 +17,14 @@ class State:
     def __init__(self, vocab_sizes, E, hidden, seed=0, lin_scale=1e-3, lr=0.001, beta1=0.9, beta2=0.999, eps=1e-8):
         g = torch.Generator().manual_seed(seed)
         self.E, self.hidden = E, list(hidden)
-        self.emb = [torch.nn.init.trunc_normal_(torch.empty(v, E), 0.0, 1 / math.sqrt(E), -2 / math.sqrt(E), 2 / math.sqrt(E),
-                                                generator=g) for v in vocab_sizes]
-        self.lin_w = [torch.randn(v, generator=g) * lin_scale for v in vocab_sizes]
+        # (N(0, 1/sqrt(E)) clamped at 2 sigma, drawn for 65,536 rows and tiled: torch's CPU generator is single-
+        # threaded, 1.7 G fresh draws take two minutes, and the values do not change what a step costs)
+        def tiled(v, draw):
+            base = draw(min(v, 1 << 16))
+            return base.repeat((v + len(base) - 1) // len(base), *([1] * (base.dim() - 1)))[:v].contiguous()
+        sd = 1 / math.sqrt(E)
+        self.emb = [tiled(v, lambda n: torch.empty(n, E).normal_(0.0, sd, generator=g).clamp_(-2 * sd, 2 * sd)) for v in vocab_sizes]
+        self.lin_w = [tiled(v, lambda n: torch.randn(n, generator=g) * lin_scale) for v in vocab_sizes]
         self.lin_bias = torch.zeros(1)
         self.mlp = []
         fan = len(vocab_sizes) * E
