@@ -136,6 +136,19 @@ int32_t mi_embed_fm_linear_bwd(const float* d_concat, int64_t ld_dconcat, const 
                                const float* d_logit_lin, const int32_t* pos, int64_t B, int32_t F,
                                int32_t E, float* d_rows, float* d_lin, mi_stream_t stream);
 
+/* Requester-side half of the sparse "reduce-scatter" (multi-GPU): the entries of a chunk that asked for the
+ * same row are summed BEFORE the gradient all-to-all, so one gradient row per distinct request travels.
+ * For distinct requests u in [u_begin, u_begin + u_count) (segments of mi_sort_unique_rows over the request
+ * keys): out_rows[u,:] = sum over the segment's entries e = (b, f), in ascending entry order, of
+ *   d_concat[b - b0, f*E:(f+1)*E] + d_logit_fm[b - b0] * (sumv[b - b0,:] - rows[u,:])
+ * and out_lin[u] = sum of d_logit_lin[b - b0]; rows [*,E] = the exchange's receive buffer (slot u), the
+ * per-example arrays belong to examples b0.. (one chunk).  Segments longer than 48 entries are summed by a
+ * workgroup in fixed slices, like mi_sparse_apply's. */
+int32_t mi_entry_grads_segsum(const float* rows, const int32_t* seg_start, const int32_t* sorted_entry, int64_t u_begin,
+                              int64_t u_count, const float* d_concat, int64_t ld_dconcat, const float* sumv,
+                              const float* d_logit_fm, const float* d_logit_lin, int64_t b0, int32_t F, int32_t E,
+                              float* out_rows, float* out_lin, mi_stream_t stream);
+
 /* (a4) backward of the numeric embedding: dV[j,e] = sum_b x[b,j]*g[b,j,e] with
  * g = d_concat + d_logit_fm*(sumv - concat);  dw_num[j] = sum_b d_logit_lin[b]*x[b,j].
  * Deterministic two-stage reduction; workspace from mi_numeric_embed_bwd_workspace_bytes. */
@@ -166,13 +179,22 @@ int32_t mi_sort_unique_rows(const int32_t* rows, int64_t n, int64_t num_rows_tot
 /* Routing helpers of the row-sharded multi-GPU path (row r lives on rank r % world as local row
  * r / world; the reference's own multi-worker mode is TF's parameter-server placement of whole
  * variables, distributed.md:58-82 — see DESIGN.md "Multi-GPU").
- *   mi_shard_route : owner[i] = (i / entries_per_chunk) * world + rows[i] % world (chunk-major key of a
- *                    pipelined step; entries_per_chunk == 0: one chunk), local_row[i] = rows[i] / world
- *   mi_invert_perm : inv[perm[i]] = i
- *   mi_gather_u32  : out[i] = src[idx[i]] for 4-byte elements (int32 ids or f32 values) */
-int32_t mi_shard_route(const int32_t* rows, int64_t n, int32_t world, int64_t entries_per_chunk, int32_t* owner,
-                       int32_t* local_row, mi_stream_t stream);
-int32_t mi_invert_perm(const int32_t* perm, int64_t n, int32_t* inv, mi_stream_t stream);
+ *   mi_shard_keys     : keys[i] = ((i / entries_per_chunk) * world + rows[i] % world) * rows_per_rank + rows[i] / world
+ *                       (chunk-major request key of a pipelined step; entries_per_chunk == 0: one chunk).
+ *                       mi_sort_unique_rows of the keys orders the entries by (chunk, owner, row); its unique
+ *                       keys are the DISTINCT rows each chunk needs from each owner — what travels.
+ *   mi_route_requests : per distinct request u < *num_uniq: send_rows[u] = owner-local row;
+ *                       counts[chunk * world + owner] = number of distinct requests of that group (device;
+ *                       zeroed here) — the all-to-all split sizes
+ *   mi_segment_slots  : slot_of_entry[e] = u, the distinct request entry e belongs to (the received row's
+ *                       slot in the exchange buffer)
+ *   mi_gather_u32     : out[i] = src[idx[i]] for 4-byte elements (int32 ids or f32 values) */
+int32_t mi_shard_keys(const int32_t* rows, int64_t n, int32_t world, int64_t entries_per_chunk, int64_t rows_per_rank,
+                      int32_t* keys, mi_stream_t stream);
+int32_t mi_route_requests(const int32_t* uniq_keys, const int32_t* num_uniq, int64_t n_max, int64_t rows_per_rank,
+                          int32_t n_groups, int32_t* send_rows, int32_t* counts, mi_stream_t stream);
+int32_t mi_segment_slots(const int32_t* seg_start, const int32_t* sorted_entry, const int32_t* num_uniq, int64_t n,
+                         int32_t* slot_of_entry, mi_stream_t stream);
 int32_t mi_gather_u32(const void* src, const int32_t* idx, int64_t n, void* out, mi_stream_t stream);
 
 /* rows[b*F+f] = field_off[f] + ids[b*F+f]  (int32 global row per entry) */
@@ -265,10 +287,13 @@ int32_t mi_sparse_catchup(float* table, float* t_m, float* t_v, float* lin_w, fl
 /* Matrix-pipe path of the GEMMs below (process-wide switch):
  *   1 (default) 16-bit operand split.  On CDNA4 the fp32-input MFMA runs at 1/16 of the f16/bf16
  *      rate; a product of two 16-bit floats is exact in fp32 and the MFMA accumulates in fp32.
- *      - "f16x2", when the call carries both operands' abs-max (mi_gemm_amax_t): each operand is
- *        scaled by a power of two (largest magnitude -> [2^14, 2^15)) and split into fp16 high + low
- *        parts; three products per k-step (dropped terms <= 2^-21 |ab|);
- *      - "bf16x3" otherwise: three bf16 parts, six products (dropped <= 3*2^-24 |ab|), any input.
+ *      - "f16x2", mi_dense_bwd_weight[_gathered] only, when the call carries both operands' abs-max
+ *        (mi_gemm_amax_t): each operand is scaled by ONE power of two (largest magnitude -> [2^14, 2^15))
+ *        and split into fp16 high + low parts; three products per k-step (dropped terms <= 2^-21 |ab|).
+ *        A matrix-wide scale loses the low bits of rows far below the matrix abs-max — harmless where the
+ *        reduction runs over those rows (the weight gradient), not for a forward pass or a data gradient,
+ *        whose per-row form is mi_dense_fwd_planes / mi_dense_bwd_data_planes;
+ *      - "bf16x3" otherwise: three bf16 parts, six products (dropped <= 3*2^-24 |ab|), any input, no scale.
  *      Both measure the same max error against fp64 as the fp32-input MFMA on the layer shapes.
  *   0 "fp32": v_mfma_f32_32x32x2_f32 (exact fp32 products).
  * Operands that cannot be read as float4 (e.g. the N = 1 logits layer) always take path 0. */

@@ -610,7 +610,12 @@ int32_t launch(GemmArgs& a, int splits, hipStream_t st, const char* what) {
   }
   const dim3 g((unsigned)nblocks), b(kThreads);
   if (g_gemm_mode == 1 && a.vecA && a.vecB) {
-    if (a.amax_a && a.amax_b) {
+    // The f16x2 split scales an operand by ONE power of two (its abs-max): rows far below the matrix abs-max
+    // lose their low bits.  That is harmless only where the reduction runs over those rows — the weight
+    // gradient (both operands mn-contiguous: k = examples) — so only it takes the matrix-wide scales.  The
+    // forward pass and the data gradient take per-row exponents (mi_dense_fwd_planes / mi_dense_bwd_data_planes)
+    // or, through these any-shape entries, the scale-free bf16x3 split.
+    if (a.amax_a && a.amax_b && LA == MC && LB == MC) {
       // whole tiles, lane offsets that fit 32 bits, and (forward gather) k-tiles inside one field
       const bool whole = a.M % BM == 0 && a.N % BN == 0 && a.K % BK == 0 && a.k_per_split % BK == 0 &&
                          a.lda < (1 << 22) && a.ldb < (1 << 22) &&

@@ -106,6 +106,7 @@ __device__ __forceinline__ void st4_nt(float* p, float4 v) {
 // [B*F, E] gradient matrix is never written or re-read.
 struct FusedGrad {
   const float* d_concat; int64_t ldd; const float* sumv; const float* dlf; const float* dll; int F;
+  int64_t b0;        // d_concat / sumv / dlf / dll belong to examples b0.. of the batch (a chunk of a pipelined step)
 };
 
 // Segments longer than this are left to sparse_apply_long_k (a workgroup per row instead of a lane
@@ -119,6 +120,9 @@ struct ApplyArgs {
   const int32_t* uniq_rows; const int32_t* seg_start; const int32_t* sorted_entry; const int32_t* num_uniq;
   const float* d_rows; const float* d_lin;
   int E, step;
+  // STORE form (mi_entry_grads_segsum): the summed gradients of distinct requests u_begin .. u_begin + u_count
+  // are written to out_rows / out_lin instead of being applied; "row" u is slot u of the exchange buffer
+  float* out_rows; float* out_lin; int u_begin, u_count;
 };
 
 // sum of the gradients of entries sorted_entry[k_beg..k_end) of one row, in that order
@@ -129,8 +133,9 @@ __device__ __forceinline__ void seg_accumulate(const ApplyArgs& a, const FusedGr
   for (int k = k_beg; k < k_end; ++k) {
     const int64_t e = a.sorted_entry[k];
     if constexpr (FUSED) {
-      const int64_t b = e / fg.F;
-      const int f = static_cast<int>(e - b * fg.F);
+      const int64_t bg = e / fg.F;
+      const int f = static_cast<int>(e - bg * fg.F);
+      const int64_t b = bg - fg.b0;
       if (a.table && lane_on) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (fg.d_concat) v = ld4(fg.d_concat + b * fg.ldd + static_cast<int64_t>(f) * E + 4 * l);
@@ -194,21 +199,28 @@ __device__ __forceinline__ void apply_row(const ApplyArgs& a, const Hp& h, int64
 }
 
 // one lane group per unique row: duplicates summed in ascending entry order (TF's CPU order)
-template <int LPR, bool FUSED>
+__device__ __forceinline__ void store_row(const ApplyArgs& a, int64_t u, int l, bool lane_on, const float4& g, float gl) {
+  if (a.out_rows && lane_on) st4(a.out_rows + u * a.E + 4 * l, g);
+  if (a.out_lin && l == 0) a.out_lin[u] = gl;
+}
+
+template <int LPR, bool FUSED, bool STORE = false>
 __global__ __launch_bounds__(kBlock) void sparse_apply_k(const ApplyArgs a, const Hp h, const FusedGrad fg) {
-  const int64_t u = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) / LPR;
+  int64_t u = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) / LPR;
   const int l = threadIdx.x & (LPR - 1);
-  if (u >= *a.num_uniq) return;
+  if (u >= (STORE ? a.u_count : *a.num_uniq)) return;
+  if (STORE) u += a.u_begin;
   const int s_beg = a.seg_start[u], s_end = a.seg_start[u + 1];
   if (s_end - s_beg > kLongSeg) return;            // sparse_apply_long_k's
-  const int64_t r = a.uniq_rows[u];
+  const int64_t r = STORE ? u : static_cast<int64_t>(a.uniq_rows[u]);
   const bool lane_on = 4 * l < a.E;
   float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
   float gl = 0.f;
   float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
   if (a.table && lane_on) w = ld4(a.table + r * a.E + 4 * l);
   seg_accumulate<FUSED>(a, fg, s_beg, s_end, l, lane_on, w, g, gl);
-  apply_row(a, h, r, l, lane_on, w, g, gl);
+  if constexpr (STORE) store_row(a, u, l, lane_on, g, gl);
+  else apply_row(a, h, r, l, lane_on, w, g, gl);
 }
 
 // Rows with more than kLongSeg entries: a workgroup per row.  Workgroup j looks at the rows
@@ -216,14 +228,15 @@ __global__ __launch_bounds__(kBlock) void sparse_apply_k(const ApplyArgs a, cons
 // the long ones, and for each splits the segment into kBlock/LPR contiguous slices, one per lane
 // group, summed in order; the slice sums are then added in slice order.  A fixed order, so results
 // are reproducible; it differs from the one-pass order only in fp32 association.
-template <int LPR, bool FUSED>
+template <int LPR, bool FUSED, bool STORE = false>
 __global__ __launch_bounds__(kBlock) void sparse_apply_long_k(const ApplyArgs a, const Hp h, const FusedGrad fg) {
   constexpr int G = kBlock / LPR;
   __shared__ int list[kBlock];
   __shared__ int n_list;
   __shared__ float4 part[kBlock];                  // [G][LPR]
   __shared__ float part_l[G];
-  const int U = *a.num_uniq;
+  const int U = STORE ? a.u_count : *a.num_uniq;
+  const int ub = STORE ? a.u_begin : 0;
   const int t = threadIdx.x, l = t & (LPR - 1), grp = t / LPR;
   const bool lane_on = 4 * l < a.E;
   const int64_t per_round = static_cast<int64_t>(kBlock) * gridDim.x;
@@ -231,12 +244,12 @@ __global__ __launch_bounds__(kBlock) void sparse_apply_long_k(const ApplyArgs a,
     if (t == 0) n_list = 0;
     __syncthreads();
     const int64_t u = base + static_cast<int64_t>(t) * gridDim.x + blockIdx.x;
-    if (u < U && a.seg_start[u + 1] - a.seg_start[u] > kLongSeg) list[atomicAdd(&n_list, 1)] = static_cast<int>(u);
+    if (u < U && a.seg_start[ub + u + 1] - a.seg_start[ub + u] > kLongSeg) list[atomicAdd(&n_list, 1)] = static_cast<int>(ub + u);
     __syncthreads();
     const int n = n_list;
     for (int j = 0; j < n; ++j) {
       const int uu = list[j];
-      const int64_t r = a.uniq_rows[uu];
+      const int64_t r = STORE ? static_cast<int64_t>(uu) : static_cast<int64_t>(a.uniq_rows[uu]);
       const int s_beg = a.seg_start[uu], s_end = a.seg_start[uu + 1];
       const int per = (s_end - s_beg + G - 1) / G;
       const int k0 = min(s_end, s_beg + grp * per), k1 = min(s_end, k0 + per);
@@ -257,7 +270,8 @@ __global__ __launch_bounds__(kBlock) void sparse_apply_long_k(const ApplyArgs a,
           g.x += v.x; g.y += v.y; g.z += v.z; g.w += v.w;
           gl += part_l[q];
         }
-        apply_row(a, h, r, l, lane_on, w, g, gl);
+        if constexpr (STORE) store_row(a, uu, l, lane_on, g, gl);
+        else apply_row(a, h, r, l, lane_on, w, g, gl);
       }
       __syncthreads();
     }
@@ -548,7 +562,7 @@ int32_t mi_sparse_apply_fused(float* table, float* t_slot0, float* t_slot1, floa
   const int64_t blocks = mi::ceil_div(n_max * lpr, kBlock);
   MI_REQUIRE(blocks <= INT32_MAX, "sparse_apply_fused: grid too large");
   const Hp h = make_hp(hp);
-  const FusedGrad fg{d_concat, ld_dconcat, sumv, d_logit_fm, d_logit_lin, F};
+  const FusedGrad fg{d_concat, ld_dconcat, sumv, d_logit_fm, d_logit_lin, F, 0};
   const ApplyArgs a{table, t_slot0, t_slot1, lin_w, l_slot0, l_slot1, last_step, uniq_rows, seg_start, sorted_entry,
                     num_uniq, nullptr, nullptr, E, step};
   MI_DISPATCH_LPR(lpr, (sparse_apply_k<L, true><<<dim3((unsigned)blocks), dim3(kBlock), 0, mi::as_stream(stream)>>>(a, h, fg)));
@@ -556,6 +570,40 @@ int32_t mi_sparse_apply_fused(float* table, float* t_slot0, float* t_slot1, floa
   if (n_max > kLongSeg) {
     MI_DISPATCH_LPR(lpr, (sparse_apply_long_k<L, true><<<dim3(long_grid(n_max)), dim3(kBlock), 0, mi::as_stream(stream)>>>(a, h, fg)));
     MI_CHECK_LAUNCH("sparse_apply_fused(long segments)");
+  }
+  return MI_OK;
+}
+
+int32_t mi_entry_grads_segsum(const float* rows, const int32_t* seg_start, const int32_t* sorted_entry, int64_t u_begin,
+                              int64_t u_count, const float* d_concat, int64_t ld_dconcat, const float* sumv,
+                              const float* d_logit_fm, const float* d_logit_lin, int64_t b0, int32_t F, int32_t E,
+                              float* out_rows, float* out_lin, mi_stream_t stream) {
+  MI_REQUIRE(u_begin >= 0 && u_count >= 0 && u_begin + u_count <= INT32_MAX && F > 0 && b0 >= 0, "entry_grads_segsum: u_begin=%lld u_count=%lld",
+             (long long)u_begin, (long long)u_count);
+  if (u_count == 0) return MI_OK;
+  MI_REQUIRE(seg_start && sorted_entry && (out_rows || out_lin), "entry_grads_segsum: null buffer");
+  MI_REQUIRE(!out_rows || (E >= 4 && E <= 256 && (E & 3) == 0 && mi::aligned16(out_rows) && (d_concat || d_logit_fm)),
+             "entry_grads_segsum: row gradients need E multiple of 4 in [4,256] and d_concat and/or d_logit_fm");
+  MI_REQUIRE(!d_concat || (ld_dconcat >= (int64_t)F * E && (ld_dconcat & 3) == 0 && mi::aligned16(d_concat)),
+             "entry_grads_segsum: d_concat leading dimension / alignment");
+  MI_REQUIRE(!d_logit_fm || (sumv && rows && mi::aligned16(sumv) && mi::aligned16(rows)), "entry_grads_segsum: the FM gradient needs sumv and the rows");
+  MI_REQUIRE(!out_lin || d_logit_lin, "entry_grads_segsum: out_lin needs d_logit_lin");
+  const int lpr = out_rows ? lanes_per_row(E) : 1;
+  const int64_t blocks = mi::ceil_div(u_count * lpr, kBlock);
+  MI_REQUIRE(blocks <= INT32_MAX, "entry_grads_segsum: grid too large");
+  const FusedGrad fg{d_concat, ld_dconcat, sumv, d_logit_fm, d_logit_lin, F, b0};
+  ApplyArgs a{};
+  a.table = out_rows ? const_cast<float*>(rows) : nullptr;     // read only: w of d fm / d v = sumv - w
+  if (out_rows && !rows) a.table = out_rows;                    // (no FM term: w is never read; any valid pointer turns the row part on)
+  a.lin_w = out_lin ? out_lin : nullptr;                        // (non-null turns the linear part on; never read)
+  a.seg_start = seg_start; a.sorted_entry = sorted_entry;
+  a.E = E; a.out_rows = out_rows; a.out_lin = out_lin; a.u_begin = (int)u_begin; a.u_count = (int)u_count;
+  const Hp h{};
+  MI_DISPATCH_LPR(lpr, (sparse_apply_k<L, true, true><<<dim3((unsigned)blocks), dim3(kBlock), 0, mi::as_stream(stream)>>>(a, h, fg)));
+  MI_CHECK_LAUNCH("entry_grads_segsum");
+  if (u_count > 0) {
+    MI_DISPATCH_LPR(lpr, (sparse_apply_long_k<L, true, true><<<dim3(long_grid(u_count)), dim3(kBlock), 0, mi::as_stream(stream)>>>(a, h, fg)));
+    MI_CHECK_LAUNCH("entry_grads_segsum(long segments)");
   }
   return MI_OK;
 }

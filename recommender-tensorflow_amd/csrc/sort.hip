@@ -314,22 +314,45 @@ int32_t mi_sort_unique_rows(const int32_t* rows, int64_t n, int64_t num_rows_tot
 // ---- routing helpers of the row-sharded (multi-GPU) path ------------------------------------
 namespace {
 
-__global__ __launch_bounds__(kBlock) void shard_route_k(const int32_t* __restrict__ rows, int64_t n,
-                                                        int world, int64_t entries_per_chunk,
-                                                        int32_t* __restrict__ owner,
-                                                        int32_t* __restrict__ local_row) {
+// request key of entry i for row r: ((chunk * world + owner) * rows_per_rank + local row); sorting by it
+// (mi_sort_unique_rows) orders the entries by (chunk, owner, row) and its unique keys are the DISTINCT rows
+// a chunk needs from an owner: a row asked for by many entries of a batch crosses the link once.
+__global__ __launch_bounds__(kBlock) void shard_keys_k(const int32_t* __restrict__ rows, int64_t n, int world,
+                                                       int64_t entries_per_chunk, int64_t rows_per_rank,
+                                                       int32_t* __restrict__ keys) {
   const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
   if (i >= n) return;
   const int32_t r = rows[i];
-  const int32_t chunk = entries_per_chunk > 0 ? static_cast<int32_t>(i / entries_per_chunk) : 0;
-  owner[i] = chunk * world + r % world;
-  local_row[i] = r / world;
+  const int64_t chunk = entries_per_chunk > 0 ? i / entries_per_chunk : 0;
+  keys[i] = static_cast<int32_t>((chunk * world + r % world) * rows_per_rank + r / world);
 }
 
-__global__ __launch_bounds__(kBlock) void invert_perm_k(const int32_t* __restrict__ perm, int64_t n,
-                                                        int32_t* __restrict__ inv) {
-  const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
-  if (i < n) inv[perm[i]] = static_cast<int32_t>(i);
+// per distinct request u: the owner-local row to ask for, and the request counts per (chunk, owner) group
+__global__ __launch_bounds__(kBlock) void route_requests_k(const int32_t* __restrict__ uniq_keys,
+                                                           const int32_t* __restrict__ num_uniq, int64_t rows_per_rank,
+                                                           int32_t* __restrict__ send_rows, int32_t* __restrict__ counts) {
+  const int64_t u = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (u >= *num_uniq) return;
+  const int64_t key = uniq_keys[u];
+  const int64_t grp = key / rows_per_rank;
+  send_rows[u] = static_cast<int32_t>(key - grp * rows_per_rank);
+  atomicAdd(counts + grp, 1);
+}
+
+// slot[e] = index of the distinct request that entry e belongs to (binary search of the sorted position in
+// seg_start)
+__global__ __launch_bounds__(kBlock) void segment_slots_k(const int32_t* __restrict__ seg_start,
+                                                          const int32_t* __restrict__ sorted_entry,
+                                                          const int32_t* __restrict__ num_uniq, int64_t n,
+                                                          int32_t* __restrict__ slot) {
+  const int64_t k = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (k >= n) return;
+  int lo = 0, hi = *num_uniq;                      // largest u with seg_start[u] <= k
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (seg_start[mid] <= k) lo = mid; else hi = mid;
+  }
+  slot[sorted_entry[k]] = lo;
 }
 
 __global__ __launch_bounds__(kBlock) void gather_u32_k(const uint32_t* __restrict__ src,
@@ -343,22 +366,44 @@ __global__ __launch_bounds__(kBlock) void gather_u32_k(const uint32_t* __restric
 
 extern "C" {
 
-int32_t mi_shard_route(const int32_t* rows, int64_t n, int32_t world, int64_t entries_per_chunk, int32_t* owner,
-                       int32_t* local_row, mi_stream_t stream) {
-  MI_REQUIRE(n >= 0 && world > 0 && entries_per_chunk >= 0, "shard_route: n=%lld world=%d", (long long)n, world);
+int32_t mi_shard_keys(const int32_t* rows, int64_t n, int32_t world, int64_t entries_per_chunk, int64_t rows_per_rank,
+                      int32_t* keys, mi_stream_t stream) {
+  MI_REQUIRE(n >= 0 && world > 0 && entries_per_chunk >= 0 && rows_per_rank > 0, "shard_keys: n=%lld world=%d", (long long)n, world);
   if (n == 0) return MI_OK;
-  MI_REQUIRE(rows && owner && local_row, "shard_route: null buffer");
-  shard_route_k<<<dim3((unsigned)mi::ceil_div(n, kBlock)), dim3(kBlock), 0, mi::as_stream(stream)>>>(rows, n, world, entries_per_chunk, owner, local_row);
-  MI_CHECK_LAUNCH("shard_route");
+  MI_REQUIRE(rows && keys, "shard_keys: null buffer");
+  const int64_t chunks = entries_per_chunk > 0 ? mi::ceil_div(n, entries_per_chunk) : 1;
+  MI_REQUIRE(chunks * world * rows_per_rank <= INT32_MAX, "shard_keys: %lld chunks x %d ranks x %lld rows per rank does not fit an int32 key",
+             (long long)chunks, world, (long long)rows_per_rank);
+  shard_keys_k<<<dim3((unsigned)mi::ceil_div(n, kBlock)), dim3(kBlock), 0, mi::as_stream(stream)>>>(rows, n, world, entries_per_chunk,
+                                                                                                   rows_per_rank, keys);
+  MI_CHECK_LAUNCH("shard_keys");
   return MI_OK;
 }
 
-int32_t mi_invert_perm(const int32_t* perm, int64_t n, int32_t* inv, mi_stream_t stream) {
-  MI_REQUIRE(n >= 0, "invert_perm: n=%lld", (long long)n);
+int32_t mi_route_requests(const int32_t* uniq_keys, const int32_t* num_uniq, int64_t n_max, int64_t rows_per_rank,
+                          int32_t n_groups, int32_t* send_rows, int32_t* counts, mi_stream_t stream) {
+  MI_REQUIRE(n_max >= 0 && rows_per_rank > 0 && n_groups > 0, "route_requests: n_max=%lld", (long long)n_max);
+  MI_REQUIRE(counts, "route_requests: null counts");
+  hipStream_t st = mi::as_stream(stream);
+  if (hipMemsetAsync(counts, 0, sizeof(int32_t) * n_groups, st) != hipSuccess) {
+    mi::set_error("route_requests: memset failed");
+    return MI_ERR_LAUNCH;
+  }
+  if (n_max == 0) return MI_OK;
+  MI_REQUIRE(uniq_keys && num_uniq && send_rows, "route_requests: null buffer");
+  route_requests_k<<<dim3((unsigned)mi::ceil_div(n_max, kBlock)), dim3(kBlock), 0, st>>>(uniq_keys, num_uniq, rows_per_rank, send_rows, counts);
+  MI_CHECK_LAUNCH("route_requests");
+  return MI_OK;
+}
+
+int32_t mi_segment_slots(const int32_t* seg_start, const int32_t* sorted_entry, const int32_t* num_uniq, int64_t n,
+                         int32_t* slot_of_entry, mi_stream_t stream) {
+  MI_REQUIRE(n >= 0, "segment_slots: n=%lld", (long long)n);
   if (n == 0) return MI_OK;
-  MI_REQUIRE(perm && inv, "invert_perm: null buffer");
-  invert_perm_k<<<dim3((unsigned)mi::ceil_div(n, kBlock)), dim3(kBlock), 0, mi::as_stream(stream)>>>(perm, n, inv);
-  MI_CHECK_LAUNCH("invert_perm");
+  MI_REQUIRE(seg_start && sorted_entry && num_uniq && slot_of_entry, "segment_slots: null buffer");
+  segment_slots_k<<<dim3((unsigned)mi::ceil_div(n, kBlock)), dim3(kBlock), 0, mi::as_stream(stream)>>>(seg_start, sorted_entry, num_uniq, n,
+                                                                                                      slot_of_entry);
+  MI_CHECK_LAUNCH("segment_slots");
   return MI_OK;
 }
 

@@ -70,15 +70,17 @@ SIGNATURES = {
     "mi_numeric_raw_bwd_workspace_bytes": (_sz, [_i64, _i32]),
     "mi_numeric_raw_bwd": (_i32, [_p, _p, _i64, _i32, _p, _p, _sz, _p]),
     "mi_embed_fm_linear_bwd": (_i32, [_p, _i64, _p, _i64, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p, _p, _p]),
+    "mi_entry_grads_segsum": (_i32, [_p, _p, _p, _i64, _i64, _p, _i64, _p, _p, _p, _i64, _i32, _i32, _p, _p, _p]),
     "mi_numeric_embed_bwd_workspace_bytes": (_sz, [_i64, _i32, _i32]),
     "mi_numeric_embed_bwd": (_i32, [_p, _p, _i64, _p, _i64, _i64, _p, _p, _p, _i64, _i32, _i32, _p,
                                     _p, _p, _sz, _p]),
     "mi_sort_unique_workspace_bytes": (_sz, [_i64]),
     "mi_sort_unique_rows": (_i32, [_p, _i64, _i64, _p, _p, _p, _p, _p, _sz, _p]),
     "mi_global_rows": (_i32, [_p, _p, _i64, _i32, _p, _p]),
-    "mi_shard_route": (_i32, [_p, _i64, _i32, _i64, _p, _p, _p]),
+    "mi_shard_keys": (_i32, [_p, _i64, _i32, _i64, _i64, _p, _p]),
+    "mi_route_requests": (_i32, [_p, _p, _i64, _i64, _i32, _p, _p, _p]),
+    "mi_segment_slots": (_i32, [_p, _p, _p, _i64, _p, _p]),
     "mi_axpy": (_i32, [_p, _p, _i64, _f32, _p]),
-    "mi_invert_perm": (_i32, [_p, _i64, _p, _p]),
     "mi_gather_u32": (_i32, [_p, _p, _i64, _p, _p]),
     "mi_dense_apply": (_i32, [_p, _p, _p, _p, _i64, C.POINTER(OptHparams), _p]),
     "mi_sparse_apply": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _p, _i32, _i32,

@@ -38,9 +38,9 @@ class LinearClassifier(Estimator):
         opt = optimizer or OptimizerSpec("Ftrl", _linear_lr(len(cat) + len(num)))
 
         def model_fn(features, labels, mode, params):
-            return run_batch(features, labels, mode, params, lambda plan, dev: DeepFM(
+            return run_batch(features, labels, mode, params, lambda plan, dev, shard=None: DeepFM(
                 plan.vocab_sizes, n_numeric=len(plan.numeric), numeric="raw", use_linear=True, use_mf=False,
-                use_dnn=False, optimizer=opt, reduction="sum", device=dev))
+                use_dnn=False, optimizer=opt, reduction="sum", device=dev, shard=shard))
         super().__init__(model_fn, model_dir, config, {"categorical_columns": cat, "numeric_columns": num,
                                                        "tf_model": "linear"})
 
@@ -53,10 +53,10 @@ class DNNClassifier(Estimator):
         hidden = list(hidden_units)
 
         def model_fn(features, labels, mode, params):
-            return run_batch(features, labels, mode, params, lambda plan, dev: DeepFM(
+            return run_batch(features, labels, mode, params, lambda plan, dev, shard=None: DeepFM(
                 plan.vocab_sizes, n_numeric=len(plan.numeric), numeric="raw", embedding_size=E, hidden_units=hidden,
                 use_linear=False, use_mf=False, use_dnn=True, dropout=dropout or 0.0, optimizer=opt, reduction="sum",
-                device=dev))
+                device=dev, shard=shard))
         super().__init__(model_fn, model_dir, config, {"categorical_columns": cat, "numeric_columns": num,
                                                        "tf_model": "dnn"})
 
@@ -80,12 +80,12 @@ class DNNLinearCombinedClassifier(Estimator):
         hidden = list(dnn_hidden_units or [])
 
         def model_fn(features, labels, mode, params):
-            return run_batch(features, labels, mode, params, lambda plan, dev: DeepFM(
+            return run_batch(features, labels, mode, params, lambda plan, dev, shard=None: DeepFM(
                 plan.vocab_sizes, n_numeric=len(plan.numeric), numeric="raw", embedding_size=E, hidden_units=hidden,
                 use_linear=bool(lin_all), use_mf=False, use_dnn=bool(dnn_all), dropout=dnn_dropout or 0.0, optimizer=d_opt,
-                linear_optimizer=l_opt if (lin_all and dnn_all) else None, reduction="sum", device=dev)
+                linear_optimizer=l_opt if (lin_all and dnn_all) else None, reduction="sum", device=dev, shard=shard)
                 if dnn_all else DeepFM(
                 plan.vocab_sizes, n_numeric=len(plan.numeric), numeric="raw", use_linear=True, use_mf=False, use_dnn=False,
-                optimizer=l_opt, reduction="sum", device=dev))
+                optimizer=l_opt, reduction="sum", device=dev, shard=shard))
         super().__init__(model_fn, model_dir, config, {"categorical_columns": lin or dnn, "numeric_columns": lin_num or dnn_num,
                                                        "tf_model": "dnn_linear_combined"})

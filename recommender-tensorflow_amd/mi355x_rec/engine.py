@@ -288,9 +288,10 @@ class DeepFM:
         # concat [B, F*E] is never materialised.
         self.gather_mlp = self.use_dnn and self.n_numeric == 0 and self.F > 0
         # Matrix-pipe path of the MLP GEMMs (all: fp32 in, fp32 accumulate, fp32-level error):
-        #   "f16x2"  operands scaled by a power of two and split into fp16 high + low parts, three
-        #            products per k-step; every kernel that produces a GEMM operand also emits its
-        #            abs-max (self._amax), so the scales cost no extra pass;
+        #   "f16x2"  operands as fp16 high + low parts, three products per k-step: forward and data gradient
+        #            on pre-split planes with one exponent per ROW (self.planes, below; layers whose widths
+        #            are not multiples of 16 fall back to bf16x3), the weight gradient on the fp32 copies
+        #            with one exponent per matrix from abs-max vectors the producers emit (self._amax);
         #   "bf16x3" three bf16 parts, six products, no scales;   "fp32"  fp32-input MFMA.
         if gemm not in ("f16x2", "bf16x3", "fp32"):
             raise ValueError("gemm must be 'f16x2', 'bf16x3' or 'fp32'")

@@ -9,8 +9,9 @@ Differences from TensorFlow that matter to a user switching over:
   * checkpoints are ``model.ckpt-<step>.pt`` (torch.save of engine.state_dict()), newest
     ``keep_checkpoint_max`` kept, listed in ``checkpoint.json``; a TF-checkpoint importer would map
     the variable names of SURVEY A.8;
-  * local mode only: multi-GPU runs launch one process per GPU (torch.distributed.run) instead of
-    TF_CONFIG parameter servers (distributed.md:58-82).
+  * multi-GPU runs launch one process per GPU (torch.distributed.run; trainers/_cli.py reads RANK /
+    WORLD_SIZE) instead of TF_CONFIG parameter servers (distributed.md:58-82): synchronous steps, row-
+    sharded tables, per-rank checkpoint files.
 """
 import collections
 import glob
@@ -91,12 +92,25 @@ class Estimator:
         return self.params["_store"].get("engine")
 
     @property
+    def _shard(self):
+        return self.params.get("_shard")
+
+    @property
+    def _rank_tag(self):
+        """multi-GPU: every rank keeps its own shard of the tables (+ the replicated dense variables)"""
+        return "" if self._shard is None else ".rank%d" % self._shard.rank
+
+    @property
+    def is_chief(self):
+        return self._shard is None or self._shard.rank == 0
+
+    @property
     def global_step(self):
         e = self._engine()
         return e.step if e is not None else 0
 
     def latest_checkpoint(self):
-        idx = os.path.join(self.model_dir, "checkpoint.json")
+        idx = os.path.join(self.model_dir, "checkpoint%s.json" % self._rank_tag)
         if not os.path.exists(idx):
             return None
         with open(idx) as f:
@@ -110,7 +124,8 @@ class Estimator:
         ck = self.latest_checkpoint()
         if ck:
             self._engine().load_state_dict(torch.load(ck, weights_only=True))
-            print("INFO: restored %s (global_step %d)" % (ck, self.global_step))
+            if self.is_chief:
+                print("INFO: restored %s (global_step %d)" % (ck, self.global_step))
         elif self.warm_start_from:
             import numpy as np
             from . import tf_names
@@ -123,9 +138,9 @@ class Estimator:
 
     def save_checkpoint(self):
         os.makedirs(self.model_dir, exist_ok=True)
-        name = "model.ckpt-%d.pt" % self.global_step
+        name = "model.ckpt-%d%s.pt" % (self.global_step, self._rank_tag)
         torch.save(self._engine().state_dict(), os.path.join(self.model_dir, name))
-        idx = os.path.join(self.model_dir, "checkpoint.json")
+        idx = os.path.join(self.model_dir, "checkpoint%s.json" % self._rank_tag)
         files = []
         if os.path.exists(idx):
             with open(idx) as f:
@@ -173,7 +188,7 @@ class Estimator:
             loss = spec.loss
             done += 1
             n_log += 1
-            if self.global_step % self.config.log_step_count_steps == 0:
+            if self.global_step % self.config.log_step_count_steps == 0 and self.is_chief:
                 now = time.time()
                 print("INFO: loss = %.6f, step = %d (%.1f global_step/sec)" %
                       (float(loss), self.global_step, n_log / max(now - t_log, 1e-9)))
@@ -204,7 +219,8 @@ class Estimator:
                 break
         out = store["metrics_result"]() if n else {}
         out["global_step"] = self.global_step
-        print("INFO: Saving dict for global step %d: %s" % (self.global_step, ", ".join(
+        if self.is_chief:
+            print("INFO: Saving dict for global step %d: %s" % (self.global_step, ", ".join(
             "%s = %.6g" % (k, v) for k, v in sorted(out.items()))))
         return out
 
@@ -239,7 +255,7 @@ def train_and_evaluate(estimator, train_spec, eval_spec):
         state["last_eval"], state["evaluated_step"] = now, estimator.global_step
         estimator.evaluate(eval_spec.input_fn, steps=eval_spec.steps)
         exporters = eval_spec.exporters
-        if exporters is not None:
+        if exporters is not None and estimator.is_chief:      # (multi-GPU: rank 0's shard + the dense variables)
             for ex in (exporters if isinstance(exporters, (list, tuple)) else [exporters]):
                 ex.export(estimator, os.path.join(estimator.model_dir, "export"))
     estimator.train(train_spec.input_fn, max_steps=train_spec.max_steps, on_checkpoint=after_checkpoint)

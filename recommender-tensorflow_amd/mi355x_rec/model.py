@@ -39,10 +39,14 @@ def run_batch(features, labels, mode, params, make_engine):
         plan = FieldPlan(params.get("categorical_columns", []), params.get("numeric_columns", []))
         device = params.get("device", "cuda")
         store["plan"] = plan
-        eng = store["engine"] = make_engine(plan, device)
+        shard = params.get("_shard")           # parallel.RowShard of a multi-GPU launch (trainers/_cli.py), else None
+        eng = store["engine"] = make_engine(plan, device, shard) if shard is not None else make_engine(plan, device)
         gen = torch.Generator(device=eng.device)
-        gen.manual_seed(int(params.get("seed", 0)))
+        gen.manual_seed(int(params.get("seed", 0)) + (0 if shard is None else 7919 * shard.rank))
         eng.init_variables(gen)                # TF initialisers; a checkpoint restore overrides
+        if shard is not None:
+            from .parallel import broadcast_dense
+            broadcast_dense(eng)               # the replicated MLP starts identical on every rank
         store["counters"] = None
     if mode == "_build":
         return None
@@ -55,11 +59,16 @@ def run_batch(features, labels, mode, params, make_engine):
     if labels is not None:
         y = torch.from_numpy(np.ascontiguousarray(np.asarray(labels).reshape(-1)).astype(np.uint8)).to(dev)
 
+    # multi-GPU: a rank's loss is its SHARE of the global-batch mean (already divided by the global batch); times
+    # world = the mean over its own examples — what is logged, and, with every rank evaluating the same batches,
+    # the eval loss
+    rescale = (lambda l: l * float(eng.shard.world)) if (eng.shard is not None and eng.reduction == "mean") else (lambda l: l)
     if mode == ModeKeys.TRAIN:
         loss, logits = eng.train_step(ids, y, x)
-        return EstimatorSpec(mode, predictions=None, loss=loss, train_op=eng.step)
+        return EstimatorSpec(mode, predictions=None, loss=rescale(loss), train_op=eng.step)
     if mode == ModeKeys.EVAL:
         loss, logits = eng.loss(ids, y, x)
+        loss = rescale(loss)
         if store["counters"] is None:
             store["counters"] = _EvalCounters(dev)
         ctr = store["counters"]

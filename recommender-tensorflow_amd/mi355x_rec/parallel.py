@@ -10,9 +10,11 @@ synchronous and mapped onto xGMI:
                 the concatenated batch)
   table rows    row r lives on rank r % world (interleaved: Zipf heads spread evenly) at local
                 index r // world, together with its optimizer slots and Adam step stamp
-  forward       ids -> owners (all_to_all) ; owners gather rows ; rows -> requesters (all_to_all)
-  backward      per-entry row gradients -> owners (all_to_all) = the sparse "reduce-scatter";
-                owners sum duplicates and apply the optimizer locally
+  forward       DISTINCT row requests -> owners (all_to_all) ; owners gather rows ; rows -> requesters
+                (all_to_all): a row many entries of a batch ask for (skewed ids) crosses the link once
+  backward      requesters sum the entry gradients of each distinct request, then gradient rows -> owners
+                (all_to_all) = the sparse "reduce-scatter"; owners sum over requesters and apply the
+                optimizer locally.  Volumes are U_local x E, not B F x E.
   dense grads   one flat buffer, one all_reduce(SUM); every rank applies the same update
   pipelining    a train step splits its local batch into chunks: while chunk c runs forward and
                 backward, the rows of chunk c+1 and the row gradients of chunk c-1 are on the
@@ -51,16 +53,20 @@ class Comm:
         self.rank = dist.get_rank(group)
         self.direct = dist.get_backend(group) == "nccl"   # RCCL: device tensors go straight in
 
-    def exchange_counts(self, send_counts, device):
-        """send_counts[c][j] entries of chunk c go to rank j -> recv_counts[c][j] arrive from rank j
-        (host ints; one small all_to_all and one device->host copy per step)."""
-        C = len(send_counts)
-        flat = [send_counts[c][j] for j in range(self.world) for c in range(C)]      # [dest rank][chunk]
-        t = torch.tensor(flat, dtype=torch.int64, device=device if self.direct else "cpu")
-        out = torch.empty_like(t)
-        dist.all_to_all_single(out, t, group=self.group)
-        o = out.tolist()
-        return [[int(o[j * C + c]) for j in range(self.world)] for c in range(C)]
+    def exchange_counts(self, counts_dev, C):
+        """counts_dev [C * world] int32 (device): distinct requests of chunk c for rank j at c * world + j.
+        One small all_to_all on the device buffers, then ONE device->host copy of both tables (the split
+        sizes of all_to_all_single must be host integers): (send_counts[c][j], recv_counts[c][j])."""
+        W = self.world
+        send = counts_dev.view(C, W).t().contiguous().view(-1).to(torch.int64)       # [dest rank][chunk]
+        if not self.direct:
+            send = send.cpu()
+        recv = torch.empty_like(send)
+        dist.all_to_all_single(recv, send, group=self.group)
+        both = torch.stack([send, recv]).cpu().tolist()                                # the step's one host sync
+        sc = [[int(both[0][j * C + c]) for j in range(W)] for c in range(C)]
+        rc = [[int(both[1][j * C + c]) for j in range(W)] for c in range(C)]
+        return sc, rc
 
     def all_to_all(self, out, inp, out_counts, in_counts, async_op=False):
         """Rows (dim 0) of `inp`, split by in_counts, go to the ranks; `out` receives out_counts rows.
@@ -129,33 +135,29 @@ def _n_chunks(m, B, train):
 
 
 def _route(m, ids, C):
-    """Plan the exchange for this batch, C chunks of B/C examples.  Entry (b,f) travels in slot
-    pos[b*F+f] of the send buffer, which is ordered by (chunk, owner rank): chunk c owns the slots
-    [c*n/C, (c+1)*n/C).  Returns (pos, send_ids, send_counts[c][rank], recv_counts[c][rank])."""
+    """Plan the exchange for this batch, C chunks of B/C examples.  The entries are sorted by request key
+    (chunk, owner, owner-local row); the DISTINCT keys are the requests that travel, in send order.  Returns
+    (slot [B*F]: distinct request of every entry = slot of its row in the receive buffer, send_rows [U]: the
+    owner-local rows to ask for, the sort's (sorted_entry, seg_start) over the entries, send_counts[c][rank],
+    recv_counts[c][rank])."""
     k, sh = m.k, m.shard
     comm = _comm(m)
     i32 = torch.int32
     B = ids.shape[0]
     n = B * m.F
+    Rl = (m.R + sh.world - 1) // sh.world                     # rows per rank (upper bound): the key's row range
     rows = m._buf("rows", (n,), i32)
     k.mi_global_rows(ids, m.field_off, B, m.F, rows)
-    key = m._buf("route_owner", (n,), i32)
-    local = m._buf("route_local", (n,), i32)
-    k.mi_shard_route(rows, n, sh.world, (n // C) if C > 1 else 0, key, local)
-    order, present, seg, npresent = m._sort_unique(key, n, sh.world * C, "route")   # stable partition by (chunk, owner)
-    send_ids = m._buf("send_ids", (n,), i32)
-    k.mi_gather_u32(local, order, n, send_ids)
-    pos = m._buf("route_pos", (n,), i32)
-    k.mi_invert_perm(order, n, pos)
-    # split sizes must be host integers: one small device->host copy per step
-    npres = int(npresent.item())
-    pres = present[:npres].tolist()
-    segs = seg[:npres + 1].tolist()
-    send_counts = [[0] * sh.world for _ in range(C)]
-    for j, key_j in enumerate(pres):
-        send_counts[key_j // sh.world][key_j % sh.world] = segs[j + 1] - segs[j]
-    recv_counts = comm.exchange_counts(send_counts, m.device)
-    return pos, send_ids, send_counts, recv_counts
+    key = m._buf("route_key", (n,), i32)
+    k.mi_shard_keys(rows, n, sh.world, (n // C) if C > 1 else 0, Rl, key)
+    sorted_entry, uniq, seg, num_uniq = m._sort_unique(key, n, C * sh.world * Rl, "route")
+    send_rows = m._buf("send_rows", (n,), i32)
+    counts = m._buf("route_counts", (C * sh.world,), i32)
+    k.mi_route_requests(uniq, num_uniq, n, Rl, C * sh.world, send_rows, counts)
+    slot = m._buf("route_slot", (n,), i32)
+    k.mi_segment_slots(seg, sorted_entry, num_uniq, n, slot)
+    send_counts, recv_counts = comm.exchange_counts(counts, C)
+    return slot, send_rows, sorted_entry, seg, send_counts, recv_counts
 
 
 def _zero_off(m):
@@ -177,19 +179,24 @@ def _sharded_step(m, ids, labels, x_num, train):
     n = B * F
     C = _n_chunks(m, B, train)
     Bc = B // C
-    nc = Bc * F                                         # entries (= send slots) per chunk
-    pos, send_ids, send_counts, recv_counts = _route(m, ids, C)
+    slot, send_rows, sorted_entry, seg, send_counts, recv_counts = _route(m, ids, C)
+    nsc = [sum(sc) for sc in send_counts]               # distinct requests of chunk c (all owners)
+    uoff = [0]
+    for v in nsc:
+        uoff.append(uoff[-1] + v)
+    U = uoff[-1]
     nrc = [sum(rc) for rc in recv_counts]
     roff = [0]
     for v in nrc:
         roff.append(roff[-1] + v)
     nr = roff[-1]
+    m.last_exchange = {"entries": n, "requests_sent": U, "requests_received": nr}    # (tests / bench: the dedup's effect)
 
-    # ids to their owners (small), then the owners' bookkeeping for the WHOLE step: which rows are
+    # requests to their owners (small), then the owners' bookkeeping for the WHOLE step: which rows are
     # touched, and TF Adam's catch-up on them before any of them is read
     recv_ids = m._buf("recv_ids", (max(nr, 1),), i32)[:nr]
     for c in range(C):
-        comm.all_to_all(recv_ids[roff[c]:roff[c + 1]], send_ids[c * nc:(c + 1) * nc], recv_counts[c], send_counts[c])
+        comm.all_to_all(recv_ids[roff[c]:roff[c + 1]], send_rows[uoff[c]:uoff[c + 1]], recv_counts[c], send_counts[c])
     book = None
     if train and nr > 0:
         book = m._sort_unique(recv_ids, nr, m.R_local, "own")     # (sorted_entry, uniq, seg, num_uniq)
@@ -198,8 +205,8 @@ def _sharded_step(m, ids, labels, x_num, train):
 
     own_rows = m._buf("own_rows", (max(nr, 1), E))[:nr] if m.use_emb else None
     own_lin = m._buf("own_lin", (max(nr, 1),))[:nr] if m.use_linear else None
-    got_rows = m._buf("got_rows", (n, E)) if m.use_emb else None
-    got_lin = m._buf("got_lin", (n,)) if m.use_linear else None
+    got_rows = m._buf("got_rows", (max(U, 1), E)) if m.use_emb else None
+    got_lin = m._buf("got_lin", (max(U, 1),)) if m.use_linear else None
 
     def serve(c):
         """owners gather chunk c's rows and send them back; returns the exchange handles"""
@@ -208,21 +215,21 @@ def _sharded_step(m, ids, labels, x_num, train):
         if m.use_emb:
             k.mi_gather_rows(m.table, m.lin_w if m.use_linear else None, recv_ids[lo:hi], hi - lo, E, own_rows[lo:hi],
                              own_lin[lo:hi] if m.use_linear else None)
-            hs.append(comm.all_to_all(got_rows[c * nc:(c + 1) * nc], own_rows[lo:hi], send_counts[c], recv_counts[c], True))
+            hs.append(comm.all_to_all(got_rows[uoff[c]:uoff[c + 1]], own_rows[lo:hi], send_counts[c], recv_counts[c], True))
         elif m.use_linear:
             k.mi_gather_u32(m.lin_w, recv_ids[lo:hi], hi - lo, own_lin[lo:hi])
         if m.use_linear:
-            hs.append(comm.all_to_all(got_lin[c * nc:(c + 1) * nc], own_lin[lo:hi], send_counts[c], recv_counts[c], True))
+            hs.append(comm.all_to_all(got_lin[uoff[c]:uoff[c + 1]], own_lin[lo:hi], send_counts[c], recv_counts[c], True))
         return hs
 
-    d_rows = m._buf("d_rows", (n, E)) if (train and m.use_emb) else None           # send (chunk, owner) order
-    d_lin = m._buf("d_lin", (n,)) if (train and m.use_linear) else None
+    d_rows = m._buf("d_rows", (max(U, 1), E)) if (train and m.use_emb) else None      # one row per distinct request, send order
+    d_lin = m._buf("d_lin", (max(U, 1),)) if (train and m.use_linear) else None
     r_rows = m._buf("recv_d_rows", (max(nr, 1), E))[:nr] if (train and m.use_emb) else None
     r_lin = m._buf("recv_d_lin", (max(nr, 1),))[:nr] if (train and m.use_linear) else None
     logits_all = m._buf("logits_all", (B,)) if C > 1 else None
     loss_all = m._buf("loss_all", (1,)) if C > 1 else None
     acc = m._buf("d_grad_acc", (m.P,)) if (train and C > 1) else None
-    pos2 = pos.view(B, F)
+    slot2 = slot.view(B, F)
     zero_off = _zero_off(m)
 
     rows_h = serve(0)
@@ -234,7 +241,7 @@ def _sharded_step(m, ids, labels, x_num, train):
         rows_h = nxt
         sl = slice(c * Bc, (c + 1) * Bc)
         m._chunk = c
-        cc = m._forward(ids[sl], None if x_num is None else x_num[sl], train, (got_rows, got_lin, zero_off, pos2[sl]))
+        cc = m._forward(ids[sl], None if x_num is None else x_num[sl], train, (got_rows, got_lin, zero_off, slot2[sl]))
         logits, loss, dlogit = m._head(cc, None if labels is None else labels[sl], train, global_batch=B * m.shard.world)
         if C > 1:
             logits_all[sl].copy_(logits)
@@ -251,12 +258,18 @@ def _sharded_step(m, ids, labels, x_num, train):
                 acc.copy_(m.d_grad)
             else:
                 k.mi_axpy(acc, m.d_grad, m.P, 1.0)
-        m._entry_grads(cc, d_concat, dlogit, pos2[sl], d_rows, d_lin)      # written at their send slots
+        # the chunk's entry gradients summed per distinct request, written at the request's send slot
+        ulo, uhi = uoff[c], uoff[c + 1]
+        if uhi > ulo:
+            k.mi_entry_grads_segsum(got_rows if m.use_mf else None, seg, sorted_entry, ulo, uhi - ulo,
+                                    d_concat if m.use_emb else None, m.D, cc["sumv"] if m.use_mf else None,
+                                    dlogit if m.use_mf else None, dlogit if m.use_linear else None, c * Bc, F, E,
+                                    d_rows, d_lin)
         lo, hi = roff[c], roff[c + 1]
         if m.use_emb:
-            grad_h.append(comm.all_to_all(r_rows[lo:hi], d_rows[c * nc:(c + 1) * nc], recv_counts[c], send_counts[c], True))
+            grad_h.append(comm.all_to_all(r_rows[lo:hi], d_rows[ulo:uhi], recv_counts[c], send_counts[c], True))
         if m.use_linear:
-            grad_h.append(comm.all_to_all(r_lin[lo:hi], d_lin[c * nc:(c + 1) * nc], recv_counts[c], send_counts[c], True))
+            grad_h.append(comm.all_to_all(r_lin[lo:hi], d_lin[ulo:uhi], recv_counts[c], send_counts[c], True))
     m._chunk = 0
     if C > 1:
         logits, loss = logits_all, (loss_all if loss is not None else None)
@@ -267,8 +280,8 @@ def _sharded_step(m, ids, labels, x_num, train):
     comm.all_reduce(m.d_grad)                                   # dense gradients: SUM over ranks
     _wait(grad_h)
     if book is not None:
-        sorted_entry, uniq, seg, num_uniq = book
-        m._apply(uniq, seg, sorted_entry, num_uniq, nr, r_rows, r_lin)
+        bs_entry, buniq, bseg, bnum = book
+        m._apply(buniq, bseg, bs_entry, bnum, nr, r_rows, r_lin)
     else:
         m._apply(None, None, None, None, 0, None, None)
     return loss, logits

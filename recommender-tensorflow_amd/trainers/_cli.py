@@ -1,5 +1,6 @@
 """Shared argument table and run loop of the four trainer CLIs (flags and defaults of the
 reference: trainers/deep_fm.py:182-207, linear.py:50-65, deep.py:54-73, linear_deep.py:55-74)."""
+import os
 import shutil
 from argparse import ArgumentParser
 
@@ -18,6 +19,11 @@ _COMMON = [
     ("--device", dict(default="cuda", help="torch device of the MI355X to run on (default: %(default)s)")),
     ("--warm-start-from", dict(default=None, help=".npz of TensorFlow-named variables (a dumped TF-1.12 checkpoint of "
                                                    "the reference) to start from when job_dir has no checkpoint")),
+    ("--world-size", dict(type=int, default=None, help="number of MI355X (one process each): launch with `python -m "
+                                                       "torch.distributed.run --nproc-per-node N -m trainers.<model> ...`; the flag "
+                                                       "only checks the launch (default: WORLD_SIZE of the launcher, else 1)")),
+    ("--synthetic", dict(type=int, default=None, metavar="N", help="train on N generated MovieLens-shaped examples (and evaluate on "
+                                                                   "N/10) instead of --train-csv / --test-csv")),
 ]
 _OPTIONAL = {
     "hidden_units": ("--hidden-units", dict(type=int, nargs="+", default=[16, 16],
@@ -40,17 +46,55 @@ def make_parser(model, extra=()):
     return p
 
 
+def init_distributed(args):
+    """One process per GPU (torch.distributed.run sets RANK / LOCAL_RANK / WORLD_SIZE; the reference's multi-worker
+    mode is TF_CONFIG parameter servers, distributed.md:58-82).  Returns (rank, world, device, shard).  Runs before any
+    GPU work: the process group and the device choice come first, nothing is re-executed afterwards."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if getattr(args, "world_size", None) not in (None, world):
+        raise SystemExit("--world-size %d but the launcher started %d process(es): use python -m torch.distributed.run "
+                         "--nproc-per-node %d -m trainers.<model> ..." % (args.world_size, world, args.world_size))
+    device = getattr(args, "device", "cuda")
+    if world == 1:
+        return 0, 1, device, None
+    import torch
+    import torch.distributed as dist
+    from mi355x_rec.parallel import RowShard
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if device.startswith("cuda"):
+        device = "cuda:%d" % local
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device(device))
+    else:
+        dist.init_process_group("gloo")
+    return rank, world, device, RowShard(rank, world)
+
+
 def run(args, make_estimator):
     """Common body of train_and_evaluate(args): wipe job_dir unless --restore, build the estimator
-    from the MovieLens feature columns, train with periodic eval + export."""
-    if not args.restore:
+    from the MovieLens feature columns, train with periodic eval + export.  With N processes (one per GPU) the
+    embedding tables are row-sharded, every rank trains on its own shuffled stream of --batch-size examples
+    (global batch N x batch size, synchronous), all ranks evaluate the same test batches, and rank r keeps its
+    shard in model.ckpt-<step>.rank<r>.pt."""
+    rank, world, device, shard = init_distributed(args)
+    if getattr(args, "synthetic", None):
+        args.train_csv, args.test_csv = "synthetic:%d:1" % args.synthetic, "synthetic:%d:2" % max(args.synthetic // 10, 1)
+    if not args.restore and rank == 0:
         shutil.rmtree(args.job_dir, ignore_errors=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
     columns = get_feature_columns(embedding_size=args.embedding_size)
     config = get_run_config()
-    config.device = getattr(args, "device", "cuda")
+    config.device = device
     estimator = make_estimator(columns, config)
     estimator.warm_start_from = getattr(args, "warm_start_from", None)
-    train_spec = get_train_spec(get_input_fn(args.train_csv, batch_size=args.batch_size), args.train_steps)
+    estimator.params["_shard"] = shard
+    train_spec = get_train_spec(get_input_fn(args.train_csv, batch_size=args.batch_size, seed=rank if world > 1 else None),
+                                args.train_steps)
     eval_spec = get_eval_spec(get_input_fn(args.test_csv, ModeKeys.EVAL, batch_size=args.batch_size),
                               get_exporter(serving_input_fn))
     return _tae(estimator, train_spec, eval_spec)

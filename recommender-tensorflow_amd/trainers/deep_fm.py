@@ -25,12 +25,12 @@ def model_fn(features, labels, mode, params):
     if activation not in ("relu", None) and getattr(activation, "__name__", "") != "relu":
         raise NotImplementedError("the fused GEMM epilogue implements relu (the reference default)")
 
-    def make(plan, device):
+    def make(plan, device, shard=None):
         opt = get_optimizer(params.get("optimizer", "Adam"), params.get("learning_rate", 0.001))
         return DeepFM(plan.vocab_sizes, n_numeric=len(plan.numeric), embedding_size=params.get("embedding_size", 4),
                       hidden_units=params.get("hidden_units", [16, 16]), use_linear=flags[0], use_mf=flags[1],
                       use_dnn=flags[2], dropout=params.get("dropout", 0), optimizer=opt, reduction="mean",
-                      device=device, seed=params.get("seed", 0))
+                      device=device, seed=params.get("seed", 0), shard=shard)
 
     return run_batch(features, labels, mode, params, make)
 

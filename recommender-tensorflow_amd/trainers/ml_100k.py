@@ -41,8 +41,38 @@ def get_feature_columns(embedding_size=4):
     return {"linear": linear, "deep": [fc.embedding_column(c, embedding_size) for c in linear]}
 
 
+_OCCUPATIONS = ["administrator", "artist", "doctor", "educator", "engineer", "entertainment", "executive", "healthcare",
+                "homemaker", "lawyer", "librarian", "marketing", "none", "other", "programmer", "retired", "salesman",
+                "scientist", "student", "technician", "writer"]
+
+
+def synthetic_columns(n, seed=0):
+    """n synthetic examples with the MovieLens-100k schema and value ranges (943 users, 1682 items, ratings 1-5
+    with a learnable dependence on two genre flags): what `--synthetic N` trains on when the CSV files of the
+    reference's offline ETL (src/data/ml_100k.py: needs the network) are not at hand."""
+    rng = np.random.default_rng(seed)
+    cols = {}
+    for name, default in zip(COLUMNS, DEFAULTS):
+        cols[name] = np.zeros(n, np.int32) if isinstance(default[0], int) else np.array(["null"] * n, dtype=object)
+    g = rng.integers(0, 2, (n, len(GENRE)))
+    like = np.where(rng.random(n) < 0.85, g[:, 1] & (1 - g[:, 8]), rng.integers(0, 2, n))
+    cols.update(user_id=rng.integers(1, 944, n).astype(np.int32), item_id=rng.integers(1, 1683, n).astype(np.int32),
+                rating=np.where(like == 1, 5, rng.integers(1, 5, n)).astype(np.int32),
+                age=rng.integers(7, 74, n).astype(np.int32),
+                gender=np.array(rng.choice(["F", "M"], n), dtype=object),
+                occupation=np.array(rng.choice(_OCCUPATIONS, n), dtype=object),
+                zipcode=np.array(["%05d" % z for z in rng.integers(0, 99999, n)], dtype=object),
+                release_year=rng.integers(1922, 1999, n).astype(np.int32))
+    cols.update({k: g[:, j].astype(np.int32) for j, k in enumerate(GENRE)})
+    return cols, n
+
+
 def _read_csv(path):
-    """Whole file -> dict of typed numpy columns (missing / empty fields take DEFAULTS)."""
+    """Whole file -> dict of typed numpy columns (missing / empty fields take DEFAULTS).  "synthetic:N[:seed]"
+    instead of a path: N generated examples (synthetic_columns)."""
+    if isinstance(path, str) and path.startswith("synthetic:"):
+        parts = path.split(":")
+        return synthetic_columns(int(parts[1]), int(parts[2]) if len(parts) > 2 else 0)
     with open(path, newline="") as f:
         rd = csv.reader(f)
         next(rd, None)                                    # header (dataset.skip(1))

@@ -35,17 +35,47 @@ class NumpyKernels:
     def mi_global_rows(self, ids, field_off, B, F, rows):
         _np(rows)[:] = (_np(ids).astype(np.int64) + _np(field_off)[None, :]).reshape(-1)
 
-    def mi_shard_route(self, rows, n, world, entries_per_chunk, owner, local):
-        r = _np(rows)[:n]
+    def mi_shard_keys(self, rows, n, world, entries_per_chunk, rows_per_rank, keys):
+        r = _np(rows)[:n].astype(np.int64)
         chunk = (np.arange(n) // entries_per_chunk) if entries_per_chunk > 0 else 0
-        _np(owner)[:n] = chunk * world + r % world
-        _np(local)[:n] = r // world
+        _np(keys)[:n] = (chunk * world + r % world) * rows_per_rank + r // world
+
+    def mi_route_requests(self, uniq, num_uniq, n_max, rows_per_rank, n_groups, send_rows, counts):
+        U = int(_np(num_uniq)[0])
+        key = _np(uniq)[:U].astype(np.int64)
+        _np(send_rows)[:U] = key % rows_per_rank
+        _np(counts)[:n_groups] = np.bincount(key // rows_per_rank, minlength=n_groups)
+
+    def mi_segment_slots(self, seg, sorted_entry, num_uniq, n, slot):
+        U = int(_np(num_uniq)[0])
+        sg, se = _np(seg), _np(sorted_entry)
+        for u in range(U):
+            _np(slot)[se[sg[u]:sg[u + 1]]] = u
+
+    def mi_entry_grads_segsum(self, rows, seg, sorted_entry, u_begin, u_count, d_concat, ldd, sumv, dlf, dll, b0, F, E,
+                              out_rows, out_lin):
+        sg, se = _np(seg), _np(sorted_entry)
+        for u in range(u_begin, u_begin + u_count):
+            g = np.zeros(E, np.float32)
+            gl = np.float32(0)
+            for e in se[sg[u]:sg[u + 1]]:
+                b, f = int(e) // F - b0, int(e) % F
+                if out_rows is not None:
+                    v = np.zeros(E, np.float32)
+                    if d_concat is not None:
+                        v = v + _np(d_concat)[b, f * E:(f + 1) * E]
+                    if dlf is not None:
+                        v = v + _np(dlf)[b] * (_np(sumv)[b] - _np(rows)[u])
+                    g = g + v
+                if out_lin is not None:
+                    gl = gl + _np(dll)[b]
+            if out_rows is not None:
+                _np(out_rows)[u] = g
+            if out_lin is not None:
+                _np(out_lin)[u] = gl
 
     def mi_axpy(self, y, x, n, alpha):
         _np(y)[:n] += np.float32(alpha) * _np(x)[:n]
-
-    def mi_invert_perm(self, perm, n, inv):
-        _np(inv)[_np(perm)[:n]] = np.arange(n, dtype=np.int32)
 
     def mi_gather_u32(self, src, idx, n, out):
         _np(out)[:n] = _np(src)[_np(idx)[:n]]

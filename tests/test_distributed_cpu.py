@@ -61,7 +61,7 @@ def _worker(rank, world, port, cfg, out_q, device="cpu", backend="gloo"):
         losses = []
         t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(device)
         for _ in range(steps):
-            ids_s = np.stack([rng.integers(0, v, B * world) for v in vocab], 1).astype(np.int32)
+            ids_s = _draw_ids(rng, vocab, B * world, extra)
             ids_s[1] = ids_s[0]
             ids_s[B % len(ids_s)] = ids_s[0]         # the same rows requested from both ranks
             sl = slice(rank * B, (rank + 1) * B)
@@ -71,11 +71,20 @@ def _worker(rank, world, port, cfg, out_q, device="cpu", backend="gloo"):
             losses.append((float(tot.item()), logits.cpu().numpy().copy()))
         ev_loss, ev_logits = m.loss(t(ids[rank * B:(rank + 1) * B]), t(y[rank * B:(rank + 1) * B]),
                                     t(None if x is None else x[rank * B:(rank + 1) * B]))
-        out_q.put((rank, "ok", losses, m.export_numpy(), ev_logits.cpu().numpy().copy()))
+        exported = m.export_numpy()
+        exported["exchange"] = dict(m.last_exchange)            # of the eval step: one chunk
+        out_q.put((rank, "ok", losses, exported, ev_logits.cpu().numpy().copy()))
         dist.barrier()
         dist.destroy_process_group()
     except Exception:                                  # surface the traceback in the parent
         out_q.put((rank, "error", traceback.format_exc(), None, None))
+
+
+def _draw_ids(rng, vocab, n, extra):
+    """a step's ids: uniform, or (extra["zipf"]) heavily skewed — most entries of a field hit a few hot rows"""
+    if extra.get("zipf"):
+        return np.stack([np.minimum(rng.geometric(0.35, n) - 1, v - 1) for v in vocab], 1).astype(np.int32)
+    return np.stack([rng.integers(0, v, n) for v in vocab], 1).astype(np.int32)
 
 
 def _problem(cfg, world):
@@ -144,7 +153,7 @@ def check_against_big_batch(cfg, res, world, tol=1.0):
     st = O.TrainState(p, OO.Hyper(opt_name, lr), OO.Hyper(*extra["lin_opt"]) if "lin_opt" in extra else None)
     rng = np.random.default_rng(5)
     for s in range(steps):
-        ids_s = np.stack([rng.integers(0, v, B * world) for v in vocab], 1).astype(np.int32)
+        ids_s = _draw_ids(rng, vocab, B * world, extra)
         ids_s[1] = ids_s[0]
         ids_s[B % len(ids_s)] = ids_s[0]
         lo, logit_o = O.train_step(p, st, ids_s, y, x, *flags, reduction=red, numeric=numeric)
@@ -171,6 +180,25 @@ def check_against_big_batch(cfg, res, world, tol=1.0):
     c = O.forward(p, ids, x, *flags, numeric=numeric)
     for r in range(world):
         assert np.allclose(res[r][2], c["logits"][r * B:(r + 1) * B], rtol=1e-4 * tol, atol=2e-6 * tol)
+
+
+def test_skewed_ids_cross_the_link_once_per_distinct_row():
+    """VERDICT r1 (7a/7c): rows and gradients travel per DISTINCT row of a chunk, not per (example, field) entry.
+    Zipf-like ids, world 2, two chunks: results equal the big-batch oracle, and every rank sends exactly as many
+    requests as its batch has distinct (chunk, row) pairs — far fewer than entries."""
+    vocab = [50, 40, 30]
+    cfg = (vocab, 8, [16, 8], 64, 0, "Adam", 0.001, 3, (True, True, True), 2, dict(zipf=True))
+    res = _run(cfg, 2)
+    check_against_big_batch(cfg, res, 2)
+    p, ids, x, y = _problem(cfg, 2)                     # the eval batch the workers ran last (one chunk)
+    off = np.concatenate([[0], np.cumsum(vocab)])[:-1]
+    for r in range(2):
+        ex = res[r][1]["exchange"]
+        rows = ids[r * 64:(r + 1) * 64].astype(np.int64) + off[None, :]
+        assert ex["entries"] == 64 * 3
+        assert ex["requests_sent"] == len(np.unique(rows))
+    # the hot rows dominate: a small fraction of the entries travels
+    assert sum(res[r][1]["exchange"]["requests_sent"] for r in range(2)) < 0.8 * 2 * 64 * 3
 
 
 def test_row_shard_layout():

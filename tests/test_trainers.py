@@ -171,3 +171,65 @@ def test_model_utils_helpers(device):
     assert set(mt) == {"accuracy", "auc", "auc_precision_recall", "average_loss"} and mt["accuracy"] == pytest.approx(2 / 3)
     s = model_utils.layer_summary(torch.tensor([[0.0, 1.0], [2.0, 0.0]], device="cuda"))
     assert s["fraction_of_zero_values"] == 0.5 and s["max"] == 2.0
+
+
+def _cli_rank(rank, world, port, job_dir, q):
+    """one process of a 2-rank `python -m torch.distributed.run ... -m trainers.deep_fm --synthetic` launch on CPU"""
+    import sys, traceback
+    try:
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        for p in (root, os.path.join(root, "recommender-tensorflow_amd")):
+            if p not in sys.path:
+                sys.path.insert(0, p)
+        os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        from mi355x_rec import engine
+        from tests.cpu_kernels import NumpyKernels
+        engine.HipKernels = NumpyKernels                      # host logic run: kernels stood in by numpy
+        from trainers import deep_fm as T, _cli
+        args = _cli.make_parser("deep_fm", ("exclude_linear", "exclude_mf", "exclude_dnn", "hidden_units", "dropout")).parse_args(
+            ["--job-dir", job_dir, "--synthetic", "400", "--train-steps", "6", "--batch-size", "16", "--device", "cpu",
+             "--world-size", str(world), "--dropout", "0"])
+        est = T.train_and_evaluate(args)
+        eng = est._engine()
+        q.put((rank, "ok", est.global_step, eng.R_local, eng.dense.clone().numpy(), sorted(os.listdir(job_dir))))
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:
+        q.put((rank, "error", traceback.format_exc(), None, None, None))
+
+
+def test_cli_two_rank_launch_cpu(tmp_path):
+    """the trainers read RANK / WORLD_SIZE of a torch.distributed.run launch, shard the tables by
+    row, train synchronously and checkpoint per rank; --synthetic replaces the CSV files."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    job = str(tmp_path / "job")
+    procs = [ctx.Process(target=_cli_rank, args=(r, 2, port, job, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2):
+        r = q.get(timeout=240)
+        assert r[1] == "ok", r[2]
+        res[r[0]] = r
+    for p in procs:
+        p.join(timeout=60)
+    assert res[0][2] == res[1][2] == 6                               # one global step counter, synchronous
+    assert res[0][3] + res[1][3] == 4106 and abs(res[0][3] - res[1][3]) <= 1   # rows split r % 2
+    assert np.array_equal(res[0][4], res[1][4])                      # replicated dense variables stay identical
+    files = res[0][5]
+    assert "model.ckpt-6.rank0.pt" in files and "model.ckpt-6.rank1.pt" in files and "checkpoint.rank1.json" in files
+    with pytest.raises(SystemExit):
+        os.environ.pop("WORLD_SIZE", None)
+        _cli.init_distributed(_cli.make_parser("linear").parse_args(["--world-size", "4"]))
+
+
+def test_synthetic_input():
+    cols, n = ml_100k.synthetic_columns(50, seed=3)
+    assert n == 50 and set(cols) == set(ml_100k.COLUMNS)
+    f, l = next(ml_100k.get_input_fn("synthetic:64:1", "eval", batch_size=32)())
+    assert len(l) == 32 and f["user_id"].dtype == np.int32 and f["gender"][0] in ("F", "M")
