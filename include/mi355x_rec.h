@@ -82,11 +82,16 @@ int32_t mi_bucketize_f32(const float* values, int64_t n, const float* boundaries
  * receives max |table[row(b,f), :]| over the rows read, for the MLP's layer-1 GEMMs; with concat == NULL the kernel only READS rows — the form the
  * single-GPU path uses, where layer 1 gathers its operand itself, and the one bench.py prices
  * against the HBM read roofline; with table == NULL only the wide part lin is produced).  E must be a multiple of 4 and <= 256.  Fields must already be
- * in the reference's sorted-by-column-name order. */
+ * in the reference's sorted-by-column-name order.
+ * lin_stride: element stride of the wide part's per-row state, here and in mi_gather_rows / mi_sparse_apply* /
+ * mi_sparse_catchup / mi_catchup_gap_keys — 1: lin_w, l_slot0, l_slot1 and last_step are four separate arrays;
+ * 4: one 16-byte record per row {weight, slot0, slot1, stamp} (lin_w = rec, l_slot0 = rec + 1, l_slot1 = rec + 2,
+ * last_step = (int32_t*)rec + 3): a row's wide-part state then costs one memory sector instead of four
+ * (round 1's catchup_lin_k fetched 569 MB for 20 MB of state). */
 int32_t mi_embed_fm_linear_fwd(const float* table, const float* lin_w, const int64_t* field_off,
                                const int32_t* ids, int64_t B, int32_t F, int32_t E,
                                float* concat, int64_t ld_concat, float* sumv, float* fm, float* lin,
-                               float* amax_rows, mi_stream_t stream);
+                               float* amax_rows, int32_t lin_stride, mi_stream_t stream);
 
 /* The gather with the concat written as fp16 high/low planes (struct mi_planes, below): the operand of
  * the layer-1 GEMMs mi_dense_fwd_planes / mi_dense_bwd_weight_planes.  One exponent per example, from the
@@ -99,9 +104,10 @@ int32_t mi_embed_fm_planes_fwd(const float* table, const int64_t* field_off, con
                                mi_stream_t stream);
 
 /* Owner-side half of the row-sharded path (multi-GPU): out_rows[i,:] = table[rows[i],:],
- * out_lin[i] = lin_w[rows[i]].  rows [n] int32 local row ids. */
+ * out_lin[i] = lin_w[rows[i] * lin_stride].  rows [n] int32 local row ids; table (with out_rows) or lin_w
+ * (with out_lin) may be NULL. */
 int32_t mi_gather_rows(const float* table, const float* lin_w, const int32_t* rows, int64_t n,
-                       int32_t E, float* out_rows, float* out_lin, mi_stream_t stream);
+                       int32_t E, float* out_rows, float* out_lin, int32_t lin_stride, mi_stream_t stream);
 
 /* (a4) numeric embedding, deep_fm.py:62-70: out[b, j*E+e] = x[b,j] * V[j,e], written at
  * concat[b, col0 + j*E + e]; also accumulates into sumv / fm so the FM term sees the numeric
@@ -244,7 +250,7 @@ int32_t mi_sparse_apply(float* table, float* t_slot0, float* t_slot1, float* lin
                         const int32_t* seg_start, const int32_t* sorted_entry,
                         const int32_t* num_uniq, int64_t n_max, const float* d_rows,
                         const float* d_lin, int32_t E, int32_t step, const mi_opt_hparams* hp,
-                        mi_stream_t stream);
+                        int32_t lin_stride, mi_stream_t stream);
 
 /* Single-GPU form of mi_sparse_apply with mi_embed_fm_linear_bwd folded in: the gradient of entry
  * e = (b, f) = (e / F, e % F) is rebuilt inside the kernel as
@@ -256,7 +262,7 @@ int32_t mi_sparse_apply_fused(float* table, float* t_slot0, float* t_slot1, floa
                               const int32_t* seg_start, const int32_t* sorted_entry, const int32_t* num_uniq,
                               int64_t n_max, const float* d_concat, int64_t ld_dconcat, const float* sumv,
                               const float* d_logit_fm, const float* d_logit_lin, int32_t F, int32_t E,
-                              int32_t step, const mi_opt_hparams* hp, mi_stream_t stream);
+                              int32_t step, const mi_opt_hparams* hp, int32_t lin_stride, mi_stream_t stream);
 
 /* TF-1.12 AdamOptimizer._apply_sparse decays m and v of EVERY row and moves EVERY row each step
  * (SURVEY Appendix A.6).  Instead of sweeping the table, rows carry last_step[r] and are brought
@@ -273,12 +279,13 @@ int32_t mi_sparse_apply_fused(float* table, float* t_slot0, float* t_slot1, floa
  * key_range 64, then mi_gather_u32 of uniq_rows through the permutation) groups rows of equal
  * staleness, which halves the catch-up's divergence; the valid rows stay in front. */
 int32_t mi_catchup_gap_keys(const int32_t* uniq_rows, const int32_t* num_uniq, const int32_t* last_step, int64_t n_max,
-                            int32_t step_to, int32_t* keys, mi_stream_t stream);
+                            int32_t step_to, int32_t* keys, int32_t lin_stride, mi_stream_t stream);
 
 int32_t mi_sparse_catchup(float* table, float* t_m, float* t_v, float* lin_w, float* l_m, float* l_v,
                           int32_t* last_step, const int32_t* uniq_rows, const int32_t* num_uniq,
                           int64_t n_max, int32_t E, int32_t step_to, const float* lr_table,
-                          float beta1, float beta2, float epsilon, int32_t defer_slots, mi_stream_t stream);
+                          float beta1, float beta2, float epsilon, int32_t defer_slots, int32_t lin_stride,
+                          mi_stream_t stream);
 
 /* ---- (a6) the [hidden_units] MLP: fp32 GEMMs on the matrix cores with fused epilogues -----------
  * replaces tf.layers.dense / tf.layers.dropout (deep_fm.py:98-108).  Row-major everywhere.

@@ -33,7 +33,7 @@ __global__ __launch_bounds__(kBlock) void embed_fm_linear_fwd_k(
     const float* __restrict__ table, const float* __restrict__ lin_w,
     const int64_t* __restrict__ field_off, const int32_t* __restrict__ ids, int64_t B, int F, int E,
     float* __restrict__ concat, int64_t ldc, float* __restrict__ sumv, float* __restrict__ fm,
-    float* __restrict__ lin, float* __restrict__ amax_rows) {
+    float* __restrict__ lin, float* __restrict__ amax_rows, int ls) {
   constexpr int U = kRowsInFlight;
   float mx = 0.f;                   // largest |row element| seen (scale of the layer-1 GEMM operand)
   const int64_t g = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) / LPR;
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(kBlock) void embed_fm_linear_fwd_k(
       int32_t myrow = 0;
       if (fl < F) {
         myrow = static_cast<int32_t>(field_off[fl] + idrow[fl]);
-        if (lin_w) lacc += lin_w[myrow];
+        if (lin_w) lacc += lin_w[static_cast<int64_t>(myrow) * ls];
       }
       const int nf = min(LPR, F - fb);
       for (int j0 = 0; j0 < nf; j0 += U) {
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(kBlock) void embed_fm_linear_fwd_k(
       for (int u = 0; u < U; ++u) {
         r[u] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (f0 + u < F && lane_on) r[u] = ld4(table + static_cast<int64_t>(row[u]) * E + eo);
-        if (lin_w && f0 + u < F && ((f0 + u) & (LPR - 1)) == l) lacc += lin_w[row[u]];
+        if (lin_w && f0 + u < F && ((f0 + u) & (LPR - 1)) == l) lacc += lin_w[static_cast<int64_t>(row[u]) * ls];
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(kBlock) void gather_rows_k(const float* __restrict_
                                                         const float* __restrict__ lin_w,
                                                         const int32_t* __restrict__ rows, int64_t n,
                                                         int E, float* __restrict__ out_rows,
-                                                        float* __restrict__ out_lin) {
+                                                        float* __restrict__ out_lin, int ls) {
   constexpr int U = kRowsInFlight;
   const int64_t g = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) / LPR;
   const int l = threadIdx.x & (LPR - 1);
@@ -223,13 +223,13 @@ __global__ __launch_bounds__(kBlock) void gather_rows_k(const float* __restrict_
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     r[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (i0 + u < n && lane_on) r[u] = ld4(table + static_cast<int64_t>(row[u]) * E + 4 * l);
+    if (table && i0 + u < n && lane_on) r[u] = ld4(table + static_cast<int64_t>(row[u]) * E + 4 * l);
   }
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     if (i0 + u < n) {
-      if (lane_on) st4(out_rows + (i0 + u) * E + 4 * l, r[u]);
-      if (lin_w && out_lin && (u & (LPR - 1)) == l) out_lin[i0 + u] = lin_w[row[u]];
+      if (table && lane_on) st4(out_rows + (i0 + u) * E + 4 * l, r[u]);
+      if (lin_w && out_lin && (u & (LPR - 1)) == l) out_lin[i0 + u] = lin_w[static_cast<int64_t>(row[u]) * ls];
     }
   }
 }
@@ -273,11 +273,11 @@ __global__ __launch_bounds__(kBlock) void embed_fm_linear_bwd_k(
 __global__ __launch_bounds__(kBlock) void linear_only_fwd_k(const float* __restrict__ lin_w,
                                                             const int64_t* __restrict__ field_off,
                                                             const int32_t* __restrict__ ids, int64_t B,
-                                                            int F, float* __restrict__ lin) {
+                                                            int F, float* __restrict__ lin, int ls) {
   const int64_t b = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
   if (b >= B) return;
   float acc = 0.f;
-  for (int f = 0; f < F; ++f) acc += lin_w[field_off[f] + ids[b * F + f]];
+  for (int f = 0; f < F; ++f) acc += lin_w[(field_off[f] + ids[b * F + f]) * ls];
   lin[b] = acc;
 }
 
@@ -445,14 +445,14 @@ extern "C" {
 int32_t mi_embed_fm_linear_fwd(const float* table, const float* lin_w, const int64_t* field_off,
                                const int32_t* ids, int64_t B, int32_t F, int32_t E, float* concat,
                                int64_t ld_concat, float* sumv, float* fm, float* lin, float* amax_rows,
-                               mi_stream_t stream) {
-  MI_REQUIRE(B >= 0 && F > 0, "embed_fm_linear_fwd: B=%lld F=%d", (long long)B, F);
+                               int32_t lin_stride, mi_stream_t stream) {
+  MI_REQUIRE(B >= 0 && F > 0 && lin_stride >= 1, "embed_fm_linear_fwd: B=%lld F=%d lin_stride=%d", (long long)B, F, lin_stride);
   if (!table) {  // wide part only
     MI_REQUIRE(!concat && !sumv && !fm && lin && lin_w && field_off && ids,
                "embed_fm_linear_fwd: without a table only lin can be produced");
     if (B == 0) return MI_OK;
     linear_only_fwd_k<<<dim3((unsigned)mi::ceil_div(B, kBlock)), dim3(kBlock), 0, mi::as_stream(stream)>>>(
-        lin_w, field_off, ids, B, F, lin);
+        lin_w, field_off, ids, B, F, lin, lin_stride);
     MI_CHECK_LAUNCH("embed_fm_linear_fwd(linear only)");
     return MI_OK;
   }
@@ -470,7 +470,7 @@ int32_t mi_embed_fm_linear_fwd(const float* table, const float* lin_w, const int
   MI_REQUIRE(blocks <= INT32_MAX, "embed_fm_linear_fwd: grid too large");
   MI_DISPATCH_LPR(lpr, (embed_fm_linear_fwd_k<L><<<dim3((unsigned)blocks), dim3(kBlock), 0, mi::as_stream(stream)>>>(
                            table, lin ? lin_w : nullptr, field_off, ids, B, F, E, concat, ld_concat, sumv, fm, lin,
-                           amax_rows)));
+                           amax_rows, lin_stride)));
   MI_CHECK_LAUNCH("embed_fm_linear_fwd");
   return MI_OK;
 }
@@ -517,18 +517,19 @@ int32_t mi_embed_fm_planes_fwd(const float* table, const int64_t* field_off, con
 }
 
 int32_t mi_gather_rows(const float* table, const float* lin_w, const int32_t* rows, int64_t n,
-                       int32_t E, float* out_rows, float* out_lin, mi_stream_t stream) {
+                       int32_t E, float* out_rows, float* out_lin, int32_t lin_stride, mi_stream_t stream) {
+  if (!table) E = 4;                       // wide part only: the row half of the kernel is off
   if (int32_t rc = check_E("gather_rows", E)) return rc;
-  MI_REQUIRE(n >= 0, "gather_rows: n=%lld", (long long)n);
+  MI_REQUIRE(n >= 0 && lin_stride >= 1, "gather_rows: n=%lld lin_stride=%d", (long long)n, lin_stride);
   if (n == 0) return MI_OK;
-  MI_REQUIRE(table && rows && out_rows, "gather_rows: null buffer");
-  MI_REQUIRE(mi::aligned16(table) && mi::aligned16(out_rows), "gather_rows: 16-byte alignment");
+  MI_REQUIRE(rows && ((table && out_rows) || (lin_w && out_lin)), "gather_rows: null buffer");
+  MI_REQUIRE(!table || (mi::aligned16(table) && mi::aligned16(out_rows)), "gather_rows: 16-byte alignment");
   const int lpr = lanes_per_row(E);
   const int64_t groups = mi::ceil_div(n, kRowsInFlight);
   const int64_t blocks = mi::ceil_div(groups * lpr, kBlock);
   MI_REQUIRE(blocks <= INT32_MAX, "gather_rows: grid too large");
   MI_DISPATCH_LPR(lpr, (gather_rows_k<L><<<dim3((unsigned)blocks), dim3(kBlock), 0, mi::as_stream(stream)>>>(
-                           table, lin_w, rows, n, E, out_rows, out_lin)));
+                           table, lin_w, rows, n, E, out_rows, out_lin, lin_stride)));
   MI_CHECK_LAUNCH("gather_rows");
   return MI_OK;
 }

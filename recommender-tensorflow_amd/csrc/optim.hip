@@ -123,6 +123,9 @@ struct ApplyArgs {
   // STORE form (mi_entry_grads_segsum): the summed gradients of distinct requests u_begin .. u_begin + u_count
   // are written to out_rows / out_lin instead of being applied; "row" u is slot u of the exchange buffer
   float* out_rows; float* out_lin; int u_begin, u_count;
+  // element stride of lin_w / l0 / l1 / last_step: 1 = four separate arrays, 4 = one 16-byte record per row
+  // {w, slot0, slot1, stamp} (a row's wide-part state then costs one memory sector instead of four)
+  int ls;
 };
 
 // sum of the gradients of entries sorted_entry[k_beg..k_end) of one row, in that order
@@ -166,7 +169,7 @@ __device__ __forceinline__ void apply_row(const ApplyArgs& a, const Hp& h, int64
                                           const float4& g, float gl) {
   int missed = 0;
   if (h.kind == MI_OPT_ADAM && a.last_step) {
-    const int ls = a.last_step[r];
+    const int ls = a.last_step[r * a.ls];
     missed = ls > 0 ? max(0, a.step - 1 - ls) : 0;
   }
   if (a.table && lane_on) {
@@ -187,14 +190,15 @@ __device__ __forceinline__ void apply_row(const ApplyArgs& a, const Hp& h, int64
   }
   if (l == 0) {
     if (a.lin_w) {
-      float lw = a.lin_w[r], s0 = a.l0 ? a.l0[r] : 0.f, s1 = a.l1 ? a.l1[r] : 0.f;
+      const int64_t o = r * a.ls;
+      float lw = a.lin_w[o], s0 = a.l0 ? a.l0[o] : 0.f, s1 = a.l1 ? a.l1[o] : 0.f;
       for (int j = 0; j < missed; ++j) { s0 = s0 * h.beta1; s1 = s1 * h.beta2; }
       sparse_rule(h, lw, s0, s1, gl);
-      a.lin_w[r] = lw;
-      if (a.l0) a.l0[r] = s0;
-      if (a.l1) a.l1[r] = s1;
+      a.lin_w[o] = lw;
+      if (a.l0) a.l0[o] = s0;
+      if (a.l1) a.l1[o] = s1;
     }
-    if (a.last_step) a.last_step[r] = a.step;
+    if (a.last_step) a.last_step[r * a.ls] = a.step;
   }
 }
 
@@ -334,11 +338,11 @@ __device__ __forceinline__ bool catchup_params_in_range(int steps, float lr_last
 __global__ __launch_bounds__(kBlock) void catchup_lin_k(
     float* __restrict__ lin_w, float* __restrict__ lm, float* __restrict__ lv, const int32_t* __restrict__ last_step,
     const int32_t* __restrict__ uniq_rows, const int32_t* __restrict__ num_uniq, int64_t n_max, int step_to,
-    const float* __restrict__ lr_table, float b1, float b2, float eps, bool defer_slots) {
+    const float* __restrict__ lr_table, float b1, float b2, float eps, bool defer_slots, int st) {
   const int64_t u = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
   const int64_t count = uniq_rows ? static_cast<int64_t>(*num_uniq) : n_max;
   const bool on = u < count;
-  const int64_t r = on ? (uniq_rows ? static_cast<int64_t>(uniq_rows[u]) : u) : 0;
+  const int64_t r = (on ? (uniq_rows ? static_cast<int64_t>(uniq_rows[u]) : u) : 0) * st;   // (element offset of the row's state)
   const int ls = on ? last_step[r] : step_to;
   const bool work = on && ls > 0 && ls < step_to;
   float w = 0.f, m = 0.f, v = 0.f;
@@ -364,13 +368,13 @@ __global__ __launch_bounds__(kBlock) void sparse_catchup_k(
     float* __restrict__ table, float* __restrict__ tm, float* __restrict__ tv,
     int32_t* __restrict__ last_step, const int32_t* __restrict__ uniq_rows,
     const int32_t* __restrict__ num_uniq, int64_t n_max, int E, int step_to,
-    const float* __restrict__ lr_table, float b1, float b2, float eps, bool defer_slots) {
+    const float* __restrict__ lr_table, float b1, float b2, float eps, bool defer_slots, int st) {
   const int64_t u = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) / LPR;
   const int l = threadIdx.x & (LPR - 1);
   const int64_t count = uniq_rows ? static_cast<int64_t>(*num_uniq) : n_max;
   if (u >= count) return;
   const int64_t r = uniq_rows ? static_cast<int64_t>(uniq_rows[u]) : u;
-  const int ls = last_step[r];
+  const int ls = last_step[r * st];
   if (ls >= step_to) return;
   // a row that was never applied has m = v = 0: every replayed step subtracts exactly 0
   if (ls > 0) {
@@ -410,7 +414,7 @@ __global__ __launch_bounds__(kBlock) void sparse_catchup_k(
   // writes them anyway) from the old stamp, so neither they nor the stamp are written here — a third
   // of this kernel's HBM traffic.
   // every lane of the group has read last_step[r] above (same wave, program order) before lane 0 writes
-  if (l == 0 && !defer_slots) last_step[r] = step_to;
+  if (l == 0 && !defer_slots) last_step[r * st] = step_to;
 }
 
 // key[u] = number of steps row uniq_rows[u] has to be replayed over (clamped to 62), 63 for the slots past
@@ -420,12 +424,12 @@ __global__ __launch_bounds__(kBlock) void sparse_catchup_k(
 __global__ __launch_bounds__(kBlock) void gap_keys_k(const int32_t* __restrict__ uniq_rows,
                                                      const int32_t* __restrict__ num_uniq,
                                                      const int32_t* __restrict__ last_step, int64_t n_max, int step_to,
-                                                     int32_t* __restrict__ keys) {
+                                                     int32_t* __restrict__ keys, int st) {
   const int64_t u = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
   if (u >= n_max) return;
   int32_t key = 63;
   if (u < *num_uniq) {
-    const int ls = last_step[uniq_rows[u]];
+    const int ls = last_step[static_cast<int64_t>(uniq_rows[u]) * st];
     key = (ls > 0 && ls < step_to) ? min(step_to - ls, 62) : 0;
   }
   keys[u] = key;
@@ -506,8 +510,9 @@ int32_t mi_sparse_apply(float* table, float* t_slot0, float* t_slot1, float* lin
                         const int32_t* seg_start, const int32_t* sorted_entry,
                         const int32_t* num_uniq, int64_t n_max, const float* d_rows,
                         const float* d_lin, int32_t E, int32_t step, const mi_opt_hparams* hp,
-                        mi_stream_t stream) {
+                        int32_t lin_stride, mi_stream_t stream) {
   if (int32_t rc = check_hp("sparse_apply", hp)) return rc;
+  MI_REQUIRE(lin_stride >= 1, "sparse_apply: lin_stride=%d", lin_stride);
   MI_REQUIRE(n_max >= 0, "sparse_apply: n_max=%lld", (long long)n_max);
   if (n_max == 0) return MI_OK;
   MI_REQUIRE(table || lin_w, "sparse_apply: nothing to update");
@@ -523,8 +528,9 @@ int32_t mi_sparse_apply(float* table, float* t_slot0, float* t_slot1, float* lin
   const int64_t blocks = mi::ceil_div(n_max * lpr, kBlock);
   MI_REQUIRE(blocks <= INT32_MAX, "sparse_apply: grid too large");
   const Hp h = make_hp(hp);
-  const ApplyArgs a{table, t_slot0, t_slot1, lin_w, l_slot0, l_slot1, last_step, uniq_rows, seg_start, sorted_entry,
-                    num_uniq, d_rows, d_lin, E, step};
+  ApplyArgs a{table, t_slot0, t_slot1, lin_w, l_slot0, l_slot1, last_step, uniq_rows, seg_start, sorted_entry,
+              num_uniq, d_rows, d_lin, E, step};
+  a.ls = lin_stride;
   MI_DISPATCH_LPR(lpr, (sparse_apply_k<L, false><<<dim3((unsigned)blocks), dim3(kBlock), 0, mi::as_stream(stream)>>>(
                            a, h, FusedGrad{})));
   MI_CHECK_LAUNCH("sparse_apply");
@@ -541,8 +547,9 @@ int32_t mi_sparse_apply_fused(float* table, float* t_slot0, float* t_slot1, floa
                               const int32_t* seg_start, const int32_t* sorted_entry, const int32_t* num_uniq,
                               int64_t n_max, const float* d_concat, int64_t ld_dconcat, const float* sumv,
                               const float* d_logit_fm, const float* d_logit_lin, int32_t F, int32_t E,
-                              int32_t step, const mi_opt_hparams* hp, mi_stream_t stream) {
+                              int32_t step, const mi_opt_hparams* hp, int32_t lin_stride, mi_stream_t stream) {
   if (int32_t rc = check_hp("sparse_apply_fused", hp)) return rc;
+  MI_REQUIRE(lin_stride >= 1, "sparse_apply_fused: lin_stride=%d", lin_stride);
   MI_REQUIRE(n_max >= 0 && F > 0, "sparse_apply_fused: n_max=%lld F=%d", (long long)n_max, F);
   if (n_max == 0) return MI_OK;
   MI_REQUIRE(table || lin_w, "sparse_apply_fused: nothing to update");
@@ -563,8 +570,9 @@ int32_t mi_sparse_apply_fused(float* table, float* t_slot0, float* t_slot1, floa
   MI_REQUIRE(blocks <= INT32_MAX, "sparse_apply_fused: grid too large");
   const Hp h = make_hp(hp);
   const FusedGrad fg{d_concat, ld_dconcat, sumv, d_logit_fm, d_logit_lin, F, 0};
-  const ApplyArgs a{table, t_slot0, t_slot1, lin_w, l_slot0, l_slot1, last_step, uniq_rows, seg_start, sorted_entry,
-                    num_uniq, nullptr, nullptr, E, step};
+  ApplyArgs a{table, t_slot0, t_slot1, lin_w, l_slot0, l_slot1, last_step, uniq_rows, seg_start, sorted_entry,
+              num_uniq, nullptr, nullptr, E, step};
+  a.ls = lin_stride;
   MI_DISPATCH_LPR(lpr, (sparse_apply_k<L, true><<<dim3((unsigned)blocks), dim3(kBlock), 0, mi::as_stream(stream)>>>(a, h, fg)));
   MI_CHECK_LAUNCH("sparse_apply_fused");
   if (n_max > kLongSeg) {
@@ -597,7 +605,7 @@ int32_t mi_entry_grads_segsum(const float* rows, const int32_t* seg_start, const
   if (out_rows && !rows) a.table = out_rows;                    // (no FM term: w is never read; any valid pointer turns the row part on)
   a.lin_w = out_lin ? out_lin : nullptr;                        // (non-null turns the linear part on; never read)
   a.seg_start = seg_start; a.sorted_entry = sorted_entry;
-  a.E = E; a.out_rows = out_rows; a.out_lin = out_lin; a.u_begin = (int)u_begin; a.u_count = (int)u_count;
+  a.E = E; a.out_rows = out_rows; a.out_lin = out_lin; a.u_begin = (int)u_begin; a.u_count = (int)u_count; a.ls = 1;
   const Hp h{};
   MI_DISPATCH_LPR(lpr, (sparse_apply_k<L, true, true><<<dim3((unsigned)blocks), dim3(kBlock), 0, mi::as_stream(stream)>>>(a, h, fg)));
   MI_CHECK_LAUNCH("entry_grads_segsum");
@@ -609,12 +617,12 @@ int32_t mi_entry_grads_segsum(const float* rows, const int32_t* seg_start, const
 }
 
 int32_t mi_catchup_gap_keys(const int32_t* uniq_rows, const int32_t* num_uniq, const int32_t* last_step, int64_t n_max,
-                            int32_t step_to, int32_t* keys, mi_stream_t stream) {
-  MI_REQUIRE(n_max >= 0 && step_to >= 0, "catchup_gap_keys: n_max=%lld", (long long)n_max);
+                            int32_t step_to, int32_t* keys, int32_t lin_stride, mi_stream_t stream) {
+  MI_REQUIRE(n_max >= 0 && step_to >= 0 && lin_stride >= 1, "catchup_gap_keys: n_max=%lld", (long long)n_max);
   if (n_max == 0) return MI_OK;
   MI_REQUIRE(uniq_rows && num_uniq && last_step && keys, "catchup_gap_keys: null buffer");
   gap_keys_k<<<dim3((unsigned)mi::ceil_div(n_max, kBlock)), dim3(kBlock), 0, mi::as_stream(stream)>>>(
-      uniq_rows, num_uniq, last_step, n_max, step_to, keys);
+      uniq_rows, num_uniq, last_step, n_max, step_to, keys, lin_stride);
   MI_CHECK_LAUNCH("catchup_gap_keys");
   return MI_OK;
 }
@@ -622,8 +630,9 @@ int32_t mi_catchup_gap_keys(const int32_t* uniq_rows, const int32_t* num_uniq, c
 int32_t mi_sparse_catchup(float* table, float* t_m, float* t_v, float* lin_w, float* l_m, float* l_v,
                           int32_t* last_step, const int32_t* uniq_rows, const int32_t* num_uniq,
                           int64_t n_max, int32_t E, int32_t step_to, const float* lr_table,
-                          float beta1, float beta2, float epsilon, int32_t defer_slots, mi_stream_t stream) {
-  MI_REQUIRE(n_max >= 0 && step_to >= 0, "sparse_catchup: n_max=%lld step_to=%d", (long long)n_max, step_to);
+                          float beta1, float beta2, float epsilon, int32_t defer_slots, int32_t lin_stride,
+                          mi_stream_t stream) {
+  MI_REQUIRE(n_max >= 0 && step_to >= 0 && lin_stride >= 1, "sparse_catchup: n_max=%lld step_to=%d", (long long)n_max, step_to);
   if (n_max == 0 || step_to == 0) return MI_OK;
   MI_REQUIRE(last_step && lr_table, "sparse_catchup: null buffer");
   MI_REQUIRE(table || lin_w, "sparse_catchup: nothing to update");
@@ -634,7 +643,7 @@ int32_t mi_sparse_catchup(float* table, float* t_m, float* t_v, float* lin_w, fl
   const bool defer = defer_slots != 0 && uniq_rows != nullptr;
   if (lin_w) {
     catchup_lin_k<<<dim3((unsigned)mi::ceil_div(n_max, kBlock)), dim3(kBlock), 0, mi::as_stream(stream)>>>(
-        lin_w, l_m, l_v, last_step, uniq_rows, num_uniq, n_max, step_to, lr_table, beta1, beta2, epsilon, defer);
+        lin_w, l_m, l_v, last_step, uniq_rows, num_uniq, n_max, step_to, lr_table, beta1, beta2, epsilon, defer, lin_stride);
     MI_CHECK_LAUNCH("sparse_catchup(wide part)");
   }
   const int lpr = table ? lanes_per_row(E) : 1;
@@ -642,7 +651,7 @@ int32_t mi_sparse_catchup(float* table, float* t_m, float* t_v, float* lin_w, fl
   MI_REQUIRE(blocks <= INT32_MAX, "sparse_catchup: grid too large");
   MI_DISPATCH_LPR(lpr, (sparse_catchup_k<L><<<dim3((unsigned)blocks), dim3(kBlock), 0, mi::as_stream(stream)>>>(
                            table, t_m, t_v, last_step, uniq_rows, num_uniq, n_max, E, step_to, lr_table, beta1, beta2,
-                           epsilon, defer)));
+                           epsilon, defer, lin_stride)));
   MI_CHECK_LAUNCH("sparse_catchup");
   return MI_OK;
 }

@@ -11,9 +11,11 @@ Variable layout in HBM
   table   [R, E] f32   all embedding tables stacked row-major; field f owns rows
                        [field_off[f], field_off[f+1])  (fields in sorted column-name order,
                        SURVEY A.2) -- one coalesced 4E-byte read per (example, field)
-  lin_w   [R]    f32   linear_model weights, same row numbering
-  t_s0/t_s1, l_s0/l_s1 optimizer slots shaped like table / lin_w
-  last_step [R]  i32   Adam only: step at which a row was last brought up to date
+  lin_state [R, 4] f32 the wide part's per-row record {weight, slot0, slot1, Adam stamp}: lin_w, l_s0, l_s1 and
+                       last_step are strided views of it (one memory sector per row)
+  t_s0/t_s1            optimizer slots shaped like table
+  last_step [R]  i32   Adam only: step at which a row was last brought up to date (a view of lin_state, or a
+                       plain array when there is no wide part)
   dense   [P]    f32   every dense variable back to back (16-float aligned segments): first TF's
                        "dnn" scope — kernel_0, bias_0, ..., kernel_logits, bias_logits,
                        numeric_embeddings — then, from wide_off on, the dense part of its "linear" scope —
@@ -232,14 +234,31 @@ class DeepFM:
 
         f32 = dict(dtype=torch.float32, device=dev)
         self.table = torch.zeros(self.R_local, self.E, **f32) if (self.use_emb and self.F) else None
-        self.lin_w = torch.zeros(self.R_local, **f32) if (self.use_linear and self.F) else None
         sparse_lin_opt = self.lin_opt or self.opt
         self.t_s0, self.t_s1 = self._slots(self.table, self.opt)
-        self.l_s0, self.l_s1 = self._slots(self.lin_w, sparse_lin_opt)
         t_adam = self.opt.name == "Adam" and self.table is not None
-        l_adam = sparse_lin_opt.name == "Adam" and self.lin_w is not None
+        l_adam = sparse_lin_opt.name == "Adam" and self.use_linear and self.F > 0
         self.adam_rows = t_adam or l_adam
-        self.last_step = torch.zeros(self.R_local, dtype=torch.int32, device=dev) if self.adam_rows else None
+        # The wide part's per-row state is ONE 16-byte record {weight, slot0, slot1, Adam stamp}: lin_w, l_s0,
+        # l_s1 and last_step are strided views of it (self.ls = 4 elements), so the catch-up and the apply
+        # touch one memory sector per row instead of four.  Without a wide part the stamps are a plain array.
+        self.lin_state = self.lin_w = self.l_s0 = self.l_s1 = self.last_step = None
+        self.ls = 1
+        if self.use_linear and self.F:
+            self.lin_state = torch.zeros(self.R_local, 4, **f32)
+            self.ls = 4
+            self.lin_w = self.lin_state[:, 0]
+            a, b = sparse_lin_opt.slot_init
+            if a is not None:
+                self.l_s0 = self.lin_state[:, 1]
+                self.l_s0.fill_(a)
+            if b is not None:
+                self.l_s1 = self.lin_state[:, 2]
+                self.l_s1.fill_(b)
+            if self.adam_rows:
+                self.last_step = self.lin_state.view(torch.int32)[:, 3]
+        elif self.adam_rows:
+            self.last_step = torch.zeros(self.R_local, dtype=torch.int32, device=dev)
         adam_spec = self.opt if self.opt.name == "Adam" else (sparse_lin_opt if sparse_lin_opt.name == "Adam" else None)
         if self.lin_opt is not None and self.lin_opt.name == "Adam" and self.opt.name == "Adam" and \
                 (self.lin_opt.lr, self.lin_opt.beta1, self.lin_opt.beta2, self.lin_opt.epsilon) != \
@@ -493,6 +512,7 @@ class DeepFM:
         self._last_B = B
         c = {"B": B}
         table, lin_w, field_off, rid = src if src is not None else (self.table, self.lin_w, self.field_off, ids)
+        ls = self.ls if src is None else 1              # (rows received from their owners: plain arrays)
         concat = sumv = fm = None
         ld = self.D
         gathered = self.gather_mlp
@@ -526,23 +546,23 @@ class DeepFM:
                 k.mi_embed_fm_planes_fwd(table, field_off, rid, B, F, self.E, sumv, fm, self._planes("x0p", B, ld), rows_amax)
             elif concat is not None or sumv is not None or rows_amax is not None:
                 k.mi_embed_fm_linear_fwd(table, None, field_off, rid, B, F, self.E, concat, ld, sumv, fm, None,
-                                         rows_amax)
+                                         rows_amax, 1)
             side = self._ws.get("side_stream")
             if side is None:
                 side = self._ws["side_stream"] = torch.cuda.Stream(device=self.device)
             side.wait_stream(torch.cuda.current_stream())        # the catch-up of these rows ran on the main stream
             with torch.cuda.stream(side):
                 k.tagged("mi_embed_fm_linear_fwd", "/wide")(None, lin_w, field_off, rid, B, F, self.E, None, 0, None,
-                                                            None, lin, None)
+                                                            None, lin, None, ls)
             c["lin_join"] = side
         elif pl_gather:
             k.mi_embed_fm_planes_fwd(table, field_off, rid, B, F, self.E, sumv, fm, self._planes("x0p", B, ld), rows_amax)
             if lin is not None:
-                k.tagged("mi_embed_fm_linear_fwd", "/wide")(None, lin_w, field_off, rid, B, F, self.E, None, 0, None, None, lin, None)
+                k.tagged("mi_embed_fm_linear_fwd", "/wide")(None, lin_w, field_off, rid, B, F, self.E, None, 0, None, None, lin, None, ls)
         elif concat is not None or sumv is not None or lin is not None or rows_amax is not None:
             emb_on = self.use_emb
             k.mi_embed_fm_linear_fwd(table if emb_on else None, lin_w if self.use_linear else None, field_off,
-                                     rid, B, F, self.E, concat if emb_on else None, ld, sumv, fm, lin, rows_amax)
+                                     rid, B, F, self.E, concat if emb_on else None, ld, sumv, fm, lin, rows_amax, ls)
         if self.n_numeric:
             wn = self._seg(self.dense, self.lin_num_off, (self.n_numeric,)) if self.use_linear else None
             if self.raw_numeric:
@@ -673,7 +693,7 @@ class DeepFM:
         if uniq is not None and n_max >= self.GAP_SORT_MIN:
             # rows of equal staleness into the same wave (the replay runs as long as a wave's stalest row)
             keys = self._buf("gap_keys", (n_max,), torch.int32)
-            self.k.mi_catchup_gap_keys(uniq, num_uniq, self.last_step, n_max, self.step, keys)
+            self.k.mi_catchup_gap_keys(uniq, num_uniq, self.last_step, n_max, self.step, keys, self.ls)
             perm = self._buf("gap_perm", (n_max,), torch.int32)
             ws = self._bytes("sort_ws", self.k.query("mi_sort_unique_workspace_bytes", n_max))
             self.k.mi_sort_unique_rows(keys, n_max, 64, perm, None, None, None, ws, ws.numel())   # permutation only
@@ -684,7 +704,7 @@ class DeepFM:
                                  self.t_s1 if t_adam else None, self.lin_w if l_adam else None,
                                  self.l_s0 if l_adam else None, self.l_s1 if l_adam else None, self.last_step,
                                  uniq, num_uniq, n_max, self.E, self.step, self.sched.table, s.beta1, s.beta2,
-                                 s.epsilon, 1 if defer else 0)
+                                 s.epsilon, 1 if defer else 0, self.ls)
 
     def _sort_unique(self, keys, n, key_range, tag):
         """mi_sort_unique_rows into persistent buffers named after `tag`."""
@@ -841,11 +861,11 @@ class DeepFM:
                                             d_concat if tb is not None else None, self.D,
                                             sumv if (tb is not None and self.use_mf) else None,
                                             dlogit if (tb is not None and self.use_mf) else None,
-                                            dlogit if lw is not None else None, self.F, self.E, step, h)
+                                            dlogit if lw is not None else None, self.F, self.E, step, h, self.ls)
                 else:
                     k.mi_sparse_apply(*slots, self.last_step, uniq, seg, sorted_entry, num_uniq, n_max,
                                       d_rows if tb is not None else None, d_lin if lw is not None else None, self.E,
-                                      step, h)
+                                      step, h, self.ls)
         self.step = step
 
     def layer_summaries(self):
@@ -887,7 +907,7 @@ class DeepFM:
         for key in self._STATE_KEYS:
             v = getattr(self, key, None)
             if v is not None:
-                sd[key] = v.detach().cpu()
+                sd[key] = v.detach().to("cpu", copy=True).contiguous()    # (views of one record array: independent copies)
         return sd
 
     def load_state_dict(self, sd):

@@ -214,10 +214,10 @@ def _sharded_step(m, ids, labels, x_num, train):
         hs = []
         if m.use_emb:
             k.mi_gather_rows(m.table, m.lin_w if m.use_linear else None, recv_ids[lo:hi], hi - lo, E, own_rows[lo:hi],
-                             own_lin[lo:hi] if m.use_linear else None)
+                             own_lin[lo:hi] if m.use_linear else None, m.ls)
             hs.append(comm.all_to_all(got_rows[uoff[c]:uoff[c + 1]], own_rows[lo:hi], send_counts[c], recv_counts[c], True))
         elif m.use_linear:
-            k.mi_gather_u32(m.lin_w, recv_ids[lo:hi], hi - lo, own_lin[lo:hi])
+            k.mi_gather_rows(None, m.lin_w, recv_ids[lo:hi], hi - lo, E, None, own_lin[lo:hi], m.ls)
         if m.use_linear:
             hs.append(comm.all_to_all(got_lin[uoff[c]:uoff[c + 1]], own_lin[lo:hi], send_counts[c], recv_counts[c], True))
         return hs

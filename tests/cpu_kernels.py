@@ -1,4 +1,5 @@
 """numpy stand-ins for the device entry points of libmi355x_rec.so — TEST INFRASTRUCTURE ONLY.
+(The wide part's strided state views arrive as strided numpy views: lin_stride needs no handling here.)
 
 The CPU (gloo, world_size 2) tests hand an instance to ``DeepFM(_kernels=...)`` so that the REAL
 host orchestration (engine.py) and the REAL multi-rank exchange plumbing (parallel.py) run without a
@@ -95,7 +96,7 @@ class NumpyKernels:
         _np(num_uniq)[0] = U
 
     # ---- embedding side ------------------------------------------------------------------
-    def mi_embed_fm_linear_fwd(self, table, lin_w, field_off, ids, B, F, E, concat, ld, sumv, fm, lin, amax=None):
+    def mi_embed_fm_linear_fwd(self, table, lin_w, field_off, ids, B, F, E, concat, ld, sumv, fm, lin, amax=None, ls=1):
         rows = _np(ids).astype(np.int64) + _np(field_off)[None, :]
         if table is not None:
             v = _np(table)[rows]                               # [B,F,E]
@@ -109,9 +110,10 @@ class NumpyKernels:
         if lin is not None:
             _np(lin)[:] = _np(lin_w)[rows].sum(1)
 
-    def mi_gather_rows(self, table, lin_w, rows, n, E, out_rows, out_lin):
+    def mi_gather_rows(self, table, lin_w, rows, n, E, out_rows, out_lin, ls=1):
         r = _np(rows)[:n]
-        _np(out_rows)[:n] = _np(table)[r]
+        if table is not None:
+            _np(out_rows)[:n] = _np(table)[r]
         if lin_w is not None and out_lin is not None:
             _np(out_lin)[:n] = _np(lin_w)[r]
 
@@ -221,7 +223,7 @@ class NumpyKernels:
         OO.dense_apply(h, _np(param)[:n], _np(s0)[:n] if s0 is not None else z, _np(s1)[:n] if s1 is not None else z,
                        _np(grad)[:n], np.float32(hp.lr_t))
 
-    def mi_catchup_gap_keys(self, uniq, num_uniq, last_step, n_max, step_to, keys):
+    def mi_catchup_gap_keys(self, uniq, num_uniq, last_step, n_max, step_to, keys, ls=1):
         U = int(_np(num_uniq)[0])
         k = np.full(n_max, 63, np.int32)
         ls = _np(last_step)[_np(uniq)[:U]]
@@ -229,7 +231,7 @@ class NumpyKernels:
         _np(keys)[:n_max] = k
 
     def mi_sparse_catchup(self, table, tm, tv, lin_w, lm, lv, last_step, uniq, num_uniq, n_max, E, step_to, lr_table,
-                          b1, b2, eps, defer_slots=0):
+                          b1, b2, eps, defer_slots=0, ls=1):
         defer = bool(defer_slots) and uniq is not None
         rows = np.arange(n_max) if uniq is None else _np(uniq)[:int(_np(num_uniq)[0])]
         ls = _np(last_step)
@@ -254,7 +256,7 @@ class NumpyKernels:
                 ls[r] = step_to
 
     def mi_sparse_apply(self, table, t0, t1, lin_w, l0, l1, last_step, uniq, seg, sorted_entry, num_uniq, n_max,
-                        d_rows, d_lin, E, step, hp):
+                        d_rows, d_lin, E, step, hp, ls=1):
         h = _hyper(hp)
         U = int(_np(num_uniq)[0])
         rows = _np(uniq)[:U].astype(np.int64)
@@ -308,7 +310,7 @@ class NumpyKernels:
         self.mi_dense_bwd_weight(X, F * E, dY, lddy, dW, db, M, N, F * E, ws, wsb)
 
     def mi_sparse_apply_fused(self, table, t0, t1, lin_w, l0, l1, last_step, uniq, seg, sorted_entry, num_uniq,
-                              n_max, d_concat, ldd, sumv, dlf, dll, F, E, step, hp):
+                              n_max, d_concat, ldd, sumv, dlf, dll, F, E, step, hp, ls=1):
         n = int(_np(seg)[int(_np(num_uniq)[0])])
         e = np.arange(n)
         b, f = e // F, e % F

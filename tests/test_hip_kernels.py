@@ -59,7 +59,7 @@ def test_embed_fm_linear_fwd(lib, E, B, F):
     fm = torch.empty(B, device="cuda")
     lin = torch.empty(B, device="cuda")
     _chk(lib.mi_embed_fm_linear_fwd(_p(t), _p(lw), _p(fo), _p(di), B, F, E, _p(concat), ld, _p(sumv), _p(fm),
-                                    _p(lin), None, _st()))
+                                    _p(lin), None, 1, _st()))
     rows = off[:-1][None, :] + ids
     ref = table[rows]                                  # [B,F,E]
     got = concat.cpu().numpy()
@@ -86,7 +86,7 @@ def test_embed_fwd_linear_only_and_gather_rows(lib):
     ids = np.stack([rng.integers(0, v, B) for v in vocab], 1).astype(np.int32)
     lw, fo, di = dev(lin_w), dev(off[:-1].copy()), dev(ids)
     lin = torch.empty(B, device="cuda")
-    _chk(lib.mi_embed_fm_linear_fwd(None, _p(lw), _p(fo), _p(di), B, F, E, None, 0, None, None, _p(lin), None, _st()))
+    _chk(lib.mi_embed_fm_linear_fwd(None, _p(lw), _p(fo), _p(di), B, F, E, None, 0, None, None, _p(lin), None, 1, _st()))
     rows = (off[:-1][None, :] + ids)
     ref = np.zeros(B, np.float32)
     for f in range(F):
@@ -99,7 +99,7 @@ def test_embed_fwd_linear_only_and_gather_rows(lib):
     out = torch.empty(B * F, E, device="cuda")
     olin = torch.empty(B * F, device="cuda")
     t = dev(table)
-    _chk(lib.mi_gather_rows(_p(t), _p(lw), _p(grow), B * F, E, _p(out), _p(olin), _st()))
+    _chk(lib.mi_gather_rows(_p(t), _p(lw), _p(grow), B * F, E, _p(out), _p(olin), 1, _st()))
     assert np.array_equal(out.cpu().numpy(), table[rows.reshape(-1)])
     assert np.array_equal(olin.cpu().numpy(), lin_w[rows.reshape(-1)])
 
@@ -218,7 +218,7 @@ def test_gathered_layer1_matches_materialised_bitwise(lib, B, F, E, N):
     dY = rng.standard_normal((B, N)).astype(np.float32)
     t, fo, di, w, bb, dy = dev(table), dev(off[:-1].copy()), dev(ids), dev(W), dev(b), dev(dY)
     concat = torch.empty(B, K, device="cuda")
-    _chk(lib.mi_embed_fm_linear_fwd(_p(t), None, _p(fo), _p(di), B, F, E, _p(concat), K, None, None, None, None, _st()))
+    _chk(lib.mi_embed_fm_linear_fwd(_p(t), None, _p(fo), _p(di), B, F, E, _p(concat), K, None, None, None, None, 1, _st()))
     Y0 = torch.empty(B, N, device="cuda"); Y1 = torch.empty(B, N, device="cuda")
     _chk(lib.mi_dense_fwd(_p(concat), K, _p(w), _p(bb), _p(Y0), N, B, N, K, 1, 0.9, 77, None, _st()))
     _chk(lib.mi_dense_fwd_gathered(_p(t), _p(fo), _p(di), F, E, _p(w), _p(bb), _p(Y1), N, B, N, 1, 0.9, 77, None, _st()))
@@ -376,7 +376,7 @@ def test_f16x2_gathered_layer1_matches_materialised_bitwise(lib, B, F, E, N):
     from mi355x_rec import _lib as L
     concat = torch.empty(B, K, device="cuda")
     arows = torch.zeros(L.AMAX_SLOTS, device="cuda")
-    _chk(lib.mi_embed_fm_linear_fwd(_p(t), None, _p(fo), _p(di), B, F, E, _p(concat), K, None, None, None, _p(arows), _st()))
+    _chk(lib.mi_embed_fm_linear_fwd(_p(t), None, _p(fo), _p(di), B, F, E, _p(concat), K, None, None, None, _p(arows), 1, _st()))
     assert float(arows.max()) == float(concat.abs().max())
     aw, ady = _amax_vec(lib, w), _amax_vec(lib, dy)
     Y0 = torch.empty(B, N, device="cuda"); Y1 = torch.empty(B, N, device="cuda")
@@ -434,13 +434,13 @@ def test_sparse_apply_fused_equals_bwd_then_apply_bitwise(lib, name):
         if fused:
             _chk(lib.mi_sparse_apply_fused(_p(T), _p(t0), _p(t1), _p(L), _p(l0), _p(l1), None, _p(uq), _p(sg), _p(se),
                                            _p(nu), n, _p(d_dc), F * E, _p(d_sv), _p(d_dl), _p(d_dl), F, E, 1,
-                                           C.byref(h), _st()))
+                                           C.byref(h), 1, _st()))
         else:
             d_rows = torch.empty(n, E, device="cuda"); d_lin = torch.empty(n, device="cuda")
             _chk(lib.mi_embed_fm_linear_bwd(_p(d_dc), F * E, _p(d_cc), F * E, None, _p(d_sv), _p(d_dl), _p(d_dl), None, B, F,
                                             E, _p(d_rows), _p(d_lin), _st()))
             _chk(lib.mi_sparse_apply(_p(T), _p(t0), _p(t1), _p(L), _p(l0), _p(l1), None, _p(uq), _p(sg), _p(se),
-                                     _p(nu), n, _p(d_rows), _p(d_lin), E, 1, C.byref(h), _st()))
+                                     _p(nu), n, _p(d_rows), _p(d_lin), E, 1, C.byref(h), 1, _st()))
         torch.cuda.synchronize()
         res.append((T.cpu(), L.cpu(), t0.cpu(), t1.cpu()))
     for x, y in zip(*res):
@@ -475,7 +475,7 @@ def test_sparse_apply_long_segments(lib, E):
     for _ in range(2):
         T, L = dev(table), dev(lin_w)
         _chk(lib.mi_sparse_apply(_p(T), None, None, _p(L), None, None, None, _p(uq), _p(sg), _p(se), _p(nu), n, _p(dr),
-                                 _p(dli), E, 1, C.byref(h), _st()))
+                                 _p(dli), E, 1, C.byref(h), 1, _st()))
         torch.cuda.synchronize()
         outs.append((T.cpu().numpy(), L.cpu().numpy()))
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
@@ -524,7 +524,7 @@ def test_catchup_exact_at_range_edges(lib):
                 elw[r] = elw[r] - (lr[s] * elm[r]) / (np.sqrt(elv[r]) + eps)
     dW, dM, dV, dL, dLm, dLv, dlast, dlr = dev(w), dev(m), dev(v), dev(lw), dev(lmm), dev(lvv), dev(last), dev(lr)
     _chk(lib.mi_sparse_catchup(_p(dW), _p(dM), _p(dV), _p(dL), _p(dLm), _p(dLv), _p(dlast), None, None, R, E, step_to,
-                               _p(dlr), float(b1), float(b2), float(eps), 0, _st()))
+                               _p(dlr), float(b1), float(b2), float(eps), 0, 1, _st()))
     torch.cuda.synchronize()
     for got, exp in ((dW, ew), (dM, em), (dV, ev), (dL, elw), (dLm, elm), (dLv, elv)):
         assert np.array_equal(got.cpu().numpy().view(np.uint32), exp.view(np.uint32))
@@ -674,17 +674,17 @@ def test_sparse_apply_and_catchup_bit_exact(lib, name, E):
         if name == "Adam" and step > 1:
             assert abs(sched.lr_t(step) - float(lr_t)) == 0.0
             _chk(lib.mi_sparse_catchup(_p(dW), _p(d_ws0), _p(d_ws1), _p(dL), _p(d_ls0), _p(d_ls1), _p(last), _p(uq),
-                                       _p(nu), n, E, step - 1, _p(sched.table), hp.beta1, hp.beta2, hp.epsilon, 0, _st()))
+                                       _p(nu), n, E, step - 1, _p(sched.table), hp.beta1, hp.beta2, hp.epsilon, 0, 1, _st()))
         h = spec.hparams(float(lr_t))
         dg, dgl = dev(g), dev(gl[:, 0].copy())      # keep references: launches are asynchronous
         _chk(lib.mi_sparse_apply(_p(dW), _p(d_ws0) if need0 else None, _p(d_ws1) if need1 else None, _p(dL),
                                  _p(d_ls0) if need0 else None, _p(d_ls1) if need1 else None,
                                  _p(last) if name == "Adam" else None, _p(uq), _p(sg), _p(se), _p(nu), n,
-                                 _p(dg), _p(dgl), E, step, C.byref(h), _st()))
+                                 _p(dg), _p(dgl), E, step, C.byref(h), 1, _st()))
         torch.cuda.synchronize()
     if name == "Adam":   # bring the rows that sat out the last steps up to date: all-rows catch-up
         _chk(lib.mi_sparse_catchup(_p(dW), _p(d_ws0), _p(d_ws1), _p(dL), _p(d_ls0), _p(d_ls1), _p(last), None, None,
-                                   R, E, steps, _p(sched.table), hp.beta1, hp.beta2, hp.epsilon, 0, _st()))
+                                   R, E, steps, _p(sched.table), hp.beta1, hp.beta2, hp.epsilon, 0, 1, _st()))
         assert np.all(last.cpu().numpy() == steps)
     assert np.array_equal(dW.cpu().numpy(), W)
     assert np.array_equal(dL.cpu().numpy(), L[:, 0])

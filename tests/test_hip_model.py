@@ -187,7 +187,7 @@ def test_full_size_properties():
     sel = torch.arange(0, B, 997, device="cuda")
     # the materialising form of the gather kernel is an exact copy of the addressed rows
     concat = torch.empty(B, F * E, device="cuda")
-    m.k.mi_embed_fm_linear_fwd(m.table, None, m.field_off, ids, B, F, E, concat, F * E, None, None, None, None)
+    m.k.mi_embed_fm_linear_fwd(m.table, None, m.field_off, ids, B, F, E, concat, F * E, None, None, None, None, 1)
     concat = concat.view(B, F, E)
     assert torch.equal(concat[sel], m.table[rows[sel]])
     assert "concat" not in m._ws          # the training path never materialises it (gathered layer-1 operand)
@@ -297,7 +297,7 @@ def test_config5_one_rank_share_properties():
     rows = ids.long() + m.field_off[None, :]
     assert int(rows.max()) * E * 4 > 2 ** 34
     concat = torch.empty(B, F * E, device="cuda")
-    m.k.mi_embed_fm_linear_fwd(m.table, None, m.field_off, ids, B, F, E, concat, F * E, None, None, None, None)
+    m.k.mi_embed_fm_linear_fwd(m.table, None, m.field_off, ids, B, F, E, concat, F * E, None, None, None, None, 1)
     sel = torch.arange(0, B, 331, device="cuda")
     assert torch.equal(concat[sel].view(-1, F, E), m.table[rows[sel]])
     del concat

@@ -257,7 +257,7 @@ def test_embed_fm_planes_fwd(lib, E, F, B):
                                     amax.data_ptr(), _st()))
     concat = torch.empty(B, F * E, device="cuda"); sumv2 = torch.empty(B, E, device="cuda"); fm2 = torch.empty(B, device="cuda")
     _chk(lib.mi_embed_fm_linear_fwd(t.data_ptr(), None, fo.data_ptr(), di.data_ptr(), B, F, E, concat.data_ptr(), F * E,
-                                    sumv2.data_ptr(), fm2.data_ptr(), None, None, _st()))
+                                    sumv2.data_ptr(), fm2.data_ptr(), None, None, 1, _st()))
     rows = ids.astype(np.int64) + off[:-1][None, :]
     assert np.array_equal(concat.cpu().numpy(), table[rows].reshape(B, F * E))
     hb, he = host_planes(concat.cpu().numpy())
