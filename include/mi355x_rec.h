@@ -324,7 +324,8 @@ typedef struct mi_gemm_amax {
  * after the optimizer step, a concat received from an all-to-all). */
 int32_t mi_absmax(const float* x, int64_t n, float* amax_out, mi_stream_t stream);
 
-/* Y[M,N] = act( X[M,K] * W[K,N] + bias[N] ), act = relu if relu != 0.  If keep_prob < 1 the
+/* Y[M,N] = act( X[M,K] * W[K,N] + bias[N] ); `relu` selects the activation of tf.layers.dense (deep_fm.py:22,100:
+ * params["activation"], default tf.nn.relu): 0 none, 1 relu, 2 sigmoid, 3 tanh.  If keep_prob < 1 the
  * TRAIN-mode dropout of deep_fm.py:102-103 is applied after the activation with a counter-based
  * mask (seed, layer, element index): survivors scaled by 1/keep_prob. */
 int32_t mi_dense_fwd(const float* X, int64_t ldx, const float* W, const float* bias, float* Y,
@@ -347,10 +348,13 @@ int32_t mi_dense_bwd_weight_gathered(const float* table, const int64_t* field_of
 /* dX[M,K] = (dY[M,N] * W[K,N]^T) .* mask.  When Xact != NULL (the previous layer's stored
  * post-relu, post-dropout output) mask = (Xact > 0) / keep_prob — a unit with Xact > 0 was both
  * relu-active and kept, every other unit gets gradient 0 — so dX is the gradient w.r.t. the
- * previous layer's PRE-activation, ready to be that layer's dY. */
+ * previous layer's PRE-activation, ready to be that layer's dY.
+ * activation (as mi_dense_fwd's): for sigmoid / tanh / none the factor is act'(pre) expressed through the stored
+ * output (y (1 - y), 1 - y^2, 1) divided by keep_prob; with dropout a stored output that is exactly 0 counts
+ * as dropped. */
 int32_t mi_dense_bwd_data(const float* dY, int64_t lddy, const float* W, const float* Xact,
                           int64_t ldxa, float* dX, int64_t lddx, int64_t M, int32_t N, int32_t K,
-                          float keep_prob, const mi_gemm_amax_t* amax, mi_stream_t stream);
+                          float keep_prob, int32_t activation, const mi_gemm_amax_t* amax, mi_stream_t stream);
 
 /* dW[K,N] = X[M,K]^T * dY[M,N], db[N] = column sums of dY.  Split-K over M with a
  * fixed-order slab reduction (bitwise reproducible). */
@@ -443,6 +447,14 @@ int32_t mi_colsum(const float* X, int64_t ldx, int64_t M, int32_t N, float* out,
 size_t mi_layer_stats_workspace_bytes(int64_t n);
 int32_t mi_layer_stats(const float* x, int64_t n, float* out4, void* workspace,
                        size_t workspace_bytes, mi_stream_t stream);
+
+/* The histogram of layer_summary (tf.summary.histogram("activation", value), model_utils.py:6): counts[b] += 1
+ * for b = number of limits <= x[i] (std::upper_bound over the ascending fp64 bucket limits, as TensorFlow's
+ * histogram::Histogram::Add; its default limits are +-1e-12 * 1.1^k up to 1e20, 0 and +-DBL_MAX: 1,551 of
+ * them — mi355x_rec/metrics.py builds them), sums[0] += sum x, sums[1] += sum x^2 (fp64).  counts
+ * [n_limits + 1] int64 and sums [2] are accumulated into: zero them first.  n_limits <= 2048. */
+int32_t mi_layer_histogram(const float* x, int64_t n, const double* limits, int32_t n_limits, int64_t* counts,
+                           double* sums, mi_stream_t stream);
 
 /* ---- (f3) streaming eval metrics: tf.metrics.auc confusion counts --------
  * Accumulates (integer atomics, order independent) into device arrays the caller zeroed:

@@ -92,8 +92,16 @@ def init_params(rng, vocab_sizes, E, hidden_units, n_numeric=0, dtype=np.float32
     return Params(emb, lin_w, lin_bias, mlp, num_emb, lin_num)
 
 
+ACTIVATIONS = {   # params["activation"] (deep_fm.py:22): name -> (f, f' expressed through the output y)
+    "relu": (lambda v: np.maximum(v, 0), lambda y: (y > 0).astype(y.dtype)),
+    "sigmoid": (lambda v: 1 / (1 + np.exp(-v)), lambda y: y * (1 - y)),
+    "tanh": (np.tanh, lambda y: 1 - y * y),
+    None: (lambda v: v, lambda y: np.ones_like(y)),
+}
+
+
 def forward(p, ids, x_num=None, use_linear=True, use_mf=True, use_dnn=True, dropout_masks=None, numeric="embed",
-            keep_prob=1.0):
+            keep_prob=1.0, activation="relu"):
     """model_fn forward (deep_fm.py:36-115).  ids [B,F] per-field local ids; x_num [B,n_d].
     dropout_masks: per hidden layer, a [B,h] array of {0, 1} keep flags (TRAIN) or None; tf.layers.dropout
     (deep_fm.py:102-103) is tf.nn.dropout: div(x, keep_prob) * mask — a division, not a multiplication by 1/keep.
@@ -107,7 +115,8 @@ def forward(p, ids, x_num=None, use_linear=True, use_mf=True, use_dnn=True, drop
     B, F = ids.shape
     if numeric == "raw" and use_mf:
         raise ValueError("raw numeric columns belong to the canned estimators, which have no FM term")
-    c = {"ids": ids, "x_num": x_num, "flags": (use_linear, use_mf, use_dnn), "numeric": numeric, "keep_prob": keep_prob}
+    c = {"ids": ids, "x_num": x_num, "flags": (use_linear, use_mf, use_dnn), "numeric": numeric, "keep_prob": keep_prob,
+         "activation": activation}
     logits = np.zeros(B, dt)                                      # deep_fm.py:36
     if use_linear:                                                # deep_fm.py:37-44 linear_model
         lin = np.zeros(B, dt)
@@ -143,7 +152,7 @@ def forward(p, ids, x_num=None, use_linear=True, use_mf=True, use_dnn=True, drop
         nh = len(p.mlp) - 1
         for i in range(nh):
             k, b = p.mlp[i]
-            net = np.maximum(net @ k + b, 0)                      # tf.layers.dense(relu) :100
+            net = ACTIVATIONS[activation][0](net @ k + b).astype(dt)   # tf.layers.dense(activation) :100
             if dropout_masks is not None and dropout_masks[i] is not None:
                 net = (net / dt.type(keep_prob)) * dropout_masks[i].astype(dt)   # tf.layers.dropout :102-103
             acts.append(net)
@@ -198,10 +207,14 @@ def backward(p, c, d_logits, dropout_masks=None):
         g_hidden = []
         for i in range(nh - 1, -1, -1):
             a = c["acts"][i]                 # post-relu, post-dropout activation
-            if dropout_masks is not None and dropout_masks[i] is not None:
+            dropped = dropout_masks is not None and dropout_masks[i] is not None
+            if dropped:
                 d_net = (d_net * dropout_masks[i].astype(dt)) / dt.type(c["keep_prob"])
-            # a > 0  <=>  (pre-activation > 0 and the unit was kept); dropped units already got 0
-            d_pre = d_net * (a > 0)
+            # relu: a > 0  <=>  (pre-activation > 0 and the unit was kept); dropped units already got 0.
+            # other activations: f'(pre) through the un-dropped output a * keep
+            act = c.get("activation", "relu")
+            y = a * dt.type(c["keep_prob"]) if (dropped and act != "relu") else a
+            d_pre = d_net * ACTIVATIONS[act][1](y).astype(dt)
             inp = c["acts"][i - 1] if i else c["concat"]
             k_i = p.mlp[i][0]
             g_hidden.append((inp.T @ d_pre, d_pre.sum(0)))
@@ -261,11 +274,11 @@ class TrainState:
 
 
 def train_step(p, st, ids, labels, x_num=None, use_linear=True, use_mf=True, use_dnn=True,
-               reduction="mean", dropout_masks=None, global_batch=None, numeric="embed", keep_prob=1.0):
+               reduction="mean", dropout_masks=None, global_batch=None, numeric="embed", keep_prob=1.0, activation="relu"):
     """One optimizer.minimize(loss) (deep_fm.py:119-125 TRAIN branch): forward, head, backward,
     apply_gradients (dense vars: fused Apply*, embedding / linear tables: sparse apply with
     duplicate-summing), beta powers / global_step update.  Returns (loss, logits)."""
-    c = forward(p, ids, x_num, use_linear, use_mf, use_dnn, dropout_masks, numeric, keep_prob)
+    c = forward(p, ids, x_num, use_linear, use_mf, use_dnn, dropout_masks, numeric, keep_prob, activation)
     loss, d_logits, _, _ = head(c["logits"], labels, reduction, global_batch)
     dense_g, d_rows, d_lin = backward(p, c, d_logits, dropout_masks)
     apply_gradients(p, st, ids, dense_g, d_rows, d_lin)

@@ -209,6 +209,25 @@ __device__ __forceinline__ void read_frag(const float* __restrict__ S, int mn, i
   }
 }
 
+// activation of tf.layers.dense (deep_fm.py:22,100: params["activation"], default tf.nn.relu): 0 none, 1 relu,
+// 2 sigmoid, 3 tanh; and its derivative expressed through the activation's OUTPUT y (what the forward stored)
+__device__ __forceinline__ float act_apply(int kind, float v) {
+  switch (kind) {
+    case 1: return fmaxf(v, 0.f);
+    case 2: return 1.f / (1.f + __expf(-v));
+    case 3: return tanhf(v);
+    default: return v;
+  }
+}
+__device__ __forceinline__ float act_deriv_from_output(int kind, float y) {
+  switch (kind) {
+    case 1: return y > 0.f ? 1.f : 0.f;
+    case 2: return y * (1.f - y);
+    case 3: return 1.f - y * y;
+    default: return 1.f;
+  }
+}
+
 // ---- epilogue shared by the fp32-MFMA and the bf16x3-split kernels --------------------------
 // C/D register map of every 32x32 MFMA (dtype independent): col = lane&31,
 // row = (r&3) + 8*(r>>2) + 4*(lane>>5).  i = lane&31, h = lane>>5.
@@ -235,12 +254,18 @@ __device__ __forceinline__ void store_tile_c(const GemmArgs& a, const f32x16 (&a
         float v = acc[mi][ni][r] * sa * sb;
         if (a.epi == EPI_BIAS_ACT) {
           v += bv;
-          if (a.relu) v = fmaxf(v, 0.f);
+          v = act_apply(a.relu, v);
           if (a.keep_prob < 1.f) v = dropout_keep(a.seed, row, col, thresh) ? v / a.keep_div : 0.f;
         } else if (a.epi == EPI_MASK) {
           if (a.mask_src) {
             const float x = a.mask_src[static_cast<int64_t>(row) * a.ldm + col];
-            v = (x > 0.f) ? v / a.keep_div : 0.f;
+            if (a.relu == 1) {
+              v = (x > 0.f) ? v / a.keep_div : 0.f;          // active and kept
+            } else {
+              // stored output x = act(pre) / keep or 0 (dropped; with dropout an output that is exactly 0 counts as dropped)
+              const bool dropped = a.keep_div < 1.f && x == 0.f;
+              v = dropped ? 0.f : (v / a.keep_div) * act_deriv_from_output(a.relu, x * a.keep_div);
+            }
           }
         }
         Cb[static_cast<int64_t>(row) * a.ldc + col] = v;
@@ -504,7 +529,7 @@ __global__ __launch_bounds__(kThreads) void gemv_fwd_k(const float* __restrict__
       const int64_t m = m0 + j * groups;
       if (m < M && l == 0) {
         float v = acc[j] + b0;
-        if (relu) v = fmaxf(v, 0.f);
+        v = act_apply(relu, v);
         if (keep_prob < 1.f) v = dropout_keep(seed, static_cast<uint32_t>(m), 0u, thresh) ? v / keep_div : 0.f;
         Y[m * ldy] = v;
         mx = fmaxf(mx, fabsf(v));
@@ -519,7 +544,7 @@ __global__ __launch_bounds__(kThreads) void gemv_fwd_k(const float* __restrict__
 __global__ __launch_bounds__(kThreads) void gemv_dgrad_k(const float* __restrict__ dY, int64_t lddy,
                                                          const float* __restrict__ W, const float* __restrict__ Xact,
                                                          int64_t ldxa, float* __restrict__ dX, int64_t lddx, int64_t M,
-                                                         int K, float keep_div, float* __restrict__ amax_out) {
+                                                         int K, float keep_div, int act, float* __restrict__ amax_out) {
   const int kq = K >> 2;
   const int64_t total = M * kq, stride = static_cast<int64_t>(gridDim.x) * kThreads;
   float mx = 0.f;
@@ -542,8 +567,16 @@ __global__ __launch_bounds__(kThreads) void gemv_dgrad_k(const float* __restrict
       if (base + j * stride >= total) break;
       float4 v = make_float4(gv[j] * wv[j].x, gv[j] * wv[j].y, gv[j] * wv[j].z, gv[j] * wv[j].w);
       if (Xact) {
-        v.x = xv[j].x > 0.f ? v.x / keep_div : 0.f; v.y = xv[j].y > 0.f ? v.y / keep_div : 0.f;
-        v.z = xv[j].z > 0.f ? v.z / keep_div : 0.f; v.w = xv[j].w > 0.f ? v.w / keep_div : 0.f;
+        if (act == 1) {
+          v.x = xv[j].x > 0.f ? v.x / keep_div : 0.f; v.y = xv[j].y > 0.f ? v.y / keep_div : 0.f;
+          v.z = xv[j].z > 0.f ? v.z / keep_div : 0.f; v.w = xv[j].w > 0.f ? v.w / keep_div : 0.f;
+        } else {
+          const bool dr = keep_div < 1.f;
+          v.x = (dr && xv[j].x == 0.f) ? 0.f : (v.x / keep_div) * act_deriv_from_output(act, xv[j].x * keep_div);
+          v.y = (dr && xv[j].y == 0.f) ? 0.f : (v.y / keep_div) * act_deriv_from_output(act, xv[j].y * keep_div);
+          v.z = (dr && xv[j].z == 0.f) ? 0.f : (v.z / keep_div) * act_deriv_from_output(act, xv[j].z * keep_div);
+          v.w = (dr && xv[j].w == 0.f) ? 0.f : (v.w / keep_div) * act_deriv_from_output(act, xv[j].w * keep_div);
+        }
       }
       *reinterpret_cast<float4*>(dX + mm[j] * lddx + kk[j]) = v;
       mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
@@ -691,6 +724,7 @@ int32_t mi_dense_fwd(const float* X, int64_t ldx, const float* W, const float* b
   MI_REQUIRE(X && W && Y, "dense_fwd: null buffer");
   MI_REQUIRE(ldx >= K && ldy >= N, "dense_fwd: ldx=%lld ldy=%lld", (long long)ldx, (long long)ldy);
   MI_REQUIRE(keep_prob > 0.f && keep_prob <= 1.f, "dense_fwd: keep_prob=%f", keep_prob);
+  MI_REQUIRE(relu >= 0 && relu <= 3, "dense_fwd: activation=%d (0 none, 1 relu, 2 sigmoid, 3 tanh)", relu);
   if (N == 1 && gemv_ok(X, ldx, W, K)) {
     const int64_t blocks = std::min<int64_t>(mi::ceil_div(M * kGvLanes, 2 * kThreads), 2048);
     gemv_fwd_k<<<dim3((unsigned)blocks), dim3(kThreads), 0, mi::as_stream(stream)>>>(
@@ -710,7 +744,8 @@ int32_t mi_dense_fwd(const float* X, int64_t ldx, const float* W, const float* b
 
 int32_t mi_dense_bwd_data(const float* dY, int64_t lddy, const float* W, const float* Xact,
                           int64_t ldxa, float* dX, int64_t lddx, int64_t M, int32_t N, int32_t K,
-                          float keep_prob, const mi_gemm_amax_t* amax, mi_stream_t stream) {
+                          float keep_prob, int32_t activation, const mi_gemm_amax_t* amax, mi_stream_t stream) {
+  MI_REQUIRE(activation >= 0 && activation <= 3, "dense_bwd_data: activation=%d (0 none, 1 relu, 2 sigmoid, 3 tanh)", activation);
   MI_REQUIRE(M >= 0 && M <= INT32_MAX && N > 0 && K > 0, "dense_bwd_data: M=%lld N=%d K=%d", (long long)M, N, K);
   if (M == 0) return MI_OK;
   MI_REQUIRE(dY && W && dX, "dense_bwd_data: null buffer");
@@ -720,7 +755,7 @@ int32_t mi_dense_bwd_data(const float* dY, int64_t lddy, const float* W, const f
       (!Xact || (mi::aligned16(Xact) && (ldxa & 3) == 0))) {
     const int64_t blocks = std::min<int64_t>(mi::ceil_div(M * (K >> 2), 4 * kThreads), 4096);
     gemv_dgrad_k<<<dim3((unsigned)blocks), dim3(kThreads), 0, mi::as_stream(stream)>>>(
-        dY, lddy, W, Xact, ldxa, dX, lddx, M, K, Xact ? keep_prob : 1.f, amax ? amax->out : nullptr);
+        dY, lddy, W, Xact, ldxa, dX, lddx, M, K, Xact ? keep_prob : 1.f, activation, amax ? amax->out : nullptr);
     MI_CHECK_LAUNCH("dense_bwd_data(N = 1)");
     return MI_OK;
   }
@@ -728,7 +763,7 @@ int32_t mi_dense_bwd_data(const float* dY, int64_t lddy, const float* W, const f
   a.A = dY; a.lda = lddy; a.B = W; a.ldb = N; a.C = dX; a.ldc = lddx;
   a.M = (int)M; a.N = K; a.K = N; a.k_per_split = ((N + BK - 1) / BK) * BK;
   a.vecA = vec_ok(dY, lddy, N); a.vecB = vec_ok(W, N, N);
-  a.epi = EPI_MASK; a.mask_src = Xact; a.ldm = ldxa;
+  a.epi = EPI_MASK; a.mask_src = Xact; a.ldm = ldxa; a.relu = activation;
   a.keep_prob = keep_prob; a.keep_div = Xact ? keep_prob : 1.f;
   set_amax(a, amax);
   return launch<KC, KC>(a, 1, mi::as_stream(stream), "dense_bwd_data");

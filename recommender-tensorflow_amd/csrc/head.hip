@@ -5,6 +5,7 @@
 // metric contract is spelled out by trainers/model_utils.py:9-54) and layer_summary
 // (model_utils.py:4-6).  Reductions are two-stage with a fixed order: bitwise reproducible.
 #include "common.h"
+#include <algorithm>
 
 namespace {
 
@@ -261,3 +262,55 @@ int32_t mi_eval_accumulate(const float* logits, const uint8_t* labels, int64_t B
 }
 
 }  // extern "C"
+
+// ---- (a10) the histogram half of layer_summary (tf.summary.histogram, model_utils.py:6) -------------------
+namespace {
+constexpr int kHistMaxLimits = 2048;
+// counts[b] += 1 for b = number of limits <= x (std::upper_bound, as tensorflow::histogram::Histogram::Add);
+// limits ascending, fp64; sums += (sum x, sum x^2) in fp64.  LDS histogram per block, integer atomics.
+__global__ __launch_bounds__(256) void layer_histogram_k(const float* __restrict__ x, int64_t n, const double* __restrict__ limits,
+                                                         int nl, unsigned long long* __restrict__ counts,
+                                                         double* __restrict__ sums) {
+  __shared__ double lim[kHistMaxLimits];
+  __shared__ unsigned int cnt[kHistMaxLimits + 1];
+  __shared__ double red[2][4];
+  for (int i = threadIdx.x; i < nl; i += 256) lim[i] = limits[i];
+  for (int i = threadIdx.x; i <= nl; i += 256) cnt[i] = 0u;
+  __syncthreads();
+  double s = 0.0, q = 0.0;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * 256;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < n; i += stride) {
+    const double v = static_cast<double>(x[i]);
+    int lo = 0, hi = nl;                       // first index with lim[idx] > v
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (lim[mid] > v) hi = mid; else lo = mid + 1;
+    }
+    atomicAdd(&cnt[lo], 1u);
+    s += v; q += v * v;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = q; }
+  __syncthreads();
+  for (int i = threadIdx.x; i <= nl; i += 256)
+    if (cnt[i]) atomicAdd(counts + i, static_cast<unsigned long long>(cnt[i]));
+  if (threadIdx.x == 0) {
+    atomicAdd(sums, (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]));
+    atomicAdd(sums + 1, (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]));
+  }
+}
+}  // namespace
+
+extern "C" int32_t mi_layer_histogram(const float* x, int64_t n, const double* limits, int32_t n_limits, int64_t* counts,
+                                      double* sums, mi_stream_t stream) {
+  MI_REQUIRE(n >= 0 && n_limits > 0 && n_limits <= kHistMaxLimits, "layer_histogram: n=%lld n_limits=%d (<= %d)", (long long)n, n_limits,
+             kHistMaxLimits);
+  if (n == 0) return MI_OK;
+  MI_REQUIRE(x && limits && counts && sums, "layer_histogram: null buffer");
+  const int64_t blocks = std::min<int64_t>(mi::ceil_div(n, 256 * 8), 1024);
+  layer_histogram_k<<<dim3((unsigned)blocks), dim3(256), 0, mi::as_stream(stream)>>>(
+      x, n, limits, n_limits, reinterpret_cast<unsigned long long*>(counts), sums);
+  MI_CHECK_LAUNCH("layer_histogram");
+  return MI_OK;
+}

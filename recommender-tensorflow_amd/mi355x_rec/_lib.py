@@ -96,7 +96,7 @@ SIGNATURES = {
     "mi_absmax": (_i32, [_p, _i64, _p, _p]),
     "mi_get_gemm_mode": (_i32, []),
     "mi_dense_fwd": (_i32, [_p, _i64, _p, _p, _p, _i64, _i64, _i32, _i32, _i32, _f32, _u64, _amax, _p]),
-    "mi_dense_bwd_data": (_i32, [_p, _i64, _p, _p, _i64, _p, _i64, _i64, _i32, _i32, _f32, _amax, _p]),
+    "mi_dense_bwd_data": (_i32, [_p, _i64, _p, _p, _i64, _p, _i64, _i64, _i32, _i32, _f32, _i32, _amax, _p]),
     "mi_dense_bwd_weight_workspace_bytes": (_sz, [_i64, _i32, _i32]),
     "mi_dense_bwd_weight": (_i32, [_p, _i64, _p, _i64, _p, _p, _i64, _i32, _i32, _p, _sz, _amax, _p]),
     "mi_planes_bytes": (_sz, [_i64, _i32]),
@@ -112,6 +112,7 @@ SIGNATURES = {
     "mi_colsum": (_i32, [_p, _i64, _i64, _i32, _p, _p, _sz, _p]),
     "mi_layer_stats_workspace_bytes": (_sz, [_i64]),
     "mi_layer_stats": (_i32, [_p, _i64, _p, _p, _sz, _p]),
+    "mi_layer_histogram": (_i32, [_p, _i64, _p, _i32, _p, _p, _p]),
     "mi_eval_accumulate": (_i32, [_p, _p, _i64, _p, _p, _p, _p]),
 }
 

@@ -189,12 +189,18 @@ class DeepFM:
     def __init__(self, vocab_sizes, n_numeric=0, embedding_size=4, hidden_units=(16, 16),
                  use_linear=True, use_mf=True, use_dnn=True, dropout=0.0, optimizer=None,
                  linear_optimizer=None, reduction="mean", device="cuda", seed=0, shard=None,
-                 gemm="f16x2", numeric="embed", _kernels=None):
+                 gemm="f16x2", numeric="embed", activation="relu", _kernels=None):
         if len(vocab_sizes) + n_numeric == 0:
             raise ValueError("At least 1 feature column of categorical_columns or numeric_columns "
                              "must be specified.")            # deep_fm.py:31-32
         if not (use_linear or use_mf or use_dnn):
             raise ValueError("At least 1 of linear, mf or dnn component must be used.")  # :33-34
+        # params["activation"] of model_fn (deep_fm.py:22; the reference passes a TF callable, default tf.nn.relu)
+        acts = {"relu": 1, None: 0, "identity": 0, "linear": 0, "sigmoid": 2, "tanh": 3}
+        name = activation if (activation is None or isinstance(activation, str)) else getattr(activation, "__name__", None)
+        if name not in acts:
+            raise NotImplementedError("activation %r: the GEMM epilogues implement relu, sigmoid, tanh and identity" % (activation,))
+        self.act = acts[name]
         if numeric not in ("embed", "raw"):
             raise ValueError("numeric must be 'embed' or 'raw'")
         if numeric == "raw" and use_mf:
@@ -322,7 +328,7 @@ class DeepFM:
         # staging, 512-column tiles).  Every hidden layer's widths must be multiples of 16; the weight
         # gradient still runs on the fp32 copies (gemm.hip, matrix-wide scales: its reduction runs over the
         # examples, where a per-example exponent cannot be undone).
-        self.planes = (gemm == "f16x2" and self.use_dnn and len(self.hidden) > 0 and
+        self.planes = (gemm == "f16x2" and self.use_dnn and len(self.hidden) > 0 and self.act == 1 and
                        getattr(self.k, "supports_planes", False) and self.D % 16 == 0 and
                        all(h % 16 == 0 for h in self.hidden))
         self._pl = {}
@@ -606,10 +612,10 @@ class DeepFM:
                     xp = "x%dp" % (i + 1)
                 elif i == 0 and gathered:
                     k.mi_dense_fwd_gathered(table, field_off, rid, F, self.E, self.kernel(0), self.bias(0), y, h,
-                                            B, h, 0 if last else 1, 1.0 if last else keep, self._layer_seed(0),
+                                            B, h, 0 if last else self.act, 1.0 if last else keep, self._layer_seed(0),
                                             self._ga("x0", "w", "x1"))
                 else:
-                    k.mi_dense_fwd(x, ldx, self.kernel(i), self.bias(i), y, h, B, h, fan, 0 if last else 1,
+                    k.mi_dense_fwd(x, ldx, self.kernel(i), self.bias(i), y, h, B, h, fan, 0 if last else self.act,
                                    1.0 if last else keep, self._layer_seed(i),
                                    None if self.planes else self._ga("x%d" % i, "w", "x%d" % (i + 1)))
                 acts.append(y)
@@ -810,7 +816,7 @@ class DeepFM:
                         k.mi_split_rows(dx, fan, B, fan, 0, dxp, None)
                 else:
                     k.mi_dense_bwd_data(dy, lddy, self.kernel(i), x if i else None, ldx, dx, fan, B, h, fan,
-                                        keep if i else 1.0, None if self.planes else ga_d)
+                                        keep if i else 1.0, self.act, None if self.planes else ga_d)
                     if self.planes and i == nh and i > 0:
                         # the logits layer's matrix-vector data gradient writes fp32: split it for the layer below
                         k.mi_split_rows(dx, fan, B, fan, 0, self._planes("dy%dp" % (i - 1), B, fan), self._av("dy%d" % (i - 1)))
@@ -890,11 +896,26 @@ class DeepFM:
         if "logits" in self._ws:
             named.append(("logits", self._ws["logits"][:B]))
         out = self._buf("layer_stats", (len(named), 4))
+        hist = getattr(k, "mi_layer_histogram", None) is not None and self.device.type == "cuda"
+        if hist:
+            from .metrics import histogram_limits, histogram_proto
+            lim = self._ws.get("hist_limits")
+            if lim is None:
+                lim = self._ws["hist_limits"] = torch.from_numpy(histogram_limits()).to(self.device)
+            counts = torch.zeros(len(named), lim.numel() + 1, dtype=torch.int64, device=self.device)
+            sums = torch.zeros(len(named), 2, dtype=torch.float64, device=self.device)
         for j, (_, x) in enumerate(named):
             ws = self._bytes("layer_stats_ws", k.query("mi_layer_stats_workspace_bytes", x.numel()))
             k.mi_layer_stats(x, x.numel(), out[j], ws, ws.numel())
+            if hist:
+                k.mi_layer_histogram(x, x.numel(), lim, lim.numel(), counts[j], sums[j])
         vals = out.cpu().tolist()
-        return {n: dict(zip(("fraction_of_zero_values", "min", "max", "mean"), v)) for (n, _), v in zip(named, vals)}
+        res = {n: dict(zip(("fraction_of_zero_values", "min", "max", "mean"), v)) for (n, _), v in zip(named, vals)}
+        if hist:        # tf.summary.histogram("activation", value): the second half of layer_summary
+            cn, sm, ln = counts.cpu().numpy(), sums.cpu().numpy(), lim.cpu().numpy()
+            for j, (n, _) in enumerate(named):
+                res[n]["activation"] = histogram_proto(ln, cn[j], sm[j], res[n]["min"], res[n]["max"])
+        return res
 
     # ------------------------------------------------------------------ checkpoint
     _STATE_KEYS = ("dense", "d_s0", "d_s1", "table", "lin_w", "t_s0", "t_s1", "l_s0", "l_s1", "last_step",

@@ -48,3 +48,24 @@ def metrics_from_counters(hist, counts, sums):
         "precision": tp5 / max(tp5 + fp5, 1),
         "recall": tp5 / max(tp5 + fn5, 1),
     }
+
+
+def histogram_limits():
+    """TensorFlow's default histogram bucket limits (core/lib/histogram/histogram.cc InitDefaultBucketsInner,
+    what tf.summary.histogram of layer_summary — model_utils.py:6 — bins with): 1e-12 * 1.1^k below 1e20,
+    DBL_MAX, their negatives and 0; ascending, 1,551 values."""
+    pos, v = [], 1.0e-12
+    while v < 1.0e20:
+        pos.append(v)
+        v *= 1.1
+    pos.append(np.finfo(np.float64).max)
+    return np.asarray([-x for x in reversed(pos)] + [0.0] + pos, np.float64)
+
+
+def histogram_proto(limits, counts, sums, vmin, vmax):
+    """The fields of a tensorflow.HistogramProto, empty buckets dropped (bucket b holds limit[b-1] <= x < limit[b])"""
+    counts = np.asarray(counts, np.int64)
+    nz = np.flatnonzero(counts)
+    lim = np.append(limits, np.finfo(np.float64).max)
+    return {"min": float(vmin), "max": float(vmax), "num": int(counts.sum()), "sum": float(sums[0]), "sum_squares": float(sums[1]),
+            "bucket_limit": [float(lim[b]) for b in nz], "bucket": [int(counts[b]) for b in nz]}

@@ -21,16 +21,15 @@ def model_fn(features, labels, mode, params):
         raise ValueError("At least 1 feature column of categorical_columns or numeric_columns must be specified.")
     if not any(flags):
         raise ValueError("At least 1 of linear, mf or dnn component must be used.")
-    activation = params.get("activation", "relu")
-    if activation not in ("relu", None) and getattr(activation, "__name__", "") != "relu":
-        raise NotImplementedError("the fused GEMM epilogue implements relu (the reference default)")
+    activation = params.get("activation", "relu")      # deep_fm.py:22 (a callable there): "relu" | "sigmoid" | "tanh" | None,
+                                                       # or a callable with one of those names
 
     def make(plan, device, shard=None):
         opt = get_optimizer(params.get("optimizer", "Adam"), params.get("learning_rate", 0.001))
         return DeepFM(plan.vocab_sizes, n_numeric=len(plan.numeric), embedding_size=params.get("embedding_size", 4),
                       hidden_units=params.get("hidden_units", [16, 16]), use_linear=flags[0], use_mf=flags[1],
                       use_dnn=flags[2], dropout=params.get("dropout", 0), optimizer=opt, reduction="mean",
-                      device=device, seed=params.get("seed", 0), shard=shard)
+                      device=device, seed=params.get("seed", 0), shard=shard, activation=activation)
 
     return run_batch(features, labels, mode, params, make)
 

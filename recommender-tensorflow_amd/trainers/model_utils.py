@@ -12,14 +12,23 @@ _OPTIMIZERS = ("Adagrad", "Adam", "Ftrl", "RMSProp", "SGD")
 
 
 def layer_summary(value):
-    """zero fraction + range of an activation tensor (tf.summary.scalar / histogram in the reference)."""
+    """zero fraction + histogram of an activation tensor (tf.summary.scalar("fraction_of_zero_values", zero_fraction(x))
+    and tf.summary.histogram("activation", x) in the reference, model_utils.py:4-6; TensorFlow's default bucket limits)."""
+    from mi355x_rec.metrics import histogram_limits, histogram_proto
     k = HipKernels()
     x = value.contiguous().view(-1)
     out = torch.empty(4, device=x.device)
     ws = torch.empty(k.query("mi_layer_stats_workspace_bytes", x.numel()) + 256, dtype=torch.uint8, device=x.device)
     k.mi_layer_stats(x, x.numel(), out, ws, ws.numel())
     z, mn, mx, mean = out.tolist()
-    return {"fraction_of_zero_values": z, "min": mn, "max": mx, "mean": mean}
+    res = {"fraction_of_zero_values": z, "min": mn, "max": mx, "mean": mean}
+    if getattr(k, "mi_layer_histogram", None) is not None and x.device.type == "cuda":
+        lim = torch.from_numpy(histogram_limits()).to(x.device)
+        counts = torch.zeros(lim.numel() + 1, dtype=torch.int64, device=x.device)
+        sums = torch.zeros(2, dtype=torch.float64, device=x.device)
+        k.mi_layer_histogram(x, x.numel(), lim, lim.numel(), counts, sums)
+        res["activation"] = histogram_proto(lim.cpu().numpy(), counts.cpu().numpy(), sums.cpu().numpy(), mn, mx)
+    return res
 
 
 def get_binary_predictions(logits):
@@ -53,7 +62,24 @@ def get_optimizer(optimizer_name="Adam", learning_rate=0.001):
     return OptimizerSpec(optimizer_name, learning_rate)
 
 
+class TrainOp:
+    """What ``optimizer.minimize(loss, global_step)`` is here: there is no graph, so the op is a callable bound to
+    an optimizer spec; ``op(engine, ids, labels, x_num=None)`` runs one train step — forward, head, backward and
+    that optimizer's apply on every variable, global_step += 1 — on an engine built with that spec (model_fn's
+    TRAIN branch does exactly this through engine.DeepFM.train_step)."""
+
+    def __init__(self, loss, optimizer):
+        self.loss, self.optimizer = loss, optimizer
+
+    def __call__(self, engine, ids, labels, x_num=None):
+        o, e = self.optimizer, engine.opt
+        if (o.name, o.lr) != (e.name, e.lr):
+            raise ValueError("train op for %s(%g) applied to an engine built with %s(%g)" % (o.name, o.lr, e.name, e.lr))
+        return engine.train_step(ids, labels, x_num)
+
+
 def get_train_op(loss, optimizer):
-    raise NotImplementedError(
-        "there is no graph to attach a train op to: the step (forward, backward, optimizer apply) runs inside "
-        "model_fn(mode=TRAIN) / engine.DeepFM.train_step with the OptimizerSpec from get_optimizer()")
+    """model_utils.py:69-72: ``optimizer.minimize(loss, global_step=tf.train.get_global_step())``"""
+    if not isinstance(optimizer, OptimizerSpec):
+        raise TypeError("optimizer must come from get_optimizer()")
+    return TrainOp(loss, optimizer)

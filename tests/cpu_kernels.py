@@ -175,17 +175,22 @@ class NumpyKernels:
 
     def mi_dense_fwd(self, X, ldx, W, bias, Y, ldy, M, N, K, relu, keep, seed, amax=None):
         y = _np(X)[:, :K] @ _np(W) + _np(bias)
-        if relu:
-            y = np.maximum(y, 0)
+        y = {0: lambda v: v, 1: lambda v: np.maximum(v, 0), 2: lambda v: 1 / (1 + np.exp(-v)), 3: np.tanh}[int(relu)](y).astype(np.float32)
         if keep < 1.0:
             y = (y / np.float32(keep)) * dropout_mask(seed, M, N, keep)
         _np(Y)[:, :N] = y
 
-    def mi_dense_bwd_data(self, dY, lddy, W, Xact, ldxa, dX, lddx, M, N, K, keep, amax=None):
+    def mi_dense_bwd_data(self, dY, lddy, W, Xact, ldxa, dX, lddx, M, N, K, keep, act=1, amax=None):
         dy = _np(dY).reshape(M, -1)[:, :N]
         g = dy @ _np(W).T
         if Xact is not None:
-            g = (g * (_np(Xact)[:, :K] > 0)) / np.float32(keep)
+            xa = _np(Xact)[:, :K]
+            if act == 1:
+                g = (g * (xa > 0)) / np.float32(keep)
+            else:
+                y = xa * np.float32(keep)
+                d = {0: np.ones_like(y), 2: y * (1 - y), 3: 1 - y * y}[int(act)]
+                g = np.where((keep < 1) & (xa == 0), 0, (g / np.float32(keep)) * d).astype(np.float32)
         _np(dX)[:, :K] = g
 
     def mi_dense_bwd_weight(self, X, ldx, dY, lddy, dW, db, M, N, K, ws, wsb, amax=None):

@@ -66,7 +66,7 @@ def _compare(m, p, atol):
 
 
 def _run(device, vocab, E, hidden, B, nn, numeric, flags, hp, lin_hp, dropout=0.0, steps=3, seed=21, atol=2e-5,
-         reduction="sum"):
+         reduction="sum", activation="relu"):
     ul, um, ud = flags
     rng0 = np.random.default_rng(seed)
     p = O.init_params(rng0, vocab, E, hidden, n_numeric=nn, dtype=np.float32, lin_scale=0.05, use_dnn=ud, numeric=numeric)
@@ -74,7 +74,7 @@ def _run(device, vocab, E, hidden, B, nn, numeric, flags, hp, lin_hp, dropout=0.
     for _, b in p.mlp:
         b[:] = (rng0.standard_normal(b.shape) * 0.05).astype(np.float32)
     kw = dict(n_numeric=nn, numeric=numeric, embedding_size=E, hidden_units=hidden, use_linear=ul, use_mf=um, use_dnn=ud,
-              dropout=dropout, reduction=reduction, optimizer=_spec(hp.name, hp.lr), seed=3)
+              dropout=dropout, reduction=reduction, optimizer=_spec(hp.name, hp.lr), seed=3, activation=activation)
     if lin_hp is not None:
         kw["linear_optimizer"] = _spec(lin_hp.name, lin_hp.lr)
     m = _engine(device, vocab, **kw)
@@ -89,7 +89,8 @@ def _run(device, vocab, E, hidden, B, nn, numeric, flags, hp, lin_hp, dropout=0.
         x = rng.standard_normal((B, nn)).astype(np.float32) if nn else None
         y = (rng.random(B) < 0.3).astype(np.uint8)
         masks = [dropout_mask(m._layer_seed(i), B, h, keep) for i, h in enumerate(hidden)] if (dropout and ud) else None
-        lo, logit_o = O.train_step(p, st, ids, y, x, ul, um, ud, reduction, masks, numeric=numeric, keep_prob=keep)
+        lo, logit_o = O.train_step(p, st, ids, y, x, ul, um, ud, reduction, masks, numeric=numeric, keep_prob=keep,
+                                   activation=activation)
         lg, logit_g = m.train_step(_t(ids, device), _t(y, device), _t(x, device))
         assert abs(lg.item() - float(lo)) <= 2e-5 * abs(float(lo)) + 1e-6, step
         lo_a, lg_a = logit_o, logit_g.cpu().numpy()
@@ -150,6 +151,13 @@ def test_numeric_only_deepfm(device):
     """deep_fm.py:57-70 allows a model with numeric columns only (no categorical column at all)."""
     _run(device, [], 8, [12, 6], 32, 3, "embed", (True, True, True), OO.Hyper("Adam", 0.001), None, reduction="mean",
          atol=2e-6)
+
+
+@pytest.mark.parametrize("activation,dropout", [("sigmoid", 0.0), ("tanh", 0.2), (None, 0.0), ("sigmoid", 0.2)])
+def test_activation_other_than_relu(device, activation, dropout):
+    """model_fn's params["activation"] (deep_fm.py:22,100; the reference passes a TF callable, default relu)"""
+    _run(device, [9, 13, 5, 6], 8, [16, 8], 48, 0, "embed", (True, True, True), OO.Hyper("Adam", 0.001), None, dropout=dropout,
+         reduction="mean", atol=3e-6, activation=activation)
 
 
 def test_config4_shape_small_vocab(device):

@@ -180,12 +180,12 @@ def test_dense_bwd_data_and_weight(lib, M, N, K):
     x, w, dy = dev(X), dev(W), dev(dY)
     dX = torch.empty(M, K, device="cuda")
     keep = 0.8
-    _chk(lib.mi_dense_bwd_data(_p(dy), N, _p(w), _p(x), K, _p(dX), K, M, N, K, keep, None, _st()))
+    _chk(lib.mi_dense_bwd_data(_p(dy), N, _p(w), _p(x), K, _p(dX), K, M, N, K, keep, 1, None, _st()))
     full = dY.astype(np.float64) @ W.astype(np.float64).T
     ref = full * (X > 0) / np.float64(np.float32(keep))
     scale = np.sqrt(np.mean(full * full)) + 1e-30
     assert np.max(np.abs(dX.cpu().numpy() - ref)) / scale < 2 * TOL
-    _chk(lib.mi_dense_bwd_data(_p(dy), N, _p(w), None, K, _p(dX), K, M, N, K, 1.0, None, _st()))
+    _chk(lib.mi_dense_bwd_data(_p(dy), N, _p(w), None, K, _p(dX), K, M, N, K, 1.0, 1, None, _st()))
     assert np.max(np.abs(dX.cpu().numpy() - full)) / scale < TOL
     # weight + bias gradient (split-K over M)
     nb = lib.mi_dense_bwd_weight_workspace_bytes(M, N, K)
@@ -250,7 +250,7 @@ def test_bf16x3_and_fp32_gemm_modes_agree(lib, M, N, K):
         _chk(lib.mi_set_gemm_mode(mode))
         Y = torch.empty(M, N, device="cuda"); dX = torch.empty(M, K, device="cuda")
         _chk(lib.mi_dense_fwd(_p(x), K, _p(w), _p(bb), _p(Y), N, M, N, K, 1, 0.9, 5, None, _st()))
-        _chk(lib.mi_dense_bwd_data(_p(dy), N, _p(w), _p(x), K, _p(dX), K, M, N, K, 0.9, None, _st()))
+        _chk(lib.mi_dense_bwd_data(_p(dy), N, _p(w), _p(x), K, _p(dX), K, M, N, K, 0.9, 1, None, _st()))
         outs[tag] = (Y.cpu(), dX.cpu())
     _chk(lib.mi_set_gemm_mode(1))
     pre = X.astype(np.float64) @ W.astype(np.float64) + b
@@ -321,7 +321,7 @@ def test_f16x2_gemms_against_fp64(lib, M, N, K):
     ref = np.maximum(pre, 0) / np.float64(np.float32(0.9)) * dropout_mask(5, M, N, 0.9)
     assert np.max(np.abs(Y.cpu().numpy() - ref)) / np.sqrt(np.mean(pre * pre)) < TOL
     assert float(ay.max()) == float(Y.abs().max())
-    _chk(lib.mi_dense_bwd_data(_p(dy), N, _p(w), _p(x), K, _p(dX), K, M, N, K, 0.9, _ga(ady, aw), _st()))
+    _chk(lib.mi_dense_bwd_data(_p(dy), N, _p(w), _p(x), K, _p(dX), K, M, N, K, 0.9, 1, _ga(ady, aw), _st()))
     full = dY.astype(np.float64) @ W.astype(np.float64).T
     refd = full * (X > 0) / np.float64(np.float32(0.9))
     assert np.max(np.abs(dX.cpu().numpy() - refd)) / np.sqrt(np.mean(full * full)) < 2 * TOL
@@ -741,9 +741,28 @@ def test_gemm_entries_row_relative_error_with_rows_far_below_the_matrix_absmax(l
     _chk(lib.mi_dense_fwd(_p(x), K, _p(w), _p(bb), _p(Y), N, M, N, K, 0, 1.0, 0, _ga(ax, aw), _st()))
     assert rowrel(Y.cpu().numpy().astype(np.float64), X.astype(np.float64) @ W.astype(np.float64)) < TOL
     dX = torch.empty(M, K, device="cuda")
-    _chk(lib.mi_dense_bwd_data(_p(dy), N, _p(w), None, K, _p(dX), K, M, N, K, 1.0, _ga(ady, aw), _st()))
+    _chk(lib.mi_dense_bwd_data(_p(dy), N, _p(w), None, K, _p(dX), K, M, N, K, 1.0, 1, _ga(ady, aw), _st()))
     assert rowrel(dX.cpu().numpy().astype(np.float64), dY.astype(np.float64) @ W.astype(np.float64).T) < TOL
     ws = torch.empty(lib.mi_dense_bwd_weight_workspace_bytes(M, N, K) + 256, dtype=torch.uint8, device="cuda")
     dW = torch.empty(K, N, device="cuda"); db = torch.empty(N, device="cuda")
     _chk(lib.mi_dense_bwd_weight(_p(x), K, _p(dy), N, _p(dW), _p(db), M, N, K, _p(ws), ws.numel(), _ga(ax, ady), _st()))
     assert rowrel(dW.cpu().numpy().astype(np.float64), X.astype(np.float64).T @ dY.astype(np.float64)) < TOL
+
+
+def test_layer_histogram_matches_tensorflow_bucketing(lib):
+    """the histogram half of layer_summary (model_utils.py:6): TensorFlow's default limits, upper_bound bucketing"""
+    from mi355x_rec.metrics import histogram_limits, histogram_proto
+    rng = np.random.default_rng(3)
+    x = np.concatenate([np.maximum(rng.standard_normal(50000), 0), -np.abs(rng.standard_normal(777)) * 1e-5, [0.0, 1e-13, 3e19]]).astype(np.float32)
+    lim = histogram_limits()
+    assert len(lim) == 1551 and lim[775] == 0.0 and np.all(np.diff(lim) > 0)
+    counts = torch.zeros(len(lim) + 1, dtype=torch.int64, device="cuda")
+    sums = torch.zeros(2, dtype=torch.float64, device="cuda")
+    dx, dl = dev(x), dev(lim)
+    _chk(lib.mi_layer_histogram(_p(dx), len(x), _p(dl), len(lim), _p(counts), _p(sums), _st()))
+    ref = np.bincount(np.searchsorted(lim, x.astype(np.float64), side="right"), minlength=len(lim) + 1)
+    assert np.array_equal(counts.cpu().numpy(), ref)
+    assert abs(sums[0].item() - x.astype(np.float64).sum()) < 1e-6 * np.abs(x).sum()
+    assert abs(sums[1].item() - (x.astype(np.float64) ** 2).sum()) < 1e-6 * (x.astype(np.float64) ** 2).sum()
+    pr = histogram_proto(lim, counts.cpu().numpy(), sums.cpu().numpy(), x.min(), x.max())
+    assert pr["num"] == len(x) and sum(pr["bucket"]) == len(x) and len(pr["bucket"]) == len(pr["bucket_limit"]) < 400

@@ -171,6 +171,18 @@ def test_model_utils_helpers(device):
     assert set(mt) == {"accuracy", "auc", "auc_precision_recall", "average_loss"} and mt["accuracy"] == pytest.approx(2 / 3)
     s = model_utils.layer_summary(torch.tensor([[0.0, 1.0], [2.0, 0.0]], device="cuda"))
     assert s["fraction_of_zero_values"] == 0.5 and s["max"] == 2.0
+    assert s["activation"]["num"] == 4 and s["activation"]["bucket"] == [2, 1, 1] and s["activation"]["sum"] == 3.0   # tf.summary.histogram
+    # get_train_op (model_utils.py:69-72): the callable that runs one minimize() step on an engine built with that optimizer
+    from mi355x_rec.engine import DeepFM
+    opt = model_utils.get_optimizer("Adagrad", 0.05)
+    op = model_utils.get_train_op(ls["loss"], opt)
+    eng = DeepFM([5, 4], embedding_size=4, hidden_units=[8], optimizer=opt, device="cuda")
+    eng.init_variables()
+    ids = torch.tensor([[1, 2], [3, 0], [4, 3]], dtype=torch.int32, device="cuda")
+    loss, logits = op(eng, ids, torch.tensor([0, 1, 1], dtype=torch.uint8, device="cuda"))
+    assert eng.step == 1 and np.isfinite(loss.item())
+    with pytest.raises(ValueError):
+        model_utils.get_train_op(ls["loss"], model_utils.get_optimizer("SGD", 0.1))(eng, ids, None)
 
 
 def _cli_rank(rank, world, port, job_dir, q):

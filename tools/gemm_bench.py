@@ -42,7 +42,7 @@ for K, N in shapes:
         ops = [
             ("fwd", lambda: L.mi_dense_fwd(p(X), K, p(W), p(b), p(Y), N, M, N, K, 1, 1.0, 123, ga(aX, aW, aout), st()),
              lambda: (Y[:R].double() - ref_f).abs().max().item() / ref_f.abs().max().item()),
-            ("dgrad", lambda: L.mi_dense_bwd_data(p(dY), N, p(W), None, K, p(dX), K, M, N, K, 1.0, ga(adY, aW), st()),
+            ("dgrad", lambda: L.mi_dense_bwd_data(p(dY), N, p(W), None, K, p(dX), K, M, N, K, 1.0, 1, ga(adY, aW), st()),
              lambda: (dX[:R].double() - ref_d).abs().max().item() / ref_d.abs().max().item()),
             ("wgrad", lambda: L.mi_dense_bwd_weight(p(X), K, p(dY), N, p(dW), p(db), M, N, K, p(ws), ws.numel(), ga(aX, adY), st()),
              lambda: (dW.double() - ref_w).abs().max().item() / ref_w.abs().max().item()),

@@ -27,7 +27,7 @@ L.mi_set_gemm_mode(1)
 for mode in ("f16x2", "bf16x3"):
     ga = (lambda a, b_: _lib.GemmAmax(p(a), p(b_), None)) if mode == "f16x2" else (lambda a, b_: None)
     for op, fn, nk in (("fwd", lambda: L.mi_dense_fwd(p(X), K, p(W), p(b), p(Y), N, M, N, K, 1, 1.0, 123, ga(aX, aW), st()), 52),
-                       ("dgrad", lambda: L.mi_dense_bwd_data(p(dY), N, p(W), None, K, p(dX), K, M, N, K, 1.0, ga(adY, aW), st()), 16),
+                       ("dgrad", lambda: L.mi_dense_bwd_data(p(dY), N, p(W), None, K, p(dX), K, M, N, K, 1.0, 1, ga(adY, aW), st()), 16),
                        ("wgrad", lambda: L.mi_dense_bwd_weight(p(X), K, p(dY), N, p(dW), p(db), M, N, K, p(ws), ws.numel(), ga(aX, adY), st()), 64)):
         for _ in range(3):
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
