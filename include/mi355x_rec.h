@@ -44,6 +44,24 @@ int32_t mi_abi_version(void);       /* bumps when a signature changes (currently
 const char* mi_last_error(void);    /* thread-local, never NULL */
 const char* mi_build_info(void);    /* "gfx950 hipcc <ver>" */
 
+/* ---- replayable steps (hipGraph) -------------------------------------------------------------------------
+ * A captured train step must not carry per-step values in its launch arguments.  While a device-resident step
+ * state is registered (process-wide, like the GEMM mode: one process per GPU), the entries below read them from
+ * it AT RUN TIME instead of from their scalar arguments:
+ *   mi_sparse_apply[_fused]              step <- state->step, hp->lr_t <- state->lr_t
+ *   mi_dense_apply                       hp->lr_t <- state->lr_t
+ *   mi_sparse_catchup, mi_catchup_gap_keys   step_to <- state->step - 1
+ *   mi_dense_fwd[_gathered|_planes]      seed <- seed + state->seed_term       (dropout masks differ every step)
+ * mi_step_advance (the first node of the captured step): step += 1, lr_t = lr_table[step], seed_term = step * 1000003.
+ * Register the state only while capturing; eager calls between replays keep using their arguments. */
+typedef struct mi_step_state {
+  int32_t step;        /* the step being executed (1-based, as the global step after it) */
+  float lr_t;          /* Adam: lr * sqrt(1 - beta2^step) / (1 - beta1^step) */
+  uint64_t seed_term;
+} mi_step_state_t;
+int32_t mi_set_step_state(const mi_step_state_t* device_state);   /* NULL: off */
+int32_t mi_step_advance(mi_step_state_t* device_state, const float* lr_table, mi_stream_t stream);
+
 /* ---- (a1) categorical id transforms, host side --------------------------------------------
  * replaces the column constructors of trainers/ml_100k.py:19-35.
  * All integer work; results are bit exact against oracle/fingerprint.py. */

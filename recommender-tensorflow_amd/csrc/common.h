@@ -20,6 +20,9 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// device-resident step state registered by mi_set_step_state (host_ids.cpp), or nullptr
+const mi_step_state_t* step_state();
+
 }  // namespace mi
 
 // Publish a workgroup's abs-max into an abs-max vector (MI_AMAX_SLOTS floats, value = largest entry).

@@ -49,6 +49,7 @@ struct GemmArgs {
   // abs-max vectors (MI_AMAX_SLOTS floats each, value = largest entry): of the operands, for the
   // f16x2 split's scales; of the result, accumulated by the epilogue.  Any may be NULL.
   const float* amax_a; const float* amax_b; float* amax_c;
+  const mi_step_state_t* st;   // device-resident step state of a captured step (seed += st->seed_term), or nullptr
 };
 
 // Counter-based dropout mask in 32-bit arithmetic only (64-bit multiplies are several quarter-rate
@@ -240,6 +241,7 @@ __device__ __forceinline__ void store_tile_c(const GemmArgs& a, const f32x16 (&a
   float mx = 0.f;
   if (a.epi == EPI_SLAB) Cb += static_cast<int64_t>(split) * a.M * a.ldc;
   const uint32_t thresh = static_cast<uint32_t>(a.keep_prob * 16777216.0f);
+  const uint64_t seed = a.seed + (a.st ? a.st->seed_term : 0ull);
 #pragma unroll
   for (int ni = 0; ni < 2; ++ni) {
     const int col = n0 + wn * 64 + ni * 32 + i;
@@ -255,7 +257,7 @@ __device__ __forceinline__ void store_tile_c(const GemmArgs& a, const f32x16 (&a
         if (a.epi == EPI_BIAS_ACT) {
           v += bv;
           v = act_apply(a.relu, v);
-          if (a.keep_prob < 1.f) v = dropout_keep(a.seed, row, col, thresh) ? v / a.keep_div : 0.f;
+          if (a.keep_prob < 1.f) v = dropout_keep(seed, row, col, thresh) ? v / a.keep_div : 0.f;
         } else if (a.epi == EPI_MASK) {
           if (a.mask_src) {
             const float x = a.mask_src[static_cast<int64_t>(row) * a.ldm + col];
@@ -504,7 +506,8 @@ __global__ __launch_bounds__(kThreads) void gemv_fwd_k(const float* __restrict__
                                                        const float* __restrict__ W, const float* __restrict__ bias,
                                                        float* __restrict__ Y, int64_t ldy, int64_t M, int K, int relu,
                                                        float keep_prob, float keep_div, uint64_t seed,
-                                                       float* __restrict__ amax_out) {
+                                                       float* __restrict__ amax_out, const mi_step_state_t* __restrict__ st) {
+  if (st) seed += st->seed_term;
   const int l = threadIdx.x & (kGvLanes - 1);
   const int64_t groups = static_cast<int64_t>(gridDim.x) * (kThreads / kGvLanes);
   const uint32_t thresh = static_cast<uint32_t>(keep_prob * 16777216.0f);
@@ -728,7 +731,7 @@ int32_t mi_dense_fwd(const float* X, int64_t ldx, const float* W, const float* b
   if (N == 1 && gemv_ok(X, ldx, W, K)) {
     const int64_t blocks = std::min<int64_t>(mi::ceil_div(M * kGvLanes, 2 * kThreads), 2048);
     gemv_fwd_k<<<dim3((unsigned)blocks), dim3(kThreads), 0, mi::as_stream(stream)>>>(
-        X, ldx, W, bias, Y, ldy, M, K, relu, keep_prob, keep_prob, seed, amax ? amax->out : nullptr);
+        X, ldx, W, bias, Y, ldy, M, K, relu, keep_prob, keep_prob, seed, amax ? amax->out : nullptr, mi::step_state());
     MI_CHECK_LAUNCH("dense_fwd(N = 1)");
     return MI_OK;
   }
@@ -737,7 +740,7 @@ int32_t mi_dense_fwd(const float* X, int64_t ldx, const float* W, const float* b
   a.M = (int)M; a.N = N; a.K = K; a.k_per_split = ((K + BK - 1) / BK) * BK;
   a.vecA = vec_ok(X, ldx, K); a.vecB = vec_ok(W, N, N);
   a.epi = EPI_BIAS_ACT; a.bias = bias; a.relu = relu;
-  a.keep_prob = keep_prob; a.keep_div = keep_prob; a.seed = seed;
+  a.keep_prob = keep_prob; a.keep_div = keep_prob; a.seed = seed; a.st = mi::step_state();
   set_amax(a, amax);
   return launch<KC, MC>(a, 1, mi::as_stream(stream), "dense_fwd");
 }
@@ -791,7 +794,7 @@ int32_t mi_dense_fwd_gathered(const float* table, const int64_t* field_off, cons
   a.M = (int)M; a.N = N; a.K = K; a.k_per_split = ((K + BK - 1) / BK) * BK;
   a.vecA = 1; a.vecB = vec_ok(W, N, N);
   a.epi = EPI_BIAS_ACT; a.bias = bias; a.relu = relu;
-  a.keep_prob = keep_prob; a.keep_div = keep_prob; a.seed = seed;
+  a.keep_prob = keep_prob; a.keep_div = keep_prob; a.seed = seed; a.st = mi::step_state();
   a.g_ids = ids; a.g_off = field_off; a.g_F = F; a.g_E = E;
   set_amax(a, amax);
   return launch<KC, MC, false, true>(a, 1, mi::as_stream(stream), "dense_fwd_gathered");
@@ -881,14 +884,17 @@ static int32_t bwd_weight_impl(const float* X, int64_t ldx, const float* dY, int
   a.A = X; a.lda = ldx; a.B = dY; a.ldb = lddy;
   a.M = K; a.N = N; a.K = (int)M; a.k_per_split = (int)wgrad_k_per_split(M, splits);
   a.vecA = vec_ok(X, ldx, K); a.vecB = vec_ok(dY, lddy, N);
-  a.C = slab; a.ldc = N; a.epi = EPI_SLAB; a.keep_prob = 1.f; a.keep_div = 1.f;
-  a.colsum_part = db ? cpart : nullptr;
+  // one split: the "slab" IS the result (the small-batch step saves the two reduce launches per layer)
+  const bool direct = splits == 1;
+  a.C = direct ? dW : slab; a.ldc = N; a.epi = EPI_SLAB; a.keep_prob = 1.f; a.keep_div = 1.f;
+  a.colsum_part = db ? (direct ? db : cpart) : nullptr;
   set_amax(a, amax);
   a.amax_c = nullptr;                 // the slabs are partial sums; dW is nobody's matrix operand
   if (g_ids) {
     a.vecA = 1; a.g_ids = g_ids; a.g_off = g_off; a.g_F = g_F; a.g_E = g_E;
     if (int32_t rc = launch<MC, MC, true, true>(a, splits, st, "dense_bwd_weight_gathered(split-K)")) return rc;
   } else if (int32_t rc = launch<MC, MC, true>(a, splits, st, "dense_bwd_weight(split-K)")) return rc;
+  if (direct) return MI_OK;
   slab_reduce_k<<<dim3((unsigned)mi::ceil_div(n, 64)), dim3(kThreads), 0, st>>>(slab, splits, n, dW);
   MI_CHECK_LAUNCH("dense_bwd_weight(reduce)");
   if (db) {

@@ -59,6 +59,7 @@ struct PlArgs {
   const float* bias; int relu; float keep_prob, keep_div; uint64_t seed;
   const char* mask; int64_t bsm;                        // dgrad: planes of the stored activation (hi > 0 <=> active & kept)
   float* amax_c;                                        // abs-max vector of the result (gemm.hip's weight gradient) or NULL
+  const mi_step_state_t* st;                            // device-resident step state of a captured step, or NULL
 };
 
 __device__ __forceinline__ float pl_pow2(int s) { return __uint_as_float(static_cast<uint32_t>(127 + s) << 23); }
@@ -245,6 +246,7 @@ __global__ __launch_bounds__(PL_THREADS, 2) void gemm_pl_k(const PlArgs a) {
   __syncthreads();
 
   const uint32_t thresh = static_cast<uint32_t>(a.keep_prob * 16777216.0f);
+  const uint64_t seed = a.seed + (a.st ? a.st->seed_term : 0ull);
   const int nw = wn * 32 * TN;                      // this wave's first column inside the tile
   float rmx[TM];
 #pragma unroll
@@ -274,7 +276,7 @@ __global__ __launch_bounds__(PL_THREADS, 2) void gemm_pl_k(const PlArgs a) {
             v += e_bias[nl + j];
             if (a.relu) v = fmaxf(v, 0.f);
             if (a.keep_prob < 1.f)
-              v = pl_dropout_keep(a.seed, static_cast<uint32_t>(m), static_cast<uint32_t>(n0 + nl + j), thresh) ? v / a.keep_div : 0.f;
+              v = pl_dropout_keep(seed, static_cast<uint32_t>(m), static_cast<uint32_t>(n0 + nl + j), thresh) ? v / a.keep_div : 0.f;
           } else {
             if (a.mask) {
               const uint32_t w32 = (j < 2) ? mk.x : mk.y;
@@ -692,7 +694,7 @@ int32_t mi_dense_fwd_planes(const mi_planes_t* X, const mi_planes_t* Wt, const f
   a.M = (int)M; a.N = N; a.K = K;
   a.C = Y; a.ldc = ldy;
   if (Yp) { a.Cp = static_cast<char*>(Yp->data); a.bsc = Yp->blk_stride; a.c_exp = Yp->row_exp; }
-  a.bias = bias; a.relu = relu; a.keep_prob = keep_prob; a.keep_div = keep_prob; a.seed = seed;
+  a.bias = bias; a.relu = relu; a.keep_prob = keep_prob; a.keep_div = keep_prob; a.seed = seed; a.st = mi::step_state();
   a.amax_c = amax_out;
   return launch_pl<PL_FWD>(a, mi::as_stream(stream), "dense_fwd_planes");
 }

@@ -12,7 +12,11 @@
 
 #include "common.h"
 
+static const mi_step_state_t* g_step_state = nullptr;
+
 namespace mi {
+
+const mi_step_state_t* step_state() { return g_step_state; }
 
 static thread_local char g_err[512] = "";
 
@@ -163,6 +167,11 @@ static uint64_t hash64(const uint8_t* s, size_t len) {
 }  // namespace mi
 
 extern "C" {
+
+int32_t mi_set_step_state(const mi_step_state_t* device_state) {
+  g_step_state = device_state;
+  return MI_OK;
+}
 
 int32_t mi_abi_version(void) { return 9; }
 

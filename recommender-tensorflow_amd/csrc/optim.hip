@@ -72,7 +72,8 @@ __device__ __forceinline__ void sparse_rule(const Hp& h, float& w, float& s0, fl
 __global__ __launch_bounds__(kBlock) void dense_apply_k(float* __restrict__ w, float* __restrict__ s0,
                                                         float* __restrict__ s1,
                                                         const float* __restrict__ g, int64_t n,
-                                                        const Hp h) {
+                                                        Hp h, const mi_step_state_t* __restrict__ st) {
+  if (st) h.lr_t = st->lr_t;
   const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride) {
     float wv = w[i], a = s0 ? s0[i] : 0.f, b = s1 ? s1[i] : 0.f;
@@ -126,6 +127,7 @@ struct ApplyArgs {
   // element stride of lin_w / l0 / l1 / last_step: 1 = four separate arrays, 4 = one 16-byte record per row
   // {w, slot0, slot1, stamp} (a row's wide-part state then costs one memory sector instead of four)
   int ls;
+  const mi_step_state_t* st;   // device-resident step / lr_t of a replayable (captured) step, or nullptr
 };
 
 // sum of the gradients of entries sorted_entry[k_beg..k_end) of one row, in that order
@@ -209,7 +211,8 @@ __device__ __forceinline__ void store_row(const ApplyArgs& a, int64_t u, int l, 
 }
 
 template <int LPR, bool FUSED, bool STORE = false>
-__global__ __launch_bounds__(kBlock) void sparse_apply_k(const ApplyArgs a, const Hp h, const FusedGrad fg) {
+__global__ __launch_bounds__(kBlock) void sparse_apply_k(ApplyArgs a, Hp h, const FusedGrad fg) {
+  if (a.st) { a.step = a.st->step; h.lr_t = a.st->lr_t; }
   int64_t u = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) / LPR;
   const int l = threadIdx.x & (LPR - 1);
   if (u >= (STORE ? a.u_count : *a.num_uniq)) return;
@@ -233,7 +236,8 @@ __global__ __launch_bounds__(kBlock) void sparse_apply_k(const ApplyArgs a, cons
 // group, summed in order; the slice sums are then added in slice order.  A fixed order, so results
 // are reproducible; it differs from the one-pass order only in fp32 association.
 template <int LPR, bool FUSED, bool STORE = false>
-__global__ __launch_bounds__(kBlock) void sparse_apply_long_k(const ApplyArgs a, const Hp h, const FusedGrad fg) {
+__global__ __launch_bounds__(kBlock) void sparse_apply_long_k(ApplyArgs a, Hp h, const FusedGrad fg) {
+  if (a.st) { a.step = a.st->step; h.lr_t = a.st->lr_t; }
   constexpr int G = kBlock / LPR;
   __shared__ int list[kBlock];
   __shared__ int n_list;
@@ -338,7 +342,9 @@ __device__ __forceinline__ bool catchup_params_in_range(int steps, float lr_last
 __global__ __launch_bounds__(kBlock) void catchup_lin_k(
     float* __restrict__ lin_w, float* __restrict__ lm, float* __restrict__ lv, const int32_t* __restrict__ last_step,
     const int32_t* __restrict__ uniq_rows, const int32_t* __restrict__ num_uniq, int64_t n_max, int step_to,
-    const float* __restrict__ lr_table, float b1, float b2, float eps, bool defer_slots, int st) {
+    const float* __restrict__ lr_table, float b1, float b2, float eps, bool defer_slots, int st,
+    const mi_step_state_t* __restrict__ ss) {
+  if (ss) step_to = ss->step - 1;
   const int64_t u = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
   const int64_t count = uniq_rows ? static_cast<int64_t>(*num_uniq) : n_max;
   const bool on = u < count;
@@ -368,7 +374,9 @@ __global__ __launch_bounds__(kBlock) void sparse_catchup_k(
     float* __restrict__ table, float* __restrict__ tm, float* __restrict__ tv,
     int32_t* __restrict__ last_step, const int32_t* __restrict__ uniq_rows,
     const int32_t* __restrict__ num_uniq, int64_t n_max, int E, int step_to,
-    const float* __restrict__ lr_table, float b1, float b2, float eps, bool defer_slots, int st) {
+    const float* __restrict__ lr_table, float b1, float b2, float eps, bool defer_slots, int st,
+    const mi_step_state_t* __restrict__ ss) {
+  if (ss) step_to = ss->step - 1;
   const int64_t u = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) / LPR;
   const int l = threadIdx.x & (LPR - 1);
   const int64_t count = uniq_rows ? static_cast<int64_t>(*num_uniq) : n_max;
@@ -424,7 +432,9 @@ __global__ __launch_bounds__(kBlock) void sparse_catchup_k(
 __global__ __launch_bounds__(kBlock) void gap_keys_k(const int32_t* __restrict__ uniq_rows,
                                                      const int32_t* __restrict__ num_uniq,
                                                      const int32_t* __restrict__ last_step, int64_t n_max, int step_to,
-                                                     int32_t* __restrict__ keys, int st) {
+                                                     int32_t* __restrict__ keys, int st,
+                                                     const mi_step_state_t* __restrict__ ss) {
+  if (ss) step_to = ss->step - 1;
   const int64_t u = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
   if (u >= n_max) return;
   int32_t key = 63;
@@ -478,7 +488,21 @@ unsigned long_grid(int64_t n_max) {
   return static_cast<unsigned>(std::min<int64_t>(1024, mi::ceil_div(n_max, kBlock)));
 }
 
+__global__ void step_advance_k(mi_step_state_t* __restrict__ st, const float* __restrict__ lr_table) {
+  const int s = st->step + 1;
+  st->step = s;
+  st->lr_t = lr_table ? lr_table[s] : 0.f;
+  st->seed_term = static_cast<uint64_t>(s) * 1000003ull;
+}
+
 extern "C" {
+
+int32_t mi_step_advance(mi_step_state_t* device_state, const float* lr_table, mi_stream_t stream) {
+  MI_REQUIRE(device_state, "step_advance: null state");
+  step_advance_k<<<dim3(1), dim3(1), 0, mi::as_stream(stream)>>>(device_state, lr_table);
+  MI_CHECK_LAUNCH("step_advance");
+  return MI_OK;
+}
 
 int32_t mi_axpy(float* y, const float* x, int64_t n, float alpha, mi_stream_t stream) {
   MI_REQUIRE(n >= 0 && (n == 0 || (x && y)), "axpy: n=%lld", (long long)n);
@@ -500,7 +524,7 @@ int32_t mi_dense_apply(float* param, float* slot0, float* slot1, const float* gr
              "dense_apply: optimizer needs slot1");
   int64_t nb = mi::ceil_div(n, kBlock);
   if (nb > 4096) nb = 4096;
-  dense_apply_k<<<dim3((unsigned)nb), dim3(kBlock), 0, mi::as_stream(stream)>>>(param, slot0, slot1, grad, n, make_hp(hp));
+  dense_apply_k<<<dim3((unsigned)nb), dim3(kBlock), 0, mi::as_stream(stream)>>>(param, slot0, slot1, grad, n, make_hp(hp), mi::step_state());
   MI_CHECK_LAUNCH("dense_apply");
   return MI_OK;
 }
@@ -531,6 +555,7 @@ int32_t mi_sparse_apply(float* table, float* t_slot0, float* t_slot1, float* lin
   ApplyArgs a{table, t_slot0, t_slot1, lin_w, l_slot0, l_slot1, last_step, uniq_rows, seg_start, sorted_entry,
               num_uniq, d_rows, d_lin, E, step};
   a.ls = lin_stride;
+  a.st = mi::step_state();
   MI_DISPATCH_LPR(lpr, (sparse_apply_k<L, false><<<dim3((unsigned)blocks), dim3(kBlock), 0, mi::as_stream(stream)>>>(
                            a, h, FusedGrad{})));
   MI_CHECK_LAUNCH("sparse_apply");
@@ -573,6 +598,7 @@ int32_t mi_sparse_apply_fused(float* table, float* t_slot0, float* t_slot1, floa
   ApplyArgs a{table, t_slot0, t_slot1, lin_w, l_slot0, l_slot1, last_step, uniq_rows, seg_start, sorted_entry,
               num_uniq, nullptr, nullptr, E, step};
   a.ls = lin_stride;
+  a.st = mi::step_state();
   MI_DISPATCH_LPR(lpr, (sparse_apply_k<L, true><<<dim3((unsigned)blocks), dim3(kBlock), 0, mi::as_stream(stream)>>>(a, h, fg)));
   MI_CHECK_LAUNCH("sparse_apply_fused");
   if (n_max > kLongSeg) {
@@ -622,7 +648,7 @@ int32_t mi_catchup_gap_keys(const int32_t* uniq_rows, const int32_t* num_uniq, c
   if (n_max == 0) return MI_OK;
   MI_REQUIRE(uniq_rows && num_uniq && last_step && keys, "catchup_gap_keys: null buffer");
   gap_keys_k<<<dim3((unsigned)mi::ceil_div(n_max, kBlock)), dim3(kBlock), 0, mi::as_stream(stream)>>>(
-      uniq_rows, num_uniq, last_step, n_max, step_to, keys, lin_stride);
+      uniq_rows, num_uniq, last_step, n_max, step_to, keys, lin_stride, mi::step_state());
   MI_CHECK_LAUNCH("catchup_gap_keys");
   return MI_OK;
 }
@@ -633,7 +659,7 @@ int32_t mi_sparse_catchup(float* table, float* t_m, float* t_v, float* lin_w, fl
                           float beta1, float beta2, float epsilon, int32_t defer_slots, int32_t lin_stride,
                           mi_stream_t stream) {
   MI_REQUIRE(n_max >= 0 && step_to >= 0 && lin_stride >= 1, "sparse_catchup: n_max=%lld step_to=%d", (long long)n_max, step_to);
-  if (n_max == 0 || step_to == 0) return MI_OK;
+  if (n_max == 0 || (step_to == 0 && !mi::step_state())) return MI_OK;
   MI_REQUIRE(last_step && lr_table, "sparse_catchup: null buffer");
   MI_REQUIRE(table || lin_w, "sparse_catchup: nothing to update");
   MI_REQUIRE(!table || (t_m && t_v && E >= 4 && E <= 256 && (E & 3) == 0 && mi::aligned16(table)),
@@ -643,7 +669,7 @@ int32_t mi_sparse_catchup(float* table, float* t_m, float* t_v, float* lin_w, fl
   const bool defer = defer_slots != 0 && uniq_rows != nullptr;
   if (lin_w) {
     catchup_lin_k<<<dim3((unsigned)mi::ceil_div(n_max, kBlock)), dim3(kBlock), 0, mi::as_stream(stream)>>>(
-        lin_w, l_m, l_v, last_step, uniq_rows, num_uniq, n_max, step_to, lr_table, beta1, beta2, epsilon, defer, lin_stride);
+        lin_w, l_m, l_v, last_step, uniq_rows, num_uniq, n_max, step_to, lr_table, beta1, beta2, epsilon, defer, lin_stride, mi::step_state());
     MI_CHECK_LAUNCH("sparse_catchup(wide part)");
   }
   const int lpr = table ? lanes_per_row(E) : 1;
@@ -651,7 +677,7 @@ int32_t mi_sparse_catchup(float* table, float* t_m, float* t_v, float* lin_w, fl
   MI_REQUIRE(blocks <= INT32_MAX, "sparse_catchup: grid too large");
   MI_DISPATCH_LPR(lpr, (sparse_catchup_k<L><<<dim3((unsigned)blocks), dim3(kBlock), 0, mi::as_stream(stream)>>>(
                            table, t_m, t_v, last_step, uniq_rows, num_uniq, n_max, E, step_to, lr_table, beta1, beta2,
-                           epsilon, defer, lin_stride)));
+                           epsilon, defer, lin_stride, mi::step_state())));
   MI_CHECK_LAUNCH("sparse_catchup");
   return MI_OK;
 }

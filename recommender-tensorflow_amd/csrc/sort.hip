@@ -244,6 +244,49 @@ Layout layout_for(int64_t n) {
 
 }  // namespace
 
+// ---- n <= kSmallN: the whole sort + unique in ONE workgroup (the launch-bound small-batch step: B = 32 x 26 fields
+// = 832 keys would otherwise take a dozen launches).  Stable by construction: rank = number of keys that are
+// smaller, or equal with a smaller index.
+namespace {
+constexpr int kSmallN = 1024;
+__global__ __launch_bounds__(kBlock) void sort_small_k(const int32_t* __restrict__ keys, int n, int32_t* __restrict__ sorted_entry,
+                                                       int32_t* __restrict__ uniq_rows, int32_t* __restrict__ seg_start,
+                                                       int32_t* __restrict__ num_uniq) {
+  __shared__ int32_t k[kSmallN], sk[kSmallN], head[kSmallN];
+  __shared__ int32_t wsum[4];
+  const int t = threadIdx.x;
+  for (int i = t; i < n; i += kBlock) k[i] = keys[i];
+  __syncthreads();
+  for (int i = t; i < n; i += kBlock) {
+    const int32_t ki = k[i];
+    int rank = 0;
+    for (int j = 0; j < n; ++j) rank += (k[j] < ki) || (k[j] == ki && j < i);
+    sk[rank] = ki;
+    sorted_entry[rank] = i;
+  }
+  if (!uniq_rows) return;
+  __syncthreads();
+  // head flags -> exclusive scan (4 passes of 256) -> compaction
+  int carry = 0;
+  for (int c0 = 0; c0 < n; c0 += kBlock) {
+    const int i = c0 + t;
+    const int v = (i < n && (i == 0 || sk[i] != sk[i - 1])) ? 1 : 0;
+    const int incl = wave_incl_scan(v, t & 63);
+    __syncthreads();
+    if ((t & 63) == 63) wsum[t >> 6] = incl;
+    __syncthreads();
+    int pre = carry;
+    for (int w = 0; w < (t >> 6); ++w) pre += wsum[w];
+    if (i < n) head[i] = v ? pre + incl - 1 : -1;
+    carry += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  }
+  __syncthreads();
+  for (int i = t; i < n; i += kBlock)
+    if (head[i] >= 0) { uniq_rows[head[i]] = sk[i]; seg_start[head[i]] = i; }
+  if (t == 0) { seg_start[carry] = n; *num_uniq = carry; }
+}
+}  // namespace
+
 extern "C" {
 
 size_t mi_sort_unique_workspace_bytes(int64_t n) { return static_cast<size_t>(layout_for(n).bytes); }
@@ -265,6 +308,11 @@ int32_t mi_sort_unique_rows(const int32_t* rows, int64_t n, int64_t num_rows_tot
     return MI_ERR_WORKSPACE;
   }
   hipStream_t st = mi::as_stream(stream);
+  if (n <= kSmallN) {
+    sort_small_k<<<dim3(1), dim3(kBlock), 0, st>>>(rows, static_cast<int>(n), sorted_entry, uniq_rows, seg_start, num_uniq);
+    MI_CHECK_LAUNCH("sort_unique_rows(small)");
+    return MI_OK;
+  }
   char* ws = static_cast<char*>(workspace);
   int32_t* kbuf[2] = {reinterpret_cast<int32_t*>(ws + L.keysA), reinterpret_cast<int32_t*>(ws + L.keysB)};
   int32_t* vbuf[2] = {reinterpret_cast<int32_t*>(ws + L.valsA), reinterpret_cast<int32_t*>(ws + L.valsB)};

@@ -59,6 +59,8 @@ SIGNATURES = {
     "mi_abi_version": (_i32, []),
     "mi_last_error": (C.c_char_p, []),
     "mi_build_info": (C.c_char_p, []),
+    "mi_set_step_state": (_i32, [_p]),
+    "mi_step_advance": (_i32, [_p, _p, _p]),
     "mi_fingerprint64": (_u64, [_p, _sz]),
     "mi_hash_bucket_i64": (_i32, [_p, _i64, _i64, _p]),
     "mi_hash_bucket_bytes": (_i32, [_p, _p, _i64, _i64, _p]),

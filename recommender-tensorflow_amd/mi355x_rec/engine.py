@@ -497,7 +497,10 @@ class DeepFM:
     def _layer_seed(self, layer):
         rank = 0 if self.shard is None else self.shard.rank
         chunk = getattr(self, "_chunk", 0)              # pipelined multi-GPU step: a mask per chunk
-        return (self.seed * 0x9E3779B97F4A7C15 + (self.step + 1) * 1000003 + layer * 7919 + rank * 104729 +
+        # (while a step is being captured into a hipGraph the step term comes from the device-resident step state:
+        # mi_step_advance sets seed_term = step * 1000003 and the kernels add it — the same masks as the eager step)
+        step_term = 0 if getattr(self, "_capturing", False) else (self.step + 1) * 1000003
+        return (self.seed * 0x9E3779B97F4A7C15 + step_term + layer * 7919 + rank * 104729 +
                 chunk * 15485863) & (2 ** 64 - 1)
 
     @property
@@ -873,6 +876,63 @@ class DeepFM:
                                       d_rows if tb is not None else None, d_lin if lw is not None else None, self.E,
                                       step, h, self.ls)
         self.step = step
+
+    # ------------------------------------------------------------------ replayable step (hipGraph)
+    def graph_train_step(self, ids, labels):
+        """train_step as ONE hipGraph launch (single GPU, no numeric columns): the launch-bound small-batch
+        configurations (trainers.deep_fm's defaults: B = 32, ~50 launches) pay one graph launch instead of ~50
+        kernel launches.  The first call runs eagerly (it sizes the workspaces), the second captures, later
+        calls copy the batch into the captured buffers and replay.  Per-step scalars — global step, Adam's lr_t,
+        the dropout seeds — live in a device-resident step state that the captured mi_step_advance node
+        advances (include/mi355x_rec.h), so a replay is bit-identical to the eager step it replaces."""
+        if self.shard is not None or self.n_numeric or self.device.type != "cuda":
+            raise NotImplementedError("graph_train_step: single-GPU models without numeric columns")
+        self._prep(ids, labels, None)
+        g = getattr(self, "_graph", None)
+        if g is None or g["shape"] != tuple(ids.shape):
+            if not getattr(self, "_graph_warm", None) == tuple(ids.shape):
+                self._graph_warm = tuple(ids.shape)
+                return self.train_step(ids, labels)                     # sizes every workspace
+            g = self._graph = self._capture(ids, labels)
+            return g["loss"], g["logits"]
+        if self.sched is not None and self.step + 2 >= len(self.sched.host):
+            self._graph = None                                          # the lr_t table has to grow: capture again
+            return self.graph_train_step(ids, labels)
+        if g["dev_step"] != self.step:                                  # eager steps ran in between: resync
+            self._write_step_state(g["state"])
+            g["dev_step"] = self.step
+        g["ids"].copy_(ids)
+        g["y"].copy_(labels)
+        g["graph"].replay()
+        self.step += 1
+        g["dev_step"] = self.step
+        return g["loss"], g["logits"]
+
+    def _write_step_state(self, state):
+        blob = np.zeros(1, np.dtype([("step", np.int32), ("lr_t", np.float32), ("seed_term", np.uint64)]))
+        blob["step"] = self.step
+        state.copy_(torch.from_numpy(blob.view(np.uint8)))
+
+    def _capture(self, ids, labels):
+        if self.sched is not None:                                      # the lr_t table must not move under the graph
+            self.sched.lr_t(self.step + (1 << 20))
+        state = torch.zeros(16, dtype=torch.uint8, device=self.device)
+        self._write_step_state(state)
+        g_ids, g_y = ids.clone(), labels.clone()
+        graph = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize()
+        self.k.query("mi_set_step_state", state.data_ptr())
+        self._capturing = True
+        try:
+            with torch.cuda.graph(graph):
+                self.k.mi_step_advance(state, self.sched.table if self.sched is not None else None)
+                loss, logits = self.train_step(g_ids, g_y)
+        finally:
+            self._capturing = False
+            self.k.query("mi_set_step_state", None)
+        graph.replay()                                                  # capture records, this executes the step
+        return {"graph": graph, "state": state, "ids": g_ids, "y": g_y, "loss": loss, "logits": logits,
+                "shape": tuple(ids.shape), "dev_step": self.step}
 
     def layer_summaries(self):
         """What the reference's layer_summary calls record (model_utils.py:4-6 at deep_fm.py:43,89,105,

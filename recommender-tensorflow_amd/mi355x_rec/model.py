@@ -64,7 +64,10 @@ def run_batch(features, labels, mode, params, make_engine):
     # the eval loss
     rescale = (lambda l: l * float(eng.shard.world)) if (eng.shard is not None and eng.reduction == "mean") else (lambda l: l)
     if mode == ModeKeys.TRAIN:
-        loss, logits = eng.train_step(ids, y, x)
+        if params.get("hip_graph") and x is None and eng.shard is None and eng.device.type == "cuda":
+            loss, logits = eng.graph_train_step(ids, y)      # the whole step as one hipGraph launch (small batches)
+        else:
+            loss, logits = eng.train_step(ids, y, x)
         return EstimatorSpec(mode, predictions=None, loss=rescale(loss), train_op=eng.step)
     if mode == ModeKeys.EVAL:
         loss, logits = eng.loss(ids, y, x)

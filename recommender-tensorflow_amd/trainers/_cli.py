@@ -22,6 +22,7 @@ _COMMON = [
     ("--world-size", dict(type=int, default=None, help="number of MI355X (one process each): launch with `python -m "
                                                        "torch.distributed.run --nproc-per-node N -m trainers.<model> ...`; the flag "
                                                        "only checks the launch (default: WORLD_SIZE of the launcher, else 1)")),
+    ("--hip-graph", dict(action="store_true", help="replay the train step as one hipGraph launch (launch-bound small batches)")),
     ("--synthetic", dict(type=int, default=None, metavar="N", help="train on N generated MovieLens-shaped examples (and evaluate on "
                                                                    "N/10) instead of --train-csv / --test-csv")),
 ]
@@ -93,6 +94,7 @@ def run(args, make_estimator):
     estimator = make_estimator(columns, config)
     estimator.warm_start_from = getattr(args, "warm_start_from", None)
     estimator.params["_shard"] = shard
+    estimator.params["hip_graph"] = bool(getattr(args, "hip_graph", False))
     train_spec = get_train_spec(get_input_fn(args.train_csv, batch_size=args.batch_size, seed=rank if world > 1 else None),
                                 args.train_steps)
     eval_spec = get_eval_spec(get_input_fn(args.test_csv, ModeKeys.EVAL, batch_size=args.batch_size),

@@ -316,3 +316,32 @@ def test_config5_one_rank_share_properties():
     assert float(err.max()) < 1e-5
     table0 = m.table.clone()
     _props_after_steps(m, ids, y, None, table0, rows, replay=False)    # (the replay check would hold 200 GB of clones)
+
+
+@pytest.mark.parametrize("vocab,E,hidden,B", [(ML100K_VOCAB, 4, [16, 16], 32), ([50, 30, 20, 40], 64, [512, 256, 128], 128)])
+def test_graph_train_step_replays_the_eager_step_bitwise(vocab, E, hidden, B):
+    """The train step captured into one hipGraph (global step, Adam lr_t and the dropout seeds live in a device-
+    resident step state advanced by the graph's first node) must leave the model bit for bit where the same
+    sequence of eager steps leaves it: fresh batch every step, dropout on, rows sitting out steps, an eager step
+    in between (the device step is resynchronised)."""
+    from mi355x_rec.engine import OptimizerSpec
+    p, ids, x, y = make_problem(9, vocab, E, hidden, B)
+    ms = []
+    for _ in range(2):
+        m = _engine(vocab, E, hidden, dropout=0.25, seed=5, optimizer=OptimizerSpec("Adam", 0.001))
+        m.load_oracle_params(p)
+        ms.append(m)
+    eager, graph = ms
+    rng = np.random.default_rng(2)
+    for step in range(9):
+        ids_s = dev(np.stack([rng.integers(0, v, B) for v in vocab], 1).astype(np.int32))
+        ys = dev((rng.random(B) < 0.3).astype(np.uint8))
+        le, ge = eager.train_step(ids_s, ys)
+        if step == 5:
+            lg, gg = graph.train_step(ids_s, ys)                  # an eager step between replays
+        else:
+            lg, gg = graph.graph_train_step(ids_s, ys)
+        assert torch.equal(le, lg) and torch.equal(ge, gg), step
+    assert graph._graph is not None and graph.step == eager.step == 9
+    for k in ("table", "t_s0", "t_s1", "lin_state", "dense", "d_s0", "d_s1"):
+        assert torch.equal(getattr(eager, k), getattr(graph, k)), k

@@ -13,9 +13,10 @@ for B in (32, 1024):
     m.init_variables(g, lin_scale=1e-3)
     ids = torch.stack([torch.randint(0, v, (B,), device="cuda", generator=g) for v in VOCAB], 1).to(torch.int32).contiguous()
     y = (torch.rand(B, device="cuda", generator=g) < 0.3).to(torch.uint8)
-    for _ in range(20): m.train_step(ids, y)
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    n = 300
-    for _ in range(n): m.train_step(ids, y)
-    torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    print("B=%5d  %.1f us/step  (%.0f steps/s, %.0f examples/s)" % (B, dt / n * 1e6, n / dt, n * B / dt))
+    for name, step in (("eager (one launch per kernel)", m.train_step), ("hipGraph replay", m.graph_train_step)):
+        for _ in range(20): step(ids, y)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        n = 300
+        for _ in range(n): step(ids, y)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        print("B=%5d  %-30s %.1f us/step  (%.0f steps/s, %.0f examples/s)" % (B, name, dt / n * 1e6, n / dt, n * B / dt))
