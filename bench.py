@@ -321,13 +321,15 @@ def main():
         # concat SURVEY counts) + sumv + fm + the example's exponent.  `achieved` counts both directions — the
         # kernel is HBM bound on their sum; `row_read_GBs` is the read side alone (what round 1's read-only
         # kernel reported: that form never wrote the concat, each of the layer-1 GEMMs re-gathered the rows).
-        row_bytes = B * F * 4 * E
+        g_key = "mi_embed_fm_planes_fwd" if planes_gather else "mi_embed_fm_linear_fwd"
+        Bl = B * args.steps / km[g_key][1]               # examples per launch (N > 1: one launch per chunk of the local batch)
+        row_bytes = Bl * F * 4 * E
         wide_split = "mi_embed_fm_linear_fwd/wide" in km  # the wide part's 4-byte gathers run as their own kernel
         if planes_gather:
-            gather_bytes = B * (F * (4 * E + 4) + F * 4 * E + 4 * E + 8)
+            gather_bytes = Bl * (F * (4 * E + 4) + F * 4 * E + 4 * E + 8)
         else:
             gather_bytes = row_bytes
-        total_bytes = gather_bytes if planes_gather else B * (F * (4 * E + (4 if wide_split else 8)) + 4 * E + (4 if wide_split else 8))
+        total_bytes = gather_bytes if planes_gather else Bl * (F * (4 * E + (4 if wide_split else 8)) + 4 * E + (4 if wide_split else 8))
         achieved = gather_bytes / (g_ms * 1e-3) / 1e9
         gemm_ms = sum(v[2] for k, v in km.items() if k in ("mi_dense_fwd", "mi_dense_fwd_gathered", "mi_dense_bwd_data", "mi_dense_bwd_weight",
                                                         "mi_dense_bwd_weight_gathered", "mi_dense_fwd_planes",
@@ -365,7 +367,7 @@ def main():
                                     "embed_fm_linear_fwd_k (embedding gather + FM second order; read-only form)"), "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "frac_of_measured_copy_peak": achieved / HBM_MEASURED_GBS,
-                         "algorithmic_bytes_per_launch": gather_bytes, "avg_launch_ms": g_ms,
+                         "algorithmic_bytes_per_launch": int(gather_bytes), "examples_per_launch": int(Bl), "avg_launch_ms": g_ms,
                          "row_read_GBs": row_bytes / (g_ms * 1e-3) / 1e9, "row_read_frac": row_bytes / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "traffic": traffic,
                          "traffic_note": "HBM bytes/launch from rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE), profiles/"},
