@@ -291,6 +291,25 @@ def main():
     # what the matrix-pipe path and the exact-Adam semantics cost (single GPU, short legs after the headline)
     extras = {}
     if world == 1 and not args.no_extras:
+        # the same step replayed as ONE hipGraph launch (engine.graph_train_step): what the ~50 launch gaps cost.
+        # Not the headline: the per-kernel HIP events of `roofline` / `kernel_ms_per_step` cannot sit inside a replay.
+        def run_graph(nsteps):
+            out = None
+            for _ in range(nsteps):
+                ids, y = batches[cursor[0] % len(batches)]
+                cursor[0] += 1
+                out = m.graph_train_step(ids, y)
+            return out
+        run_graph(4)                                      # eager step (sizes), capture, two replays
+        sync()
+        t0 = time.perf_counter()
+        run_graph(10)
+        sync()
+        gdt = time.perf_counter() - t0
+        extras["hip_graph"] = {"value": B * 10 / gdt, "unit": "examples/sec", "ms_per_step": gdt / 10 * 1e3,
+                               "note": "the whole train step as one hipGraph launch (bitwise the same step; global step, lr_t and "
+                                       "dropout seeds in a device-resident step state)"}
+        m._graph = None
         if args.gemm != "fp32":
             keep = (m.gemm, m.planes, m.gather_mlp)
             m.gemm, m.planes, m.gather_mlp = "fp32", False, True
