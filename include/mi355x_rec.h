@@ -40,7 +40,7 @@ enum mi_status {
 };
 
 /* ---- library ---------------------------------------------------------------------------- */
-int32_t mi_abi_version(void);       /* bumps when a signature changes (currently 9) */
+int32_t mi_abi_version(void);       /* bumps when a signature changes (currently 10) */
 const char* mi_last_error(void);    /* thread-local, never NULL */
 const char* mi_build_info(void);    /* "gfx950 hipcc <ver>" */
 
@@ -50,7 +50,7 @@ const char* mi_build_info(void);    /* "gfx950 hipcc <ver>" */
  * it AT RUN TIME instead of from their scalar arguments:
  *   mi_sparse_apply[_fused]              step <- state->step, hp->lr_t <- state->lr_t
  *   mi_dense_apply                       hp->lr_t <- state->lr_t
- *   mi_sparse_catchup, mi_catchup_gap_keys   step_to <- state->step - 1
+ *   mi_sparse_catchup, mi_catchup_gap_keys, mi_catchup_rows_by_gap   step_to <- state->step - 1
  *   mi_dense_fwd[_gathered|_planes]      seed <- seed + state->seed_term       (dropout masks differ every step)
  * mi_step_advance (the first node of the captured step): step += 1, lr_t = lr_table[step], seed_term = step * 1000003.
  * Register the state only while capturing; eager calls between replays keep using their arguments. */
@@ -298,6 +298,15 @@ int32_t mi_sparse_apply_fused(float* table, float* t_slot0, float* t_slot1, floa
  * staleness, which halves the catch-up's divergence; the valid rows stay in front. */
 int32_t mi_catchup_gap_keys(const int32_t* uniq_rows, const int32_t* num_uniq, const int32_t* last_step, int64_t n_max,
                             int32_t step_to, int32_t* keys, int32_t lin_stride, mi_stream_t stream);
+
+/* The three steps above in one entry: rows_out[0 .. *num_uniq) = uniq_rows stably sorted by that key (slots past
+ * *num_uniq: unspecified), with the key computed inside the sort's histogram kernel and the row ids carried as the
+ * sort's values — two launches fewer than mi_catchup_gap_keys + mi_sort_unique_rows + mi_gather_u32.
+ * workspace: mi_sort_unique_workspace_bytes(n_max), 256-byte aligned. */
+int32_t mi_catchup_rows_by_gap(const int32_t* uniq_rows, const int32_t* num_uniq, const int32_t* last_step, int64_t n_max,
+                               int32_t step_to, int32_t lin_stride, int32_t* rows_out, void* workspace,
+                               size_t workspace_bytes, mi_stream_t stream);
+
 
 int32_t mi_sparse_catchup(float* table, float* t_m, float* t_v, float* lin_w, float* l_m, float* l_v,
                           int32_t* last_step, const int32_t* uniq_rows, const int32_t* num_uniq,

@@ -455,11 +455,17 @@ __global__ __launch_bounds__(kThreads) void absmax_k(const float* __restrict__ x
 
 // out[i] = sum_s slab[s][i] in a fixed order (bitwise reproducible split-K).  64 outputs per block;
 // the 4 waves take every 4th slab each, then fold through LDS as (w0+w1)+(w2+w3).
+// A second vector (the bias gradient's partials) rides in the same launch: blocks past ceil(n / 64) reduce it.
 __global__ __launch_bounds__(kThreads) void slab_reduce_k(const float* __restrict__ slab, int nsplit,
-                                                          int64_t n, float* __restrict__ out) {
+                                                          int64_t n, float* __restrict__ out,
+                                                          const float* __restrict__ slab2 = nullptr, int64_t n2 = 0,
+                                                          float* __restrict__ out2 = nullptr) {
   __shared__ float red[4][64];
   const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
-  const int64_t i = static_cast<int64_t>(blockIdx.x) * 64 + c;
+  int64_t blk = blockIdx.x;
+  const int64_t nb1 = (n + 63) >> 6;
+  if (blk >= nb1) { blk -= nb1; slab = slab2; n = n2; out = out2; }      // (block-uniform)
+  const int64_t i = blk * 64 + c;
   float acc = 0.f;
   if (i < n) {
 #pragma unroll 4
@@ -872,12 +878,8 @@ static int32_t bwd_weight_impl(const float* X, int64_t ldx, const float* dY, int
     gemv_wgrad_k<<<dim3((unsigned)mi::ceil_div(K, 16), (unsigned)splits), dim3(kThreads), 0, st>>>(
         X, ldx, dY, lddy, M, K, rows, slab, db ? cpart : nullptr);
     MI_CHECK_LAUNCH("dense_bwd_weight(N = 1)");
-    slab_reduce_k<<<dim3((unsigned)mi::ceil_div(n, 64)), dim3(kThreads), 0, st>>>(slab, splits, n, dW);
+    slab_reduce_k<<<dim3((unsigned)(mi::ceil_div(n, 64) + (db ? 1 : 0))), dim3(kThreads), 0, st>>>(slab, splits, n, dW, cpart, 1, db);
     MI_CHECK_LAUNCH("dense_bwd_weight(reduce)");
-    if (db) {
-      slab_reduce_k<<<dim3(1), dim3(kThreads), 0, st>>>(cpart, splits, 1, db);
-      MI_CHECK_LAUNCH("dense_bwd_weight(reduce bias)");
-    }
     return MI_OK;
   }
   GemmArgs a{};                       // dW[K,N] = X[M,K]^T * dY[M,N] : gemm K x N x (reduce M)
@@ -895,12 +897,9 @@ static int32_t bwd_weight_impl(const float* X, int64_t ldx, const float* dY, int
     if (int32_t rc = launch<MC, MC, true, true>(a, splits, st, "dense_bwd_weight_gathered(split-K)")) return rc;
   } else if (int32_t rc = launch<MC, MC, true>(a, splits, st, "dense_bwd_weight(split-K)")) return rc;
   if (direct) return MI_OK;
-  slab_reduce_k<<<dim3((unsigned)mi::ceil_div(n, 64)), dim3(kThreads), 0, st>>>(slab, splits, n, dW);
+  slab_reduce_k<<<dim3((unsigned)(mi::ceil_div(n, 64) + (db ? mi::ceil_div(N, 64) : 0))), dim3(kThreads), 0, st>>>(
+      slab, splits, n, dW, cpart, N, db);
   MI_CHECK_LAUNCH("dense_bwd_weight(reduce)");
-  if (db) {
-    slab_reduce_k<<<dim3((unsigned)mi::ceil_div(N, 64)), dim3(kThreads), 0, st>>>(cpart, splits, N, db);
-    MI_CHECK_LAUNCH("dense_bwd_weight(reduce bias)");
-  }
   return MI_OK;
 }
 

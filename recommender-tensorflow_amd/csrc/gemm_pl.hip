@@ -439,6 +439,74 @@ __global__ __launch_bounds__(256) void split_rows_k(const float* __restrict__ X,
   }
 }
 
+// The same split for K % 16 == 0 and 16-byte aligned rows: a lane owns whole 16-k blocks (64 B in, 64 B out as
+// four 16-byte stores) and LPR lanes share a row, so that a wave works on 64 / LPR rows — the one-wave-per-row
+// kernel above leaves most lanes idle at K = 128 and writes 2-byte pieces.
+template <int LPR>
+__global__ __launch_bounds__(256) void split_rows_blk_k(const float* __restrict__ X, int64_t ldx, int64_t rows, int K,
+                                                        char* __restrict__ out, int64_t ldo_b,
+                                                        int32_t* __restrict__ row_exp, float* __restrict__ amax_out) {
+  const int t = threadIdx.x, l = t & (LPR - 1);
+  const int64_t r = (static_cast<int64_t>(blockIdx.x) * 256 + t) / LPR;
+  const int nkb = K >> 4;
+  const bool on = r < rows;
+  const float* src = X + (on ? r : 0) * ldx;
+  float mx = 0.f;
+  if (on)
+    for (int kb = l; kb < nkb; kb += LPR) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 v = *reinterpret_cast<const float4*>(src + kb * 16 + q * 4);
+        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+      }
+    }
+#pragma unroll
+  for (int o = LPR >> 1; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  if (on) {
+    const int s = pl_exp_for(mx);
+    const float sc = pl_pow2(s);
+    if (l == 0) row_exp[r] = s;
+    for (int kb = l; kb < nkb; kb += LPR) {
+      uint32_t ph[8], pq[8];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 v = *reinterpret_cast<const float4*>(src + kb * 16 + q * 4);
+        const float u[4] = {v.x * sc, v.y * sc, v.z * sc, v.w * sc};
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const fl32x2 uu = {u[2 * e], u[2 * e + 1]};
+          h16x2 hh = __builtin_convertvector(uu, h16x2);
+          uint32_t hb = __builtin_bit_cast(uint32_t, hh);
+          if (uu[0] > 0.f && (hb & 0xffffu) == 0u) hb |= 1u;          // positive stays positive (mask reads hi > 0)
+          if (uu[1] > 0.f && (hb >> 16) == 0u) hb |= 0x10000u;
+          hh = __builtin_bit_cast(h16x2, hb);
+          const fl32x2 rr2 = {uu[0] - static_cast<float>(hh[0]), uu[1] - static_cast<float>(hh[1])};
+          ph[2 * q + e] = hb;
+          pq[2 * q + e] = __builtin_bit_cast(uint32_t, __builtin_convertvector(rr2, h16x2));
+        }
+      }
+      uint4* d = reinterpret_cast<uint4*>(out + kb * ldo_b + r * PL_ROWB);
+      d[0] = make_uint4(ph[0], ph[1], ph[2], ph[3]);
+      d[1] = make_uint4(ph[4], ph[5], ph[6], ph[7]);
+      d[2] = make_uint4(pq[0], pq[1], pq[2], pq[3]);
+      d[3] = make_uint4(pq[4], pq[5], pq[6], pq[7]);
+    }
+  }
+  if (amax_out) {                       // (every thread of the block reaches this)
+    __shared__ float part[4];
+#pragma unroll
+    for (int o = 32; o >= LPR; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((t & 63) == 0) part[t >> 6] = mx;
+    __syncthreads();
+    if (t == 0) {
+      const float m4 = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
+      unsigned int* slot = reinterpret_cast<unsigned int*>(amax_out) + (blockIdx.x & (MI_AMAX_SLOTS - 1));
+      const unsigned int bits = __float_as_uint(m4);
+      if (bits > *reinterpret_cast<volatile unsigned int*>(slot)) atomicMax(slot, bits);
+    }
+  }
+}
+
 // ---- the transposed split (weights of the forward pass: X is [K][rows], output row r = column r of X) in
 // one launch: a block owns 32 output rows; pass 1 their abs-max over all k (coalesced 128-B row pieces),
 // pass 2 64-k tiles transposed through LDS and written as planes (the tiles come back from L2).
@@ -631,6 +699,26 @@ int32_t mi_split_rows(const float* X, int64_t ldx, int64_t rows, int32_t K, int3
     split_t_k<<<dim3((unsigned)tb), dim3(256), 0, mi::as_stream(stream)>>>(X, ldx, rows, K, static_cast<char*>(out->data),
                                                                            out->blk_stride, out->row_exp, amax_out);
     MI_CHECK_LAUNCH("split_rows(transposed)");
+    return MI_OK;
+  }
+  if ((K & 15) == 0 && (ldx & 3) == 0 && (reinterpret_cast<uintptr_t>(X) & 15u) == 0) {
+    int lpr = 1;
+    while (lpr < 64 && lpr < (K >> 4)) lpr <<= 1;
+    const int64_t nb = mi::ceil_div(rows * lpr, 256);
+    MI_REQUIRE(nb <= INT32_MAX, "split_rows: grid too large");
+#define MI_SPLIT_BLK(L) split_rows_blk_k<L><<<dim3((unsigned)nb), dim3(256), 0, mi::as_stream(stream)>>>( \
+        X, ldx, rows, K, static_cast<char*>(out->data), out->blk_stride, out->row_exp, amax_out)
+    switch (lpr) {
+      case 1: MI_SPLIT_BLK(1); break;
+      case 2: MI_SPLIT_BLK(2); break;
+      case 4: MI_SPLIT_BLK(4); break;
+      case 8: MI_SPLIT_BLK(8); break;
+      case 16: MI_SPLIT_BLK(16); break;
+      case 32: MI_SPLIT_BLK(32); break;
+      default: MI_SPLIT_BLK(64); break;
+    }
+#undef MI_SPLIT_BLK
+    MI_CHECK_LAUNCH("split_rows(blocks)");
     return MI_OK;
   }
   const int64_t blocks = mi::ceil_div(rows, 4);

@@ -10,8 +10,8 @@
 //   hist_k      per-tile digit histogram (LDS atomics) + per-digit totals (global integer atomics)
 //   bin_scan_k  one workgroup per digit: base = sum of the lower digits' totals, then an
 //               exclusive scan of that digit's per-tile counts (wave shuffles, carried in chunks)
-//   scatter_k   stable scatter: lanes find their equal-digit peers in the wave with ballots,
-//               waves are chained through LDS counters, rounds through a running count
+//   scatter_k   stable scatter: lanes find their equal-digit peers in the wave with ballots; a wave owns
+//               a contiguous quarter of the tile and keeps its own running slot per digit in LDS
 // then head_count_k / compact_k mark the first entry of every distinct row (coalesced reads,
 // ballot ranks) and emit uniq_rows / seg_start / sorted_entry.
 #include "common.h"
@@ -43,6 +43,41 @@ __global__ __launch_bounds__(kBlock) void hist_k(const int32_t* __restrict__ key
     const unsigned int c = h[b];
     hist[static_cast<int64_t>(b) * ntiles + blockIdx.x] = static_cast<int32_t>(c);
     if (c) atomicAdd(&bin_total[b], static_cast<int32_t>(c));
+  }
+}
+
+// hist_k of the catch-up's staleness key, computed on the way (the key of mi_catchup_gap_keys: steps to replay,
+// clamped to 62; 63 for the slots past num_uniq) and kept for the scatter
+__global__ __launch_bounds__(kBlock) void gap_hist_k(const int32_t* __restrict__ uniq_rows, const int32_t* __restrict__ num_uniq,
+                                                     const int32_t* __restrict__ last_step, int64_t n, int step_to, int st,
+                                                     const mi_step_state_t* __restrict__ ss, int32_t* __restrict__ keys,
+                                                     int ntiles, int32_t* __restrict__ hist, int32_t* __restrict__ bin_total) {
+  __shared__ unsigned int h[64];
+  if (ss) step_to = ss->step - 1;
+  if (threadIdx.x < 64) h[threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t base = static_cast<int64_t>(blockIdx.x) * kTile;
+  const int64_t U = *num_uniq;
+  int32_t key[kItems];
+#pragma unroll
+  for (int r = 0; r < kItems; ++r) {
+    const int64_t i = base + r * kBlock + threadIdx.x;
+    key[r] = 63;
+    if (i < U) {
+      const int ls = last_step[static_cast<int64_t>(uniq_rows[i]) * st];
+      key[r] = (ls > 0 && ls < step_to) ? min(step_to - ls, 62) : 0;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < kItems; ++r) {
+    const int64_t i = base + r * kBlock + threadIdx.x;
+    if (i < n) { keys[i] = key[r]; atomicAdd(&h[key[r]], 1u); }
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const unsigned int c = h[threadIdx.x];
+    hist[static_cast<int64_t>(threadIdx.x) * ntiles + blockIdx.x] = static_cast<int32_t>(c);
+    if (c) atomicAdd(&bin_total[threadIdx.x], static_cast<int32_t>(c));
   }
 }
 
@@ -84,29 +119,56 @@ __global__ __launch_bounds__(kBlock) void bin_scan_k(int32_t* __restrict__ hist,
   }
 }
 
+// Wave w of a tile owns its keys [w * 1024, (w + 1) * 1024) (round r: 64 consecutive keys), so the tile order
+// is wave order, then round order, then lane order.  Two block barriers in total: the waves first count
+// their digits (private LDS histograms), every wave then derives its own running offsets
+// (tile offset of the digit + the counts of the waves before it) and scatters its 16 rounds alone.
 __global__ __launch_bounds__(kBlock) void scatter_k(const int32_t* __restrict__ keys_in,
                                                     const int32_t* __restrict__ vals_in, int64_t n,
                                                     int shift, int nbits, int ntiles,
                                                     const int32_t* __restrict__ offs,
                                                     int32_t* __restrict__ keys_out,
                                                     int32_t* __restrict__ vals_out) {
-  __shared__ int32_t running[kMaxBins];       // global base + keys of earlier rounds, per digit
-  __shared__ int32_t wcount[4][kMaxBins];     // this round's per-wave digit counts
+  __shared__ int32_t running[4][kMaxBins];    // per wave: next output slot of each digit
   const int t = threadIdx.x, w = t >> 6, lane = t & 63;
   const int nbins = 1 << nbits;
-  for (int b = t; b < nbins; b += kBlock) {
-    running[b] = offs[static_cast<int64_t>(b) * ntiles + blockIdx.x];
-    wcount[0][b] = 0; wcount[1][b] = 0; wcount[2][b] = 0; wcount[3][b] = 0;
+  for (int b = t; b < 4 * kMaxBins; b += kBlock) (&running[0][0])[b] = 0;
+  __syncthreads();
+  const int64_t base = static_cast<int64_t>(blockIdx.x) * kTile + w * (64 * kItems);
+  int32_t key[kItems], val[kItems];
+#pragma unroll
+  for (int r = 0; r < kItems; ++r) {
+    const int64_t i = base + r * 64 + lane;
+    const bool valid = i < n;
+    key[r] = valid ? keys_in[i] : 0;
+    val[r] = valid ? (vals_in ? vals_in[i] : static_cast<int32_t>(i)) : 0;
+    if (valid) atomicAdd(&running[w][(static_cast<uint32_t>(key[r]) >> shift) & (nbins - 1)], 1);
   }
   __syncthreads();
-  const int64_t base = static_cast<int64_t>(blockIdx.x) * kTile;
+  // counts -> this wave's first slot per digit (each lane: digits lane, lane + 64, ...)
+  int32_t first[kMaxBins / 64];
+#pragma unroll
+  for (int q = 0; q < kMaxBins / 64; ++q) {
+    const int b = q * 64 + lane;
+    int32_t f = 0;
+    if (b < nbins) {
+      f = offs[static_cast<int64_t>(b) * ntiles + blockIdx.x];
+      for (int ww = 0; ww < w; ++ww) f += running[ww][b];
+    }
+    first[q] = f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < kMaxBins / 64; ++q)
+    if (q * 64 + lane < nbins) running[w][q * 64 + lane] = first[q];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
   const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  volatile int32_t* run = running[w];
+#pragma unroll
   for (int r = 0; r < kItems; ++r) {
-    const int64_t i = base + r * kBlock + t;
-    const bool valid = i < n;
-    const int32_t key = valid ? keys_in[i] : 0;
-    const int32_t val = valid ? (vals_in ? vals_in[i] : static_cast<int32_t>(i)) : 0;
-    const unsigned int d = (static_cast<uint32_t>(key) >> shift) & (nbins - 1);
+    const bool valid = base + r * 64 + lane < n;
+    const unsigned int d = (static_cast<uint32_t>(key[r]) >> shift) & (nbins - 1);
     // peers = lanes of this wave holding a valid key with the same digit
     unsigned long long peers = __ballot(valid);
     for (int b = 0; b < nbits; ++b) {
@@ -114,20 +176,15 @@ __global__ __launch_bounds__(kBlock) void scatter_k(const int32_t* __restrict__ 
       peers &= ((d >> b) & 1u) ? m : ~m;
     }
     const int rank = __popcll(peers & lt_mask);
-    if (valid && rank == 0) wcount[w][d] = __popcll(peers);
-    __syncthreads();
+    int32_t dst = 0;
+    if (valid) dst = run[d] + rank;
+    __builtin_amdgcn_wave_barrier();            // every peer has read the slot before its leader moves it
     if (valid) {
-      int32_t dst = running[d] + rank;
-      for (int ww = 0; ww < w; ++ww) dst += wcount[ww][d];
-      keys_out[dst] = key;
-      vals_out[dst] = val;
+      if (rank == 0) run[d] = dst + __popcll(peers);
+      keys_out[dst] = key[r];
+      vals_out[dst] = val[r];
     }
-    __syncthreads();
-    for (int b = t; b < nbins; b += kBlock) {
-      running[b] += wcount[0][b] + wcount[1][b] + wcount[2][b] + wcount[3][b];
-      wcount[0][b] = 0; wcount[1][b] = 0; wcount[2][b] = 0; wcount[3][b] = 0;
-    }
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -354,6 +411,41 @@ int32_t mi_sort_unique_rows(const int32_t* rows, int64_t n, int64_t num_rows_tot
   MI_CHECK_LAUNCH("sort_unique_rows(scan heads)");
   compact_k<<<dim3(ntiles), dim3(kBlock), 0, st>>>(kin, vin, n, heads, total, sorted_entry, uniq_rows, seg_start, num_uniq);
   MI_CHECK_LAUNCH("sort_unique_rows(compact)");
+  return MI_OK;
+}
+
+
+int32_t mi_catchup_rows_by_gap(const int32_t* uniq_rows, const int32_t* num_uniq, const int32_t* last_step, int64_t n_max,
+                               int32_t step_to, int32_t lin_stride, int32_t* rows_out, void* workspace,
+                               size_t workspace_bytes, mi_stream_t stream) {
+  MI_REQUIRE(n_max >= 0 && n_max < (int64_t)INT32_MAX - kTile && step_to >= 0 && lin_stride >= 1,
+             "catchup_rows_by_gap: n_max=%lld", (long long)n_max);
+  if (n_max == 0) return MI_OK;
+  MI_REQUIRE(uniq_rows && num_uniq && last_step && rows_out && workspace, "catchup_rows_by_gap: null buffer");
+  MI_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255u) == 0, "catchup_rows_by_gap: workspace must be 256-byte aligned");
+  const Layout L = layout_for(n_max);
+  if (workspace_bytes < static_cast<size_t>(L.bytes)) {
+    mi::set_error("catchup_rows_by_gap: workspace %zu < %lld", workspace_bytes, (long long)L.bytes);
+    return MI_ERR_WORKSPACE;
+  }
+  hipStream_t st = mi::as_stream(stream);
+  char* ws = static_cast<char*>(workspace);
+  int32_t* keys = reinterpret_cast<int32_t*>(ws + L.keysA);
+  int32_t* keys_sorted = reinterpret_cast<int32_t*>(ws + L.keysB);
+  int32_t* hist = reinterpret_cast<int32_t*>(ws + L.hist);
+  int32_t* bin_total = reinterpret_cast<int32_t*>(ws + L.bin_total);
+  const int ntiles = static_cast<int>(L.ntiles);
+  if (hipMemsetAsync(bin_total, 0, 64 * 4, st) != hipSuccess) {
+    mi::set_error("catchup_rows_by_gap: memset failed");
+    return MI_ERR_LAUNCH;
+  }
+  gap_hist_k<<<dim3(ntiles), dim3(kBlock), 0, st>>>(uniq_rows, num_uniq, last_step, n_max, step_to, lin_stride, mi::step_state(),
+                                                    keys, ntiles, hist, bin_total);
+  MI_CHECK_LAUNCH("catchup_rows_by_gap(keys + hist)");
+  bin_scan_k<<<dim3(64), dim3(kBlock), 0, st>>>(hist, ntiles, 64, bin_total);
+  MI_CHECK_LAUNCH("catchup_rows_by_gap(scan)");
+  scatter_k<<<dim3(ntiles), dim3(kBlock), 0, st>>>(keys, uniq_rows, n_max, 0, 6, ntiles, hist, keys_sorted, rows_out);
+  MI_CHECK_LAUNCH("catchup_rows_by_gap(scatter)");
   return MI_OK;
 }
 

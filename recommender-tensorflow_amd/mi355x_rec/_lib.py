@@ -16,7 +16,7 @@ import torch  # noqa: F401  (loads the HIP runtime this library must share)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmi355x_rec.so")
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class MiError(RuntimeError):
@@ -92,6 +92,7 @@ SIGNATURES = {
     "mi_dense_fwd_gathered": (_i32, [_p, _p, _p, _i32, _i32, _p, _p, _p, _i64, _i64, _i32, _i32, _f32, _u64, _amax, _p]),
     "mi_dense_bwd_weight_gathered": (_i32, [_p, _p, _p, _i32, _i32, _p, _i64, _p, _p, _i64, _i32, _p, _sz, _amax, _p]),
     "mi_catchup_gap_keys": (_i32, [_p, _p, _p, _i64, _i32, _p, _i32, _p]),
+    "mi_catchup_rows_by_gap": (_i32, [_p, _p, _p, _i64, _i32, _i32, _p, _p, _sz, _p]),
     "mi_sparse_catchup": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p, _f32, _f32,
                                  _f32, _i32, _i32, _p]),
     "mi_set_gemm_mode": (_i32, [_i32]),

@@ -701,13 +701,9 @@ class DeepFM:
         self.sched.lr_t(self.step)  # make sure the table covers step
         if uniq is not None and n_max >= self.GAP_SORT_MIN:
             # rows of equal staleness into the same wave (the replay runs as long as a wave's stalest row)
-            keys = self._buf("gap_keys", (n_max,), torch.int32)
-            self.k.mi_catchup_gap_keys(uniq, num_uniq, self.last_step, n_max, self.step, keys, self.ls)
-            perm = self._buf("gap_perm", (n_max,), torch.int32)
-            ws = self._bytes("sort_ws", self.k.query("mi_sort_unique_workspace_bytes", n_max))
-            self.k.mi_sort_unique_rows(keys, n_max, 64, perm, None, None, None, ws, ws.numel())   # permutation only
             by_gap = self._buf("uniq_by_gap", (n_max,), torch.int32)
-            self.k.mi_gather_u32(uniq, perm, n_max, by_gap)
+            ws = self._bytes("sort_ws", self.k.query("mi_sort_unique_workspace_bytes", n_max))
+            self.k.mi_catchup_rows_by_gap(uniq, num_uniq, self.last_step, n_max, self.step, self.ls, by_gap, ws, ws.numel())
             uniq = by_gap
         self.k.mi_sparse_catchup(self.table if t_adam else None, self.t_s0 if t_adam else None,
                                  self.t_s1 if t_adam else None, self.lin_w if l_adam else None,

@@ -235,6 +235,11 @@ class NumpyKernels:
         k[:U] = np.where((ls > 0) & (ls < step_to), np.minimum(step_to - ls, 62), 0)
         _np(keys)[:n_max] = k
 
+    def mi_catchup_rows_by_gap(self, uniq, num_uniq, last_step, n_max, step_to, ls, rows_out, ws, ws_bytes):
+        keys = torch.empty(n_max, dtype=torch.int32)
+        self.mi_catchup_gap_keys(uniq, num_uniq, last_step, n_max, step_to, keys, ls)
+        _np(rows_out)[:n_max] = _np(uniq)[:n_max][np.argsort(_np(keys), kind="stable")]
+
     def mi_sparse_catchup(self, table, tm, tv, lin_w, lm, lv, last_step, uniq, num_uniq, n_max, E, step_to, lr_table,
                           b1, b2, eps, defer_slots=0, ls=1):
         defer = bool(defer_slots) and uniq is not None

@@ -582,6 +582,29 @@ def test_sort_unique_rows(lib, n, R):
     assert np.array_equal(sg.cpu().numpy()[:U + 1], np.r_[starts, n].astype(np.int32))
 
 
+@pytest.mark.parametrize("n_max,U,st", [(5000, 4100, 1), (200000, 150000, 4), (4097, 4097, 1), (70, 0, 4)])
+def test_catchup_rows_by_gap_is_the_stable_sort_of_the_gap_keys(lib, n_max, U, st):
+    """mi_catchup_rows_by_gap == mi_catchup_gap_keys + stable sort + gather (the three entries it replaces)"""
+    rng = np.random.default_rng(n_max + U)
+    R, step_to = 300000, 90
+    rows = np.sort(rng.choice(R, n_max, replace=False)).astype(np.int32)
+    stamps = rng.integers(0, step_to + 2, R).astype(np.int32)          # 0: never applied; >= step_to: nothing to replay
+    rec = np.zeros((R, st), np.int32)
+    rec[:, 0] = stamps
+    r, ls, nu = dev(rows), dev(rec.reshape(-1)), dev(np.array([U], np.int32))
+    out = torch.full((n_max,), -1, dtype=torch.int32, device="cuda")
+    ws = torch.empty(lib.mi_sort_unique_workspace_bytes(n_max) + 256, dtype=torch.uint8, device="cuda")
+    _chk(lib.mi_catchup_rows_by_gap(_p(r), _p(nu), _p(ls), n_max, step_to, st, _p(out), _p(ws), ws.numel(), _st()))
+    keys = torch.empty(n_max, dtype=torch.int32, device="cuda")
+    _chk(lib.mi_catchup_gap_keys(_p(r), _p(nu), _p(ls), n_max, step_to, _p(keys), st, _st()))
+    s_ = stamps[rows[:U]]
+    want_keys = np.full(n_max, 63, np.int32)
+    want_keys[:U] = np.where((s_ > 0) & (s_ < step_to), np.minimum(step_to - s_, 62), 0)
+    assert np.array_equal(keys.cpu().numpy(), want_keys)
+    order = np.argsort(want_keys, kind="stable")
+    assert np.array_equal(out.cpu().numpy()[:U], rows[order][:U])
+
+
 def test_colsum_and_layer_stats(lib):
     rng = np.random.default_rng(3)
     M, N = 3000, 70

@@ -99,7 +99,7 @@ def rows_spread(rng, M, K, lo_exp=-30):
     return X
 
 
-@pytest.mark.parametrize("rows,K", [(1, 16), (5, 104), (300, 1664), (64, 48)])
+@pytest.mark.parametrize("rows,K", [(1, 16), (5, 104), (300, 1664), (64, 48), (1000, 128), (130, 512), (37, 32)])
 def test_split_rows_format_and_round_trip(lib, rows, K):
     rng = np.random.default_rng(rows + K)
     X = rows_spread(rng, rows, K)
