@@ -352,7 +352,7 @@ def main():
         achieved = gather_bytes / (g_ms * 1e-3) / 1e9
         gemm_ms = sum(v[2] for k, v in km.items() if k in ("mi_dense_fwd", "mi_dense_fwd_gathered", "mi_dense_bwd_data", "mi_dense_bwd_weight",
                                                         "mi_dense_bwd_weight_gathered", "mi_dense_fwd_planes",
-                                                        "mi_dense_bwd_data_planes")) / args.steps
+                                                        "mi_dense_bwd_data_planes", "mi_dense_bwd_weight_planes")) / args.steps
         dims = [F * E] + HIDDEN + [1]
         flops = 3 * 2 * B * sum(a * b for a, b in zip(dims[:-1], dims[1:]))
         traffic = None

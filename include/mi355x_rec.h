@@ -447,6 +447,18 @@ int32_t mi_dense_bwd_data_planes(const mi_planes_t* dY, const mi_planes_t* W, co
                                  int64_t lddx, const mi_planes_t* dXp, int64_t M, int32_t N, int32_t K, float keep_prob,
                                  float* amax_out, mi_stream_t stream);
 
+/* dW[K][N] = X[M][K]^T * dY[M][N] and db[N] = column sums of dY (NULL: skipped), both operands as planes
+ * (replaces the same gradients as mi_dense_bwd_weight: model_utils.py:69-72 through tf.layers.dense,
+ * deep_fm.py:98-108).  The reduction runs over the examples, so every example's planes are brought to the
+ * matrix-wide scales by one power of two (from its two row exponents and amax->a / amax->b, the abs-max vectors
+ * of X and dY, both required); examples far below the abs-max lose low bits — invisible in a sum over
+ * examples, as in mi_dense_bwd_weight's matrix-wide split.  M % 32 == 0, N % 128 == 0, K % 128 == 0 (anything
+ * else: mi_dense_bwd_weight on fp32 copies).  Split-K slabs folded in a fixed order: bitwise reproducible. */
+size_t mi_dense_bwd_weight_planes_workspace_bytes(int64_t M, int32_t N, int32_t K);
+int32_t mi_dense_bwd_weight_planes(const mi_planes_t* X, const mi_planes_t* dY, float* dW, float* db, int64_t M,
+                                   int32_t N, int32_t K, void* workspace, size_t workspace_bytes,
+                                   const mi_gemm_amax_t* amax, mi_stream_t stream);
+
 /* ---- (a7,a8) logits sum + sigmoid cross-entropy head -----------------------------------------
  * replaces `logits += ...` (deep_fm.py:36,44,90,111) and
  * tf.contrib.estimator.binary_classification_head (deep_fm.py:118-125).

@@ -433,6 +433,7 @@ __global__ __launch_bounds__(kThreads, GEMM_LB_WAVES) void gemm_f32_k(const Gemm
 }
 
 #include "gemm_split.inc"
+#include "gemm_wgrad_pl.inc"
 
 // which matrix-pipe path the vectorisable GEMMs take: 1 = 16-bit operand split (default; f16x2 when
 // the call carries the operands' abs-max, bf16x3 otherwise), 0 = fp32-input MFMA
@@ -900,6 +901,60 @@ static int32_t bwd_weight_impl(const float* X, int64_t ldx, const float* dY, int
   slab_reduce_k<<<dim3((unsigned)(mi::ceil_div(n, 64) + (db ? mi::ceil_div(N, 64) : 0))), dim3(kThreads), 0, st>>>(
       slab, splits, n, dW, cpart, N, db);
   MI_CHECK_LAUNCH("dense_bwd_weight(reduce)");
+  return MI_OK;
+}
+
+
+size_t mi_dense_bwd_weight_planes_workspace_bytes(int64_t M, int32_t N, int32_t K) {
+  return mi_dense_bwd_weight_workspace_bytes(M, N, K) + static_cast<size_t>(M > 0 ? M : 0) * 8 + 256;   // + scw, yf
+}
+
+int32_t mi_dense_bwd_weight_planes(const mi_planes_t* X, const mi_planes_t* dY, float* dW, float* db, int64_t M,
+                                   int32_t N, int32_t K, void* workspace, size_t workspace_bytes,
+                                   const mi_gemm_amax_t* amax, mi_stream_t stream) {
+  MI_REQUIRE(M > 0 && M <= INT32_MAX && N > 0 && K > 0, "dense_bwd_weight_planes: M=%lld N=%d K=%d", (long long)M, N, K);
+  MI_REQUIRE(M % BK == 0 && N % BN == 0 && K % BM == 0,
+             "dense_bwd_weight_planes: M=%lld N=%d K=%d (examples a multiple of 32, N and K multiples of 128)", (long long)M, N, K);
+  MI_REQUIRE(X && dY && X->data && dY->data && X->row_exp && dY->row_exp && dW && workspace, "dense_bwd_weight_planes: null buffer");
+  MI_REQUIRE(mi::aligned16(X->data) && mi::aligned16(dY->data) && X->blk_stride >= 64 * M && dY->blk_stride >= 64 * M &&
+                 X->blk_stride % 64 == 0 && dY->blk_stride % 64 == 0 && X->blk_stride < (1 << 28) && dY->blk_stride < (1 << 28),
+             "dense_bwd_weight_planes: planes (16-byte aligned, 64 M <= blk_stride < 2^28, a multiple of 64)");
+  MI_REQUIRE(amax && amax->a && amax->b, "dense_bwd_weight_planes: needs the abs-max vectors of X and dY");
+  MI_REQUIRE(mi::aligned16(workspace), "dense_bwd_weight_planes: workspace must be 16-byte aligned");
+  if (workspace_bytes < mi_dense_bwd_weight_planes_workspace_bytes(M, N, K)) {
+    mi::set_error("dense_bwd_weight_planes: workspace %zu < %zu", workspace_bytes,
+                  mi_dense_bwd_weight_planes_workspace_bytes(M, N, K));
+    return MI_ERR_WORKSPACE;
+  }
+  hipStream_t st = mi::as_stream(stream);
+  const int splits = wgrad_splits(M, N, K);
+  const int64_t n = static_cast<int64_t>(K) * N;
+  float* slab = static_cast<float*>(workspace);
+  float* cpart = slab + static_cast<int64_t>(splits) * n;                 // [splits][N] bias-gradient partials
+  uint32_t* scw = reinterpret_cast<uint32_t*>((reinterpret_cast<uintptr_t>(cpart + static_cast<int64_t>(splits) * N) + 15) & ~uintptr_t(15));
+  float* yf = reinterpret_cast<float*>(scw + M);
+  wgrad_scale_k<<<dim3((unsigned)mi::ceil_div(M, kThreads)), dim3(kThreads), 0, st>>>(X->row_exp, dY->row_exp, amax->a, amax->b, M, scw, yf);
+  MI_CHECK_LAUNCH("dense_bwd_weight_planes(scales)");
+  WgPlArgs wa{};
+  wa.A = static_cast<const char*>(X->data); wa.bsa = X->blk_stride;
+  wa.B = static_cast<const char*>(dY->data); wa.bsb = dY->blk_stride;
+  wa.scw = scw; wa.yf = yf;
+  GemmArgs& a = wa.g;                 // dW[K,N] = X[M,K]^T * dY[M,N] : gemm K x N x (reduce M)
+  a.M = K; a.N = N; a.K = (int)M; a.k_per_split = (int)wgrad_k_per_split(M, splits);
+  const bool direct = splits == 1;    // one split: the "slab" IS the result
+  a.C = direct ? dW : slab; a.ldc = N; a.epi = EPI_SLAB; a.keep_prob = 1.f; a.keep_div = 1.f;
+  a.colsum_part = db ? (direct ? db : cpart) : nullptr;
+  a.amax_a = amax->a; a.amax_b = amax->b; a.amax_c = nullptr;
+  a.tiles_m = K / BM; a.tiles_n = N / BN;
+  const int64_t nblocks = static_cast<int64_t>(a.tiles_m) * a.tiles_n * splits;
+  MI_REQUIRE(nblocks <= INT32_MAX, "dense_bwd_weight_planes: grid too large");
+  if (db) gemm_wgrad_pl_k<true><<<dim3((unsigned)nblocks), dim3(kThreads), 0, st>>>(wa);
+  else gemm_wgrad_pl_k<false><<<dim3((unsigned)nblocks), dim3(kThreads), 0, st>>>(wa);
+  MI_CHECK_LAUNCH("dense_bwd_weight_planes(split-K)");
+  if (direct) return MI_OK;
+  slab_reduce_k<<<dim3((unsigned)(mi::ceil_div(n, 64) + (db ? mi::ceil_div(N, 64) : 0))), dim3(kThreads), 0, st>>>(
+      slab, splits, n, dW, cpart, N, db);
+  MI_CHECK_LAUNCH("dense_bwd_weight_planes(reduce)");
   return MI_OK;
 }
 

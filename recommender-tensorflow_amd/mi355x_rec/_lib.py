@@ -101,6 +101,8 @@ SIGNATURES = {
     "mi_dense_fwd": (_i32, [_p, _i64, _p, _p, _p, _i64, _i64, _i32, _i32, _i32, _f32, _u64, _amax, _p]),
     "mi_dense_bwd_data": (_i32, [_p, _i64, _p, _p, _i64, _p, _i64, _i64, _i32, _i32, _f32, _i32, _amax, _p]),
     "mi_dense_bwd_weight_workspace_bytes": (_sz, [_i64, _i32, _i32]),
+    "mi_dense_bwd_weight_planes_workspace_bytes": (_sz, [_i64, _i32, _i32]),
+    "mi_dense_bwd_weight_planes": (_i32, [_p, _p, _p, _p, _i64, _i32, _i32, _p, _sz, _p, _p]),
     "mi_dense_bwd_weight": (_i32, [_p, _i64, _p, _i64, _p, _p, _i64, _i32, _i32, _p, _sz, _amax, _p]),
     "mi_planes_bytes": (_sz, [_i64, _i32]),
     "mi_split_rows": (_i32, [_p, _i64, _i64, _i32, _i32, _pl, _p, _p]),

@@ -325,13 +325,15 @@ class DeepFM:
         self._amax_idx = {}
         # Planes path (f16x2 only): forward and data-gradient GEMMs read operands that their producers left
         # as fp16 high/low planes with a per-row exponent (no split arithmetic in the GEMM loop, LDS-DMA
-        # staging, 512-column tiles).  Every hidden layer's widths must be multiples of 16; the weight
-        # gradient still runs on the fp32 copies (gemm.hip, matrix-wide scales: its reduction runs over the
-        # examples, where a per-example exponent cannot be undone).
+        # staging, 512-column tiles).  Every hidden layer's widths must be multiples of 16.  The weight gradient
+        # reads the same planes where whole 128 x 128 x 32 tiles fit (_wgrad_planes_ok: one power of two per
+        # example brings its rows to matrix-wide scales), and the fp32 copies are then not written at all;
+        # otherwise it runs on fp32 copies (gemm.hip, matrix-wide scales).
         self.planes = (gemm == "f16x2" and self.use_dnn and len(self.hidden) > 0 and self.act == 1 and
                        getattr(self.k, "supports_planes", False) and self.D % 16 == 0 and
                        all(h % 16 == 0 for h in self.hidden))
         self._pl = {}
+        self._acts_in_planes = set()      # hidden layers whose last training output exists as planes only
         # layer 1's operand: the gather kernel writes it as planes when the embedding size allows; otherwise
         # the concat is materialised in fp32 (as with numeric columns) and split
         self.pl_gather_ok = self.E % 16 == 0 and self.E >= 32 and self.F <= 48
@@ -607,7 +609,11 @@ class DeepFM:
                     need_p = i + 1 < nh
                     yp = self._planes("x%dp" % (i + 1), B, h) if need_p else None
                     direct = need_p and h <= 512
-                    k.mi_dense_fwd_planes(self._planes(xp, B, fan), self._pl["wt%d" % i].struct, self.bias(i), y, h,
+                    # (no fp32 copy when its only reader, the next layer's weight gradient, takes the planes)
+                    planes_only = train and direct and self._wgrad_planes_ok(B, i + 1)
+                    (self._acts_in_planes.add if planes_only else self._acts_in_planes.discard)(i)
+                    k.mi_dense_fwd_planes(self._planes(xp, B, fan), self._pl["wt%d" % i].struct, self.bias(i),
+                                          None if planes_only else y, h,
                                           yp if direct else None, B, h, fan, 1, keep, self._layer_seed(i),
                                           self._av("x%d" % (i + 1)))
                     if need_p and not direct:
@@ -770,6 +776,13 @@ class DeepFM:
                                       B, self.F, self.E, d_rows, d_lin)
         return d_rows, d_lin
 
+    def _wgrad_planes_ok(self, B, i):
+        """layer i's weight gradient can read planes: a hidden layer, whole tiles (mi_dense_bwd_weight_planes)"""
+        if not self.planes or i < 0 or i >= len(self.layers) - 1:
+            return False
+        _, _, fan, h = self.layers[i]
+        return B % 32 == 0 and fan % 128 == 0 and h % 128 == 0 and hasattr(self.k, "mi_dense_bwd_weight_planes")
+
     def _backward_dense(self, c, dlogit):
         """Fills self.d_grad (dense gradients) and returns d_concat [B, D] (or None)."""
         k = self.k
@@ -779,7 +792,8 @@ class DeepFM:
             nh = len(self.layers) - 1
             keep = c["keep"]
             dy, lddy = dlogit, 1
-            wsz = max(k.query("mi_dense_bwd_weight_workspace_bytes", B, h, fan) for (_, _, fan, h) in self.layers)
+            wsz = max(k.query("mi_dense_bwd_weight_planes_workspace_bytes" if self._wgrad_planes_ok(B, j) else
+                              "mi_dense_bwd_weight_workspace_bytes", B, h, fan) for j, (_, _, fan, h) in enumerate(self.layers))
             ws = self._bytes("wgrad_ws", wsz)
             for i in range(nh, -1, -1):
                 _, _, fan, h = self.layers[i]
@@ -790,7 +804,11 @@ class DeepFM:
                 dyn = "dy%d" % i if i < nh else None
                 ga_w = self._ga("x%d" % i, dyn, None) if dyn else None
                 ga_d = self._ga(dyn, "w", "dy%d" % (i - 1) if i else None) if (dyn or i) else None
-                if i == 0 and c["gathered"]:
+                if self._wgrad_planes_ok(B, i):
+                    k.mi_dense_bwd_weight_planes(self._pl["x%dp" % i].struct, self._pl["dy%dp" % i].struct,
+                                                 self.kernel(i, self.d_grad), self.bias(i, self.d_grad), B, h, fan, ws,
+                                                 ws.numel(), ga_w)
+                elif i == 0 and c["gathered"]:
                     k.mi_dense_bwd_weight_gathered(c["g_table"], c["g_off"], c["ids"], self.F, self.E, dy, lddy,
                                                    self.kernel(0, self.d_grad), self.bias(0, self.d_grad), B, h, ws,
                                                    ws.numel(), ga_w)
@@ -808,7 +826,10 @@ class DeepFM:
                     if i > 0 and xa is None:      # (the last hidden layer's output has no planes: make them)
                         xa = self._planes("x%dp" % i, B, fan)
                         k.mi_split_rows(x, ldx, B, fan, 0, xa, None)
-                    k.mi_dense_bwd_data_planes(self._planes("dy%dp" % i, B, h), self._pl["w%d" % i].struct, xa, dx, fan,
+                    # (the fp32 copy only where something reads it: d_concat, or a weight gradient on fp32 operands)
+                    need_f = i == 0 or not (direct and self._wgrad_planes_ok(B, i - 1))
+                    k.mi_dense_bwd_data_planes(self._planes("dy%dp" % i, B, h), self._pl["w%d" % i].struct, xa,
+                                               dx if need_f else None, fan,
                                                dxp if direct else None, B, h, fan, keep if i else 1.0,
                                                self._av("dy%d" % (i - 1)) if i else None)
                     if need_p and not direct:
@@ -947,6 +968,8 @@ class DeepFM:
         if self.use_dnn:
             for i, (_, _, _, h) in enumerate(self.layers):
                 a = self._ws.get("act%d" % i)
+                if a is not None and i in self._acts_in_planes:      # the last step wrote planes only: merge them
+                    k.mi_merge_rows(self._pl["x%dp" % (i + 1)].struct, B, h, a, h)
                 if a is not None:
                     named.append(("dnn/hiddenlayer_%d" % i if i < len(self.layers) - 1 else "dnn/logits", a[:B * h]))
         if "logits" in self._ws:

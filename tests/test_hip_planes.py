@@ -297,3 +297,45 @@ def test_split_weights_one_launch(lib):
         u = W * np.float32(2.0) ** sx
         hi = u.astype(np.float16)
         assert np.array_equal(pw.data.cpu().numpy()[:, :k, :16].transpose(1, 0, 2).reshape(k, -1)[:, :n].view(np.float16), hi)
+
+
+@pytest.mark.parametrize("M,N,K,bias", [(4096, 128, 256, True), (8192, 512, 1664, True), (1024, 256, 512, False), (32, 128, 128, True)])
+def test_dense_bwd_weight_planes_against_fp64(lib, M, N, K, bias):
+    """dW = X^T dY and db = colsum(dY) from planes whose rows span 2^-20 .. 1 (examples with tiny gradients next
+    to large ones): error relative to the rms of the exact result at fp32 level, like the fp32-operand entry;
+    twice the same bits (fixed-order split-K)."""
+    from mi355x_rec import _lib as L
+    rng = np.random.default_rng(M + N + K)
+    X = np.maximum(rows_spread(rng, M, K, -6), 0).astype(np.float32)
+    dY = (rows_spread(rng, M, N, -20) * 1e-4).astype(np.float32)
+    xp, dyp = split(lib, X), split(lib, dY)
+    ax = torch.zeros(L.AMAX_SLOTS, device="cuda"); ady = torch.zeros(L.AMAX_SLOTS, device="cuda")
+    _chk(lib.mi_absmax(dev(X).data_ptr(), X.size, ax.data_ptr(), _st()))
+    _chk(lib.mi_absmax(dev(dY).data_ptr(), dY.size, ady.data_ptr(), _st()))
+    ga = L.GemmAmax(ax.data_ptr(), ady.data_ptr(), None)
+    ws = torch.empty(lib.mi_dense_bwd_weight_planes_workspace_bytes(M, N, K) + 256, dtype=torch.uint8, device="cuda")
+    outs = []
+    for _ in range(2):
+        dW = torch.full((K, N), float("nan"), device="cuda"); db = torch.full((N,), float("nan"), device="cuda")
+        _chk(lib.mi_dense_bwd_weight_planes(xp.ref, dyp.ref, dW.data_ptr(), db.data_ptr() if bias else None, M, N, K,
+                                            ws.data_ptr(), ws.numel(), C.byref(ga), _st()))
+        outs.append((dW.cpu().numpy(), db.cpu().numpy()))
+    refW = X.astype(np.float64).T @ dY.astype(np.float64)
+    assert np.max(np.abs(outs[0][0] - refW)) / np.sqrt(np.mean(refW * refW)) < 1e-5
+    if bias:
+        refb = dY.astype(np.float64).sum(0)
+        assert np.max(np.abs(outs[0][1] - refb)) / np.sqrt(np.mean(refb * refb)) < 1e-5
+        assert np.array_equal(outs[0][1], outs[1][1])
+    assert np.array_equal(outs[0][0], outs[1][0])
+
+
+def test_dense_bwd_weight_planes_refuses_ragged_shapes(lib):
+    from mi355x_rec import _lib as L
+    xp, dyp = PB(lib, 64, 128), PB(lib, 64, 128)
+    a = torch.zeros(L.AMAX_SLOTS, device="cuda")
+    ga = L.GemmAmax(a.data_ptr(), a.data_ptr(), None)
+    ws = torch.empty(1 << 20, dtype=torch.uint8, device="cuda")
+    dW = torch.empty(128, 128, device="cuda")
+    for M, N, K in ((48, 128, 128), (64, 96, 128), (64, 128, 64)):
+        assert lib.mi_dense_bwd_weight_planes(xp.ref, dyp.ref, dW.data_ptr(), None, M, N, K, ws.data_ptr(), ws.numel(),
+                                              C.byref(ga), _st()) != 0
