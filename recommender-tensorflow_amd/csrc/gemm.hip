@@ -16,7 +16,9 @@
 // k-values per ds_read_b128 feed four consecutive MFMAs: lane half h owns k = 8s+4h+j.
 // Workgroup ids are remapped so that the blocks sharing an A row-panel run on one XCD (shared L2).
 #include "common.h"
+#include "wgrad_pl.h"
 #include <algorithm>
+#include <cstdlib>
 
 namespace {
 
@@ -905,8 +907,21 @@ static int32_t bwd_weight_impl(const float* X, int64_t ldx, const float* dY, int
 }
 
 
+// two kernels: wgrad_pl.hip (LDS-DMA staging, transposed LDS reads; N = 128 / 256 / 512) and, for the other whole-tile
+// shapes, gemm_wgrad_pl_k (register staging).  MI_WGRAD_PL=0 forces the second (A/B runs).
+static bool wgrad_plan(int64_t M, int32_t N, int32_t K, mi::WgradPlPlan* p) {
+  const char* e = getenv("MI_WGRAD_PL");          // (read per call: the tests switch it)
+  return !(e && e[0] == '0') && mi::wgrad_pl_plan(M, N, K, p);
+}
+
 size_t mi_dense_bwd_weight_planes_workspace_bytes(int64_t M, int32_t N, int32_t K) {
-  return mi_dense_bwd_weight_workspace_bytes(M, N, K) + static_cast<size_t>(M > 0 ? M : 0) * 8 + 256;   // + scw, yf
+  mi::WgradPlPlan p;
+  size_t slabs = mi_dense_bwd_weight_workspace_bytes(M, N, K);
+  if (wgrad_plan(M, N, K, &p)) {
+    const size_t s2 = (static_cast<size_t>(p.splits) * K * N + static_cast<size_t>(p.splits) * N) * sizeof(float) + 256;
+    if (s2 > slabs) slabs = s2;
+  }
+  return slabs + static_cast<size_t>(M > 0 ? M : 0) * 8 + 256;   // + the per-example factors
 }
 
 int32_t mi_dense_bwd_weight_planes(const mi_planes_t* X, const mi_planes_t* dY, float* dW, float* db, int64_t M,
@@ -920,37 +935,51 @@ int32_t mi_dense_bwd_weight_planes(const mi_planes_t* X, const mi_planes_t* dY, 
                  X->blk_stride % 64 == 0 && dY->blk_stride % 64 == 0 && X->blk_stride < (1 << 28) && dY->blk_stride < (1 << 28),
              "dense_bwd_weight_planes: planes (16-byte aligned, 64 M <= blk_stride < 2^28, a multiple of 64)");
   MI_REQUIRE(amax && amax->a && amax->b, "dense_bwd_weight_planes: needs the abs-max vectors of X and dY");
-  MI_REQUIRE(mi::aligned16(workspace), "dense_bwd_weight_planes: workspace must be 16-byte aligned");
+  MI_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 31u) == 0, "dense_bwd_weight_planes: workspace must be 32-byte aligned");
   if (workspace_bytes < mi_dense_bwd_weight_planes_workspace_bytes(M, N, K)) {
     mi::set_error("dense_bwd_weight_planes: workspace %zu < %zu", workspace_bytes,
                   mi_dense_bwd_weight_planes_workspace_bytes(M, N, K));
     return MI_ERR_WORKSPACE;
   }
   hipStream_t st = mi::as_stream(stream);
-  const int splits = wgrad_splits(M, N, K);
+  mi::WgradPlPlan plan;
+  const bool dma = wgrad_plan(M, N, K, &plan);
+  const int splits = dma ? plan.splits : wgrad_splits(M, N, K);
   const int64_t n = static_cast<int64_t>(K) * N;
-  float* slab = static_cast<float*>(workspace);
+  char* fac = static_cast<char*>(workspace);                               // per-example factors first (alignment)
+  float* slab = reinterpret_cast<float*>(fac + ((static_cast<size_t>(M) * 8 + 255) & ~size_t(255)));
   float* cpart = slab + static_cast<int64_t>(splits) * n;                 // [splits][N] bias-gradient partials
-  uint32_t* scw = reinterpret_cast<uint32_t*>((reinterpret_cast<uintptr_t>(cpart + static_cast<int64_t>(splits) * N) + 15) & ~uintptr_t(15));
-  float* yf = reinterpret_cast<float*>(scw + M);
-  wgrad_scale_k<<<dim3((unsigned)mi::ceil_div(M, kThreads)), dim3(kThreads), 0, st>>>(X->row_exp, dY->row_exp, amax->a, amax->b, M, scw, yf);
-  MI_CHECK_LAUNCH("dense_bwd_weight_planes(scales)");
-  WgPlArgs wa{};
-  wa.A = static_cast<const char*>(X->data); wa.bsa = X->blk_stride;
-  wa.B = static_cast<const char*>(dY->data); wa.bsb = dY->blk_stride;
-  wa.scw = scw; wa.yf = yf;
-  GemmArgs& a = wa.g;                 // dW[K,N] = X[M,K]^T * dY[M,N] : gemm K x N x (reduce M)
-  a.M = K; a.N = N; a.K = (int)M; a.k_per_split = (int)wgrad_k_per_split(M, splits);
   const bool direct = splits == 1;    // one split: the "slab" IS the result
-  a.C = direct ? dW : slab; a.ldc = N; a.epi = EPI_SLAB; a.keep_prob = 1.f; a.keep_div = 1.f;
-  a.colsum_part = db ? (direct ? db : cpart) : nullptr;
-  a.amax_a = amax->a; a.amax_b = amax->b; a.amax_c = nullptr;
-  a.tiles_m = K / BM; a.tiles_n = N / BN;
-  const int64_t nblocks = static_cast<int64_t>(a.tiles_m) * a.tiles_n * splits;
-  MI_REQUIRE(nblocks <= INT32_MAX, "dense_bwd_weight_planes: grid too large");
-  if (db) gemm_wgrad_pl_k<true><<<dim3((unsigned)nblocks), dim3(kThreads), 0, st>>>(wa);
-  else gemm_wgrad_pl_k<false><<<dim3((unsigned)nblocks), dim3(kThreads), 0, st>>>(wa);
-  MI_CHECK_LAUNCH("dense_bwd_weight_planes(split-K)");
+  float* out = direct ? dW : slab;
+  float* cout = db ? (direct ? db : cpart) : nullptr;
+  const dim3 sg((unsigned)mi::ceil_div(M, kThreads)), sb(kThreads);
+  if (dma) {
+    uint16_t* sx16 = reinterpret_cast<uint16_t*>(fac);
+    uint16_t* sy16 = sx16 + M;
+    wgrad_scale_k<<<sg, sb, 0, st>>>(X->row_exp, dY->row_exp, amax->a, amax->b, M, nullptr, nullptr, sx16, sy16);
+    MI_CHECK_LAUNCH("dense_bwd_weight_planes(scales)");
+    if (int32_t rc = mi::wgrad_pl_launch(plan, X, dY, sx16, sy16, amax->a, amax->b, out, cout, M, N, K, st)) return rc;
+  } else {
+    uint32_t* scw = reinterpret_cast<uint32_t*>(fac);
+    float* yf = reinterpret_cast<float*>(scw + M);
+    wgrad_scale_k<<<sg, sb, 0, st>>>(X->row_exp, dY->row_exp, amax->a, amax->b, M, scw, yf, nullptr, nullptr);
+    MI_CHECK_LAUNCH("dense_bwd_weight_planes(scales)");
+    WgPlArgs wa{};
+    wa.A = static_cast<const char*>(X->data); wa.bsa = X->blk_stride;
+    wa.B = static_cast<const char*>(dY->data); wa.bsb = dY->blk_stride;
+    wa.scw = scw; wa.yf = yf;
+    GemmArgs& a = wa.g;                 // dW[K,N] = X[M,K]^T * dY[M,N] : gemm K x N x (reduce M)
+    a.M = K; a.N = N; a.K = (int)M; a.k_per_split = (int)wgrad_k_per_split(M, splits);
+    a.C = out; a.ldc = N; a.epi = EPI_SLAB; a.keep_prob = 1.f; a.keep_div = 1.f;
+    a.colsum_part = cout;
+    a.amax_a = amax->a; a.amax_b = amax->b; a.amax_c = nullptr;
+    a.tiles_m = K / BM; a.tiles_n = N / BN;
+    const int64_t nblocks = static_cast<int64_t>(a.tiles_m) * a.tiles_n * splits;
+    MI_REQUIRE(nblocks <= INT32_MAX, "dense_bwd_weight_planes: grid too large");
+    if (db) gemm_wgrad_pl_k<true><<<dim3((unsigned)nblocks), dim3(kThreads), 0, st>>>(wa);
+    else gemm_wgrad_pl_k<false><<<dim3((unsigned)nblocks), dim3(kThreads), 0, st>>>(wa);
+    MI_CHECK_LAUNCH("dense_bwd_weight_planes(split-K)");
+  }
   if (direct) return MI_OK;
   slab_reduce_k<<<dim3((unsigned)(mi::ceil_div(n, 64) + (db ? mi::ceil_div(N, 64) : 0))), dim3(kThreads), 0, st>>>(
       slab, splits, n, dW, cpart, N, db);

@@ -299,12 +299,15 @@ def test_split_weights_one_launch(lib):
         assert np.array_equal(pw.data.cpu().numpy()[:, :k, :16].transpose(1, 0, 2).reshape(k, -1)[:, :n].view(np.float16), hi)
 
 
-@pytest.mark.parametrize("M,N,K,bias", [(4096, 128, 256, True), (8192, 512, 1664, True), (1024, 256, 512, False), (32, 128, 128, True)])
-def test_dense_bwd_weight_planes_against_fp64(lib, M, N, K, bias):
+@pytest.mark.parametrize("kernel", ["lds-dma", "register-staged"])
+@pytest.mark.parametrize("M,N,K,bias", [(4096, 128, 256, True), (8192, 512, 1664, True), (1024, 256, 512, False), (32, 128, 128, True),
+                                        (2080, 256, 384, True), (4096, 384, 128, True)])
+def test_dense_bwd_weight_planes_against_fp64(lib, M, N, K, bias, kernel, monkeypatch):
     """dW = X^T dY and db = colsum(dY) from planes whose rows span 2^-20 .. 1 (examples with tiny gradients next
     to large ones): error relative to the rms of the exact result at fp32 level, like the fp32-operand entry;
     twice the same bits (fixed-order split-K)."""
     from mi355x_rec import _lib as L
+    monkeypatch.setenv("MI_WGRAD_PL", "1" if kernel == "lds-dma" else "0")    # (N = 384 takes the register-staged kernel either way)
     rng = np.random.default_rng(M + N + K)
     X = np.maximum(rows_spread(rng, M, K, -6), 0).astype(np.float32)
     dY = (rows_spread(rng, M, N, -20) * 1e-4).astype(np.float32)

@@ -47,7 +47,7 @@ def main():
     M = 65536
     g = torch.Generator(device="cuda"); g.manual_seed(0)
     for name, N, K in (("fwd L1", 512, 1664), ("fwd L2", 256, 512), ("fwd L3", 128, 256),
-                       ("dgrad L1 (fp32 out)", 1664, 512), ("dgrad L2", 512, 256), ("dgrad L3", 256, 128)):
+                       ("dgrad L1 (fp32 out)", 1664, 512), ("dgrad L2", 512, 256), ("dgrad L3", 256, 128))[:int(os.environ.get("PL_BENCH_FWD", "6"))]:
         X = torch.randn(M, K, device="cuda", generator=g)
         W = torch.randn(K, N, device="cuda", generator=g) / K ** 0.5
         b = torch.zeros(N, device="cuda")
@@ -69,6 +69,24 @@ def main():
                                                                   None if ypl is None else ypl.ref, M, N, K, 1, 0.9, 7, None, st()), "fwd"))
             print("%-22s N=%4d K=%4d %-12s %7.1f us  %6.1f TF/s fp32-equiv" % (name, N, K, label, t * 1e3, flops / t / 1e9))
         del X, W, xp, wt, Y, yp
+    # weight gradients from planes
+    for name, N, K in (("wgrad L1", 512, 1664), ("wgrad L2", 256, 512), ("wgrad L3", 128, 256)):
+        X = torch.randn(M, K, device="cuda", generator=g)
+        dY = torch.randn(M, N, device="cuda", generator=g) * 1e-4
+        xp, dyp = split(X), split(dY)
+        ax = torch.zeros(_lib.AMAX_SLOTS, device="cuda"); ay = torch.zeros(_lib.AMAX_SLOTS, device="cuda")
+        lib.mi_absmax(X.data_ptr(), X.numel(), ax.data_ptr(), st()); lib.mi_absmax(dY.data_ptr(), dY.numel(), ay.data_ptr(), st())
+        ga = _lib.GemmAmax(ax.data_ptr(), ay.data_ptr(), None)
+        ws = torch.empty(int(lib.mi_dense_bwd_weight_planes_workspace_bytes(M, N, K)) + 256, dtype=torch.uint8, device="cuda")
+        dW = torch.empty(K, N, device="cuda"); db = torch.empty(N, device="cuda")
+        flops = 2.0 * M * N * K
+        t = timeit(lambda: _lib.check(lib.mi_dense_bwd_weight_planes(xp.ref, dyp.ref, dW.data_ptr(), db.data_ptr(), M, N, K, ws.data_ptr(),
+                                                                     ws.numel(), C.byref(ga), st()), "wgrad"))
+        print("%-22s N=%4d K=%4d planes       %7.1f us  %6.1f TF/s fp32-equiv" % (name, N, K, t * 1e3, flops / t / 1e9))
+        t = timeit(lambda: _lib.check(lib.mi_dense_bwd_weight(X.data_ptr(), K, dY.data_ptr(), N, dW.data_ptr(), db.data_ptr(), M, N, K, ws.data_ptr(),
+                                                              ws.numel(), C.byref(ga), st()), "wgrad"))
+        print("%-22s N=%4d K=%4d fp32 operands %6.1f us  %6.1f TF/s fp32-equiv" % (name, N, K, t * 1e3, flops / t / 1e9))
+        del X, dY, xp, dyp
     # the weight splits of one step
     ws = [torch.randn(k, n, device="cuda", generator=g) for k, n in ((1664, 512), (512, 256), (256, 128))]
     outs = [(PB(w.shape[1], w.shape[0]), PB(w.shape[0], w.shape[1])) for w in ws]
