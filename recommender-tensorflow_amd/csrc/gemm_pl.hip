@@ -451,12 +451,16 @@ __global__ __launch_bounds__(256) void split_rows_blk_k(const float* __restrict_
   const int nkb = K >> 4;
   const bool on = r < rows;
   const float* src = X + (on ? r : 0) * ldx;
+  // (the first block of a lane stays in registers: K <= 16 LPR, the usual case, reads the row once)
+  float4 v0[4] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f),
+                  make_float4(0.f, 0.f, 0.f, 0.f)};
   float mx = 0.f;
   if (on)
     for (int kb = l; kb < nkb; kb += LPR) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const float4 v = *reinterpret_cast<const float4*>(src + kb * 16 + q * 4);
+        if (kb == l) v0[q] = v;
         mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
       }
     }
@@ -470,7 +474,7 @@ __global__ __launch_bounds__(256) void split_rows_blk_k(const float* __restrict_
       uint32_t ph[8], pq[8];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const float4 v = *reinterpret_cast<const float4*>(src + kb * 16 + q * 4);
+        const float4 v = kb == l ? v0[q] : *reinterpret_cast<const float4*>(src + kb * 16 + q * 4);
         const float u[4] = {v.x * sc, v.y * sc, v.z * sc, v.w * sc};
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
