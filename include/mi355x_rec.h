@@ -40,7 +40,7 @@ enum mi_status {
 };
 
 /* ---- library ---------------------------------------------------------------------------- */
-int32_t mi_abi_version(void);       /* bumps when a signature changes (currently 10) */
+int32_t mi_abi_version(void);       /* bumps when a signature changes (currently 11) */
 const char* mi_last_error(void);    /* thread-local, never NULL */
 const char* mi_build_info(void);    /* "gfx950 hipcc <ver>" */
 
@@ -274,7 +274,8 @@ int32_t mi_sparse_apply(float* table, float* t_slot0, float* t_slot1, float* lin
  * e = (b, f) = (e / F, e % F) is rebuilt inside the kernel as
  *   d_concat[b, f*E:(f+1)*E] + d_logit_fm[b] * (sumv[b,:] - w)     (w = the row itself, not yet updated;
  *   equals the concat slice the forward used)  and  d_logit_lin[b] for the linear weight,
- * so the [B*F, E] per-entry gradient matrix is never written.  Same summation order, same bits. */
+ * so the [B*F, E] per-entry gradient matrix is never written.  Same summation order, same bits. * sumv == NULL with d_logit_fm set: d_concat already carries d_logit_fm * sumv (mi_dense_bwd_data_planes'
+ * fold_sumv), the kernel subtracts d_logit_fm * row only. */
 int32_t mi_sparse_apply_fused(float* table, float* t_slot0, float* t_slot1, float* lin_w, float* l_slot0,
                               float* l_slot1, int32_t* last_step, const int32_t* uniq_rows,
                               const int32_t* seg_start, const int32_t* sorted_entry, const int32_t* num_uniq,
@@ -442,10 +443,13 @@ int32_t mi_dense_fwd_planes(const mi_planes_t* X, const mi_planes_t* Wt, const f
 
 /* dX[M][K] = (dY[M][N] * W[K][N]^T) .* mask with dY as planes and W = planes of W as stored (rows = K);
  * mask from Xact (planes of the previous layer's stored output: hi > 0 <=> active and kept; NULL: none),
- * survivors divided by keep_prob.  dX (fp32) and / or dXp (planes, K <= 512). */
+ * survivors divided by keep_prob.  dX (fp32) and / or dXp (planes, K <= 512). * fold_sumv != NULL (layer 1 only: dX is d_concat, fp32, no mask): dX[m][k] += fold_dlogit[m] * fold_sumv[m][k % fold_E]
+ * — the FM term's share of the input_layer gradient (deep_fm.py:81-87 backward) added once per example here;
+ * mi_sparse_apply_fused is then called with sumv == NULL and subtracts d_logit_fm * row only. */
 int32_t mi_dense_bwd_data_planes(const mi_planes_t* dY, const mi_planes_t* W, const mi_planes_t* Xact, float* dX,
                                  int64_t lddx, const mi_planes_t* dXp, int64_t M, int32_t N, int32_t K, float keep_prob,
-                                 float* amax_out, mi_stream_t stream);
+                                 float* amax_out, const float* fold_sumv, const float* fold_dlogit, int32_t fold_E,
+                                 mi_stream_t stream);
 
 /* dW[K][N] = X[M][K]^T * dY[M][N] and db[N] = column sums of dY (NULL: skipped), both operands as planes
  * (replaces the same gradients as mi_dense_bwd_weight: model_utils.py:69-72 through tf.layers.dense,

@@ -59,6 +59,9 @@ struct PlArgs {
   const float* bias; int relu; float keep_prob, keep_div; uint64_t seed;
   const char* mask; int64_t bsm;                        // dgrad: planes of the stored activation (hi > 0 <=> active & kept)
   float* amax_c;                                        // abs-max vector of the result (gemm.hip's weight gradient) or NULL
+  // dgrad into the input_layer: the FM term's share of the concat gradient, added once here instead of once
+  // per entry in the sparse apply: C[m][n] += fold_g[m] * fold_s[m][n % fold_E]   (NULL: nothing added)
+  const float* fold_s; const float* fold_g; int fold_E;
   const mi_step_state_t* st;                            // device-resident step state of a captured step, or NULL
 };
 
@@ -256,13 +259,20 @@ __global__ __launch_bounds__(PL_THREADS, 2) void gemm_pl_k(const PlArgs a) {
     const int mc = mok ? m : a.M - 1;
     const float fx = pl_pow2(-a.b_exp[mc]);
     float mx = 0.f;
+    float fgm = 0.f;
+    const float* fsm = nullptr;
+    if constexpr (EPI == PL_DGRAD) {
+      if (a.fold_s) { fgm = a.fold_g[mc]; fsm = a.fold_s + static_cast<int64_t>(mc) * a.fold_E; }
+    }
 #pragma unroll
     for (int x = 0; x < TN; ++x) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int nl = nw + x * 32 + 8 * g + 4 * h;       // tile column of register 4 g
         uint2 mk = make_uint2(0u, 0u);
+        float4 fs4 = make_float4(0.f, 0.f, 0.f, 0.f);
         if constexpr (EPI == PL_DGRAD) {
+          if (fsm) fs4 = *reinterpret_cast<const float4*>(fsm + min(n0 + nl, a.N - 4) % a.fold_E);   // (4 columns stay inside a field: E % 4 == 0)
           if (a.mask) {
             const int gn = min(n0 + nl, a.N - 4);
             mk = *reinterpret_cast<const uint2*>(a.mask + (gn >> 4) * a.bsm + static_cast<int64_t>(mc) * PL_ROWB + (gn & 15) * 2);
@@ -284,6 +294,7 @@ __global__ __launch_bounds__(PL_THREADS, 2) void gemm_pl_k(const PlArgs a) {
               // positive fp16 (sign clear, not zero): the unit was active and kept
               v = (hbits != 0u && hbits < 0x8000u) ? v / a.keep_div : 0.f;
             }
+            v += fgm * (j == 0 ? fs4.x : j == 1 ? fs4.y : j == 2 ? fs4.z : fs4.w);
           }
           if (n0 + nl + j >= a.N) v = 0.f;
           acc[x][y][r] = v;
@@ -793,7 +804,8 @@ int32_t mi_dense_fwd_planes(const mi_planes_t* X, const mi_planes_t* Wt, const f
 
 int32_t mi_dense_bwd_data_planes(const mi_planes_t* dY, const mi_planes_t* W, const mi_planes_t* Xact, float* dX,
                                  int64_t lddx, const mi_planes_t* dXp, int64_t M, int32_t N, int32_t K, float keep_prob,
-                                 float* amax_out, mi_stream_t stream) {
+                                 float* amax_out, const float* fold_sumv, const float* fold_dlogit, int32_t fold_E,
+                                 mi_stream_t stream) {
   // dX[M][K] = dY[M][N] * W[K][N]^T : output width K, reduction over N
   MI_REQUIRE(M >= 0 && M <= INT32_MAX && N > 0 && K > 0, "dense_bwd_data_planes: M=%lld N=%d K=%d", (long long)M, N, K);
   if (M == 0) return MI_OK;
@@ -813,6 +825,11 @@ int32_t mi_dense_bwd_data_planes(const mi_planes_t* dY, const mi_planes_t* W, co
   a.keep_prob = keep_prob; a.keep_div = Xact ? keep_prob : 1.f;
   if (Xact) { a.mask = static_cast<const char*>(Xact->data); a.bsm = Xact->blk_stride; }
   a.amax_c = amax_out;
+  if (fold_sumv) {
+    MI_REQUIRE(fold_dlogit && fold_E >= 4 && (fold_E & 3) == 0 && K % fold_E == 0 && mi::aligned16(fold_sumv) && !Xact && !dXp && dX,
+               "dense_bwd_data_planes: the FM fold needs d_logit, E a multiple of 4 that divides K, an fp32 result and no mask");
+    a.fold_s = fold_sumv; a.fold_g = fold_dlogit; a.fold_E = fold_E;
+  }
   return launch_pl<PL_DGRAD>(a, mi::as_stream(stream), "dense_bwd_data_planes");
 }
 

@@ -146,9 +146,13 @@ __device__ __forceinline__ void seg_accumulate(const ApplyArgs& a, const FusedGr
         if (fg.d_concat) v = ld4(fg.d_concat + b * fg.ldd + static_cast<int64_t>(f) * E + 4 * l);
         if (fg.dlf) {
           const float gf = fg.dlf[b];
-          const float4 sv = ld4(fg.sumv + b * E + 4 * l);
-          v.x += gf * (sv.x - w.x); v.y += gf * (sv.y - w.y);
-          v.z += gf * (sv.z - w.z); v.w += gf * (sv.w - w.w);
+          if (fg.sumv) {
+            const float4 sv = ld4(fg.sumv + b * E + 4 * l);
+            v.x += gf * (sv.x - w.x); v.y += gf * (sv.y - w.y);
+            v.z += gf * (sv.z - w.z); v.w += gf * (sv.w - w.w);
+          } else {      // d_concat already carries gf * sumv (the data gradient's epilogue added it once per example)
+            v.x -= gf * w.x; v.y -= gf * w.y; v.z -= gf * w.z; v.w -= gf * w.w;
+          }
         }
         g.x += v.x; g.y += v.y; g.z += v.z; g.w += v.w;
       }
@@ -584,7 +588,8 @@ int32_t mi_sparse_apply_fused(float* table, float* t_slot0, float* t_slot1, floa
   MI_REQUIRE(!table || d_concat || d_logit_fm, "sparse_apply_fused: table update needs d_concat and/or d_logit_fm");
   MI_REQUIRE(!d_concat || (ld_dconcat >= (int64_t)F * E && (ld_dconcat & 3) == 0 && mi::aligned16(d_concat)),
              "sparse_apply_fused: d_concat leading dimension / alignment");
-  MI_REQUIRE(!d_logit_fm || (sumv && mi::aligned16(sumv)), "sparse_apply_fused: FM gradient needs sumv");
+  MI_REQUIRE(!d_logit_fm || (sumv ? mi::aligned16(sumv) : d_concat != nullptr),
+             "sparse_apply_fused: FM gradient needs sumv, or a d_concat that already carries d_logit_fm * sumv");
   MI_REQUIRE(!lin_w || d_logit_lin, "sparse_apply_fused: lin_w needs d_logit_lin");
   const bool need0 = hp->kind != MI_OPT_SGD;
   const bool need1 = hp->kind == MI_OPT_ADAM || hp->kind == MI_OPT_FTRL || hp->kind == MI_OPT_RMSPROP;

@@ -24,6 +24,7 @@ With a RowShard (N > 1 GPUs) table / lin_w / slots / last_step hold only the row
 r % world == rank, stored at r // world; the dense buffer is replicated.
 """
 import ctypes as C
+import os
 import math
 
 import numpy as np
@@ -754,10 +755,12 @@ class DeepFM:
         c = self._forward(ids, x_num, True)
         logits, loss, dlogit = self._head(c, labels, True)
         # (4) backward through the MLP (+ numeric embeddings)
-        d_concat = self._backward_dense(c, dlogit)
+        d_concat = self._backward_dense(c, dlogit, fold_fm=True)
         # (5) sparse apply on the unique rows; the per-entry row gradients (deep_fm.py:54,81-87,39
-        #     backward) are rebuilt inside the kernel from d_concat / sumv / dlogit
-        self._apply(uniq, seg, sorted_entry, num_uniq, n, None, None, fused=(d_concat, c["sumv"], dlogit))
+        #     backward) are rebuilt inside the kernel from d_concat / sumv / dlogit (sumv = None: the data
+        #     gradient's epilogue already added dlogit * sumv to d_concat)
+        self._apply(uniq, seg, sorted_entry, num_uniq, n, None, None,
+                    fused=(d_concat, None if c.get("fm_folded") else c["sumv"], dlogit))
         return loss, logits
 
     def _entry_grads(self, c, d_concat, dlogit, pos, d_rows=None, d_lin=None):
@@ -783,8 +786,12 @@ class DeepFM:
         _, _, fan, h = self.layers[i]
         return B % 32 == 0 and fan % 128 == 0 and h % 128 == 0 and hasattr(self.k, "mi_dense_bwd_weight_planes")
 
-    def _backward_dense(self, c, dlogit):
-        """Fills self.d_grad (dense gradients) and returns d_concat [B, D] (or None)."""
+    def _backward_dense(self, c, dlogit, fold_fm=False):
+        """Fills self.d_grad (dense gradients) and returns d_concat [B, D] (or None).
+        fold_fm: the layer-1 data gradient may add the FM term's dlogit * sumv to d_concat (once per example
+        instead of once per entry in the fused sparse apply); c["fm_folded"] tells whether it did.  Taken only
+        with MI_FOLD_FM=1: it removes the apply's per-entry sumv reads (0.44 GB of 3.7 GB at config 3) but those
+        come from L2 / Infinity Cache, and the data gradient's epilogue pays as much as the apply saves (DESIGN)."""
         k = self.k
         B = c["B"]
         d_concat = None
@@ -828,10 +835,14 @@ class DeepFM:
                         k.mi_split_rows(x, ldx, B, fan, 0, xa, None)
                     # (the fp32 copy only where something reads it: d_concat, or a weight gradient on fp32 operands)
                     need_f = i == 0 or not (direct and self._wgrad_planes_ok(B, i - 1))
+                    fold = (fold_fm and i == 0 and self.use_mf and self.n_numeric == 0 and fan == self.F * self.E
+                            and c["sumv"] is not None and os.environ.get("MI_FOLD_FM", "0") == "1")
+                    c["fm_folded"] = c.get("fm_folded", False) or fold
                     k.mi_dense_bwd_data_planes(self._planes("dy%dp" % i, B, h), self._pl["w%d" % i].struct, xa,
                                                dx if need_f else None, fan,
                                                dxp if direct else None, B, h, fan, keep if i else 1.0,
-                                               self._av("dy%d" % (i - 1)) if i else None)
+                                               self._av("dy%d" % (i - 1)) if i else None,
+                                               c["sumv"] if fold else None, dlogit if fold else None, self.E if fold else 0)
                     if need_p and not direct:
                         k.mi_split_rows(dx, fan, B, fan, 0, dxp, None)
                 else:

@@ -98,11 +98,14 @@ def _compare_vars(m, p, atol):
 # case is therefore held to the bound such a flip implies from step 1 on; what is not chaotic — one
 # step from identical parameters: logits AND every updated variable — is held tight in every case,
 # and the other cases are held tight over all five steps.
-@pytest.mark.parametrize("gemm", ["f16x2", "fp32"])
+@pytest.mark.parametrize("gemm", ["f16x2", "fp32", "f16x2+fm-fold"])
 @pytest.mark.parametrize("vocab,E,hidden,B,nn", CONFIGS)
-def test_adam_training_matches_oracle(vocab, E, hidden, B, nn, gemm):
+def test_adam_training_matches_oracle(vocab, E, hidden, B, nn, gemm, monkeypatch):
     """5 train steps with fresh batches (rows sit out steps, duplicates inside a batch): the lazy
-    catch-up path must reproduce TF Adam's dense-equivalent sparse update."""
+    catch-up path must reproduce TF Adam's dense-equivalent sparse update.  "+fm-fold": the layer-1 data
+    gradient adds dlogit * sumv to d_concat once per example (MI_FOLD_FM=1) instead of the apply per entry."""
+    monkeypatch.setenv("MI_FOLD_FM", "1" if gemm.endswith("fm-fold") else "0")
+    gemm = gemm.split("+")[0]
     marginal = hidden == [512, 256, 128]
     logit_tol, var_atol = (3e-4, 3e-3) if marginal else (5e-5, 2e-6)
     p, ids, x, y = make_problem(3, vocab, E, hidden, B, n_numeric=nn)

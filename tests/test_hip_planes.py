@@ -210,7 +210,7 @@ def test_dense_bwd_data_planes(lib, M, N, K):
     dyp, wp, xap = split(lib, dY), split(lib, W), split(lib, Xact)
     dX = torch.empty(M, K, device="cuda")
     dxp = PB(lib, M, K) if K <= 512 else None
-    _chk(lib.mi_dense_bwd_data_planes(dyp.ref, wp.ref, xap.ref, dX.data_ptr(), K, dxp.ref if dxp else None, M, N, K, keep, None,
+    _chk(lib.mi_dense_bwd_data_planes(dyp.ref, wp.ref, xap.ref, dX.data_ptr(), K, dxp.ref if dxp else None, M, N, K, keep, None, None, None, 0,
                                       _st()))
     ref = (dY.astype(np.float64) @ W.astype(np.float64).T) * (Xact > 0) / np.float64(np.float32(keep))
     got = dX.cpu().numpy()
@@ -221,8 +221,32 @@ def test_dense_bwd_data_planes(lib, M, N, K):
         assert np.array_equal(dxp.exp.cpu().numpy(), he)
         assert np.array_equal(dxp.bits(), hb)
     # without a mask (the layer-1 data gradient: the concat has no activation)
-    _chk(lib.mi_dense_bwd_data_planes(dyp.ref, wp.ref, None, dX.data_ptr(), K, None, M, N, K, 1.0, None, _st()))
+    _chk(lib.mi_dense_bwd_data_planes(dyp.ref, wp.ref, None, dX.data_ptr(), K, None, M, N, K, 1.0, None, None, None, 0, _st()))
     assert row_rel_err(dX.cpu().numpy(), dY.astype(np.float64) @ W.astype(np.float64).T) < 1e-5
+
+
+def test_dense_bwd_data_planes_folds_the_fm_term(lib):
+    """layer-1 form: d_concat += dlogit[m] * sumv[m][k % E], added once per example in the epilogue"""
+    M, N, F, E = 300, 512, 26, 64
+    K = F * E
+    rng = np.random.default_rng(5)
+    dY = rows_spread(rng, M, N, -8)
+    W = (rng.standard_normal((K, N)) / np.sqrt(N)).astype(np.float32)
+    sumv = rng.standard_normal((M, E)).astype(np.float32)
+    dl = (rng.standard_normal(M) * 1e-3).astype(np.float32)
+    dyp, wp = split(lib, dY), split(lib, W)
+    dX = torch.empty(M, K, device="cuda")
+    sv, g = dev(sumv), dev(dl)
+    _chk(lib.mi_dense_bwd_data_planes(dyp.ref, wp.ref, None, dX.data_ptr(), K, None, M, N, K, 1.0, None, sv.data_ptr(),
+                                      g.data_ptr(), E, _st()))
+    ref = dY.astype(np.float64) @ W.astype(np.float64).T + dl.astype(np.float64)[:, None] * np.tile(sumv.astype(np.float64), (1, F))
+    assert row_rel_err(dX.cpu().numpy(), ref) < 1e-5
+    # refused where the result is not the concat gradient (mask / planes output) or E does not divide K
+    xap = split(lib, np.abs(ref).astype(np.float32))
+    assert lib.mi_dense_bwd_data_planes(dyp.ref, wp.ref, xap.ref, dX.data_ptr(), K, None, M, N, K, 1.0, None, sv.data_ptr(),
+                                        g.data_ptr(), E, _st()) != 0
+    assert lib.mi_dense_bwd_data_planes(dyp.ref, wp.ref, None, dX.data_ptr(), K, None, M, N, K, 1.0, None, sv.data_ptr(),
+                                        g.data_ptr(), 48, _st()) != 0
 
 
 def test_planes_entries_refuse_bad_shapes(lib):
