@@ -921,7 +921,7 @@ size_t mi_dense_bwd_weight_planes_workspace_bytes(int64_t M, int32_t N, int32_t 
     const size_t s2 = (static_cast<size_t>(p.splits) * K * N + static_cast<size_t>(p.splits) * N) * sizeof(float) + 256;
     if (s2 > slabs) slabs = s2;
   }
-  return slabs + static_cast<size_t>(M > 0 ? M : 0) * 8 + 256;   // + the per-example factors
+  return slabs + static_cast<size_t>(M > 0 ? M : 0) * 12 + 256;   // + the per-example factors
 }
 
 int32_t mi_dense_bwd_weight_planes(const mi_planes_t* X, const mi_planes_t* dY, float* dW, float* db, int64_t M,
@@ -947,7 +947,7 @@ int32_t mi_dense_bwd_weight_planes(const mi_planes_t* X, const mi_planes_t* dY, 
   const int splits = dma ? plan.splits : wgrad_splits(M, N, K);
   const int64_t n = static_cast<int64_t>(K) * N;
   char* fac = static_cast<char*>(workspace);                               // per-example factors first (alignment)
-  float* slab = reinterpret_cast<float*>(fac + ((static_cast<size_t>(M) * 8 + 255) & ~size_t(255)));
+  float* slab = reinterpret_cast<float*>(fac + ((static_cast<size_t>(M) * 12 + 255) & ~size_t(255)));
   float* cpart = slab + static_cast<int64_t>(splits) * n;                 // [splits][N] bias-gradient partials
   const bool direct = splits == 1;    // one split: the "slab" IS the result
   float* out = direct ? dW : slab;
@@ -956,18 +956,21 @@ int32_t mi_dense_bwd_weight_planes(const mi_planes_t* X, const mi_planes_t* dY, 
   if (dma) {
     uint16_t* sx16 = reinterpret_cast<uint16_t*>(fac);
     uint16_t* sy16 = sx16 + M;
-    wgrad_scale_k<<<sg, sb, 0, st>>>(X->row_exp, dY->row_exp, amax->a, amax->b, M, nullptr, nullptr, sx16, sy16);
+    uint16_t* sc16 = sy16 + M;
+    int32_t* kflag = reinterpret_cast<int32_t*>(sc16 + M);                 // [M / 16]
+    wgrad_scale_k<<<sg, sb, 0, st>>>(X->row_exp, dY->row_exp, amax->a, amax->b, M, nullptr, nullptr, nullptr, sx16, sy16, sc16, kflag);
     MI_CHECK_LAUNCH("dense_bwd_weight_planes(scales)");
-    if (int32_t rc = mi::wgrad_pl_launch(plan, X, dY, sx16, sy16, amax->a, amax->b, out, cout, M, N, K, st)) return rc;
+    if (int32_t rc = mi::wgrad_pl_launch(plan, X, dY, sx16, sy16, sc16, kflag, amax->a, amax->b, out, cout, M, N, K, st)) return rc;
   } else {
     uint32_t* scw = reinterpret_cast<uint32_t*>(fac);
-    float* yf = reinterpret_cast<float*>(scw + M);
-    wgrad_scale_k<<<sg, sb, 0, st>>>(X->row_exp, dY->row_exp, amax->a, amax->b, M, scw, yf, nullptr, nullptr);
+    uint32_t* scy = scw + M;
+    float* yf = reinterpret_cast<float*>(scy + M);
+    wgrad_scale_k<<<sg, sb, 0, st>>>(X->row_exp, dY->row_exp, amax->a, amax->b, M, scw, scy, yf, nullptr, nullptr, nullptr, nullptr);
     MI_CHECK_LAUNCH("dense_bwd_weight_planes(scales)");
     WgPlArgs wa{};
     wa.A = static_cast<const char*>(X->data); wa.bsa = X->blk_stride;
     wa.B = static_cast<const char*>(dY->data); wa.bsb = dY->blk_stride;
-    wa.scw = scw; wa.yf = yf;
+    wa.scw = scw; wa.scy = scy; wa.yf = yf;
     GemmArgs& a = wa.g;                 // dW[K,N] = X[M,K]^T * dY[M,N] : gemm K x N x (reduce M)
     a.M = K; a.N = N; a.K = (int)M; a.k_per_split = (int)wgrad_k_per_split(M, splits);
     a.C = out; a.ldc = N; a.epi = EPI_SLAB; a.keep_prob = 1.f; a.keep_div = 1.f;

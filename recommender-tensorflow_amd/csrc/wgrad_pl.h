@@ -15,10 +15,10 @@ struct WgradPlPlan {
 // false: shape not covered (N must be 128, 256 or 512, K a multiple of 128, M a multiple of 16)
 bool wgrad_pl_plan(int64_t M, int N, int K, WgradPlPlan* p);
 
-// sx, sy: per-example f16 factors 2^d[m] and 2^(SY - sy[m]) (gemm.hip's wgrad_scale_k); slab [splits][K][N],
-// cpart [splits][N] or NULL
+// sx, sy, sc: per-example f16 factors of the X rows, the dY rows and the bias gradient, kflag [M / 16]: which k-steps
+// need sy (gemm.hip's wgrad_scale_k); slab [splits][K][N], cpart [splits][N] or NULL
 int32_t wgrad_pl_launch(const WgradPlPlan& p, const mi_planes_t* X, const mi_planes_t* dY, const void* sx, const void* sy,
-                        const float* amax_x, const float* amax_dy, float* slab, float* cpart, int64_t M, int N, int K,
+                        const void* sc, const int32_t* kflag, const float* amax_x, const float* amax_dy, float* slab, float* cpart, int64_t M, int N, int K,
                         hipStream_t st);
 
 }  // namespace mi

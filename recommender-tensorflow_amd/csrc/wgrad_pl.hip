@@ -12,12 +12,14 @@
 // (a permutation of the 16-byte pieces on the LDS-DMA source address) so that the two blocks a 32-lane half
 // reads fall on different banks.
 //
-// A plane row carries its own exponent: example m's products carry 2^(sx[m] + sy[m]).  One factor per example,
-// 2^d[m] with d[m] = (SX - sx[m]) + (SY - sy[m]) <= 0 (SX, SY: exponents of the matrices' abs-max), multiplied
-// into the X fragments (v_pk_mul_f16, exact unless the result is subnormal), brings every example to the
-// matrix-wide scales, which the epilogue undoes — the operand values of gemm.hip's matrix-wide f16x2 split, up
-// to the low bits of examples far below the abs-max, invisible in a sum over examples.  The factors of a
-// k-step are wave-uniform: scalar loads.
+// A plane row carries its own exponent: example m's products carry 2^(sx[m] + sy[m]).  One power of two per example,
+// 2^d[m] with d[m] = (SX - sx[m]) + (SY - sy[m]) <= 0 (SX, SY: exponents of the matrices' abs-max), shared out over
+// the two operands as f16 factors (2^max(d, -24) on X, the rest — rarely anything — on dY, zero below 2^-38: gemm.hip's wgrad_scale_k)
+// and multiplied into the fragments (v_pk_mul_f16, exact unless the result is subnormal), brings every example to
+// the matrix-wide scales, which the epilogue undoes — the products of gemm.hip's matrix-wide f16x2 split (examples
+// far below the abs-max go subnormal and lose low bits: invisible in a sum over examples; the MFMA keeps fp16
+// subnormals: test_weight_gradient_keeps_fp16_subnormal_operands).  The factors of a k-step are wave-uniform:
+// scalar loads.
 //
 // MFMA A operand = dY^T (rows = output columns n: a workgroup holds ALL N = 128 TN of them), B operand = X^T
 // (rows = input features, 64 TM per workgroup); split-K over the examples into slabs that gemm.hip's
@@ -80,7 +82,9 @@ __device__ __forceinline__ void wg_static_for(F&& f) {
 
 template <int TN, int TM>
 __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_pl_k(const WgArgs a, const uint4* __restrict__ sx_all,
-                                                            const uint4* __restrict__ sy_all) {
+                                                            const uint4* __restrict__ sy_all,
+                                                            const uint4* __restrict__ sc_all,
+                                                            const int32_t* __restrict__ kflag_all) {
   constexpr int NBUF = TN == 1 ? 3 : 4;
   constexpr int NBLK = 8 * TN + 4 * TM;                  // 1-KiB blocks (16 features x 16 examples) per stage
   constexpr int STAGE = NBLK * 1024;
@@ -167,38 +171,48 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_pl_k(const WgArgs a, cons
   // count in vmcnt and drain the LDS-DMA pipeline every k-step)
   const uint4* __restrict__ sxp = sx_all + (k0 >> 3);
   const uint4* __restrict__ syp = sy_all + (k0 >> 3);
+  const uint4* __restrict__ scp = sc_all + (k0 >> 3);
+  const int32_t* __restrict__ kfp = kflag_all + (k0 >> 4);
   const bool do_cs = a.cpart != nullptr && tile_k == 0 && wm == 0;       // (wave-uniform)
   float cs[TN];
 #pragma unroll
   for (int x = 0; x < TN; ++x) cs[x] = 0.f;
   // (fetched ONE k-step ahead into the other of two register sets — the loop below is unrolled by two so that the
   // sets alternate without copies: a scalar load issued in the k-step that needs it exposes an L2 round trip)
-  struct Factors { uint4 xa, xb, ya, yb; };
+  struct Factors { uint4 xa, xb, ca, cb; int flag; };
   Factors f0, f1;
-  f0.ya = f0.yb = f1.ya = f1.yb = make_uint4(0u, 0u, 0u, 0u);
+  f0.ca = f0.cb = f1.ca = f1.cb = make_uint4(0u, 0u, 0u, 0u);
   auto fetch_factors = [&](int kt, Factors& f) {
     const int u = __builtin_amdgcn_readfirstlane(kt);
     f.xa = sxp[2 * u]; f.xb = sxp[2 * u + 1];
-    if (do_cs) { f.ya = syp[2 * u]; f.yb = syp[2 * u + 1]; }
+    f.flag = kfp[u];
+    if (do_cs) { f.ca = scp[2 * u]; f.cb = scp[2 * u + 1]; }
   };
   auto mul8 = [](f16x8 v, uint4 s) { return v * __builtin_bit_cast(f16x8, s); };
-  auto scale_and_sum = [&](const Factors& f) {
-    const uint4 sv = h ? f.xb : f.xa;
-#pragma unroll
-    for (int y = 0; y < TM; ++y) { bh[y] = mul8(bh[y], sv); bl[y] = mul8(bl[y], sv); }
-    if (do_cs) {
-      const uint4 yv = h ? f.yb : f.ya;
-      const uint32_t yw[4] = {yv.x, yv.y, yv.z, yv.w};
+  auto scale_and_sum = [&](int kt, const Factors& f) {
+    if (do_cs) {                      // (from the fragments as stored: the bias gradient has its own factor)
+      const uint4 cv = h ? f.cb : f.ca;
+      const uint32_t cw[4] = {cv.x, cv.y, cv.z, cv.w};
 #pragma unroll
       for (int x = 0; x < TN; ++x) {
         const uint4 hv = __builtin_bit_cast(uint4, ah[x]), lv = __builtin_bit_cast(uint4, al[x]);
         const uint32_t hw[4] = {hv.x, hv.y, hv.z, hv.w}, lw[4] = {lv.x, lv.y, lv.z, lv.w};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          cs[x] = __builtin_amdgcn_fdot2(__builtin_bit_cast(h16x2, hw[r]), __builtin_bit_cast(h16x2, yw[r]), cs[x], false);
-          cs[x] = __builtin_amdgcn_fdot2(__builtin_bit_cast(h16x2, lw[r]), __builtin_bit_cast(h16x2, yw[r]), cs[x], false);
+          cs[x] = __builtin_amdgcn_fdot2(__builtin_bit_cast(h16x2, hw[r]), __builtin_bit_cast(h16x2, cw[r]), cs[x], false);
+          cs[x] = __builtin_amdgcn_fdot2(__builtin_bit_cast(h16x2, lw[r]), __builtin_bit_cast(h16x2, cw[r]), cs[x], false);
         }
       }
+    }
+    const uint4 sv = h ? f.xb : f.xa;
+#pragma unroll
+    for (int y = 0; y < TM; ++y) { bh[y] = mul8(bh[y], sv); bl[y] = mul8(bl[y], sv); }
+    if (f.flag) {                     // rare: an example more than 2^-24 below the abs-max — the rest of its factor
+      const int u = __builtin_amdgcn_readfirstlane(kt);
+      const uint4 ya = syp[2 * u], yb = syp[2 * u + 1];
+      const uint4 yv = h ? yb : ya;
+#pragma unroll
+      for (int x = 0; x < TN; ++x) { ah[x] = mul8(ah[x], yv); al[x] = mul8(al[x], yv); }
     }
   };
   // L(t): share of stage t - 1 + NBUF into the buffer tile t - 1 has left, then the fragments of tile t
@@ -224,7 +238,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_pl_k(const WgArgs a, cons
     phase_l(t);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);                     // nothing that reads a fragment moves above the wait
-    scale_and_sum(cur);
+    scale_and_sum(t, cur);
     fetch_factors(min(t + 1, nk - 1), nxt);
     wg_wait_vmcnt<LPS*(NBUF - 2)>();
     __builtin_amdgcn_sched_barrier(0);
@@ -295,23 +309,24 @@ bool wgrad_pl_plan(int64_t M, int N, int K, WgradPlPlan* p) {
 }
 
 int32_t wgrad_pl_launch(const WgradPlPlan& p, const mi_planes_t* X, const mi_planes_t* dY, const void* sx, const void* sy,
-                        const float* amax_x, const float* amax_dy, float* slab, float* cpart, int64_t M, int N, int K,
+                        const void* sc, const int32_t* kflag, const float* amax_x, const float* amax_dy, float* slab, float* cpart, int64_t M, int N, int K,
                         hipStream_t st) {
   WgArgs a{};
   a.A = static_cast<const char*>(dY->data); a.bsa = dY->blk_stride;
   a.B = static_cast<const char*>(X->data); a.bsb = X->blk_stride;
   const uint4* sx4 = static_cast<const uint4*>(sx);
   const uint4* sy4 = static_cast<const uint4*>(sy);
+  const uint4* sc4 = static_cast<const uint4*>(sc);
   a.amax_a = amax_x; a.amax_b = amax_dy;
   a.M = static_cast<int>(M); a.N = N; a.K = K;
   a.k_per_split = p.k_per_split; a.tiles_k = p.tiles_k;
   a.slab = slab; a.cpart = cpart;
   const dim3 g(static_cast<unsigned>(p.tiles_k * p.splits)), b(WG_THREADS);
-  if (p.tn == 4 && p.tm == 2) wgrad_pl_k<4, 2><<<g, b, 0, st>>>(a, sx4, sy4);
-  else if (p.tn == 2 && p.tm == 4) wgrad_pl_k<2, 4><<<g, b, 0, st>>>(a, sx4, sy4);
-  else if (p.tn == 2 && p.tm == 2) wgrad_pl_k<2, 2><<<g, b, 0, st>>>(a, sx4, sy4);
-  else if (p.tn == 1 && p.tm == 4) wgrad_pl_k<1, 4><<<g, b, 0, st>>>(a, sx4, sy4);
-  else if (p.tn == 1 && p.tm == 2) wgrad_pl_k<1, 2><<<g, b, 0, st>>>(a, sx4, sy4);
+  if (p.tn == 4 && p.tm == 2) wgrad_pl_k<4, 2><<<g, b, 0, st>>>(a, sx4, sy4, sc4, kflag);
+  else if (p.tn == 2 && p.tm == 4) wgrad_pl_k<2, 4><<<g, b, 0, st>>>(a, sx4, sy4, sc4, kflag);
+  else if (p.tn == 2 && p.tm == 2) wgrad_pl_k<2, 2><<<g, b, 0, st>>>(a, sx4, sy4, sc4, kflag);
+  else if (p.tn == 1 && p.tm == 4) wgrad_pl_k<1, 4><<<g, b, 0, st>>>(a, sx4, sy4, sc4, kflag);
+  else if (p.tn == 1 && p.tm == 2) wgrad_pl_k<1, 2><<<g, b, 0, st>>>(a, sx4, sy4, sc4, kflag);
   else {
     set_error("wgrad_pl_launch: no kernel for tile %d x %d", p.tn, p.tm);
     return MI_ERR_INVALID;

@@ -366,3 +366,30 @@ def test_dense_bwd_weight_planes_refuses_ragged_shapes(lib):
     for M, N, K in ((48, 128, 128), (64, 96, 128), (64, 128, 64)):
         assert lib.mi_dense_bwd_weight_planes(xp.ref, dyp.ref, dW.data_ptr(), None, M, N, K, ws.data_ptr(), ws.numel(),
                                               C.byref(ga), _st()) != 0
+
+
+@pytest.mark.parametrize("kernel", ["lds-dma", "register-staged"])
+def test_weight_gradient_keeps_fp16_subnormal_operands(lib, kernel, monkeypatch):
+    """An example 2^-30 below the matrices' abs-max reaches the matrix pipe as fp16 SUBNORMAL values (the per-example
+    factor 2^d brings its rows to matrix-wide scales).  The MFMA must not flush them: with one such example
+    carrying all of the signal, dW is its outer product (exact here: powers of two)."""
+    from mi355x_rec import _lib as L
+    monkeypatch.setenv("MI_WGRAD_PL", "1" if kernel == "lds-dma" else "0")
+    M, N, K = 32, 128, 128
+    X = np.zeros((M, K), np.float32); dY = np.zeros((M, N), np.float32)
+    X[0, :] = 1.0                       # example 0: full-size activations, a gradient 2^-30 below the batch maximum
+    dY[0, :] = 2.0 ** -30
+    X[1, 0] = 1.0                       # example 1 sets the abs-max of dY and contributes to dW[0, :] only
+    dY[1, :] = 1.0
+    xp, dyp = split(lib, X), split(lib, dY)
+    ax = torch.zeros(L.AMAX_SLOTS, device="cuda"); ady = torch.zeros(L.AMAX_SLOTS, device="cuda")
+    _chk(lib.mi_absmax(dev(X).data_ptr(), X.size, ax.data_ptr(), _st()))
+    _chk(lib.mi_absmax(dev(dY).data_ptr(), dY.size, ady.data_ptr(), _st()))
+    ga = L.GemmAmax(ax.data_ptr(), ady.data_ptr(), None)
+    ws = torch.empty(lib.mi_dense_bwd_weight_planes_workspace_bytes(M, N, K) + 256, dtype=torch.uint8, device="cuda")
+    dW = torch.empty(K, N, device="cuda")
+    _chk(lib.mi_dense_bwd_weight_planes(xp.ref, dyp.ref, dW.data_ptr(), None, M, N, K, ws.data_ptr(), ws.numel(), C.byref(ga), _st()))
+    ref = X.astype(np.float64).T @ dY.astype(np.float64)
+    got = dW.cpu().numpy()
+    assert np.array_equal(got[1:], ref[1:].astype(np.float32)), (got[1, :4], ref[1, :4])     # rows fed by the tiny example alone
+    assert np.allclose(got[0], ref[0], rtol=1e-6)
