@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
-"""Would the Adam catch-up hide under the backward GEMMs?    Runs config-3 train
-steps with an EXTRA catch-up of the same size on shadow copies of the table and slots — (a) not at all,
-(b) serialised on the main stream before the backward, (c) on a side stream beside the backward — and
-compares step times.  (b) - (a) is the catch-up's cost; (c) - (a) is what is left of it when overlapped."""
+"""Would the Adam catch-up hide under the backward GEMMs — or under the sparse apply?    Runs
+config-3 train steps with an EXTRA catch-up of the same size on shadow copies of the table and slots — (a) not at
+all, (b) serialised on the main stream before the phase, (c) on a side stream beside it — and compares step
+times.  (b) - (a) is the catch-up's cost; (c) - (a) is what is left of it when overlapped.
+PROBE=backward (default): beside the backward GEMMs; PROBE=apply: beside mi_sparse_apply_fused."""
 import os, sys, time
+PHASE = os.environ.get("PROBE", "backward")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "recommender-tensorflow_amd"))
 import torch
@@ -17,8 +19,8 @@ t2, m2, v2 = m.table.clone(), torch.rand_like(m.table) * 1e-6, torch.rand_like(m
 last2 = torch.ones(m.R, dtype=torch.int32, device="cuda")
 side = torch.cuda.Stream()
 mode = {"v": "none"}
-orig = m._backward_dense
-def patched(c, dlogit):
+orig = m._backward_dense if PHASE == "backward" else m._apply
+def patched(*a, **kw):
     if mode["v"] != "none" and m.step > 20:
         uniq, nu = m._ws["uniq_by_gap"] if "uniq_by_gap" in m._ws else m._ws["own_uniq"], m._ws["own_nu"]
         n = B * F
@@ -32,11 +34,14 @@ def patched(c, dlogit):
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 launch()
-    out = orig(c, dlogit)
+    out = orig(*a, **kw)
     if mode["v"] == "side" and m.step > 20:
         torch.cuda.current_stream().wait_stream(side)
     return out
-m._backward_dense = patched
+if PHASE == "backward":
+    m._backward_dense = patched
+else:
+    m._apply = patched
 for i in range(30):
     m.train_step(*batches[i % 64])
 res = {}
@@ -50,4 +55,4 @@ for md in ("none", "serial", "side", "none", "serial", "side"):
 for md, v in res.items():
     print("%-7s %s ms/step" % (md, " ".join("%.3f" % x for x in v)))
 a, b, c = (min(res[k]) for k in ("none", "serial", "side"))
-print("extra catch-up: %.3f ms serialised, %.3f ms beside the backward GEMMs (%.0f %% hidden)" % (b - a, c - a, 100 * (1 - (c - a) / (b - a))))
+print("extra catch-up: %.3f ms serialised, %.3f ms beside the %s (%.0f %% hidden)" % (b - a, c - a, "backward GEMMs" if PHASE == "backward" else "sparse apply", 100 * (1 - (c - a) / (b - a))))
