@@ -41,7 +41,7 @@ if "c5-rank" in which:
 if "c4" in which:
     for E in (64, 4):
         vocab = [1_000_000] * 26
-        m = DeepFM(vocab, n_numeric=13, embedding_size=E, hidden_units=[512, 256, 128] if E == 64 else [16, 16], use_mf=False,
+        m = DeepFM(vocab, n_numeric=13, numeric="raw", embedding_size=E, hidden_units=[512, 256, 128] if E == 64 else [16, 16], use_mf=False,
                    dropout=0.1, optimizer=OptimizerSpec("Adagrad", 0.05), linear_optimizer=OptimizerSpec("Ftrl", 0.1961), reduction="sum")
         run("c4 E=%d" % E, m, 65536, 13, vocab)
         del m; torch.cuda.empty_cache()
