@@ -19,9 +19,10 @@ Workload (config.workload): trainers.deep_fm with --embedding-size 64 --hidden-u
 per GPU (weak scaling; --scaling strong divides 65536 over the GPUs instead), embedding rows
 sharded row % N with all-to-all over RCCL.
 
-Prints ONE JSON line on rank 0 with `roofline` (embedding gather kernel, HBM bound, timed live
-with HIP events on the launch stream) and `cpu_baseline` (the numpy oracle restating the
-reference's TF graph, timed on this host on a bounded sample).
+Prints ONE JSON line on rank 0 with `roofline` (embedding gather kernel, HBM bound: algorithmic bytes read
+and written per launch / launch time, timed live with HIP events on the launch stream) and `cpu_baseline`
+(oracle/cpu_torch.py: the reference's TF graph restated on multi-threaded PyTorch-CPU at the full vocabulary,
+timed on this host's cores for a few steps).
 """
 import argparse
 import json

@@ -40,7 +40,7 @@ enum mi_status {
 };
 
 /* ---- library ---------------------------------------------------------------------------- */
-int32_t mi_abi_version(void);       /* bumps when a signature changes (currently 11) */
+int32_t mi_abi_version(void);       /* bumps when a signature changes (currently 12) */
 const char* mi_last_error(void);    /* thread-local, never NULL */
 const char* mi_build_info(void);    /* "gfx950 hipcc <ver>" */
 
@@ -450,6 +450,14 @@ int32_t mi_dense_bwd_data_planes(const mi_planes_t* dY, const mi_planes_t* W, co
                                  int64_t lddx, const mi_planes_t* dXp, int64_t M, int32_t N, int32_t K, float keep_prob,
                                  float* amax_out, const float* fold_sumv, const float* fold_dlogit, int32_t fold_E,
                                  mi_stream_t stream);
+
+/* The data gradient of the N = 1 logits layer (deep_fm.py:108 backward) with the result as planes:
+ * dX[m][k] = dY[m] * W[k], kept where Xact[m][k] > 0 and divided by keep_prob (Xact == NULL: no mask) — the
+ * arithmetic of mi_dense_bwd_data's N = 1 form with ReLU, bit for bit — into dXp (required) and, if not NULL, dX.
+ * amax_out as everywhere.  K a multiple of 16. */
+int32_t mi_dense_bwd_data_vec_planes(const float* dY, int64_t lddy, const float* W, const float* Xact, int64_t ldxa,
+                                     float keep_prob, float* dX, int64_t lddx, const mi_planes_t* dXp, int64_t M, int32_t K,
+                                     float* amax_out, mi_stream_t stream);
 
 /* dW[K][N] = X[M][K]^T * dY[M][N] and db[N] = column sums of dY (NULL: skipped), both operands as planes
  * (replaces the same gradients as mi_dense_bwd_weight: model_utils.py:69-72 through tf.layers.dense,

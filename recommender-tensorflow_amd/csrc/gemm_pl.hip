@@ -522,6 +522,102 @@ __global__ __launch_bounds__(256) void split_rows_blk_k(const float* __restrict_
   }
 }
 
+// ---- data gradient of the N = 1 logits layer (deep_fm.py:108 backward) written straight as planes ----------------
+// dX[m][k] = dY[m] * W[k], masked by the stored activation (ReLU: kept where Xact > 0, divided by keep_prob) — the
+// arithmetic of gemm.hip's gemv_dgrad_k, hence the same bits — then the split of split_rows_blk_k on the values
+// still in registers: the fp32 matrix is neither written nor read back (it has no other reader once the weight
+// gradient takes planes).
+template <int LPR>
+__global__ __launch_bounds__(256) void vec_dgrad_planes_k(const float* __restrict__ dY, int64_t lddy, const float* __restrict__ W,
+                                                          const float* __restrict__ Xact, int64_t ldxa, float keep_div,
+                                                          int64_t rows, int K, int rows_per_block, float* __restrict__ dX,
+                                                          int64_t lddx, char* __restrict__ out, int64_t ldo_b,
+                                                          int32_t* __restrict__ row_exp, float* __restrict__ amax_out) {
+  // LPR lanes share a row; a lane owns the float4 groups l, l + LPR, ... (adjacent lanes read adjacent 16 bytes).
+  // The plane pieces of the block's rows go through LDS as [16-k block][row][64 B] and leave as ONE contiguous run
+  // per 16-k block (consecutive lanes, 16 bytes each): written piece by piece from the lanes that computed them,
+  // a store instruction would scatter 32-byte fragments over K / 16 regions 64 M bytes apart (measured 3x slower).
+  extern __shared__ __attribute__((aligned(16))) char stage[];           // [K / 16][rows_per_block][64]
+  const int t = threadIdx.x, l = t & (LPR - 1);
+  const int nq = K >> 2, nkb = K >> 4;
+  const int64_t r0 = static_cast<int64_t>(blockIdx.x) * rows_per_block;
+  const int nrows = static_cast<int>(min(static_cast<int64_t>(rows_per_block), rows - r0));
+  float bmx = 0.f;
+  for (int rl = t / LPR; rl < rows_per_block; rl += 256 / LPR) {            // (uniform trip count: shuffles below)
+    const bool on = rl < nrows;
+    const int64_t r = r0 + (on ? rl : 0);
+    const float g = dY[r * lddy];
+    auto value4 = [&](int k) {
+      const float4 w = *reinterpret_cast<const float4*>(W + k);
+      float4 v = make_float4(g * w.x, g * w.y, g * w.z, g * w.w);
+      if (Xact) {
+        const float4 x = *reinterpret_cast<const float4*>(Xact + r * ldxa + k);
+        v.x = x.x > 0.f ? v.x / keep_div : 0.f; v.y = x.y > 0.f ? v.y / keep_div : 0.f;
+        v.z = x.z > 0.f ? v.z / keep_div : 0.f; v.w = x.w > 0.f ? v.w / keep_div : 0.f;
+      }
+      return v;
+    };
+    float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float mx = 0.f;
+    if (on)
+      for (int q = l; q < nq; q += LPR) {
+        const float4 v = value4(4 * q);
+        if (q == l) v0 = v;
+        if (dX) *reinterpret_cast<float4*>(dX + r * lddx + 4 * q) = v;
+        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+      }
+#pragma unroll
+    for (int o = LPR >> 1; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    bmx = fmaxf(bmx, mx);
+    if (on) {
+      const int s = pl_exp_for(mx);
+      const float sc = pl_pow2(s);
+      if (l == 0) row_exp[r] = s;
+      for (int q = l; q < nq; q += LPR) {
+        const float4 v = q == l ? v0 : value4(4 * q);
+        const float u[4] = {v.x * sc, v.y * sc, v.z * sc, v.w * sc};
+        uint32_t ph[2], pq[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const fl32x2 uu = {u[2 * e], u[2 * e + 1]};
+          h16x2 hh = __builtin_convertvector(uu, h16x2);
+          uint32_t hb = __builtin_bit_cast(uint32_t, hh);
+          if (uu[0] > 0.f && (hb & 0xffffu) == 0u) hb |= 1u;          // positive stays positive (mask reads hi > 0)
+          if (uu[1] > 0.f && (hb >> 16) == 0u) hb |= 0x10000u;
+          hh = __builtin_bit_cast(h16x2, hb);
+          const fl32x2 rr2 = {uu[0] - static_cast<float>(hh[0]), uu[1] - static_cast<float>(hh[1])};
+          ph[e] = hb;
+          pq[e] = __builtin_bit_cast(uint32_t, __builtin_convertvector(rr2, h16x2));
+        }
+        char* d = stage + ((q >> 2) * rows_per_block + rl) * PL_ROWB + (q & 3) * 8;
+        *reinterpret_cast<uint2*>(d) = make_uint2(ph[0], ph[1]);
+        *reinterpret_cast<uint2*>(d + 32) = make_uint2(pq[0], pq[1]);
+      }
+    }
+  }
+  __syncthreads();
+  const int run16 = nrows * 4;                           // 16-byte pieces of one block's run
+  for (int kb = 0; kb < nkb; ++kb) {
+    const uint4* src = reinterpret_cast<const uint4*>(stage + kb * rows_per_block * PL_ROWB);
+    uint4* dst = reinterpret_cast<uint4*>(out + kb * ldo_b + r0 * PL_ROWB);
+    for (int p = t; p < run16; p += 256) dst[p] = src[p];
+  }
+  if (amax_out) {                       // (every thread of the block reaches this)
+    __shared__ float part[4];
+    float mx = bmx;
+#pragma unroll
+    for (int o = 32; o >= LPR; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((t & 63) == 0) part[t >> 6] = mx;
+    __syncthreads();
+    if (t == 0) {
+      const float m4 = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
+      unsigned int* slot = reinterpret_cast<unsigned int*>(amax_out) + (blockIdx.x & (MI_AMAX_SLOTS - 1));
+      const unsigned int bits = __float_as_uint(m4);
+      if (bits > *reinterpret_cast<volatile unsigned int*>(slot)) atomicMax(slot, bits);
+    }
+  }
+}
+
 // ---- the transposed split (weights of the forward pass: X is [K][rows], output row r = column r of X) in
 // one launch: a block owns 32 output rows; pass 1 their abs-max over all k (coalesced 128-B row pieces),
 // pass 2 64-k tiles transposed through LDS and written as planes (the tiles come back from L2).
@@ -831,6 +927,42 @@ int32_t mi_dense_bwd_data_planes(const mi_planes_t* dY, const mi_planes_t* W, co
     a.fold_s = fold_sumv; a.fold_g = fold_dlogit; a.fold_E = fold_E;
   }
   return launch_pl<PL_DGRAD>(a, mi::as_stream(stream), "dense_bwd_data_planes");
+}
+
+
+int32_t mi_dense_bwd_data_vec_planes(const float* dY, int64_t lddy, const float* W, const float* Xact, int64_t ldxa,
+                                     float keep_prob, float* dX, int64_t lddx, const mi_planes_t* dXp, int64_t M, int32_t K,
+                                     float* amax_out, mi_stream_t stream) {
+  MI_REQUIRE(M >= 0 && K > 0 && (K & 15) == 0, "dense_bwd_data_vec_planes: M=%lld K=%d (K a multiple of 16)", (long long)M, K);
+  if (M == 0) return MI_OK;
+  MI_REQUIRE(dY && W && lddy >= 1 && mi::aligned16(W), "dense_bwd_data_vec_planes: dY / W");
+  MI_REQUIRE(!Xact || (mi::aligned16(Xact) && ldxa >= K && (ldxa & 3) == 0), "dense_bwd_data_vec_planes: Xact leading dimension / alignment");
+  MI_REQUIRE(!dX || (mi::aligned16(dX) && lddx >= K && (lddx & 3) == 0), "dense_bwd_data_vec_planes: dX leading dimension / alignment");
+  MI_REQUIRE(planes_ok(dXp, M, K), "dense_bwd_data_vec_planes: output planes");
+  MI_REQUIRE(keep_prob > 0.f && keep_prob <= 1.f, "dense_bwd_data_vec_planes: keep_prob=%f", keep_prob);
+  int lpr = 4;                                   // lanes per row: one per float4, 4 .. 64
+  while (lpr < 64 && lpr < (K >> 2)) lpr <<= 1;
+  // rows per block: a 32 KB LDS image of their planes, at least one pass of the block's lanes, at most 256
+  int rpb = 8192 / K;
+  if (rpb < 256 / lpr) rpb = 256 / lpr;
+  if (rpb > 256) rpb = 256;
+  rpb -= rpb % (256 / lpr);
+  const size_t lds = static_cast<size_t>(K >> 4) * rpb * PL_ROWB;
+  MI_REQUIRE(lds <= 64 * 1024, "dense_bwd_data_vec_planes: K=%d too wide", K);
+  const int64_t nb = mi::ceil_div(M, rpb);
+  MI_REQUIRE(nb <= INT32_MAX, "dense_bwd_data_vec_planes: grid too large");
+#define MI_VEC_DGRAD(L) vec_dgrad_planes_k<L><<<dim3((unsigned)nb), dim3(256), lds, mi::as_stream(stream)>>>( \
+      dY, lddy, W, Xact, ldxa, Xact ? keep_prob : 1.f, M, K, rpb, dX, lddx, static_cast<char*>(dXp->data), dXp->blk_stride, dXp->row_exp, amax_out)
+  switch (lpr) {
+    case 4: MI_VEC_DGRAD(4); break;
+    case 8: MI_VEC_DGRAD(8); break;
+    case 16: MI_VEC_DGRAD(16); break;
+    case 32: MI_VEC_DGRAD(32); break;
+    default: MI_VEC_DGRAD(64); break;
+  }
+#undef MI_VEC_DGRAD
+  MI_CHECK_LAUNCH("dense_bwd_data_vec_planes");
+  return MI_OK;
 }
 
 }  // extern "C"

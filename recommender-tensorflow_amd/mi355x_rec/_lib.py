@@ -16,7 +16,7 @@ import torch  # noqa: F401  (loads the HIP runtime this library must share)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmi355x_rec.so")
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 
 class MiError(RuntimeError):
@@ -101,6 +101,7 @@ SIGNATURES = {
     "mi_dense_fwd": (_i32, [_p, _i64, _p, _p, _p, _i64, _i64, _i32, _i32, _i32, _f32, _u64, _amax, _p]),
     "mi_dense_bwd_data": (_i32, [_p, _i64, _p, _p, _i64, _p, _i64, _i64, _i32, _i32, _f32, _i32, _amax, _p]),
     "mi_dense_bwd_weight_workspace_bytes": (_sz, [_i64, _i32, _i32]),
+    "mi_dense_bwd_data_vec_planes": (_i32, [_p, _i64, _p, _p, _i64, _f32, _p, _i64, _pl, _i64, _i32, _p, _p]),
     "mi_dense_bwd_weight_planes_workspace_bytes": (_sz, [_i64, _i32, _i32]),
     "mi_dense_bwd_weight_planes": (_i32, [_p, _p, _p, _p, _i64, _i32, _i32, _p, _sz, _p, _p]),
     "mi_dense_bwd_weight": (_i32, [_p, _i64, _p, _i64, _p, _p, _i64, _i32, _i32, _p, _sz, _amax, _p]),

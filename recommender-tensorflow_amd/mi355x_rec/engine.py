@@ -845,6 +845,12 @@ class DeepFM:
                                                c["sumv"] if fold else None, dlogit if fold else None, self.E if fold else 0)
                     if need_p and not direct:
                         k.mi_split_rows(dx, fan, B, fan, 0, dxp, None)
+                elif self.planes and i == nh and i > 0 and h == 1 and fan % 16 == 0:
+                    # the logits layer's matrix-vector data gradient, written straight as the planes the layer below
+                    # reads (and in fp32 only if that layer's weight gradient still runs on fp32 operands)
+                    k.mi_dense_bwd_data_vec_planes(dy, lddy, self.kernel(i), x, ldx, keep,
+                                                   None if self._wgrad_planes_ok(B, i - 1) else dx, fan,
+                                                   self._planes("dy%dp" % (i - 1), B, fan), B, fan, self._av("dy%d" % (i - 1)))
                 else:
                     k.mi_dense_bwd_data(dy, lddy, self.kernel(i), x if i else None, ldx, dx, fan, B, h, fan,
                                         keep if i else 1.0, self.act, None if self.planes else ga_d)

@@ -393,3 +393,33 @@ def test_weight_gradient_keeps_fp16_subnormal_operands(lib, kernel, monkeypatch)
     got = dW.cpu().numpy()
     assert np.array_equal(got[1:], ref[1:].astype(np.float32)), (got[1, :4], ref[1, :4])     # rows fed by the tiny example alone
     assert np.allclose(got[0], ref[0], rtol=1e-6)
+
+
+@pytest.mark.parametrize("M,K,mask", [(300, 128, True), (65, 16, False), (1000, 512, True), (33, 1040, True)])
+def test_logits_layer_data_gradient_as_planes_matches_gemv_then_split_bitwise(lib, M, K, mask):
+    """mi_dense_bwd_data_vec_planes == mi_dense_bwd_data (N = 1, ReLU) followed by mi_split_rows: same fp32 bits, same planes"""
+    rng = np.random.default_rng(M + K)
+    dY = (rng.standard_normal(M) * np.exp2(rng.integers(-20, 1, M))).astype(np.float32)
+    W = rng.standard_normal(K).astype(np.float32)
+    Xact = np.maximum(rng.standard_normal((M, K)), 0).astype(np.float32)
+    dy, w, xa = dev(dY), dev(W), dev(Xact)
+    keep = 0.9
+    ref = torch.empty(M, K, device="cuda")
+    _chk(lib.mi_dense_bwd_data(dy.data_ptr(), 1, w.data_ptr(), xa.data_ptr() if mask else None, K, ref.data_ptr(), K, M, 1, K, keep, 1,
+                               None, _st()))
+    refp = PB(lib, M, K)
+    _chk(lib.mi_split_rows(ref.data_ptr(), K, M, K, 0, refp.ref, None, _st()))
+    got = torch.full((M, K), float("nan"), device="cuda")
+    gotp = PB(lib, M, K)
+    from mi355x_rec import _lib as L
+    am = torch.zeros(L.AMAX_SLOTS, device="cuda")
+    _chk(lib.mi_dense_bwd_data_vec_planes(dy.data_ptr(), 1, w.data_ptr(), xa.data_ptr() if mask else None, K, keep, got.data_ptr(), K,
+                                          gotp.ref, M, K, am.data_ptr(), _st()))
+    assert np.array_equal(got.cpu().numpy().view(np.uint32), ref.cpu().numpy().view(np.uint32))
+    assert np.array_equal(gotp.bits(), refp.bits()) and np.array_equal(gotp.exp.cpu().numpy(), refp.exp.cpu().numpy())
+    assert float(am.max()) == float(ref.abs().max())
+    # planes only
+    gotp2 = PB(lib, M, K)
+    _chk(lib.mi_dense_bwd_data_vec_planes(dy.data_ptr(), 1, w.data_ptr(), xa.data_ptr() if mask else None, K, keep, None, 0,
+                                          gotp2.ref, M, K, None, _st()))
+    assert np.array_equal(gotp2.bits(), refp.bits())
