@@ -40,7 +40,7 @@ enum mi_status {
 };
 
 /* ---- library ---------------------------------------------------------------------------- */
-int32_t mi_abi_version(void);       /* bumps when a signature changes (currently 12) */
+int32_t mi_abi_version(void);       /* bumps when a signature changes (currently 13) */
 const char* mi_last_error(void);    /* thread-local, never NULL */
 const char* mi_build_info(void);    /* "gfx950 hipcc <ver>" */
 
@@ -199,6 +199,17 @@ int32_t mi_sort_unique_rows(const int32_t* rows, int64_t n, int64_t num_rows_tot
                             int32_t* sorted_entry, int32_t* uniq_rows, int32_t* seg_start,
                             int32_t* num_uniq, void* workspace, size_t workspace_bytes,
                             mi_stream_t stream);
+
+/* mi_global_rows + mi_sort_unique_rows in one entry for the single-GPU step: ids [B][F] (local ids, field f's rows are
+ * field_off[f] + id: disjoint ranges in ascending field order), max_vocab >= every field's id range.  Same outputs,
+ * bit for bit (equal rows keep ascending example order): sorted_entry [B*F] (entry = b * F + f), uniq_rows (global
+ * rows), seg_start, num_uniq.  Every field's ids are sorted on their own, so the radix passes cover the bits of
+ * max_vocab, not of the whole table.  B a multiple of 4096, F <= 64 (anything else: the two-entry form).
+ * workspace: mi_sort_unique_fields_workspace_bytes(B, F), 256-byte aligned. */
+size_t mi_sort_unique_fields_workspace_bytes(int64_t B, int32_t F);
+int32_t mi_sort_unique_fields(const int32_t* ids, const int64_t* field_off, int64_t B, int32_t F, int64_t max_vocab,
+                              int32_t* sorted_entry, int32_t* uniq_rows, int32_t* seg_start, int32_t* num_uniq,
+                              void* workspace, size_t workspace_bytes, mi_stream_t stream);
 
 /* Routing helpers of the row-sharded multi-GPU path (row r lives on rank r % world as local row
  * r / world; the reference's own multi-worker mode is TF's parameter-server placement of whole

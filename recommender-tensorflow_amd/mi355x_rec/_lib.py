@@ -16,7 +16,7 @@ import torch  # noqa: F401  (loads the HIP runtime this library must share)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmi355x_rec.so")
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 
 class MiError(RuntimeError):
@@ -77,6 +77,8 @@ SIGNATURES = {
     "mi_numeric_embed_bwd": (_i32, [_p, _p, _i64, _p, _i64, _i64, _p, _p, _p, _i64, _i32, _i32, _p,
                                     _p, _p, _sz, _p]),
     "mi_sort_unique_workspace_bytes": (_sz, [_i64]),
+    "mi_sort_unique_fields_workspace_bytes": (_sz, [_i64, _i32]),
+    "mi_sort_unique_fields": (_i32, [_p, _p, _i64, _i32, _i64, _p, _p, _p, _p, _p, _sz, _p]),
     "mi_sort_unique_rows": (_i32, [_p, _i64, _i64, _p, _p, _p, _p, _p, _sz, _p]),
     "mi_global_rows": (_i32, [_p, _p, _i64, _i32, _p, _p]),
     "mi_shard_keys": (_i32, [_p, _i64, _i32, _i64, _i64, _p, _p]),

@@ -210,6 +210,7 @@ class DeepFM:
         self.device = torch.device(device)
         self.vocab_sizes = [int(v) for v in vocab_sizes]
         self.F = len(self.vocab_sizes)
+        self.max_vocab = max(self.vocab_sizes) if self.vocab_sizes else 1
         self.n_numeric = int(n_numeric)
         self.numeric = numeric if self.n_numeric else "embed"
         self.raw_numeric = self.numeric == "raw"
@@ -745,9 +746,18 @@ class DeepFM:
             self._apply(None, None, None, None, 0, None, None)
             return loss, logits
         # (1) which rows does this batch touch: sort + unique (TF: unique/unsorted_segment_sum)
-        rows = self._buf("rows", (n,), torch.int32)
-        k.mi_global_rows(ids, self.field_off, B, self.F, rows)
-        sorted_entry, uniq, seg, num_uniq = self._sort_unique(rows, n, self.R, "own")
+        if B % 4096 == 0 and self.F <= 64 and hasattr(k, "mi_sort_unique_fields"):
+            # every field's ids sorted on their own: the radix passes cover a field's id range, not the whole table
+            i32 = torch.int32
+            sorted_entry, uniq = self._buf("own_sorted", (n,), i32), self._buf("own_uniq", (n,), i32)
+            seg, num_uniq = self._buf("own_seg", (n + 1,), i32), self._buf("own_nu", (1,), i32)
+            ws = self._bytes("sortf_ws", k.query("mi_sort_unique_fields_workspace_bytes", B, self.F))
+            k.mi_sort_unique_fields(ids, self.field_off, B, self.F, self.max_vocab, sorted_entry, uniq, seg, num_uniq,
+                                    ws, ws.numel())
+        else:
+            rows = self._buf("rows", (n,), torch.int32)
+            k.mi_global_rows(ids, self.field_off, B, self.F, rows)
+            sorted_entry, uniq, seg, num_uniq = self._sort_unique(rows, n, self.R, "own")
         # (2) TF Adam moved these rows on every step they sat out: replay that now
         if self.adam_rows and self.step > 0:
             self._catchup(uniq, num_uniq, n, defer=True)

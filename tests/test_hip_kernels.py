@@ -605,6 +605,36 @@ def test_catchup_rows_by_gap_is_the_stable_sort_of_the_gap_keys(lib, n_max, U, s
     assert np.array_equal(out.cpu().numpy()[:U], rows[order][:U])
 
 
+@pytest.mark.parametrize("B,F,vocab", [(4096, 26, 1_000_000), (8192, 3, 50), (4096, 40, 1_250_000), (4096, 1, 7)])
+def test_sort_unique_fields_equals_global_rows_then_sort(lib, B, F, vocab):
+    """the per-field (segmented) sort gives the outputs of mi_global_rows + mi_sort_unique_rows bit for bit"""
+    rng = np.random.default_rng(B + F)
+    vs = [max(2, vocab - 13 * f) for f in range(F)]
+    ids = np.stack([rng.integers(0, v, B) for v in vs], 1).astype(np.int32)
+    ids[B // 2] = ids[0]                                   # duplicates across examples
+    if F > 1:
+        ids[:, 1] = ids[0, 1] if B < 5000 else ids[:, 1]   # a field with ONE id: a segment of B duplicates
+    off = np.zeros(F, np.int64); off[1:] = np.cumsum(vs)[:-1]
+    n = B * F
+    d_ids, d_off = dev(ids), dev(off)
+    def outs():
+        return (torch.empty(n, dtype=torch.int32, device="cuda"), torch.empty(n, dtype=torch.int32, device="cuda"),
+                torch.empty(n + 1, dtype=torch.int32, device="cuda"), torch.empty(1, dtype=torch.int32, device="cuda"))
+    se, uq, sg, nu = outs()
+    ws = torch.empty(lib.mi_sort_unique_fields_workspace_bytes(B, F) + 256, dtype=torch.uint8, device="cuda")
+    _chk(lib.mi_sort_unique_fields(_p(d_ids), _p(d_off), B, F, max(vs), _p(se), _p(uq), _p(sg), _p(nu), _p(ws), ws.numel(), _st()))
+    rows = torch.empty(n, dtype=torch.int32, device="cuda")
+    _chk(lib.mi_global_rows(_p(d_ids), _p(d_off), B, F, _p(rows), _st()))
+    se2, uq2, sg2, nu2 = outs()
+    ws2 = torch.empty(lib.mi_sort_unique_workspace_bytes(n) + 256, dtype=torch.uint8, device="cuda")
+    _chk(lib.mi_sort_unique_rows(_p(rows), n, int(sum(vs)), _p(se2), _p(uq2), _p(sg2), _p(nu2), _p(ws2), ws2.numel(), _st()))
+    U = int(nu2.item())
+    assert int(nu.item()) == U
+    assert torch.equal(se, se2)
+    assert torch.equal(uq[:U], uq2[:U]) and torch.equal(sg[:U + 1], sg2[:U + 1])
+    assert lib.mi_sort_unique_fields(_p(d_ids), _p(d_off), B - 1, F, max(vs), _p(se), _p(uq), _p(sg), _p(nu), _p(ws), ws.numel(), _st()) != 0
+
+
 def test_colsum_and_layer_stats(lib):
     rng = np.random.default_rng(3)
     M, N = 3000, 70
