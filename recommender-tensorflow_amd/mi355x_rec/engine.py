@@ -57,6 +57,7 @@ class HipKernels:
     def __init__(self):
         self.lib = _lib.load()
         self.timers = None
+        self.timer_only = None        # a set of timer keys: bracket only these launches (an event pair costs ~10 us of stream time)
 
     def query(self, name, *args):
         """Host-side queries (``*_workspace_bytes``): no stream, returns the value."""
@@ -82,7 +83,7 @@ class HipKernels:
             a = [ptr(x) if isinstance(x, torch.Tensor) else (C.byref(x) if isinstance(x, C.Structure) else x)
                  for x in args]
             a.append(_lib.cur_stream())
-            if self.timers is None:
+            if self.timers is None or (self.timer_only is not None and key not in self.timer_only):
                 rc = fn(*a)
             else:
                 s = torch.cuda.Event(enable_timing=True)
