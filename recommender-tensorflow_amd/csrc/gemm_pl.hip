@@ -1,7 +1,8 @@
 // fp32-accurate GEMMs of the MLP on the f16 matrix pipe, operands held as PRE-SPLIT 16-bit planes.
 //
 // Replaces tf.layers.dense / tf.layers.dropout (trainers/deep_fm.py:98-108) and their data gradients
-// for every layer whose shape allows it (gemm.hip keeps the any-shape kernels and the weight gradient).
+// for every layer whose shape allows it (gemm.hip keeps the any-shape kernels; the weight gradient from planes is
+// wgrad_pl.hip).
 //
 // Operand format ("planes", mi_planes_t): a matrix [rows][K] is stored as fp16 high + fp16 low parts
 // of x * 2^s_r with ONE power-of-two exponent s_r PER ROW (row max -> [2^14, 2^15)):
@@ -58,7 +59,7 @@ struct PlArgs {
   char* Cp; int64_t bsc; int32_t* c_exp;                // planes of the result or NULL (one column tile only)
   const float* bias; int relu; float keep_prob, keep_div; uint64_t seed;
   const char* mask; int64_t bsm;                        // dgrad: planes of the stored activation (hi > 0 <=> active & kept)
-  float* amax_c;                                        // abs-max vector of the result (gemm.hip's weight gradient) or NULL
+  float* amax_c;                                        // abs-max vector of the result (the weight gradient's matrix-wide scales) or NULL
   // dgrad into the input_layer: the FM term's share of the concat gradient, added once here instead of once
   // per entry in the sparse apply: C[m][n] += fold_g[m] * fold_s[m][n % fold_E]   (NULL: nothing added)
   const float* fold_s; const float* fold_g; int fold_E;

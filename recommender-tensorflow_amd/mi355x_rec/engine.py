@@ -318,8 +318,9 @@ class DeepFM:
         # Matrix-pipe path of the MLP GEMMs (all: fp32 in, fp32 accumulate, fp32-level error):
         #   "f16x2"  operands as fp16 high + low parts, three products per k-step: forward and data gradient
         #            on pre-split planes with one exponent per ROW (self.planes, below; layers whose widths
-        #            are not multiples of 16 fall back to bf16x3), the weight gradient on the fp32 copies
-        #            with one exponent per matrix from abs-max vectors the producers emit (self._amax);
+        #            are not multiples of 16 fall back to bf16x3), the weight gradient on the same planes with
+        #            every example brought to matrix-wide scales (abs-max vectors the producers emit:
+        #            self._amax) or, for ragged shapes, on fp32 copies split with one exponent per matrix;
         #   "bf16x3" three bf16 parts, six products, no scales;   "fp32"  fp32-input MFMA.
         if gemm not in ("f16x2", "bf16x3", "fp32"):
             raise ValueError("gemm must be 'f16x2', 'bf16x3' or 'fp32'")
@@ -608,7 +609,7 @@ class DeepFM:
                 y = self._buf("act%d" % i, (B, h))
                 if self.planes and not last:
                     # the next layer's operand as planes straight from the epilogue when a workgroup owns
-                    # whole rows (h <= 512); the fp32 copy feeds the weight gradient / the logits layer
+                    # whole rows (h <= 512); the fp32 copy feeds the logits layer / a weight gradient on fp32 operands
                     need_p = i + 1 < nh
                     yp = self._planes("x%dp" % (i + 1), B, h) if need_p else None
                     direct = need_p and h <= 512
