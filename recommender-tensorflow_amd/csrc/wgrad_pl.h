@@ -6,8 +6,9 @@
 namespace mi {
 
 struct WgradPlPlan {
-  int tn, tm;          // workgroup tile: 128 tn output columns (all of N) x 64 tm input features
-  int tiles_k;         // K / (64 tm)
+  int tn, tm;          // workgroup tile: 128 tn output columns x 64 tm input features
+  int tiles_n;         // N / (128 tn)
+  int tiles_k;         // ceil(K / (64 tm))
   int splits;          // slabs over the examples
   int k_per_split;     // examples per slab (a multiple of 16)
 };

@@ -27,6 +27,7 @@
 // the workgroups of the first feature tile: v_dot2_f32_f16 of the dY fragments with 2^(SY - sy[m]).
 #include "common.h"
 #include "wgrad_pl.h"
+#include <cstdlib>
 #include <type_traits>
 
 namespace {
@@ -44,7 +45,7 @@ struct WgArgs {
   const char* B; int64_t bsb;         // X planes:  [K / 16][examples][64 B]
   const float* amax_a; const float* amax_b;   // abs-max vectors of X and dY
   int M, N, K;                        // examples; dW is [K][N]
-  int k_per_split, tiles_k;
+  int k_per_split, tiles_k, tiles_n;
   float* slab;                        // [splits][K][N]
   float* cpart;                       // [splits][N] bias-gradient partials, or NULL
 };
@@ -96,8 +97,10 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_pl_k(const WgArgs a, cons
   const int nb = gridDim.x, bid = blockIdx.x;
   const int qq = nb >> 3, rr = nb & 7, xcd = bid & 7, idx = bid >> 3;
   const int lid = (xcd < rr) ? xcd * (qq + 1) + idx : rr * (qq + 1) + (xcd - rr) * qq + idx;
-  const int tile_k = lid % a.tiles_k, split = lid / a.tiles_k;   // the feature tiles of one example range run on one XCD
-  const int kx0 = tile_k * 64 * TM;
+  // (the tiles of one example range run on one XCD: they read the same rows of both operands)
+  const int tile_k = lid % a.tiles_k, tile_n = (lid / a.tiles_k) % a.tiles_n, split = lid / (a.tiles_k * a.tiles_n);
+  const int kx0 = tile_k * 64 * TM, n0 = tile_n * 128 * TN;
+  const int kblk_last = (a.K >> 4) - 1;                  // (a ragged last feature tile re-reads the last block, stores nothing for it)
   const int k0 = split * a.k_per_split;
   const int nk = (min(a.M, k0 + a.k_per_split) - k0) / 16;
 
@@ -112,8 +115,8 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_pl_k(const WgArgs a, cons
   for (int j = 0; j < LPS; ++j) {
     const int p = j * WG_THREADS + t;
     const int b = p >> 6, e = (p >> 2) & 15, piece = (p & 3) ^ ((b & 1) << 1);
-    if (j < TN) src[j] = a.A + static_cast<int64_t>(b) * a.bsa + static_cast<int64_t>(k0 + e) * 64 + piece * 16;
-    else src[j] = a.B + static_cast<int64_t>((kx0 >> 4) + b - 8 * TN) * a.bsb + static_cast<int64_t>(k0 + e) * 64 + piece * 16;
+    if (j < TN) src[j] = a.A + static_cast<int64_t>((n0 >> 4) + b) * a.bsa + static_cast<int64_t>(k0 + e) * 64 + piece * 16;
+    else src[j] = a.B + static_cast<int64_t>(min((kx0 >> 4) + b - 8 * TN, kblk_last)) * a.bsb + static_cast<int64_t>(k0 + e) * 64 + piece * 16;
   }
 
   // ---- transposed fragment reads: lane 4 q + pp of a 16-lane group addresses example q, features 4 pp .. 4 pp + 3 ----
@@ -266,7 +269,9 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_pl_k(const WgArgs a, cons
   float* Cb = a.slab + static_cast<int64_t>(split) * a.K * a.N;
 #pragma unroll
   for (int y = 0; y < TM; ++y) {
-    float* row = Cb + static_cast<int64_t>(kx0 + wm * 32 * TM + y * 32 + i) * a.N + wn * 32 * TN + 4 * h;
+    const int kx = kx0 + wm * 32 * TM + y * 32 + i;
+    float* row = Cb + static_cast<int64_t>(kx) * a.N + n0 + wn * 32 * TN + 4 * h;
+    if (kx < a.K)
 #pragma unroll
     for (int x = 0; x < TN; ++x)
 #pragma unroll
@@ -279,7 +284,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_pl_k(const WgArgs a, cons
 #pragma unroll
     for (int x = 0; x < TN; ++x) {
       const float c = cs[x] + __shfl_xor(cs[x], 32);    // the two halves hold different examples
-      if (h == 0) a.cpart[static_cast<int64_t>(split) * a.N + wn * 32 * TN + x * 32 + i] = c * fb;
+      if (h == 0) a.cpart[static_cast<int64_t>(split) * a.N + n0 + wn * 32 * TN + x * 32 + i] = c * fb;
     }
   }
 }
@@ -289,17 +294,22 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_pl_k(const WgArgs a, cons
 namespace mi {
 
 bool wgrad_pl_plan(int64_t M, int N, int K, WgradPlPlan* p) {
-  if (M <= 0 || M % 16 != 0 || (N != 128 && N != 256 && N != 512) || K <= 0) return false;
+  if (M <= 0 || M % 16 != 0 || (N != 128 && N != 256 && N != 512) || K <= 0 || K % 16 != 0) return false;
   p->tn = N / 128;
+  p->tiles_n = 1;
   p->tm = p->tn == 2 ? 4 : 2;
-  if (K % (64 * p->tm) != 0) {
-    if (K % 128 != 0) return false;
-    p->tm = 2;
+  // N = 512: one 512-column tile x 128 features.  MI_WGRAD_TILE=256 (A/B runs): two 256-column tiles x 256 features
+  // (32 KB of operands per k-step instead of 40 KB for the same MFMAs, a half-empty last feature tile at K = 1664) —
+  // measured slower, 469 vs 451 us on the layer-1 shape: the loop is not bound by operand bytes.
+  if (p->tn == 4) {
+    const char* e = getenv("MI_WGRAD_TILE");
+    if (e && e[0] == '2') { p->tn = 2; p->tm = 4; p->tiles_n = 2; }
   }
-  p->tiles_k = K / (64 * p->tm);
+  if (K % 128 != 0) return false;
+  p->tiles_k = static_cast<int>(ceil_div(K, 64 * p->tm));      // (the last tile may be half empty)
   // one round of resident workgroups (one per CU; the 128-column tile fits two), at least 32 k-steps per split
   // (a split pays a pipeline fill and a slab of the whole tile)
-  int64_t target = (p->tn == 1 ? 512 : 256) / p->tiles_k;
+  int64_t target = (p->tn == 1 ? 512 : 256) / (p->tiles_k * p->tiles_n);
   const int64_t max_s = M / (16 * 32) > 0 ? M / (16 * 32) : 1;
   if (target > max_s) target = max_s;
   if (target < 1) target = 1;
@@ -319,9 +329,9 @@ int32_t wgrad_pl_launch(const WgradPlPlan& p, const mi_planes_t* X, const mi_pla
   const uint4* sc4 = static_cast<const uint4*>(sc);
   a.amax_a = amax_x; a.amax_b = amax_dy;
   a.M = static_cast<int>(M); a.N = N; a.K = K;
-  a.k_per_split = p.k_per_split; a.tiles_k = p.tiles_k;
+  a.k_per_split = p.k_per_split; a.tiles_k = p.tiles_k; a.tiles_n = p.tiles_n;
   a.slab = slab; a.cpart = cpart;
-  const dim3 g(static_cast<unsigned>(p.tiles_k * p.splits)), b(WG_THREADS);
+  const dim3 g(static_cast<unsigned>(p.tiles_k * p.tiles_n * p.splits)), b(WG_THREADS);
   if (p.tn == 4 && p.tm == 2) wgrad_pl_k<4, 2><<<g, b, 0, st>>>(a, sx4, sy4, sc4, kflag);
   else if (p.tn == 2 && p.tm == 4) wgrad_pl_k<2, 4><<<g, b, 0, st>>>(a, sx4, sy4, sc4, kflag);
   else if (p.tn == 2 && p.tm == 2) wgrad_pl_k<2, 2><<<g, b, 0, st>>>(a, sx4, sy4, sc4, kflag);
