@@ -322,7 +322,7 @@ def main():
                                "note": "the whole train step as one hipGraph launch (bitwise the same step; global step, lr_t and "
                                        "dropout seeds in a device-resident step state).  At this batch size the eager step is not "
                                        "launch-bound and the replay is SLOWER than `value`; the capture pays at small batches "
-                                       "(tools/small_step_bench.py: B = 32, 0.42 -> 0.25 ms)"}
+                                       "(tools/small_step_bench.py: B = 32, 0.34 -> 0.146 ms)"}
         m._graph = None
         if args.gemm != "fp32":
             keep = (m.gemm, m.planes, m.gather_mlp)

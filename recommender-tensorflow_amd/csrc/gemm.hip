@@ -878,9 +878,11 @@ static int32_t bwd_weight_impl(const float* X, int64_t ldx, const float* dY, int
   float* cpart = slab + static_cast<int64_t>(splits) * n;   // [splits][N] bias-gradient partials
   if (N == 1 && !g_ids && gemv_ok(X, ldx, X, K)) {          // logits layer: slabs of rows, then the same reduce
     const int64_t rows = mi::ceil_div(M, splits);
+    const bool one = splits == 1;       // one slab IS the result (the small-batch step saves the reduce launch)
     gemv_wgrad_k<<<dim3((unsigned)mi::ceil_div(K, 16), (unsigned)splits), dim3(kThreads), 0, st>>>(
-        X, ldx, dY, lddy, M, K, rows, slab, db ? cpart : nullptr);
+        X, ldx, dY, lddy, M, K, rows, one ? dW : slab, db ? (one ? db : cpart) : nullptr);
     MI_CHECK_LAUNCH("dense_bwd_weight(N = 1)");
+    if (one) return MI_OK;
     slab_reduce_k<<<dim3((unsigned)(mi::ceil_div(n, 64) + (db ? 1 : 0))), dim3(kThreads), 0, st>>>(slab, splits, n, dW, cpart, 1, db);
     MI_CHECK_LAUNCH("dense_bwd_weight(reduce)");
     return MI_OK;

@@ -5,6 +5,7 @@
 // metric contract is spelled out by trainers/model_utils.py:9-54) and layer_summary
 // (model_utils.py:4-6).  Reductions are two-stage with a fixed order: bitwise reproducible.
 #include "common.h"
+#include <cstdlib>
 #include <algorithm>
 
 namespace {
@@ -73,9 +74,13 @@ __global__ __launch_bounds__(kBlock) void head_k(const float* __restrict__ lin,
   }
 }
 
+// (block 1, if launched, folds a second vector: the loss and the gradient sum in one launch)
 __global__ __launch_bounds__(kBlock) void sum_partials_k(const float* __restrict__ partial, int n,
-                                                         float* __restrict__ out) {
+                                                         float* __restrict__ out, const float* __restrict__ partial2 = nullptr,
+                                                         float* __restrict__ out2 = nullptr) {
   __shared__ float red[4];
+  if (blockIdx.x == 1) { partial = partial2; out = out2; }
+  if (!partial) return;                         // (block-uniform)
   float acc = 0.f;
   for (int i = threadIdx.x; i < n; i += kBlock) acc += partial[i];
   const float tot = block_sum(acc, red);
@@ -216,18 +221,17 @@ int32_t mi_sigmoid_ce_head(const float* lin, const float* lin_bias, const float*
   }
   hipStream_t st = mi::as_stream(stream);
   const int nb = blocks_for(B);
-  float* partial = loss_out ? static_cast<float*>(workspace) : nullptr;
-  float* partial_d = d_logit_sum ? static_cast<float*>(workspace) + kMaxBlocks : nullptr;
+  // one block: its totals ARE the results (what the fold of a single partial would give, bit for bit): one launch
+  const bool single = nb == 1;
+  float* partial = loss_out ? (single ? loss_out : static_cast<float*>(workspace)) : nullptr;
+  // d_logit_sum = d loss / d linear bias (and d / d logits-layer bias when the DNN has no hidden layer)
+  float* partial_d = d_logit_sum ? (single ? d_logit_sum : static_cast<float*>(workspace) + kMaxBlocks) : nullptr;
   head_k<<<dim3(nb), dim3(kBlock), 0, st>>>(lin, lin_bias, fm, dnn, labels, B, loss_scale, logits, d_logit, partial,
                                             partial_d);
   MI_CHECK_LAUNCH("sigmoid_ce_head");
-  if (loss_out) {
-    sum_partials_k<<<dim3(1), dim3(kBlock), 0, st>>>(partial, nb, loss_out);
+  if (!single && (loss_out || d_logit_sum)) {
+    sum_partials_k<<<dim3(2), dim3(kBlock), 0, st>>>(partial, nb, loss_out, partial_d, d_logit_sum);
     MI_CHECK_LAUNCH("sigmoid_ce_head(reduce)");
-  }
-  if (d_logit_sum) {   // = d loss / d linear bias (and d / d logits-layer bias when the DNN has no hidden layer)
-    sum_partials_k<<<dim3(1), dim3(kBlock), 0, st>>>(partial_d, nb, d_logit_sum);
-    MI_CHECK_LAUNCH("sigmoid_ce_head(reduce d)");
   }
   return MI_OK;
 }

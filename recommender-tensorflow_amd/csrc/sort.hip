@@ -28,6 +28,17 @@ constexpr int kMaxBits = 9;
 constexpr int kMaxBins = 1 << kMaxBits;    // 512
 constexpr int kMaxPasses = 4;
 
+// (our own kernel instead of hipMemsetAsync: a plain kernel node when the step is captured into a hipGraph — a
+// LINEAR captured step with memset nodes faulted at replay on this ROCm, the same step with a forked side stream
+// did not — and no runtime fill-kernel in between ours)
+__global__ __launch_bounds__(256) void zero_i32_k(int32_t* __restrict__ p, int64_t n) {
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * 256) p[i] = 0;
+}
+inline void zero_i32(int32_t* p, int64_t n, hipStream_t st) {
+  const int64_t b = (n + 255) / 256;
+  zero_i32_k<<<dim3(static_cast<unsigned>(b < 64 ? b : 64)), dim3(256), 0, st>>>(p, n);
+}
+
 // Segments (mi_sort_unique_fields: one per field, tps tiles each, sorted independently): tile = seg * tps + tis,
 // hist[(seg * nbins + digit) * tps + tis], bin_total[seg * nbins + digit].  One segment: tps = ntiles.
 __global__ __launch_bounds__(kBlock) void hist_k(const int32_t* __restrict__ keys, int64_t n, int shift,
@@ -330,24 +341,37 @@ Layout layout_for(int64_t n, int nseg = 1) {
 }  // namespace
 
 // ---- n <= kSmallN: the whole sort + unique in ONE workgroup (the launch-bound small-batch step: B = 32 x 26 fields
-// = 832 keys would otherwise take a dozen launches).  Stable by construction: rank = number of keys that are
-// smaller, or equal with a smaller index.
+// = 832 keys would otherwise take a dozen launches).
 namespace {
 constexpr int kSmallN = 1024;
 __global__ __launch_bounds__(kBlock) void sort_small_k(const int32_t* __restrict__ keys, int n, int32_t* __restrict__ sorted_entry,
                                                        int32_t* __restrict__ uniq_rows, int32_t* __restrict__ seg_start,
                                                        int32_t* __restrict__ num_uniq) {
-  __shared__ int32_t k[kSmallN], sk[kSmallN], head[kSmallN];
+  // bitonic sort of (key << 10 | index) in LDS: the index makes equal keys keep their order (stable), padding sorts
+  // last.  (The first version ranked every key against every other: 87 us of the 280-us B = 32 step.)
+  __shared__ unsigned long long a[kSmallN];
+  __shared__ int32_t sk[kSmallN], head[kSmallN];
   __shared__ int32_t wsum[4];
   const int t = threadIdx.x;
-  for (int i = t; i < n; i += kBlock) k[i] = keys[i];
+  int np2 = 64;
+  while (np2 < n) np2 <<= 1;
+  for (int i = t; i < np2; i += kBlock)
+    a[i] = i < n ? (static_cast<unsigned long long>(static_cast<uint32_t>(keys[i])) << 10) | static_cast<unsigned>(i) : ~0ull;
   __syncthreads();
+  for (int k = 2; k <= np2; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = t; i < np2; i += kBlock) {
+        const int p = i ^ j;
+        if (p > i) {
+          const unsigned long long x = a[i], y = a[p];
+          if ((x > y) == ((i & k) == 0)) { a[i] = y; a[p] = x; }
+        }
+      }
+      __syncthreads();
+    }
   for (int i = t; i < n; i += kBlock) {
-    const int32_t ki = k[i];
-    int rank = 0;
-    for (int j = 0; j < n; ++j) rank += (k[j] < ki) || (k[j] == ki && j < i);
-    sk[rank] = ki;
-    sorted_entry[rank] = i;
+    sk[i] = static_cast<int32_t>(a[i] >> 10);
+    sorted_entry[i] = static_cast<int32_t>(a[i] & 1023u);
   }
   if (!uniq_rows) return;
   __syncthreads();
@@ -413,10 +437,8 @@ int32_t mi_sort_unique_rows(const int32_t* rows, int64_t n, int64_t num_rows_tot
   const int nbits = (bits + passes - 1) / passes;   // digit width, <= 9
   const int nbins = 1 << nbits;
 
-  if (hipMemsetAsync(bin_total, 0, kMaxPasses * kMaxBins * 4, st) != hipSuccess) {
-    mi::set_error("sort_unique_rows: memset failed");
-    return MI_ERR_LAUNCH;
-  }
+  zero_i32(bin_total, kMaxPasses * kMaxBins, st);
+  MI_CHECK_LAUNCH("sort_unique_rows(zero)");
   const int32_t* kin = rows;
   const int32_t* vin = nullptr;  // pass 0: value = position
   for (int p = 0; p < passes; ++p) {
@@ -463,10 +485,8 @@ int32_t mi_catchup_rows_by_gap(const int32_t* uniq_rows, const int32_t* num_uniq
   int32_t* hist = reinterpret_cast<int32_t*>(ws + L.hist);
   int32_t* bin_total = reinterpret_cast<int32_t*>(ws + L.bin_total);
   const int ntiles = static_cast<int>(L.ntiles);
-  if (hipMemsetAsync(bin_total, 0, 64 * 4, st) != hipSuccess) {
-    mi::set_error("catchup_rows_by_gap: memset failed");
-    return MI_ERR_LAUNCH;
-  }
+  zero_i32(bin_total, 64, st);
+  MI_CHECK_LAUNCH("catchup_rows_by_gap(zero)");
   gap_hist_k<<<dim3(ntiles), dim3(kBlock), 0, st>>>(uniq_rows, num_uniq, last_step, n_max, step_to, lin_stride, mi::step_state(),
                                                     keys, ntiles, hist, bin_total);
   MI_CHECK_LAUNCH("catchup_rows_by_gap(keys + hist)");
@@ -512,10 +532,8 @@ int32_t mi_sort_unique_fields(const int32_t* ids, const int64_t* field_off, int6
   const int nbits = (bits + passes - 1) / passes;   // digit width, <= 9
   const int nbins = 1 << nbits;
 
-  if (hipMemsetAsync(bin_total, 0, static_cast<size_t>(kMaxPasses) * F * kMaxBins * 4, st) != hipSuccess) {
-    mi::set_error("sort_unique_fields: memset failed");
-    return MI_ERR_LAUNCH;
-  }
+  zero_i32(bin_total, static_cast<int64_t>(kMaxPasses) * F * kMaxBins, st);
+  MI_CHECK_LAUNCH("sort_unique_fields(zero)");
   // the ids field by field (keys = local ids); pass 0 reads them from the buffer pass 1 will overwrite
   ids_field_major_k<<<dim3((unsigned)mi::ceil_div(B, 64)), dim3(kBlock), 0, st>>>(ids, B, F, kbuf[1]);
   MI_CHECK_LAUNCH("sort_unique_fields(transpose)");
@@ -619,10 +637,8 @@ int32_t mi_route_requests(const int32_t* uniq_keys, const int32_t* num_uniq, int
   MI_REQUIRE(n_max >= 0 && rows_per_rank > 0 && n_groups > 0, "route_requests: n_max=%lld", (long long)n_max);
   MI_REQUIRE(counts, "route_requests: null counts");
   hipStream_t st = mi::as_stream(stream);
-  if (hipMemsetAsync(counts, 0, sizeof(int32_t) * n_groups, st) != hipSuccess) {
-    mi::set_error("route_requests: memset failed");
-    return MI_ERR_LAUNCH;
-  }
+  zero_i32(counts, n_groups, st);
+  MI_CHECK_LAUNCH("route_requests(zero)");
   if (n_max == 0) return MI_OK;
   MI_REQUIRE(uniq_keys && num_uniq && send_rows, "route_requests: null buffer");
   route_requests_k<<<dim3((unsigned)mi::ceil_div(n_max, kBlock)), dim3(kBlock), 0, st>>>(uniq_keys, num_uniq, rows_per_rank, send_rows, counts);

@@ -548,8 +548,9 @@ class DeepFM:
         # The wide part's 4-byte weight gathers drag a whole sector each through the row-gather kernel
         # (3.9 vs 4.9 TB/s of row bytes).  On a single GPU they run as their own kernel on a side stream
         # under the matrix-bound layer-1 GEMM instead; the head joins the two streams.
+        # (from a few thousand examples on: below that a fork / join costs more than the 4-byte gathers it hides)
         side_lin = (src is None and self.device.type == "cuda" and self.use_emb and self.use_linear and self.use_dnn
-                    and self.n_numeric == 0 and F > 0)
+                    and self.n_numeric == 0 and F > 0 and B >= 4096)
         c["lin_join"] = None
         if F == 0:
             # numeric columns only (deep_fm.py:57-70 allows it): the sums start from zero (memsets)

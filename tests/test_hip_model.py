@@ -321,7 +321,10 @@ def test_config5_one_rank_share_properties():
     _props_after_steps(m, ids, y, None, table0, rows, replay=False)    # (the replay check would hold 200 GB of clones)
 
 
-@pytest.mark.parametrize("vocab,E,hidden,B", [(ML100K_VOCAB, 4, [16, 16], 32), ([50, 30, 20, 40], 64, [512, 256, 128], 128)])
+# (the third case: B * F = 26,624 entries — the multi-kernel radix sort and the staleness sort inside the captured step,
+# no side stream: a linear graph.  It faulted at replay while the sorts zeroed their counters with hipMemsetAsync.)
+@pytest.mark.parametrize("vocab,E,hidden,B", [(ML100K_VOCAB, 4, [16, 16], 32), ([50, 30, 20, 40], 64, [512, 256, 128], 128),
+                                              (ML100K_VOCAB, 4, [16, 16], 1024)])
 def test_graph_train_step_replays_the_eager_step_bitwise(vocab, E, hidden, B):
     """The train step captured into one hipGraph (global step, Adam lr_t and the dropout seeds live in a device-
     resident step state advanced by the graph's first node) must leave the model bit for bit where the same
