@@ -87,6 +87,15 @@ __device__ __forceinline__ bool pl_dropout_keep(uint64_t seed, uint32_t row, uin
 
 template <int N> __device__ __forceinline__ void pl_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+// -DMI_PL_STAMPS: clock64() stamps at the phase boundaries of every k-step, from lane 0 of waves 0 (group 0) and 4
+// (group 1) of the first 32 workgroups (tools/gemm_pl_stamps.py reads them back).  Not part of the product build.
+#ifdef MI_PL_STAMPS
+__device__ long long g_pl_stamps[32 * 2 * 128 * 8];
+#define PL_STAMP(slot) do { if (stamp_on && t < 128) g_pl_stamps[((stamp_wg * 2 + stamp_grp) * 128 + t) * 8 + (slot)] = clock64(); } while (0)
+#else
+#define PL_STAMP(slot) do {} while (0)
+#endif
+
 template <int TN, int TM, int EPI>
 __global__ __launch_bounds__(PL_THREADS, 2) void gemm_pl_k(const PlArgs a) {
   // stage buffers: 4 where one workgroup per CU runs anyway (256 registers); 3 for the 128-column tile, whose
@@ -143,22 +152,22 @@ __global__ __launch_bounds__(PL_THREADS, 2) void gemm_pl_k(const PlArgs a) {
 
   // Software pipeline: the two waves of a SIMD ping-pong.  The workgroup's 8 waves form two groups (waves
   // 0-3 and 4-7; wave w and w + 4 share a SIMD).  Every wave runs the same loop
-  //     L(t): issue its share of LDS-DMA stage t - 1 + NBUF, read the fragments of tile t from LDS
+  //     L(t): read the fragments of tile t from LDS, wait for its own LDS-DMA share of stage t + 1
   //     barrier
-  //     C(t): the 3 TN TM MFMAs of tile t, from registers only
+  //     C(t): the 3 TN TM MFMAs of tile t, from registers only, with its LDS-DMA share of stage t - 1 + NBUF
+  //           issued between them
   //     barrier
   // but group 1 enters it one barrier late (and group 0 leaves it one barrier late), so between any two
   // consecutive barriers one group is in C and the other in L: each SIMD's matrix pipe always has exactly
-  // one wave feeding it, and every LDS-DMA issue, ds_read and wait of a wave sits under its partner's
-  // MFMAs.  With the barriers numbered globally, group 0 runs L(t) in slot [2t, 2t+1] and C(t) in
-  // [2t+1, 2t+2]; group 1 runs L(t) in [2t+1, 2t+2] and C(t) in [2t+2, 2t+3].  Tile t lives in stage buffer
-  // t % NBUF.
+  // one wave feeding it, and every ds_read and wait of a wave sits under its partner's MFMAs.  With the barriers
+  // numbered globally, group 0 runs L(t) in slot [2t, 2t+1] and C(t) in [2t+1, 2t+2]; group 1 runs L(t) in
+  // [2t+1, 2t+2] and C(t) in [2t+2, 2t+3].  Tile t lives in stage buffer t % NBUF.
   //   * a wave waits for its own share of stage t + 1 at the end of L(t): all shares are complete before
   //     barrier 2t+2, the first read of tile t + 1 comes after it;
-  //   * L(t) refills the buffer tile t - 1 has left: its last reader was group 1's L(t - 1), which drained
-  //     its LDS reads (lgkmcnt(0)) before barrier 2t, and no L(t) starts before barrier 2t;
-  //   * at the end of L(t) a wave has issued stages up to t - 1 + NBUF and needs stage t + 1:
-  //     vmcnt((NBUF - 2) LPS); a share is in flight for 2 NBUF - 3 slots.
+  //   * C(t) refills the buffer tile t - 1 has left: its last reader was group 1's L(t - 1), which drained
+  //     its LDS reads (lgkmcnt(0)) before barrier 2t, and no C(t) starts before barrier 2t+1;
+  //   * at the end of L(t) a wave has issued stages up to t - 2 + NBUF (and, at t = 0, one duplicate) and needs
+  //     stage t + 1: vmcnt((NBUF - 3) LPS); a share is in flight for 2 NBUF - 4 slots.
   auto issue_share = [&](int kt, int buf) {
 #pragma unroll
     for (int j = 0; j < LPS; ++j)
@@ -180,24 +189,42 @@ __global__ __launch_bounds__(PL_THREADS, 2) void gemm_pl_k(const PlArgs a) {
       bl[y] = *reinterpret_cast<const f16x8*>(buf + offB + y * 32 * PL_ROWB + cl);
     }
   };
-  auto phase_c = [&]() {
+  // C(t): the 3 TN TM MFMAs of tile t from registers, and — spread between them — this wave's LDS-DMA share of stage
+  // t - 1 + NBUF into the buffer tile t - 1 has left.  (Stamps, tools/gemm_pl_stamps.py: issued at the head of L(t)
+  // next to the fragment reads, the 5 DMA pieces made L 1000 cycles long against C's 870 — a piece costs 100-185
+  // cycles of issue in a phase that also carries ds_reads, ~60 among bare MFMAs — and L, not the matrix pipe, set
+  // the pace.)  At t = 0 the share re-fetches stage NBUF - 1 into its own buffer: the same bytes, uniform counts.
+  // (The 128-column tile — 3 buffers, two workgroups per CU — keeps its share at the head of L(t): with one stage
+  // fewer in flight it would wait for every DMA in every k-step; measured 399 vs 390 us on the layer-1 data gradient.)
+  constexpr bool DMA_IN_C = TN != 1;
+  auto phase_c = [&](int t) {
+    int fb = t - 1 + PL_NBUF;
+    fb -= (fb / PL_NBUF) * PL_NBUF;
+    const int kt = min(t - 1 + PL_NBUF, nk - 1);          // (the tail re-issues the last tile: uniform counts)
+    // product-major order (an accumulator's three products are TN TM MFMAs apart, smallest partial product first);
+    // after every GAP MFMAs one DMA piece, pinned there (hipcc otherwise bunches the pieces and chains the
+    // dependent MFMAs back to back)
+    constexpr int NT = TN * TM, NM = 3 * NT, GAP = NM / (LPS + 1);
 #pragma unroll
-    for (int x = 0; x < TN; ++x)
-#pragma unroll
-      for (int y = 0; y < TM; ++y) {
-        f32x16 c = acc[x][y];                    // smallest partial products first
-        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[x], bh[y], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[x], bl[y], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[x], bh[y], c, 0, 0, 0);
-        acc[x][y] = c;
+    for (int idx = 0; idx < NM; ++idx) {
+      const int pr = idx / NT, x = (idx % NT) / TM, y = idx % TM;
+      acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pr == 0 ? al[x] : ah[x], pr == 1 ? bl[y] : bh[y], acc[x][y], 0, 0, 0);
+      if (DMA_IN_C && (idx + 1) % GAP == 0 && (idx + 1) / GAP <= LPS) {
+        const int j = (idx + 1) / GAP - 1;
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + kt * (j < TN ? a.bsa : a.bsb)),
+                                         (__attribute__((address_space(3))) void*)(smem + fb * STAGE + (j * PL_THREADS + wv * 64) * 16),
+                                         16, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
+    }
   };
-  // L(t): share of stage t - 1 + NBUF into the buffer tile t - 1 has left, then the fragments of tile t
+  // L(t): the fragments of tile t
   auto phase_l = [&](int t) {
-    if (t >= 1) {
+    if (!DMA_IN_C && t >= 1) {
       int fb = t - 1;
       fb -= (fb / PL_NBUF) * PL_NBUF;
-      issue_share(min(t - 1 + PL_NBUF, nk - 1), fb);      // (the tail re-issues the last tile: uniform counts)
+      issue_share(min(t - 1 + PL_NBUF, nk - 1), fb);
     }
     int rb = t;
     rb -= (rb / PL_NBUF) * PL_NBUF;
@@ -212,20 +239,31 @@ __global__ __launch_bounds__(PL_THREADS, 2) void gemm_pl_k(const PlArgs a) {
   if (g1) __builtin_amdgcn_s_barrier();                    // the stagger
   // (sched_barrier(0): hipcc otherwise moves register-only MFMAs across s_barrier, which would put both
   // groups' MFMAs into the same slot)
+#ifdef MI_PL_STAMPS
+  const bool stamp_on = lane == 0 && (wv == 0 || wv == 4) && lid < 32;
+  const int stamp_wg = lid, stamp_grp = wv >> 2;
+#endif
 #pragma unroll 1
   for (int t = 0; t < nk; ++t) {
+    PL_STAMP(0);
     phase_l(t);
+    PL_STAMP(1);                                           // DMA + fragment reads issued
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    pl_wait_vmcnt<LPS*(PL_NBUF - 2)>();                    // own share of stage t + 1
+    PL_STAMP(2);                                           // fragments in registers
+    pl_wait_vmcnt<LPS*(DMA_IN_C ? PL_NBUF - 3 : PL_NBUF - 2)>();   // own share of stage t + 1 (issued in C(t + 2 - NBUF) / L(t + 2 - NBUF))
+    PL_STAMP(3);                                           // own DMA share of the next stage has landed
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+    PL_STAMP(4);                                           // past the barrier: MFMAs start
     __builtin_amdgcn_s_setprio(1);
-    phase_c();
+    phase_c(t);
     __builtin_amdgcn_s_setprio(0);
+    PL_STAMP(5);                                           // MFMAs issued
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+    PL_STAMP(6);                                           // past the second barrier
   }
   if (!g1) __builtin_amdgcn_s_barrier();
 
@@ -965,5 +1003,11 @@ int32_t mi_dense_bwd_data_vec_planes(const float* dY, int64_t lddy, const float*
   MI_CHECK_LAUNCH("dense_bwd_data_vec_planes");
   return MI_OK;
 }
+
+#ifdef MI_PL_STAMPS
+int32_t mi_pl_stamps_read(void* dst, size_t nbytes) {
+  return static_cast<int32_t>(hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_pl_stamps), nbytes, 0, hipMemcpyDeviceToHost));
+}
+#endif
 
 }  // extern "C"

@@ -157,17 +157,28 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_pl_k(const WgArgs a, cons
       bl[y] = wg_tr_read<y * 2048>(bL);
     });
   };
-  auto phase_c = [&]() {
+  // C(t): the MFMAs of tile t in product-major order and, pinned between them, this wave's LDS-DMA share of stage
+  // t - 1 + NBUF (gemm_pl_k: issued next to the fragment reads the pieces made L longer than C); the 128-column tile
+  // (3 buffers) keeps its share at the head of L(t)
+  constexpr bool DMA_IN_C = TN != 1;
+  auto phase_c = [&](int t) {
+    int fb = t - 1 + NBUF;
+    fb -= (fb / NBUF) * NBUF;
+    const int kt = min(t - 1 + NBUF, nk - 1);             // (the tail re-issues the last tile: uniform counts)
+    constexpr int NT = TN * TM, NM = 3 * NT, GAP = NM / (LPS + 1);
 #pragma unroll
-    for (int x = 0; x < TN; ++x)
-#pragma unroll
-      for (int y = 0; y < TM; ++y) {
-        f32x16 c = acc[x][y];                    // smallest partial products first
-        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[x], bh[y], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[x], bl[y], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[x], bh[y], c, 0, 0, 0);
-        acc[x][y] = c;
+    for (int idx = 0; idx < NM; ++idx) {
+      const int pr = idx / NT, x = (idx % NT) / TM, y = idx % TM;
+      acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pr == 0 ? al[x] : ah[x], pr == 1 ? bl[y] : bh[y], acc[x][y], 0, 0, 0);
+      if (DMA_IN_C && (idx + 1) % GAP == 0 && (idx + 1) / GAP <= LPS) {
+        const int j = (idx + 1) / GAP - 1;
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + static_cast<int64_t>(kt) * 1024),
+                                         (__attribute__((address_space(3))) void*)(smem + fb * STAGE + (j * WG_THREADS + wv * 64) * 16),
+                                         16, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
+    }
   };
   // per-example factors of a k-step: 16 f16 = two 16-byte scalar loads, a lane keeps the eight of its half
   // (direct __restrict__ kernel parameters: only then does hipcc emit scalar loads — as vector loads they would
@@ -220,7 +231,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_pl_k(const WgArgs a, cons
   };
   // L(t): share of stage t - 1 + NBUF into the buffer tile t - 1 has left, then the fragments of tile t
   auto phase_l = [&](int t) {
-    if (t >= 1) {
+    if (!DMA_IN_C && t >= 1) {
       int fb = t - 1;
       fb -= (fb / NBUF) * NBUF;
       issue_share(min(t - 1 + NBUF, nk - 1), fb);         // (the tail re-issues the last tile: uniform counts)
@@ -243,12 +254,12 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_pl_k(const WgArgs a, cons
     __builtin_amdgcn_sched_barrier(0);                     // nothing that reads a fragment moves above the wait
     scale_and_sum(t, cur);
     fetch_factors(min(t + 1, nk - 1), nxt);
-    wg_wait_vmcnt<LPS*(NBUF - 2)>();
+    wg_wait_vmcnt<LPS*(DMA_IN_C ? NBUF - 3 : NBUF - 2)>();
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
-    phase_c();
+    phase_c(t);
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
