@@ -196,6 +196,8 @@ __global__ __launch_bounds__(PL_THREADS, 2) void gemm_pl_k(const PlArgs a) {
   // the pace.)  At t = 0 the share re-fetches stage NBUF - 1 into its own buffer: the same bytes, uniform counts.
   // (The 128-column tile — 3 buffers, two workgroups per CU — keeps its share at the head of L(t): with one stage
   // fewer in flight it would wait for every DMA in every k-step; measured 399 vs 390 us on the layer-1 data gradient.)
+  // (Tried: two of the five pieces back at the head of L(t), which has slack after the move — a piece there costs
+  // ~480 cycles, not 40: L 1200, C 1205 cycles, 344 vs 313 us.  All pieces stay between the MFMAs.)
   constexpr bool DMA_IN_C = TN != 1;
   auto phase_c = [&](int t) {
     int fb = t - 1 + PL_NBUF;
