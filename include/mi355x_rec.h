@@ -40,7 +40,7 @@ enum mi_status {
 };
 
 /* ---- library ---------------------------------------------------------------------------- */
-int32_t mi_abi_version(void);       /* bumps when a signature changes (currently 13) */
+int32_t mi_abi_version(void);       /* bumps when a signature changes (currently 14) */
 const char* mi_last_error(void);    /* thread-local, never NULL */
 const char* mi_build_info(void);    /* "gfx950 hipcc <ver>" */
 
@@ -319,6 +319,13 @@ int32_t mi_catchup_rows_by_gap(const int32_t* uniq_rows, const int32_t* num_uniq
                                int32_t step_to, int32_t lin_stride, int32_t* rows_out, void* workspace,
                                size_t workspace_bytes, mi_stream_t stream);
 
+
+/* Self-test of the catch-up's fast square root (no reference analogue; the exactness claim above rests on it): for the
+ * `count` fp32 bit patterns from first_bits on, mismatches[0] += how many give different bits in the replay loop's
+ * in-range sqrt (v_rsq_f32 + coupled Newton step + residual correction) than in hipcc's correctly rounded sqrtf,
+ * mismatches[1] += the same for the v_sqrt_f32 + one-ulp-test form.  mismatches: 2 x uint64 on the device, zeroed by the
+ * caller.  The fast loop is only entered with v in [2^-80, 2^20]; the test sweeps [2^-100, 2^24] and demands 0. */
+int32_t mi_selftest_sqrt(uint32_t first_bits, int64_t count, uint64_t* mismatches, mi_stream_t stream);
 
 int32_t mi_sparse_catchup(float* table, float* t_m, float* t_v, float* lin_w, float* l_m, float* l_v,
                           int32_t* last_step, const int32_t* uniq_rows, const int32_t* num_uniq,

@@ -304,17 +304,36 @@ __device__ __forceinline__ void replay(float& w, float& m, float& v, int s_from,
 // With the rows sorted by staleness the replay is bound by VALU issue.  hipcc's correctly rounded sqrtf
 // and '/' carry range scaling (v_div_scale x2, v_div_fmas, v_div_fixup; the 2^32 pre-scale, un-scale
 // and class test of sqrt) that only matters at the ends of the exponent range.  These are the same
-// two algorithms without it — v_sqrt_f32 + the one-ulp residual test, v_rcp_f32 + Newton + two
+// algorithms without it — for sqrt LLVM's rsq-based expansion (below), for '/' v_rcp_f32 + Newton + two
 // residual corrections — hence the same bits wherever no intermediate leaves the normal range;
 // catchup_in_range() is the (generous) condition under which a WAVE takes them (all its lanes in
 // range: a wave never runs both loops); otherwise it runs sqrtf and '/'.
-__device__ __forceinline__ float sqrt_rn_inrange(float x) {            // x == 0 or x >= 2^-96
+// sqrt, first form: v_sqrt_f32 + the one-ulp residual test (what hipcc emits for sqrtf, minus the range scaling): 2 integer
+// adds, 2 FMAs, 2 compares and 2 selects per element after the quarter-rate instruction — only the FMAs pack.
+__device__ __forceinline__ float sqrt_rn_fixup(float x) {              // x == 0 or x >= 2^-96
   float s = __builtin_amdgcn_sqrtf(x);
   const float sm = __uint_as_float(__float_as_uint(s) - 1u), sp = __uint_as_float(__float_as_uint(s) + 1u);
   const float rm = fmaf(-sm, s, x), rp = fmaf(-sp, s, x);
   s = (rm <= 0.f) ? sm : s;
   s = (rp > 0.f) ? sp : s;
   return s;
+}
+// sqrt, the form the replay loops use (round 2): v_rsq_f32, one coupled Newton step on (s ~ sqrt x, h ~ 1/(2 sqrt x)) and a
+// final residual correction — LLVM's other correctly rounded expansion (the one it picks when f32 denormals are flushed),
+// again without the range scaling.  Two multiplies and five FMAs, ALL of which hipcc packs two elements to an
+// instruction: per 4 elements 14 packed instructions instead of 4 packed + 24 single ones (38 packed + 8 quarter-rate
+// + 3 single per replayed step instead of 28 + 8 + 27).  That it returns the correctly rounded root — the bits of
+// sqrtf — is not taken on trust: mi_selftest_sqrt compares the two on the device for EVERY fp32 value in
+// [2^-100, 2^24] (tests/test_hip_kernels.py::test_fast_sqrt_equals_sqrtf_on_every_value_in_range).  x == 0 gives NaN
+// (0 * inf): the in-range condition below keeps v == 0 out.
+__device__ __forceinline__ float sqrt_rn_inrange(float x) {            // 2^-96 <= x <= 2^24
+  const float r = __builtin_amdgcn_rsqf(x);
+  float s = x * r, h = 0.5f * r;
+  const float e = fmaf(-h, s, 0.5f);
+  h = fmaf(h, e, h);
+  s = fmaf(s, e, s);
+  const float d = fmaf(-s, s, x);
+  return fmaf(d, h, s);
 }
 __device__ __forceinline__ float div_rn_inrange(float n, float d) {     // n == 0 or |n| >= 2^-100; d, n/d normal
   float r = __builtin_amdgcn_rcpf(d);
@@ -332,7 +351,7 @@ __device__ __forceinline__ float div_rn_inrange(float n, float d) {     // n == 
 // v*b2^k above 2^-96.
 __device__ __forceinline__ bool catchup_in_range(float m, float v) {
   const float am = fabsf(m);
-  return (am == 0.f || (am >= 0x1p-41f && am <= 0x1p60f)) && (v == 0.f || (v >= 0x1p-80f && v <= 0x1p20f));
+  return (am == 0.f || (am >= 0x1p-41f && am <= 0x1p60f)) && v >= 0x1p-80f && v <= 0x1p20f;   // (v == 0: generic loop)
 }
 // (the bounds above assume the decays of 200 steps stay above 2^-31 and 2^-3: beta1 >= 0.9, beta2 >= 0.99)
 __device__ __forceinline__ bool catchup_params_in_range(int steps, float lr_last, float eps, float b1, float b2) {
@@ -427,6 +446,24 @@ __global__ __launch_bounds__(kBlock) void sparse_catchup_k(
   // of this kernel's HBM traffic.
   // every lane of the group has read last_step[r] above (same wave, program order) before lane 0 writes
   if (l == 0 && !defer_slots) last_step[r * st] = step_to;
+}
+
+// The proof obligation of sqrt_rn_inrange: the same bits as hipcc's correctly rounded sqrtf for every value it is given.
+// One thread per fp32 bit pattern; wave-reduced counts.
+__global__ __launch_bounds__(kBlock) void selftest_sqrt_k(uint32_t first_bits, int64_t count, unsigned long long* __restrict__ mism) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  bool bad_fast = false, bad_fixup = false;
+  if (i < count) {
+    const float x = __uint_as_float(first_bits + static_cast<uint32_t>(i));
+    const uint32_t ref = __float_as_uint(sqrtf(x));
+    bad_fast = __float_as_uint(sqrt_rn_inrange(x)) != ref;
+    bad_fixup = __float_as_uint(sqrt_rn_fixup(x)) != ref;
+  }
+  const unsigned long long bf = __ballot(bad_fast), bx = __ballot(bad_fixup);
+  if ((threadIdx.x & 63) == 0) {
+    if (bf) atomicAdd(mism, static_cast<unsigned long long>(__popcll(bf)));
+    if (bx) atomicAdd(mism + 1, static_cast<unsigned long long>(__popcll(bx)));
+  }
 }
 
 // key[u] = number of steps row uniq_rows[u] has to be replayed over (clamped to 62), 63 for the slots past
@@ -644,6 +681,18 @@ int32_t mi_entry_grads_segsum(const float* rows, const int32_t* seg_start, const
     MI_DISPATCH_LPR(lpr, (sparse_apply_long_k<L, true, true><<<dim3(long_grid(u_count)), dim3(kBlock), 0, mi::as_stream(stream)>>>(a, h, fg)));
     MI_CHECK_LAUNCH("entry_grads_segsum(long segments)");
   }
+  return MI_OK;
+}
+
+int32_t mi_selftest_sqrt(uint32_t first_bits, int64_t count, uint64_t* mismatches, mi_stream_t stream) {
+  MI_REQUIRE(count >= 0 && static_cast<uint64_t>(first_bits) + static_cast<uint64_t>(count) <= (1ull << 32), "selftest_sqrt: range leaves 32 bits");
+  if (count == 0) return MI_OK;
+  MI_REQUIRE(mismatches, "selftest_sqrt: null buffer");
+  const int64_t blocks = mi::ceil_div(count, kBlock);
+  MI_REQUIRE(blocks <= INT32_MAX, "selftest_sqrt: grid too large");
+  selftest_sqrt_k<<<dim3((unsigned)blocks), dim3(kBlock), 0, mi::as_stream(stream)>>>(
+      first_bits, count, reinterpret_cast<unsigned long long*>(mismatches));
+  MI_CHECK_LAUNCH("selftest_sqrt");
   return MI_OK;
 }
 

@@ -16,7 +16,7 @@ import torch  # noqa: F401  (loads the HIP runtime this library must share)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmi355x_rec.so")
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 
 class MiError(RuntimeError):
@@ -50,7 +50,7 @@ class WeightJob(C.Structure):
 
 
 _p = C.c_void_p
-_i32, _i64, _u64, _f32, _sz = C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_size_t
+_i32, _i64, _u32, _u64, _f32, _sz = C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_float, C.c_size_t
 _amax = C.POINTER(GemmAmax)
 _pl = C.POINTER(Planes)
 
@@ -93,6 +93,7 @@ SIGNATURES = {
                                      _i32, _i32, C.POINTER(OptHparams), _i32, _p]),
     "mi_dense_fwd_gathered": (_i32, [_p, _p, _p, _i32, _i32, _p, _p, _p, _i64, _i64, _i32, _i32, _f32, _u64, _amax, _p]),
     "mi_dense_bwd_weight_gathered": (_i32, [_p, _p, _p, _i32, _i32, _p, _i64, _p, _p, _i64, _i32, _p, _sz, _amax, _p]),
+    "mi_selftest_sqrt": (_i32, [_u32, _i64, _p, _p]),
     "mi_catchup_gap_keys": (_i32, [_p, _p, _p, _i64, _i32, _p, _i32, _p]),
     "mi_catchup_rows_by_gap": (_i32, [_p, _p, _p, _i64, _i32, _i32, _p, _p, _sz, _p]),
     "mi_sparse_catchup": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p, _f32, _f32,
