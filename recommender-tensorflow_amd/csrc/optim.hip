@@ -171,17 +171,38 @@ __device__ __forceinline__ void seg_accumulate(const ApplyArgs& a, const FusedGr
 // is older than step - 1 (mi_sparse_catchup ran with defer_slots: it moved w only) first get the
 // decay of m and v for the steps they sat out — the same multiply chain the catch-up ran, hence
 // the same bits; a fully caught-up row (stamp == step - 1) and a never-applied one (m = v = 0) skip it.
-__device__ __forceinline__ void apply_row(const ApplyArgs& a, const Hp& h, int64_t r, int l, bool lane_on, float4 w,
-                                          const float4& g, float gl) {
-  int missed = 0;
-  if (h.kind == MI_OPT_ADAM && a.last_step) {
-    const int ls = a.last_step[r * a.ls];
-    missed = ls > 0 ? max(0, a.step - 1 - ls) : 0;
-  }
+// A row's optimizer state, loaded BEFORE its gradient is summed: the loads depend on the row id only, and issued next
+// to the load of w they are in flight while the segment's entries are fetched (sorted_entry -> d_concat, two dependent
+// latencies) instead of starting after them — the kernel is bound by bytes in flight per wave (its time scales with
+// occupancy), not by issue.
+struct RowState { float4 s0, s1; float lw, ls0, ls1; int stamp; };
+__device__ __forceinline__ RowState load_row_state(const ApplyArgs& a, const Hp& h, int64_t r, int l, bool lane_on) {
+  RowState q;
+  q.s0 = q.s1 = make_float4(0.f, 0.f, 0.f, 0.f);
+  q.lw = q.ls0 = q.ls1 = 0.f;
+  q.stamp = 0;
   if (a.table && lane_on) {
     const int64_t o = r * a.E + 4 * l;
-    float4 s0 = a.t0 ? ld4_nt(a.t0 + o) : make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 s1 = a.t1 ? ld4_nt(a.t1 + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.t0) q.s0 = ld4_nt(a.t0 + o);
+    if (a.t1) q.s1 = ld4_nt(a.t1 + o);
+  }
+  if (h.kind == MI_OPT_ADAM && a.last_step) q.stamp = a.last_step[r * a.ls];
+  if (l == 0 && a.lin_w) {
+    const int64_t o = r * a.ls;
+    q.lw = a.lin_w[o];
+    if (a.l0) q.ls0 = a.l0[o];
+    if (a.l1) q.ls1 = a.l1[o];
+  }
+  return q;
+}
+
+__device__ __forceinline__ void apply_row(const ApplyArgs& a, const Hp& h, int64_t r, int l, bool lane_on, float4 w,
+                                          const float4& g, float gl, const RowState& q) {
+  int missed = 0;
+  if (h.kind == MI_OPT_ADAM && a.last_step) missed = q.stamp > 0 ? max(0, a.step - 1 - q.stamp) : 0;
+  if (a.table && lane_on) {
+    const int64_t o = r * a.E + 4 * l;
+    float4 s0 = q.s0, s1 = q.s1;
     for (int j = 0; j < missed; ++j) {
       s0.x = s0.x * h.beta1; s0.y = s0.y * h.beta1; s0.z = s0.z * h.beta1; s0.w = s0.w * h.beta1;
       s1.x = s1.x * h.beta2; s1.y = s1.y * h.beta2; s1.z = s1.z * h.beta2; s1.w = s1.w * h.beta2;
@@ -197,7 +218,7 @@ __device__ __forceinline__ void apply_row(const ApplyArgs& a, const Hp& h, int64
   if (l == 0) {
     if (a.lin_w) {
       const int64_t o = r * a.ls;
-      float lw = a.lin_w[o], s0 = a.l0 ? a.l0[o] : 0.f, s1 = a.l1 ? a.l1[o] : 0.f;
+      float lw = q.lw, s0 = q.ls0, s1 = q.ls1;
       for (int j = 0; j < missed; ++j) { s0 = s0 * h.beta1; s1 = s1 * h.beta2; }
       sparse_rule(h, lw, s0, s1, gl);
       a.lin_w[o] = lw;
@@ -229,9 +250,11 @@ __global__ __launch_bounds__(kBlock) void sparse_apply_k(ApplyArgs a, Hp h, cons
   float gl = 0.f;
   float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
   if (a.table && lane_on) w = ld4(a.table + r * a.E + 4 * l);
+  RowState q;
+  if constexpr (!STORE) q = load_row_state(a, h, r, l, lane_on);
   seg_accumulate<FUSED>(a, fg, s_beg, s_end, l, lane_on, w, g, gl);
   if constexpr (STORE) store_row(a, u, l, lane_on, g, gl);
-  else apply_row(a, h, r, l, lane_on, w, g, gl);
+  else apply_row(a, h, r, l, lane_on, w, g, gl, q);
 }
 
 // Rows with more than kLongSeg entries: a workgroup per row.  Workgroup j looks at the rows
@@ -283,7 +306,7 @@ __global__ __launch_bounds__(kBlock) void sparse_apply_long_k(ApplyArgs a, Hp h,
           gl += part_l[q];
         }
         if constexpr (STORE) store_row(a, uu, l, lane_on, g, gl);
-        else apply_row(a, h, r, l, lane_on, w, g, gl);
+        else apply_row(a, h, r, l, lane_on, w, g, gl, load_row_state(a, h, r, l, lane_on));
       }
       __syncthreads();
     }
