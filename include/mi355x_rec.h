@@ -40,7 +40,7 @@ enum mi_status {
 };
 
 /* ---- library ---------------------------------------------------------------------------- */
-int32_t mi_abi_version(void);       /* bumps when a signature changes (currently 14) */
+int32_t mi_abi_version(void);       /* bumps when a signature changes (currently 15) */
 const char* mi_last_error(void);    /* thread-local, never NULL */
 const char* mi_build_info(void);    /* "gfx950 hipcc <ver>" */
 
@@ -505,6 +505,14 @@ int32_t mi_sigmoid_ce_head(const float* lin, const float* lin_bias, const float*
                            const float* dnn, const uint8_t* labels, int64_t B, float loss_scale,
                            float* logits, float* loss_out, float* d_logit, float* d_logit_sum,
                            void* workspace, size_t workspace_bytes, mi_stream_t stream);
+
+/* The head's per-example outputs: get_binary_predictions (model_utils.py:9-20; the PREDICT dict of
+ * binary_classification_head) and get_binary_losses' unreduced loss (model_utils.py:23-36).
+ *   logistic[b] = sigmoid(x)   probabilities[b] = {1 - p, p}   class_ids[b] = p > 0.5   (int64, as TF's)
+ *   unreduced_loss[b] = max(x,0) - x*y + log1p(exp(-|x|))      (needs labels)
+ * Any output may be NULL. */
+int32_t mi_binary_predictions(const float* logits, const uint8_t* labels, int64_t B, float* logistic,
+                              float* probabilities, int64_t* class_ids, float* unreduced_loss, mi_stream_t stream);
 
 /* column sums: out[j] = sum_b X[b,j] (used for bias-style gradients), deterministic. */
 size_t mi_colsum_workspace_bytes(int64_t M, int32_t N);

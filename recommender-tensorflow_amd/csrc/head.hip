@@ -304,7 +304,36 @@ __global__ __launch_bounds__(256) void layer_histogram_k(const float* __restrict
     atomicAdd(sums + 1, (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]));
   }
 }
+// get_binary_predictions / get_binary_losses (model_utils.py:9-36): per-example outputs of the head
+__global__ __launch_bounds__(kBlock) void binary_predictions_k(const float* __restrict__ logits, const uint8_t* __restrict__ labels,
+                                                               int64_t B, float* __restrict__ logistic,
+                                                               float* __restrict__ probabilities, int64_t* __restrict__ class_ids,
+                                                               float* __restrict__ unreduced_loss) {
+  const int64_t b = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (b >= B) return;
+  const float x = logits[b];
+  const float p = sigmoid_stable(x);
+  if (logistic) logistic[b] = p;
+  if (probabilities) { probabilities[2 * b] = 1.f - p; probabilities[2 * b + 1] = p; }
+  if (class_ids) class_ids[b] = p > 0.5f ? 1 : 0;
+  if (unreduced_loss) {
+    const float y = labels[b] ? 1.f : 0.f;
+    unreduced_loss[b] = fmaxf(x, 0.f) - x * y + log1pf(expf(-fabsf(x)));
+  }
+}
 }  // namespace
+
+extern "C" int32_t mi_binary_predictions(const float* logits, const uint8_t* labels, int64_t B, float* logistic,
+                                         float* probabilities, int64_t* class_ids, float* unreduced_loss, mi_stream_t stream) {
+  MI_REQUIRE(B >= 0, "binary_predictions: B=%lld", (long long)B);
+  if (B == 0) return MI_OK;
+  MI_REQUIRE(logits && (logistic || probabilities || class_ids || unreduced_loss), "binary_predictions: null buffer");
+  MI_REQUIRE(!unreduced_loss || labels, "binary_predictions: the per-example loss needs labels");
+  binary_predictions_k<<<dim3((unsigned)mi::ceil_div(B, kBlock)), dim3(kBlock), 0, mi::as_stream(stream)>>>(
+      logits, labels, B, logistic, probabilities, class_ids, unreduced_loss);
+  MI_CHECK_LAUNCH("binary_predictions");
+  return MI_OK;
+}
 
 extern "C" int32_t mi_layer_histogram(const float* x, int64_t n, const double* limits, int32_t n_limits, int64_t* counts,
                                       double* sums, mi_stream_t stream) {

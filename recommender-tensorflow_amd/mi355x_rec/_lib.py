@@ -16,7 +16,7 @@ import torch  # noqa: F401  (loads the HIP runtime this library must share)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmi355x_rec.so")
 
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 
 class MiError(RuntimeError):
@@ -121,6 +121,7 @@ SIGNATURES = {
     "mi_colsum": (_i32, [_p, _i64, _i64, _i32, _p, _p, _sz, _p]),
     "mi_layer_stats_workspace_bytes": (_sz, [_i64]),
     "mi_layer_stats": (_i32, [_p, _i64, _p, _p, _sz, _p]),
+    "mi_binary_predictions": (_i32, [_p, _p, _i64, _p, _p, _p, _p, _p]),
     "mi_layer_histogram": (_i32, [_p, _i64, _p, _i32, _p, _p, _p]),
     "mi_eval_accumulate": (_i32, [_p, _p, _i64, _p, _p, _p, _p]),
 }

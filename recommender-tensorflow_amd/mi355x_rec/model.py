@@ -11,13 +11,15 @@ from .feature_column import FieldPlan
 from .metrics import metrics_from_counters
 
 
-def binary_predictions(logits):
-    """logits [B] -> the head's PREDICT dict (same keys as the TF head)."""
-    x = logits.reshape(-1, 1)
-    p = torch.sigmoid(x)
-    cls = (p > 0.5).to(torch.int64)
-    return {"logits": x, "logistic": p, "probabilities": torch.cat([1 - p, p], 1), "class_ids": cls,
-            "classes": cls}
+def binary_predictions(logits, kernels):
+    """logits [B] -> the head's PREDICT dict (same keys as the TF head): mi_binary_predictions."""
+    x = logits.reshape(-1).contiguous()
+    B = x.numel()
+    p = torch.empty(B, 1, dtype=torch.float32, device=x.device)
+    prob = torch.empty(B, 2, dtype=torch.float32, device=x.device)
+    cls = torch.empty(B, 1, dtype=torch.int64, device=x.device)
+    kernels.mi_binary_predictions(x, None, B, p, prob, cls, None)
+    return {"logits": x.reshape(-1, 1), "logistic": p, "probabilities": prob, "class_ids": cls, "classes": cls}
 
 
 class _EvalCounters:
@@ -85,9 +87,9 @@ def run_batch(features, labels, mode, params, make_engine):
             out["loss"] = float(torch.stack(ctr.batch_losses).mean())     # tf.metrics.mean over batch losses
             return out
         store["metrics_result"] = result
-        return EstimatorSpec(mode, predictions=binary_predictions(logits), loss=loss, eval_metric_ops=result)
+        return EstimatorSpec(mode, predictions=binary_predictions(logits, eng.k), loss=loss, eval_metric_ops=result)
     if mode == ModeKeys.PREDICT:
         logits = eng.predict_logits(ids, x)
-        pr = binary_predictions(logits.clone())
+        pr = binary_predictions(logits.clone(), eng.k)
         return EstimatorSpec(mode, predictions=pr, export_outputs={"predict": pr})
     raise ValueError("unknown mode %r" % (mode,))

@@ -32,15 +32,21 @@ def layer_summary(value):
 
 
 def get_binary_predictions(logits):
-    logistic = torch.sigmoid(logits)
+    x = logits.reshape(-1).contiguous()
+    logistic = torch.empty_like(x)
+    cls = torch.empty(x.numel(), dtype=torch.int64, device=x.device)
+    HipKernels().mi_binary_predictions(x, None, x.numel(), logistic, None, cls, None)
+    logistic = logistic.reshape(logits.shape)
     return {"logits": logits, "logistic": logistic, "probabilities": logistic,
-            "class_id": (logistic > 0.5).to(torch.int32)}
+            "class_id": cls.reshape(logits.shape).to(torch.int32)}
 
 
 def get_binary_losses(labels, predictions):
-    x = predictions["logits"].reshape(-1)
-    y = labels.reshape(-1).to(x.dtype)
-    unreduced = torch.clamp(x, min=0) - x * y + torch.log1p(torch.exp(-x.abs()))
+    x = predictions["logits"].reshape(-1).contiguous()
+    y = labels.reshape(-1).to(torch.uint8).contiguous()
+    unreduced = torch.empty_like(x)
+    HipKernels().mi_binary_predictions(x, y, x.numel(), None, None, None, unreduced)
+    # (the two reductions of model_utils.py:28-29; the per-example values come from the library)
     return {"unreduced_loss": unreduced.reshape(-1, 1), "average_loss": unreduced.mean(), "loss": unreduced.sum()}
 
 

@@ -344,6 +344,19 @@ class NumpyKernels:
                              d_rows, d_lin, E, step, hp)
 
     # ---- eval counters --------------------------------------------------------------------------
+    def mi_binary_predictions(self, logits, labels, B, logistic, probabilities, class_ids, unreduced_loss):
+        from oracle import deepfm as O
+        x = _np(logits)[:B]
+        sig = O.predictions(x)["logistic"]
+        if logistic is not None:
+            _np(logistic).reshape(-1)[:B] = sig
+        if probabilities is not None:
+            _np(probabilities).reshape(-1, 2)[:B] = np.stack([1 - sig, sig], 1)
+        if class_ids is not None:
+            _np(class_ids).reshape(-1)[:B] = sig > 0.5
+        if unreduced_loss is not None:
+            _np(unreduced_loss).reshape(-1)[:B] = O.head(x, _np(labels)[:B])[2]
+
     def mi_layer_stats(self, x, n, out4, ws, wsb):
         v = _np(x).reshape(-1)[:n]
         _np(out4)[:4] = [np.mean(v == 0), v.min(), v.max(), v.mean()]

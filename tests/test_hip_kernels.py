@@ -579,6 +579,30 @@ def test_sigmoid_ce_head(lib, B):
     assert np.array_equal(logits.cpu().numpy(), fm)
 
 
+def test_binary_predictions_match_oracle(lib):
+    """mi_binary_predictions: get_binary_predictions / get_binary_losses (model_utils.py:9-36) per example."""
+    rng = np.random.default_rng(5)
+    B = 4099
+    x = np.concatenate([rng.standard_normal(B - 6) * 6, [0.0, -0.0, 40.0, -40.0, 100.0, -100.0]]).astype(np.float32)
+    y = (rng.random(B) < 0.4).astype(np.uint8)
+    dx, dy = dev(x), dev(y)
+    p = torch.empty(B, device="cuda"); pr = torch.empty(B, 2, device="cuda")
+    cls = torch.empty(B, dtype=torch.int64, device="cuda"); ul = torch.empty(B, device="cuda")
+    _chk(lib.mi_binary_predictions(_p(dx), _p(dy), B, _p(p), _p(pr), _p(cls), _p(ul), _st()))
+    x64 = x.astype(np.float64)
+    o = O.predictions(x64)
+    assert np.max(np.abs(p.cpu().numpy() - o["logistic"])) < 1e-7
+    assert np.array_equal(pr.cpu().numpy()[:, 1], p.cpu().numpy()) and np.max(np.abs(pr.cpu().numpy().sum(1) - 1)) < 1e-7
+    assert np.array_equal(cls.cpu().numpy(), (p.cpu().numpy() > 0.5).astype(np.int64))
+    near = np.abs(x) > 1e-6                                  # (class at x == 0 is p > 0.5 = False, as TF's)
+    assert np.array_equal(cls.cpu().numpy()[near], o["class_id"][near]) and cls.cpu().numpy()[B - 6] == 0
+    per = O.head(x64, y)[2]
+    assert np.max(np.abs(ul.cpu().numpy() - per) / (1 + per)) < 1e-6
+    # outputs are optional; the per-example loss needs labels
+    _chk(lib.mi_binary_predictions(_p(dx), None, B, _p(p), None, None, None, _st()))
+    assert lib.mi_binary_predictions(_p(dx), None, B, None, None, None, _p(ul), _st()) != 0
+
+
 @pytest.mark.parametrize("n,R", [(1, 10), (100, 7), (5000, 300), (70000, 4106), (200000, 26_000_000), (4097, 65536)])
 def test_sort_unique_rows(lib, n, R):
     rng = np.random.default_rng(n + R)
