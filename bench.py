@@ -65,6 +65,10 @@ def parse():
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: 65536 examples per GPU (default); strong: 65536 examples over all GPUs")
+    ap.add_argument("--force-shard", action="store_true",
+                    help="N = 1 only: run the row-sharded multi-GPU step with a one-rank RCCL group (every all_to_all is a "
+                         "copy to self) — what the sharded step's own machinery costs next to the single-GPU step")
+    ap.add_argument("--chunks", type=int, default=None, help="pipeline depth of the row-sharded step (default: parallel.py's)")
     ap.add_argument("--gemm", choices=["f16x2", "bf16x3", "fp32"], default="f16x2", help="matrix-pipe path of the MLP GEMMs")
     return ap.parse_args()
 
@@ -194,6 +198,10 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
+    if world == 1 and args.force_shard:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(args.backend, init_method="tcp://127.0.0.1:%d" % (29600 + os.getpid() % 300), rank=0,
+                                world_size=1, **({"device_id": device} if args.backend == "nccl" else {}))
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.backend == "nccl":
@@ -204,15 +212,15 @@ def main():
     from mi355x_rec.engine import DeepFM, OptimizerSpec
     B = B_FULL if args.scaling == "weak" else B_FULL // world      # examples per GPU and step
     shard = None
-    if world > 1:
+    if world > 1 or args.force_shard:
         from mi355x_rec.parallel import RowShard
-        shard = RowShard(rank, world)
+        shard = RowShard(rank, world, chunks=args.chunks)
     m = DeepFM([V] * F, embedding_size=E, hidden_units=HIDDEN, dropout=DROPOUT,
                optimizer=OptimizerSpec("Adam", 0.001), device=device, seed=SEED, shard=shard, gemm=args.gemm)
     gen = torch.Generator(device=device)
     gen.manual_seed(SEED + rank)
     m.init_variables(gen, lin_scale=1e-3)
-    if world > 1:
+    if shard is not None:
         from mi355x_rec.parallel import broadcast_dense
         broadcast_dense(m)                       # replicated MLP must start identical on every rank
     # A fresh batch every step, as in training on a real dataset: which rows sit out how many steps
@@ -302,7 +310,7 @@ def main():
 
     # what the matrix-pipe path and the exact-Adam semantics cost (single GPU, short legs after the headline)
     extras = {}
-    if world == 1 and not args.no_extras:
+    if world == 1 and not args.no_extras and not args.force_shard:
         # the same step replayed as ONE hipGraph launch (engine.graph_train_step): what the ~50 launch gaps cost.
         # Not the headline: the per-kernel HIP events of `roofline` / `kernel_ms_per_step` cannot sit inside a replay.
         def run_graph(nsteps):
@@ -393,7 +401,7 @@ def main():
                        "gemm": {"f16x2": "fp32 GEMMs via scaled fp16 high+low operand split, fp32 accumulate",
                                 "bf16x3": "fp32 GEMMs via 3-way bf16 operand split, fp32 accumulate",
                                 "fp32": "fp32-input MFMA"}[args.gemm],
-                       "parallelism": "dp%d + row-sharded embeddings (all-to-all)" % world if world > 1 else "single GPU"},
+                       "parallelism": "dp%d + row-sharded embeddings (all-to-all)" % world if (world > 1 or args.force_shard) else "single GPU"},
             "roofline": {"kernel": ("embed_fm_planes_fwd_k: embedding gather + FM second order, writes the input_layer concat as fp16 "
                                     "high/low planes with one exponent per example (the operand of the layer-1 GEMMs); the wide part's "
                                     "4-byte gathers run as linear_only_fwd_k on a side stream" if planes_gather else

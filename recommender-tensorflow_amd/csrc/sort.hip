@@ -579,16 +579,29 @@ __global__ __launch_bounds__(kBlock) void shard_keys_k(const int32_t* __restrict
   keys[i] = static_cast<int32_t>((chunk * world + r % world) * rows_per_rank + r / world);
 }
 
-// per distinct request u: the owner-local row to ask for, and the request counts per (chunk, owner) group
+// per distinct request u: the owner-local row to ask for, and the request counts per (chunk, owner) group.
+// The keys are sorted, so a group is one contiguous run: its count is (index of the first key past it) - (index of its
+// first key), and only the two threads at a run's ends touch counts[] — O(groups) atomics.  (One atomicAdd per request on
+// the group's counter, as this kernel first did, serialises 1.7 M atomics on C x world addresses: 19 ms per step with
+// one rank and 4 chunks, measured with bench.py --force-shard.)
 __global__ __launch_bounds__(kBlock) void route_requests_k(const int32_t* __restrict__ uniq_keys,
                                                            const int32_t* __restrict__ num_uniq, int64_t rows_per_rank,
                                                            int32_t* __restrict__ send_rows, int32_t* __restrict__ counts) {
   const int64_t u = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
-  if (u >= *num_uniq) return;
+  const int64_t U = *num_uniq;
+  if (u >= U) return;
   const int64_t key = uniq_keys[u];
   const int64_t grp = key / rows_per_rank;
   send_rows[u] = static_cast<int32_t>(key - grp * rows_per_rank);
-  atomicAdd(counts + grp, 1);
+  if (u + 1 == U) {
+    atomicAdd(counts + grp, static_cast<int32_t>(U));                   // the last run ends at U
+  } else {
+    const int64_t gn = static_cast<int64_t>(uniq_keys[u + 1]) / rows_per_rank;
+    if (gn != grp) {                                                    // run of grp ends, run of gn starts, at u + 1
+      atomicAdd(counts + grp, static_cast<int32_t>(u + 1));
+      atomicAdd(counts + gn, -static_cast<int32_t>(u + 1));
+    }
+  }
 }
 
 // slot[e] = index of the distinct request that entry e belongs to (binary search of the sorted position in

@@ -33,7 +33,7 @@ import torch.distributed as dist
 
 class RowShard:
     def __init__(self, rank, world, group=None, chunks=None):
-        """chunks: pipeline depth of a train step (None: 4 from 16384 examples per rank, 2 from 2048)."""
+        """chunks: pipeline depth of a train step (None: chosen from the batch and world size, see _n_chunks)."""
         if not (0 <= rank < world):
             raise ValueError("rank %d not in [0, %d)" % (rank, world))
         self.rank, self.world, self.group = int(rank), int(world), group
@@ -127,7 +127,14 @@ def _n_chunks(m, B, train):
         return 1
     c = m.shard.chunks
     if c is None:
-        c = 4 if B >= 16384 else (2 if B >= 2048 else 1)
+        # A chunk is the M of every MLP GEMM: below 32768 examples their grids no longer cover the 256 CUs (128-row
+        # tiles; measured with one rank, bench.py --force-shard, B = 65536: 5.2 / 5.9 / 7.0 ms per step with 1 / 2 / 4
+        # chunks — GEMMs 1.5 / 1.8 / 2.6 ms).  What a chunk buys is exchange time hidden under compute, (1 - 1/C) of it;
+        # xGMI is point to point, so a rank's 7/8 x 436 MB per direction share 7 links at 8 ranks but 218 MB share ONE
+        # link at 2: small worlds are exchange-bound and take the smaller chunks.  (Estimated, not measured: no
+        # multi-GPU box in this pool.)
+        size = 16384 if m.shard.world <= 4 else 32768
+        c = min(4, B // size) if B >= 2 * size else (2 if 2048 <= B < 16384 else 1)
     c = max(1, min(int(c), B))
     while B % c:
         c -= 1

@@ -579,6 +579,28 @@ def test_sigmoid_ce_head(lib, B):
     assert np.array_equal(logits.cpu().numpy(), fm)
 
 
+@pytest.mark.parametrize("U,n_groups,Rl", [(1, 1, 10), (5000, 4, 4000), (200000, 32, 50000), (70000, 7, 123457), (300, 64, 9)])
+def test_route_requests_counts_runs_of_sorted_keys(lib, U, n_groups, Rl):
+    """mi_route_requests: send_rows[u] = key % rows_per_rank, counts[g] = number of distinct keys of group
+    g = key // rows_per_rank — from the ends of the runs of the SORTED keys (empty groups in front, in between and at the
+    end; slots past *num_uniq are not looked at)."""
+    rng = np.random.default_rng(U + n_groups)
+    live = rng.random(n_groups) < 0.7 if n_groups > 2 else np.ones(n_groups, bool)     # some groups get no request
+    if not live.any():
+        live[n_groups // 2] = True
+    g = rng.choice(np.flatnonzero(live), U)
+    keys = np.unique(g.astype(np.int64) * Rl + rng.integers(0, Rl, U)).astype(np.int32)  # sorted, distinct
+    u = len(keys)
+    n_max = u + 37
+    buf = np.concatenate([keys, np.full(37, 2 ** 31 - 1, np.int32)])
+    dk, dn = dev(buf), dev(np.array([u], np.int32))
+    send = torch.full((n_max,), -1, dtype=torch.int32, device="cuda")
+    counts = torch.full((n_groups,), 12345, dtype=torch.int32, device="cuda")                 # the entry zeroes them itself
+    _chk(lib.mi_route_requests(_p(dk), _p(dn), n_max, Rl, n_groups, _p(send), _p(counts), _st()))
+    assert np.array_equal(send.cpu().numpy()[:u], keys % Rl) and np.all(send.cpu().numpy()[u:] == -1)
+    assert np.array_equal(counts.cpu().numpy(), np.bincount(keys // Rl, minlength=n_groups))
+
+
 def test_binary_predictions_match_oracle(lib):
     """mi_binary_predictions: get_binary_predictions / get_binary_losses (model_utils.py:9-36) per example."""
     rng = np.random.default_rng(5)
