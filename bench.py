@@ -69,6 +69,9 @@ def parse():
                     help="N = 1 only: run the row-sharded multi-GPU step with a one-rank RCCL group (every all_to_all is a "
                          "copy to self) — what the sharded step's own machinery costs next to the single-GPU step")
     ap.add_argument("--chunks", type=int, default=None, help="pipeline depth of the row-sharded step (default: parallel.py's)")
+    ap.add_argument("--no-presort", action="store_true",
+                    help="do not announce the next batch's ids to train_step (its sort then runs at the head of the next step "
+                         "instead of on a side stream beside this step's catch-up)")
     ap.add_argument("--gemm", choices=["f16x2", "bf16x3", "fp32"], default="f16x2", help="matrix-pipe path of the MLP GEMMs")
     return ap.parse_args()
 
@@ -245,12 +248,19 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # The ids of step t + 1 are known while step t runs (all batches exist before the timed region; a real input pipeline
+    # prefetches: tf.data in ml_100k.py:42-61).  They are announced to train_step, which sorts them on a side stream
+    # beside step t's VALU-bound catch-up (~14 small launch-bound kernels that leave most of the chip idle) instead of at
+    # the head of step t + 1.  All of a step's work still happens inside the timed region — K timed steps run K sorts —
+    # and the results are bitwise those of the plain sequence (tests/test_hip_model.py).  Single GPU only.
+    presort = [world == 1 and shard is None and not args.no_presort]
+
     def run(nsteps):
         out = None
         for _ in range(nsteps):
             ids, y = batches[cursor[0] % len(batches)]
             cursor[0] += 1
-            out = m.train_step(ids, y)
+            out = m.train_step(ids, y, next_ids=batches[cursor[0] % len(batches)][0] if presort[0] else None)
         return out
 
     def timed(nsteps):
@@ -401,7 +411,9 @@ def main():
                        "gemm": {"f16x2": "fp32 GEMMs via scaled fp16 high+low operand split, fp32 accumulate",
                                 "bf16x3": "fp32 GEMMs via 3-way bf16 operand split, fp32 accumulate",
                                 "fp32": "fp32-input MFMA"}[args.gemm],
-                       "parallelism": "dp%d + row-sharded embeddings (all-to-all)" % world if (world > 1 or args.force_shard) else "single GPU"},
+                       "parallelism": "dp%d + row-sharded embeddings (all-to-all)" % world if (world > 1 or args.force_shard) else "single GPU",
+                       "input_pipeline": ("next batch's ids announced one step ahead (train_step(next_ids=...)): their sort runs on a "
+                                          "side stream beside this step's catch-up" if presort[0] else "ids handed over step by step")},
             "roofline": {"kernel": ("embed_fm_planes_fwd_k: embedding gather + FM second order, writes the input_layer concat as fp16 "
                                     "high/low planes with one exponent per example (the operand of the layer-1 GEMMs); the wide part's "
                                     "4-byte gathers run as linear_only_fwd_k on a side stream" if planes_gather else

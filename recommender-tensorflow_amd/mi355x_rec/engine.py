@@ -311,6 +311,7 @@ class DeepFM:
             self.dl_s0, self.dl_s1 = self._slots(self.dense, self.lin_opt)
         self._ws = {}
         self._final_step = 0
+        self._presorted = None
         # Without numeric columns layer 1 of the MLP reads its input straight from the embedding table
         # (multi-GPU: from the receive buffer of the row exchange) as a gathered GEMM operand and the
         # concat [B, F*E] is never materialised.
@@ -733,13 +734,51 @@ class DeepFM:
         self.k.mi_sort_unique_rows(keys, n, key_range, sorted_entry, uniq, seg, num_uniq, ws, ws.numel())
         return sorted_entry, uniq, seg, num_uniq
 
-    def train_step(self, ids, labels, x_num=None):
-        """One optimizer.minimize(loss): returns (loss [1], logits [B]) device tensors, no host sync."""
+    PRESORT_MIN = 16384       # entries from which sorting the next batch beside this step's catch-up pays
+
+    def _sort_batch(self, ids, tag, side=False):
+        """(1) of a train step: which rows does a batch touch — sort + unique (TF: unique / unsorted_segment_sum) into
+        the persistent buffers named after `tag`.  Returns (sorted_entry, uniq, seg, num_uniq)."""
+        k = self.k
+        B = ids.shape[0]
+        n = B * self.F
+        if B % 4096 == 0 and self.F <= 64 and hasattr(k, "mi_sort_unique_fields"):
+            # every field's ids sorted on their own: the radix passes cover a field's id range, not the whole table
+            i32 = torch.int32
+            sorted_entry, uniq = self._buf(tag + "_sorted", (n,), i32), self._buf(tag + "_uniq", (n,), i32)
+            seg, num_uniq = self._buf(tag + "_seg", (n + 1,), i32), self._buf(tag + "_nu", (1,), i32)
+            ws = self._bytes("sortf_ws", k.query("mi_sort_unique_fields_workspace_bytes", B, self.F))
+            sort = k.tagged("mi_sort_unique_fields", "/next batch, side stream") if (side and hasattr(k, "tagged")) else k.mi_sort_unique_fields
+            sort(ids, self.field_off, B, self.F, self.max_vocab, sorted_entry, uniq, seg, num_uniq, ws, ws.numel())
+            return sorted_entry, uniq, seg, num_uniq
+        rows = self._buf("rows", (n,), torch.int32)
+        k.mi_global_rows(ids, self.field_off, B, self.F, rows)
+        return self._sort_unique(rows, n, self.R, tag)
+
+    def _presort(self, next_ids, tag):
+        """The sort of the NEXT batch, on a side stream, enqueued right before this step's catch-up: a pure function of
+        next_ids (no model state), made of ~14 small launches that are bound by launch latency and leave most of the
+        chip idle (0.17 ms at config 3) — beside the VALU-bound catch-up they cost nothing.  The result is used by the
+        next train_step if it is given that very tensor, unmodified; otherwise it is dropped."""
+        side = self._ws.get("presort_stream")
+        if side is None:
+            side = self._ws["presort_stream"] = torch.cuda.Stream(device=self.device)
+        main = torch.cuda.current_stream()
+        side.wait_stream(main)                       # next_ids exists, this step's own sort has left the shared workspace
+        with torch.cuda.stream(side):
+            out = self._sort_batch(next_ids, tag, side=True)
+        # (the tensor itself is kept: while it is alive its memory cannot come back as another batch's)
+        self._presorted = {"ids": next_ids, "version": next_ids._version, "tag": tag, "sorted": out, "stream": side}
+
+    def train_step(self, ids, labels, x_num=None, next_ids=None):
+        """One optimizer.minimize(loss): returns (loss [1], logits [B]) device tensors, no host sync.
+        next_ids (optional): the ids of the batch the NEXT call will be given — an input pipeline knows them (the
+        reference prefetches its tf.data batches, ml_100k.py:42-61).  Their sort then runs beside this step's catch-up
+        (see _presort) instead of at the head of the next step.  Results are those of the plain sequence, bit for bit."""
         self._prep(ids, labels, x_num)
         if self.shard is not None:
             from . import parallel
             return parallel.sharded_train_step(self, ids, labels, x_num)
-        k = self.k
         B = ids.shape[0]
         n = B * self.F
         if n == 0:                       # numeric columns only: no sparse variable exists
@@ -749,18 +788,22 @@ class DeepFM:
             self._apply(None, None, None, None, 0, None, None)
             return loss, logits
         # (1) which rows does this batch touch: sort + unique (TF: unique/unsorted_segment_sum)
-        if B % 4096 == 0 and self.F <= 64 and hasattr(k, "mi_sort_unique_fields"):
-            # every field's ids sorted on their own: the radix passes cover a field's id range, not the whole table
-            i32 = torch.int32
-            sorted_entry, uniq = self._buf("own_sorted", (n,), i32), self._buf("own_uniq", (n,), i32)
-            seg, num_uniq = self._buf("own_seg", (n + 1,), i32), self._buf("own_nu", (1,), i32)
-            ws = self._bytes("sortf_ws", k.query("mi_sort_unique_fields_workspace_bytes", B, self.F))
-            k.mi_sort_unique_fields(ids, self.field_off, B, self.F, self.max_vocab, sorted_entry, uniq, seg, num_uniq,
-                                    ws, ws.numel())
-        else:
-            rows = self._buf("rows", (n,), torch.int32)
-            k.mi_global_rows(ids, self.field_off, B, self.F, rows)
-            sorted_entry, uniq, seg, num_uniq = self._sort_unique(rows, n, self.R, "own")
+        ps, self._presorted = getattr(self, "_presorted", None), None
+        tag = "own"
+        if ps is not None:
+            torch.cuda.current_stream().wait_stream(ps["stream"])       # (also before the workspace is reused below)
+            if ps["ids"].data_ptr() == ids.data_ptr() and ps["ids"].shape == ids.shape and ps["version"] == ids._version:
+                sorted_entry, uniq, seg, num_uniq = ps["sorted"]
+                tag = ps["tag"]
+            else:
+                ps = None
+        if ps is None:
+            sorted_entry, uniq, seg, num_uniq = self._sort_batch(ids, tag)
+        if (next_ids is not None and self.device.type == "cuda" and n >= self.PRESORT_MIN and next_ids.shape == ids.shape
+                and B % 4096 == 0 and self.F <= 64 and hasattr(self.k, "mi_sort_unique_fields")   # (its own workspace)
+                and not getattr(self, "_capturing", False)):
+            self._prep(next_ids, None, x_num)
+            self._presort(next_ids, "own2" if tag == "own" else "own")
         # (2) TF Adam moved these rows on every step they sat out: replay that now
         if self.adam_rows and self.step > 0:
             self._catchup(uniq, num_uniq, n, defer=True)
@@ -963,6 +1006,9 @@ class DeepFM:
     def _capture(self, ids, labels):
         if self.sched is not None:                                      # the lr_t table must not move under the graph
             self.sched.lr_t(self.step + (1 << 20))
+        ps, self._presorted = getattr(self, "_presorted", None), None
+        if ps is not None:                                              # (nothing of another stream inside the capture)
+            torch.cuda.current_stream().wait_stream(ps["stream"])
         state = torch.zeros(16, dtype=torch.uint8, device=self.device)
         self._write_step_state(state)
         g_ids, g_y = ids.clone(), labels.clone()

@@ -351,3 +351,34 @@ def test_graph_train_step_replays_the_eager_step_bitwise(vocab, E, hidden, B):
     assert graph._graph is not None and graph.step == eager.step == 9
     for k in ("table", "t_s0", "t_s1", "lin_state", "dense", "d_s0", "d_s1"):
         assert torch.equal(getattr(eager, k), getattr(graph, k)), k
+
+
+@pytest.mark.parametrize("vocab,E,hidden,B", [([3000, 500, 4000, 50, 2500, 7000], 64, [512, 256, 128], 4096),
+                                              ([2000, 1000, 50, 1000], 4, [16, 16], 8192)])
+def test_presorted_next_batch_is_bitwise_the_plain_step(vocab, E, hidden, B):
+    """train_step(next_ids=...): the next batch's sort runs on a side stream beside this step's catch-up and is picked
+    up by the next call when it is given that very tensor — the same bits as the plain sequence; an announced batch that
+    does not come, or one modified in place after it was announced, is sorted again."""
+    from mi355x_rec.engine import OptimizerSpec
+    p, ids0, x, y = make_problem(13, vocab, E, hidden, B)
+    ms = []
+    for _ in range(2):
+        m = _engine(vocab, E, hidden, dropout=0.1, seed=7, optimizer=OptimizerSpec("Adam", 0.001))
+        m.load_oracle_params(p)
+        ms.append(m)
+    plain, pre = ms
+    rng = np.random.default_rng(4)
+    batches = [dev(np.stack([rng.integers(0, v, B) for v in vocab], 1).astype(np.int32)) for _ in range(9)]
+    ys = dev((rng.random(B) < 0.3).astype(np.uint8))
+    hits = 0
+    for i in range(8):
+        lp, gp = plain.train_step(batches[i], ys)
+        if i == 5:
+            batches[i].add_(0)                                          # in-place touch: the version counter moves
+        hits += pre._presorted is not None and pre._presorted["ids"] is batches[i] and pre._presorted["version"] == batches[i]._version
+        lq, gq = pre.train_step(batches[i], ys, next_ids=batches[i + 1] if i != 3 else batches[0])
+        assert torch.equal(lp, lq) and torch.equal(gp, gq), i
+    assert hits == 5                                                    # steps 1, 2, 3, 6, 7 (0: nothing announced; 4: another batch; 5: touched)
+    plain.finalize_rows(); pre.finalize_rows()
+    for k in ("table", "t_s0", "t_s1", "lin_state", "dense", "d_s0", "d_s1"):
+        assert torch.equal(getattr(plain, k), getattr(pre, k)), k
