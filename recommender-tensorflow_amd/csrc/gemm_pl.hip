@@ -813,7 +813,10 @@ int32_t launch_pl(PlArgs& a, hipStream_t st, const char* what) {
     const int v = atoi(e);
     if ((v == 1 || v == 2 || v == 4) && (!a.Cp || a.N <= 128 * v)) tn = v;
   }
-  const int tm = tn == 4 ? 2 : 4;
+  // 256-row tiles for the narrower column tiles — unless that leaves CUs without a workgroup (a chunk of a multi-GPU
+  // step, a small batch: M = 32768 gives 128 tiles of 256 rows for 256 CUs): then 128 rows, like the 512-column tile
+  int tm = tn == 4 ? 2 : 4;
+  if (tm == 4 && static_cast<int64_t>((a.N + 128 * tn - 1) / (128 * tn)) * ((a.M + 255) / 256) < 256) tm = 2;
   const int bn = 128 * tn, bm = 64 * tm;
   a.tiles_n = (a.N + bn - 1) / bn;
   const int64_t blocks = static_cast<int64_t>(a.tiles_n) * ((a.M + bm - 1) / bm);
@@ -826,8 +829,10 @@ int32_t launch_pl(PlArgs& a, hipStream_t st, const char* what) {
     return MI_ERR_UNSUPPORTED;
   }
   const dim3 g(static_cast<unsigned>(blocks)), b(PL_THREADS);
-  if (tn == 1) gemm_pl_k<1, 4, EPI><<<g, b, 0, st>>>(a);
-  else if (tn == 2) gemm_pl_k<2, 4, EPI><<<g, b, 0, st>>>(a);
+  if (tn == 1 && tm == 4) gemm_pl_k<1, 4, EPI><<<g, b, 0, st>>>(a);
+  else if (tn == 1) gemm_pl_k<1, 2, EPI><<<g, b, 0, st>>>(a);
+  else if (tn == 2 && tm == 4) gemm_pl_k<2, 4, EPI><<<g, b, 0, st>>>(a);
+  else if (tn == 2) gemm_pl_k<2, 2, EPI><<<g, b, 0, st>>>(a);
   else gemm_pl_k<4, 2, EPI><<<g, b, 0, st>>>(a);
   MI_CHECK_LAUNCH(what);
   return MI_OK;

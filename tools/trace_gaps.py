@@ -19,7 +19,7 @@ if len(args) > 1:
         ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "COPY " + r.get("Direction", "")))
 ev.sort()
 # the window: the last win_ms of the trace that contains our sharded-step kernels
-marks = [e for e in ev if "route_requests_k" in e[2] or "sparse_apply_k" in e[2]]
+marks = [e for e in ev if "sparse_apply_k" in e[2]]
 t_end = marks[-1][1]
 if "--end-offset-ms" in sys.argv:
     t_end -= int(float(sys.argv[sys.argv.index("--end-offset-ms") + 1]) * 1e6)
