@@ -12,9 +12,10 @@
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-enum { OP_MUL, OP_SUB, OP_CVTPK, OP_CVTBACK, OP_CVTBACK_SDWA, OP_PKFMA, OP_AND, OP_MOV, OP_LSHLADD64, OP_FMA, OP_CNDMASK, N_OPS };
+enum { OP_MUL, OP_SUB, OP_CVTPK, OP_CVTBACK, OP_CVTBACK_SDWA, OP_PKFMA, OP_AND, OP_MOV, OP_LSHLADD64, OP_FMA, OP_CNDMASK, OP_RSQ, OP_RCP, OP_PKMUL, N_OPS };
 static const char* kNames[] = {"v_mul_f32", "v_sub_f32", "v_cvt_pk_f16_f32", "v_cvt_f32_f16", "v_cvt_f32_f16_sdwa",
-                               "v_pk_fma_f32", "v_and_b32", "v_mov_b32", "v_lshl_add_u64", "v_fma_f32", "v_cndmask_b32"};
+                               "v_pk_fma_f32", "v_and_b32", "v_mov_b32", "v_lshl_add_u64", "v_fma_f32", "v_cndmask_b32",
+                               "v_rsq_f32", "v_rcp_f32", "v_pk_mul_f32"};
 
 template <int OP>
 __device__ __forceinline__ void op1(float& d, float s, double& d64) {
@@ -29,6 +30,9 @@ __device__ __forceinline__ void op1(float& d, float s, double& d64) {
   else if constexpr (OP == OP_LSHLADD64) asm volatile("v_lshl_add_u64 %0, %1, 2, %1" : "=v"(d64) : "v"(d64));
   else if constexpr (OP == OP_FMA) asm volatile("v_fma_f32 %0, %1, %1, %1" : "=v"(d) : "v"(s));
   else if constexpr (OP == OP_CNDMASK) asm volatile("v_cndmask_b32 %0, %1, %1, vcc" : "=v"(d) : "v"(s));
+  else if constexpr (OP == OP_RSQ) asm volatile("v_rsq_f32 %0, %1" : "=v"(d) : "v"(s));
+  else if constexpr (OP == OP_RCP) asm volatile("v_rcp_f32 %0, %1" : "=v"(d) : "v"(s));
+  else if constexpr (OP == OP_PKMUL) asm volatile("v_pk_mul_f32 %0, %1, %1" : "=v"(d64) : "v"(d64));
 }
 
 template <int OP, int NV, bool MFMA>
@@ -85,5 +89,6 @@ int main() {
   printf("floor: MFMA only 1 wave/SIMD %.0f, 2 waves/SIMD %.0f cycles per 8 MFMAs\n", run<OP_MUL, 0, true>(1), run<OP_MUL, 0, true>(2));
   row<OP_MUL>(); row<OP_SUB>(); row<OP_FMA>(); row<OP_CVTPK>(); row<OP_CVTBACK>(); row<OP_CVTBACK_SDWA>(); row<OP_PKFMA>();
   row<OP_AND>(); row<OP_MOV>(); row<OP_LSHLADD64>(); row<OP_CNDMASK>();
+  row<OP_RSQ>(); row<OP_RCP>(); row<OP_PKMUL>();      // the replay loop's quarter-rate and packed instructions
   return 0;
 }
