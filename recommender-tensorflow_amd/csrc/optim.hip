@@ -332,7 +332,7 @@ __device__ __forceinline__ void replay(float& w, float& m, float& v, int s_from,
 // catchup_in_range() is the (generous) condition under which a WAVE takes them (all its lanes in
 // range: a wave never runs both loops); otherwise it runs sqrtf and '/'.
 // sqrt, first form: v_sqrt_f32 + the one-ulp residual test (what hipcc emits for sqrtf, minus the range scaling): 2 integer
-// adds, 2 FMAs, 2 compares and 2 selects per element after the quarter-rate instruction — only the FMAs pack.
+// adds, 2 FMAs, 2 compares and 2 selects per element after the transcendental instruction — only the FMAs pack.
 __device__ __forceinline__ float sqrt_rn_fixup(float x) {              // x == 0 or x >= 2^-96
   float s = __builtin_amdgcn_sqrtf(x);
   const float sm = __uint_as_float(__float_as_uint(s) - 1u), sp = __uint_as_float(__float_as_uint(s) + 1u);
@@ -344,7 +344,7 @@ __device__ __forceinline__ float sqrt_rn_fixup(float x) {              // x == 0
 // sqrt, the form the replay loops use (round 2): v_rsq_f32, one coupled Newton step on (s ~ sqrt x, h ~ 1/(2 sqrt x)) and a
 // final residual correction — LLVM's other correctly rounded expansion (the one it picks when f32 denormals are flushed),
 // again without the range scaling.  Two multiplies and five FMAs, ALL of which hipcc packs two elements to an
-// instruction: per 4 elements 14 packed instructions instead of 4 packed + 24 single ones (38 packed + 8 quarter-rate
+// instruction: per 4 elements 14 packed instructions instead of 4 packed + 24 single ones (38 packed + 8 transcendental (half rate on gfx950: tools/probe/valu_cost_probe.hip)
 // + 3 single per replayed step instead of 28 + 8 + 27).  That it returns the correctly rounded root — the bits of
 // sqrtf — is not taken on trust: mi_selftest_sqrt compares the two on the device for EVERY fp32 value in
 // [2^-100, 2^24] (tests/test_hip_kernels.py::test_fast_sqrt_equals_sqrtf_on_every_value_in_range).  x == 0 gives NaN
