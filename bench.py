@@ -18,6 +18,9 @@ Workload (config.workload): trainers.deep_fm with --embedding-size 64 --hidden-u
 (Criteo-shaped), uniform ids, labels Bernoulli(0.25).  N > 1: one process per GPU, 65536 examples
 per GPU (weak scaling; --scaling strong divides 65536 over the GPUs instead), embedding rows
 sharded row % N with all-to-all over RCCL.
+On one GPU the ids of step t + 1 are announced to step t (train_step(next_ids=...): an input pipeline holds them; their
+sort then runs beside step t's catch-up; --no-presort for the plain sequence, same bits).  --force-shard [--chunks C]
+runs the multi-GPU step with a one-rank RCCL group: what that path costs by itself, links aside.
 
 Prints ONE JSON line on rank 0 with `roofline` (embedding gather kernel, HBM bound: algorithmic bytes read
 and written per launch / launch time, timed live with HIP events on the launch stream) and `cpu_baseline`
