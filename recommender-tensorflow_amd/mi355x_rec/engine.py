@@ -488,6 +488,13 @@ class DeepFM:
         hidden = self.layers[:-1]
         if len(hidden) > _lib.MAX_WEIGHT_JOBS:
             raise NotImplementedError("more than %d hidden layers on the planes path" % _lib.MAX_WEIGHT_JOBS)
+        # once per step, not once per forward: the chunks of a pipelined multi-GPU step see the same weights (the dense
+        # variables change in _apply, which moves self.step, or through torch, which moves the tensor's version)
+        stamp = (self.step, self.dense._version)
+        done = getattr(self, "_wsplit", None)
+        if done is not None and done[:2] == stamp and (done[2] or not train) and not getattr(self, "_capturing", False):
+            return
+        self._wsplit = stamp + (bool(train),)
         key = "wjobs_train" if train else "wjobs_eval"
         jobs = self._ws.get(key)
         if jobs is None:
