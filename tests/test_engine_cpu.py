@@ -139,3 +139,44 @@ def test_tf_named_variables_round_trip():
     with pytest.raises(KeyError, match="logits/dense/kernel"):
         tf_names.import_variables(mk(), dump, cols)
     assert "dnn/hiddenlayer_0/kernel" in str(tf_names.variable_names("dnn", cols, 2)["mlp"])
+
+
+def test_chunk_count_follows_batch_and_world_size():
+    """parallel._n_chunks: a chunk is the M of every MLP GEMM — at least 32768 examples from 8 ranks on (256 CUs x 128-row
+    tiles), 16384 in smaller (exchange-bound) worlds; an explicit RowShard(chunks=...) wins; evaluation never chunks."""
+    from types import SimpleNamespace
+    from mi355x_rec.parallel import RowShard, _n_chunks
+    m = lambda world, chunks=None: SimpleNamespace(shard=RowShard(0, world, chunks=chunks))
+    assert _n_chunks(m(8), 65536, True) == 2 and _n_chunks(m(8), 131072, True) == 4 and _n_chunks(m(8), 16384, True) == 1
+    assert _n_chunks(m(2), 65536, True) == 4 and _n_chunks(m(4), 32768, True) == 2 and _n_chunks(m(4), 16384, True) == 1
+    assert _n_chunks(m(8), 4096, True) == 2 and _n_chunks(m(8), 1000, True) == 1           # small batches: the old rule
+    assert _n_chunks(m(8, chunks=4), 65536, True) == 4 and _n_chunks(m(8, chunks=3), 65536, True) == 2   # (a divisor of B)
+    assert _n_chunks(m(8), 65536, False) == 1
+
+
+def test_weights_are_split_once_per_step():
+    """engine._split_weights runs once per (step, state of the dense buffer): the chunks of a pipelined multi-GPU step
+    share the planes of the weights; an apply (step + 1) or a torch-side write to the buffer makes them stale."""
+    calls = []
+
+    class K(NumpyKernels):
+        def mi_absmax(self, *a):
+            calls.append("absmax")
+
+        def mi_split_weights(self, *a):
+            calls.append("split")
+    from mi355x_rec.engine import DeepFM, OptimizerSpec
+    m = DeepFM([5, 4], embedding_size=4, hidden_units=[8, 8], optimizer=OptimizerSpec("Adam", 0.001), device="cpu", _kernels=K())
+    import mi355x_rec._lib as L
+    m._planes = lambda name, rows, K_: L.Planes()            # (no device planes on the CPU: the bookkeeping is what is tested)
+    m._av = lambda name: None
+    m._split_weights(True); m._split_weights(True); m._split_weights(False)
+    assert calls == ["absmax", "split"]
+    m.step += 1
+    m._split_weights(False)
+    assert calls == ["absmax", "split"] * 2
+    m._split_weights(True)                                     # an eval split does not cover the train-only orientation
+    assert calls == ["absmax", "split"] * 3
+    m.dense.add_(0)
+    m._split_weights(True)
+    assert calls == ["absmax", "split"] * 4
