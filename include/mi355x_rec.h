@@ -324,7 +324,7 @@ int32_t mi_catchup_rows_by_gap(const int32_t* uniq_rows, const int32_t* num_uniq
  * `count` fp32 bit patterns from first_bits on, mismatches[0] += how many give different bits in the replay loop's
  * in-range sqrt (v_rsq_f32 + coupled Newton step + residual correction) than in hipcc's correctly rounded sqrtf,
  * mismatches[1] += the same for the v_sqrt_f32 + one-ulp-test form.  mismatches: 2 x uint64 on the device, zeroed by the
- * caller.  The fast loop is only entered with v in [2^-80, 2^20]; the test sweeps [2^-100, 2^24] and demands 0. */
+ * caller.  The fast loop is only entered with v in [2^-93, 2^20]; the test sweeps [2^-100, 2^24] and demands 0. */
 int32_t mi_selftest_sqrt(uint32_t first_bits, int64_t count, uint64_t* mismatches, mi_stream_t stream);
 
 int32_t mi_sparse_catchup(float* table, float* t_m, float* t_v, float* lin_w, float* l_m, float* l_v,

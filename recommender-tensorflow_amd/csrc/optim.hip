@@ -369,12 +369,12 @@ __device__ __forceinline__ float div_rn_inrange(float n, float d) {     // n == 
   return fmaf(e3, r, q);
 }
 // m and v only shrink during the replay (by b1^k, b2^k <= 1): in range at the start and after k steps
-// means in range throughout.  |m| >= 2^-41 and k <= 200 keep lr_t*m above 2^-92 (lr_t >= 2^-20) and
-// its residuals (2^-24 below) normal; v in [2^-80, 2^20] keeps sqrt(v)+eps within [eps, 2^10] and
+// means in range throughout.  |m| >= 2^-50 and k <= 200 keep lr_t*m above 2^-101 (lr_t >= 2^-20) and
+// its residuals (2^-24 below) normal; v in [2^-93, 2^20] keeps sqrt(v)+eps within [eps, 2^10] and
 // v*b2^k above 2^-96.
 __device__ __forceinline__ bool catchup_in_range(float m, float v) {
   const float am = fabsf(m);
-  return (am == 0.f || (am >= 0x1p-41f && am <= 0x1p60f)) && v >= 0x1p-80f && v <= 0x1p20f;   // (v == 0: generic loop)
+  return (am == 0.f || (am >= 0x1p-50f && am <= 0x1p60f)) && v >= 0x1p-93f && v <= 0x1p20f;   // (v == 0: generic loop)
 }
 // (the bounds above assume the decays of 200 steps stay above 2^-31 and 2^-3: beta1 >= 0.9, beta2 >= 0.99)
 __device__ __forceinline__ bool catchup_params_in_range(int steps, float lr_last, float eps, float b1, float b2) {

@@ -493,7 +493,7 @@ def test_sparse_apply_long_segments(lib, E):
 def test_fast_sqrt_equals_sqrtf_on_every_value_in_range(lib):
     """The replay loop's square root (v_rsq_f32 + one coupled Newton step + residual correction, all packable FMAs)
     must return the bits of the correctly rounded sqrtf.  Proven by exhaustion on the device it runs on: every fp32
-    value in [2^-100, 2^24] (the loop is entered with v in [2^-80, 2^20] only, decayed by at most 2^-3), ~1.04e9
+    value in [2^-100, 2^24] (the loop is entered with v in [2^-93, 2^20] only, decayed by at most 2^-3), ~1.04e9
     values.  The v_sqrt_f32 + one-ulp-test form round 1 used is swept alongside."""
     lo = np.array([2.0 ** -100], np.float32).view(np.uint32)[0]
     hi = np.array([2.0 ** 24], np.float32).view(np.uint32)[0]
@@ -527,10 +527,23 @@ def test_catchup_exact_at_range_edges(lib):
     v[calm] = (10.0 ** rng.uniform(-14, -8, (int(calm.sum()), E))).astype(np.float32)
     m[rng.random((R, E)) < 0.05] = 0.0
     v[rng.random((R, E)) < 0.05] = 0.0
+    # whole waves AT the fast loop's limits (catchup_in_range: |m| in [2^-50, 2^60], v in [2^-93, 2^20], gaps <= 200), so
+    # that the unscaled sqrt / divide themselves run with the smallest and the largest values they are allowed to see
+    # (lr_t m down to 2^-101, its residuals down to 2^-125; v b2^k down to 2^-96) — and just outside (generic loop)
+    edge = {}
+    for gi, (mlo, mhi, vlo, vhi) in enumerate([(-50, -49, -93, -92), (59, 60, 19, 20), (-50, -49, 19, 20), (59, 60, -93, -92),
+                                               (-51, -50, -94, -93), (-45, -44, -88, -87)]):
+        rows_g = slice(64 * gi, 64 * gi + 64)
+        n_g = 64
+        m[rows_g] = (rng.choice([-1.0, 1.0], (n_g, E)) * 2.0 ** rng.uniform(mlo, mhi, (n_g, E))).astype(np.float32)
+        v[rows_g] = (2.0 ** rng.uniform(vlo, vhi, (n_g, E))).astype(np.float32)
+        edge[gi] = rows_g
     lw = rng.standard_normal(R).astype(np.float32)
     lmm = (rng.standard_normal(R) * 1e-5).astype(np.float32); lvv = (10.0 ** rng.uniform(-12, -6, R)).astype(np.float32)
     last = rng.integers(1, step_to, R).astype(np.int32)          # gaps 1 .. 299 (> 200: generic path)
     last[rng.random(R) < 0.1] = 0                                # never applied: untouched
+    for gi, rows_g in edge.items():
+        last[rows_g] = step_to - rng.integers(150, 201, 64)       # long replays inside the fast loop's step limit
     lr = (1e-3 * np.sqrt(1 - 0.999 ** np.arange(step_to + 1)) / np.maximum(1 - 0.9 ** np.arange(step_to + 1), 1e-30)).astype(np.float32)
     ew, em, ev = w.copy(), m.copy(), v.copy()
     elw, elm, elv = lw.copy(), lmm.copy(), lvv.copy()
