@@ -101,7 +101,7 @@ ACTIVATIONS = {   # params["activation"] (deep_fm.py:22): name -> (f, f' express
 
 
 def forward(p, ids, x_num=None, use_linear=True, use_mf=True, use_dnn=True, dropout_masks=None, numeric="embed",
-            keep_prob=1.0, activation="relu"):
+            keep_prob=1.0, activation="relu", relu_masks=None):
     """model_fn forward (deep_fm.py:36-115).  ids [B,F] per-field local ids; x_num [B,n_d].
     dropout_masks: per hidden layer, a [B,h] array of {0, 1} keep flags (TRAIN) or None; tf.layers.dropout
     (deep_fm.py:102-103) is tf.nn.dropout: div(x, keep_prob) * mask — a division, not a multiplication by 1/keep.
@@ -110,6 +110,11 @@ def forward(p, ids, x_num=None, use_linear=True, use_mf=True, use_dnn=True, drop
     the concat (trainers/linear_deep.py:32-39 with numeric columns in dnn_feature_columns) —
     no FM term exists there.  The engine keeps numeric columns after the categorical block in both
     forms; TF's input_layer interleaves them by column name, which only permutes kernel_0's rows.
+    relu_masks (tests only; relu only): per hidden layer a [B,h] bool array that REPLACES the sign test of relu —
+    unit (b, j) passes its pre-activation iff relu_masks[i][b, j].  A pre-activation that is 0 to within the rounding
+    of its dot product takes either side depending on summation order; a test that compares multi-step trajectories
+    hands the oracle the device's decisions (after checking that they differ from its own only on such units), so
+    that both follow the same branch.  c["pre"] holds every hidden layer's pre-activations.
     Returns a cache with logits [B] and every intermediate the backward needs."""
     dt = p.dtype
     B, F = ids.shape
@@ -149,16 +154,23 @@ def forward(p, ids, x_num=None, use_linear=True, use_mf=True, use_dnn=True, drop
     if use_dnn:                                                   # deep_fm.py:93-111
         net = concat
         acts = []
+        pres = []
         nh = len(p.mlp) - 1
         for i in range(nh):
             k, b = p.mlp[i]
-            net = ACTIVATIONS[activation][0](net @ k + b).astype(dt)   # tf.layers.dense(activation) :100
+            pre = net @ k + b
+            pres.append(pre)
+            if relu_masks is not None and relu_masks[i] is not None:
+                assert activation == "relu"
+                net = np.where(relu_masks[i], pre, 0).astype(dt)
+            else:
+                net = ACTIVATIONS[activation][0](pre).astype(dt)   # tf.layers.dense(activation) :100
             if dropout_masks is not None and dropout_masks[i] is not None:
                 net = (net / dt.type(keep_prob)) * dropout_masks[i].astype(dt)   # tf.layers.dropout :102-103
             acts.append(net)
         k, b = p.mlp[nh]
         dnn = (net @ k + b)[:, 0]                                 # :108
-        c["acts"], c["dnn"] = acts, dnn
+        c["acts"], c["dnn"], c["pre"], c["relu_masks"] = acts, dnn, pres, relu_masks
         logits = logits + dnn
     c["logits"] = logits
     return c
@@ -214,7 +226,11 @@ def backward(p, c, d_logits, dropout_masks=None):
             # other activations: f'(pre) through the un-dropped output a * keep
             act = c.get("activation", "relu")
             y = a * dt.type(c["keep_prob"]) if (dropped and act != "relu") else a
-            d_pre = d_net * ACTIVATIONS[act][1](y).astype(dt)
+            rm = c.get("relu_masks")
+            if rm is not None and rm[i] is not None:
+                d_pre = d_net * rm[i].astype(dt)          # (a dropped unit's d_net is already 0)
+            else:
+                d_pre = d_net * ACTIVATIONS[act][1](y).astype(dt)
             inp = c["acts"][i - 1] if i else c["concat"]
             k_i = p.mlp[i][0]
             g_hidden.append((inp.T @ d_pre, d_pre.sum(0)))
@@ -274,11 +290,12 @@ class TrainState:
 
 
 def train_step(p, st, ids, labels, x_num=None, use_linear=True, use_mf=True, use_dnn=True,
-               reduction="mean", dropout_masks=None, global_batch=None, numeric="embed", keep_prob=1.0, activation="relu"):
+               reduction="mean", dropout_masks=None, global_batch=None, numeric="embed", keep_prob=1.0, activation="relu",
+               relu_masks=None):
     """One optimizer.minimize(loss) (deep_fm.py:119-125 TRAIN branch): forward, head, backward,
     apply_gradients (dense vars: fused Apply*, embedding / linear tables: sparse apply with
     duplicate-summing), beta powers / global_step update.  Returns (loss, logits)."""
-    c = forward(p, ids, x_num, use_linear, use_mf, use_dnn, dropout_masks, numeric, keep_prob, activation)
+    c = forward(p, ids, x_num, use_linear, use_mf, use_dnn, dropout_masks, numeric, keep_prob, activation, relu_masks)
     loss, d_logits, _, _ = head(c["logits"], labels, reduction, global_batch)
     dense_g, d_rows, d_lin = backward(p, c, d_logits, dropout_masks)
     apply_gradients(p, st, ids, dense_g, d_rows, d_lin)

@@ -382,6 +382,39 @@ __device__ __forceinline__ bool catchup_params_in_range(int steps, float lr_last
          b1 >= 0.9f && b1 <= 1.f && b2 >= 0.99f && b2 <= 1.f;
 }
 
+// ---- the BOUNDED-ERROR replay (mi_sparse_catchup flag MI_CATCHUP_BOUNDED) --------------------------------------------
+// The exact replay above spends ~19 dependent operations per element and step on a correctly rounded sqrt and divide
+// whose only purpose is to land on TF's bits.  The contract (north star) is 1e-5 on the logits, not bit equality, so
+// this form keeps what is cheap to keep exact and approximates the rest with a stated bound:
+//   m_j = m_{j-1} * b1                 exactly the reference's chain (same bits)
+//   u_j = lr_t[s] * m_j                 exactly the reference's numerator (same bits)
+//   sqrt(v_j)  ~  s0 * rho_j            s0 = sqrtf(v_0) (correctly rounded, once per element), rho_j ~ beta2^(j/2): a per-ROW
+//                                       scalar chain rho_j = rho_{j-1} * (rho_hi + rho_lo), rho_hi + rho_lo = sqrt(beta2) to
+//                                       2^-48 (no systematic drift; rounding noise <= sqrt(j) * 2^-24 rms)
+//   w_j = fma(-u_j, rcp(fma(s0, rho_j, eps)), w_{j-1})     v_rcp_f32: 1 ulp; ONE rounding of w per step, like the reference
+// Per element and step: 4 packed-able VALU operations + 1 transcendental instead of 16 + 2; no range conditions at all
+// (v = 0, denormal m, any gap: the same loop), so no wave ever falls back to a slow generic loop.
+// Error against the reference's literal fp32 sweep, per replayed step j of a row: the update t_j = u_j / (sqrt(v_j) + eps)
+// is reproduced to |t~_j / t_j - 1| <= (2 [v_rcp_f32: 1 ulp] + 1 [s0] + 1 [fma] + 2j [rho chain, worst case; ~sqrt(j)/2
+// rms] + 3 [the reference's own sqrt, add and divide roundings] + j/2 [its v chain]) * 2^-24; the updates decay like
+// 0.9^j, so the sum over a replay is off by <~ 1e-6 of its FIRST update in the worst case and ~1e-7 of it typically —
+// of an update that is itself ~1e-3 |w|.  On top of that comes the rare step in which the difference moves RN(w - t)
+// across a rounding boundary (1 ulp of w each, about one step in 300):
+// tests/test_hip_kernels.py::test_bounded_catchup_stays_within_1e7_of_the_sweep holds every variable to 1e-7 relative
+// after 150-200 replayed steps with (m, v) from the smallest to the largest magnitudes Adam can produce.
+// m and v themselves (written back only without defer_slots) are the exact chains in both modes.
+struct RhoSplit { float hi, lo; };
+__device__ __forceinline__ RhoSplit rho_split(float b2) {
+  const double r = sqrt(static_cast<double>(b2));
+  RhoSplit q;
+  q.hi = static_cast<float>(r);
+  q.lo = static_cast<float>(r - static_cast<double>(q.hi));
+  return q;
+}
+__device__ __forceinline__ float bounded_step(float w, float u, float s0, float rj, float eps) {
+  return fmaf(-u, __builtin_amdgcn_rcpf(fmaf(s0, rj, eps)), w);
+}
+
 // The wide part: one thread per row (1/E of the work).  Its own kernel, run BEFORE the row kernel (it
 // reads the stamps the row kernel writes), so that lane 0 of a row's lane group does not drag a fifth
 // chain through a second loop of the same length.
@@ -389,7 +422,7 @@ __global__ __launch_bounds__(kBlock) void catchup_lin_k(
     float* __restrict__ lin_w, float* __restrict__ lm, float* __restrict__ lv, const int32_t* __restrict__ last_step,
     const int32_t* __restrict__ uniq_rows, const int32_t* __restrict__ num_uniq, int64_t n_max, int step_to,
     const float* __restrict__ lr_table, float b1, float b2, float eps, bool defer_slots, int st,
-    const mi_step_state_t* __restrict__ ss) {
+    const mi_step_state_t* __restrict__ ss, bool bounded) {
   if (ss) step_to = ss->step - 1;
   const int64_t u = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
   const int64_t count = uniq_rows ? static_cast<int64_t>(*num_uniq) : n_max;
@@ -399,6 +432,23 @@ __global__ __launch_bounds__(kBlock) void catchup_lin_k(
   const bool work = on && ls > 0 && ls < step_to;
   float w = 0.f, m = 0.f, v = 0.f;
   if (work) { w = lin_w[r]; m = lm[r]; v = lv[r]; }
+  if (bounded) {
+    if (work) {
+      const RhoSplit rho = rho_split(b2);
+      const float s0 = sqrtf(v);
+      float rj = 1.f;
+      for (int s = ls + 1; s <= step_to; ++s) {
+        rj = fmaf(rj, rho.lo, rj * rho.hi);
+        m = m * b1;
+        w = bounded_step(w, lr_table[s] * m, s0, rj, eps);
+      }
+      if (!defer_slots)
+        for (int s = ls + 1; s <= step_to; ++s) v = v * b2;
+      lin_w[r] = w;
+      if (!defer_slots) { lm[r] = m; lv[r] = v; }
+    }
+    return;
+  }
   const bool ok = !work || (catchup_params_in_range(step_to - ls, lr_table[step_to], eps, b1, b2) && catchup_in_range(m, v));
   if (__ballot(!ok) == 0) {
     if (work)
@@ -415,7 +465,7 @@ __global__ __launch_bounds__(kBlock) void catchup_lin_k(
   }
 }
 
-template <int LPR>
+template <int LPR, bool BOUNDED>
 __global__ __launch_bounds__(kBlock) void sparse_catchup_k(
     float* __restrict__ table, float* __restrict__ tm, float* __restrict__ tv,
     int32_t* __restrict__ last_step, const int32_t* __restrict__ uniq_rows,
@@ -435,6 +485,25 @@ __global__ __launch_bounds__(kBlock) void sparse_catchup_k(
     if (table && 4 * l < E) {
       const int64_t o = r * E + 4 * l;
       float4 w = ld4(table + o), m = ld4_nt(tm + o), v = ld4_nt(tv + o);
+      if constexpr (BOUNDED) {
+        const RhoSplit rho = rho_split(b2);
+        const float4 s0 = make_float4(sqrtf(v.x), sqrtf(v.y), sqrtf(v.z), sqrtf(v.w));
+        float rj = 1.f;
+        for (int s = ls + 1; s <= step_to; ++s) {
+          const float lr = lr_table[s];
+          rj = fmaf(rj, rho.lo, rj * rho.hi);
+          m.x = m.x * b1; m.y = m.y * b1; m.z = m.z * b1; m.w = m.w * b1;
+          w.x = bounded_step(w.x, lr * m.x, s0.x, rj, eps);
+          w.y = bounded_step(w.y, lr * m.y, s0.y, rj, eps);
+          w.z = bounded_step(w.z, lr * m.z, s0.z, rj, eps);
+          w.w = bounded_step(w.w, lr * m.w, s0.w, rj, eps);
+        }
+        st4(table + o, w);
+        if (!defer_slots) {
+          for (int s = ls + 1; s <= step_to; ++s) { v.x = v.x * b2; v.y = v.y * b2; v.z = v.z * b2; v.w = v.w * b2; }
+          st4_nt(tm + o, m); st4_nt(tv + o, v);
+        }
+      } else {
       // one loop for the four elements: one lr_t load and one loop counter per step instead of four,
       // four independent sqrt/divide chains in flight (the arithmetic per element is unchanged)
       const bool ok = catchup_params_in_range(step_to - ls, lr_table[step_to], eps, b1, b2) && catchup_in_range(m.x, v.x) &&
@@ -461,6 +530,7 @@ __global__ __launch_bounds__(kBlock) void sparse_catchup_k(
       }
       st4(table + o, w);
       if (!defer_slots) { st4_nt(tm + o, m); st4_nt(tv + o, v); }
+      }
     }
   }
   // (the wide part's scalar per row: catchup_lin_k)
@@ -733,9 +803,13 @@ int32_t mi_catchup_gap_keys(const int32_t* uniq_rows, const int32_t* num_uniq, c
 int32_t mi_sparse_catchup(float* table, float* t_m, float* t_v, float* lin_w, float* l_m, float* l_v,
                           int32_t* last_step, const int32_t* uniq_rows, const int32_t* num_uniq,
                           int64_t n_max, int32_t E, int32_t step_to, const float* lr_table,
-                          float beta1, float beta2, float epsilon, int32_t defer_slots, int32_t lin_stride,
+                          float beta1, float beta2, float epsilon, int32_t flags, int32_t lin_stride,
                           mi_stream_t stream) {
   MI_REQUIRE(n_max >= 0 && step_to >= 0 && lin_stride >= 1, "sparse_catchup: n_max=%lld step_to=%d", (long long)n_max, step_to);
+  MI_REQUIRE((flags & ~(MI_CATCHUP_DEFER_SLOTS | MI_CATCHUP_BOUNDED)) == 0, "sparse_catchup: flags=%d", flags);
+  const int32_t defer_slots = flags & MI_CATCHUP_DEFER_SLOTS;
+  // the bounded form divides by rcp(sqrt(v) + eps): eps must keep that sum a normal number (TF's default 1e-8 does)
+  const bool bounded = (flags & MI_CATCHUP_BOUNDED) != 0 && epsilon >= 1e-30f && beta2 > 0.f && beta2 <= 1.f;
   if (n_max == 0 || (step_to == 0 && !mi::step_state())) return MI_OK;
   MI_REQUIRE(last_step && lr_table, "sparse_catchup: null buffer");
   MI_REQUIRE(table || lin_w, "sparse_catchup: nothing to update");
@@ -746,15 +820,22 @@ int32_t mi_sparse_catchup(float* table, float* t_m, float* t_v, float* lin_w, fl
   const bool defer = defer_slots != 0 && uniq_rows != nullptr;
   if (lin_w) {
     catchup_lin_k<<<dim3((unsigned)mi::ceil_div(n_max, kBlock)), dim3(kBlock), 0, mi::as_stream(stream)>>>(
-        lin_w, l_m, l_v, last_step, uniq_rows, num_uniq, n_max, step_to, lr_table, beta1, beta2, epsilon, defer, lin_stride, mi::step_state());
+        lin_w, l_m, l_v, last_step, uniq_rows, num_uniq, n_max, step_to, lr_table, beta1, beta2, epsilon, defer, lin_stride, mi::step_state(),
+        bounded);
     MI_CHECK_LAUNCH("sparse_catchup(wide part)");
   }
   const int lpr = table ? lanes_per_row(E) : 1;
   const int64_t blocks = mi::ceil_div(n_max * lpr, kBlock);
   MI_REQUIRE(blocks <= INT32_MAX, "sparse_catchup: grid too large");
-  MI_DISPATCH_LPR(lpr, (sparse_catchup_k<L><<<dim3((unsigned)blocks), dim3(kBlock), 0, mi::as_stream(stream)>>>(
-                           table, t_m, t_v, last_step, uniq_rows, num_uniq, n_max, E, step_to, lr_table, beta1, beta2,
-                           epsilon, defer, lin_stride, mi::step_state())));
+  if (bounded) {
+    MI_DISPATCH_LPR(lpr, (sparse_catchup_k<L, true><<<dim3((unsigned)blocks), dim3(kBlock), 0, mi::as_stream(stream)>>>(
+                             table, t_m, t_v, last_step, uniq_rows, num_uniq, n_max, E, step_to, lr_table, beta1, beta2,
+                             epsilon, defer, lin_stride, mi::step_state())));
+  } else {
+    MI_DISPATCH_LPR(lpr, (sparse_catchup_k<L, false><<<dim3((unsigned)blocks), dim3(kBlock), 0, mi::as_stream(stream)>>>(
+                             table, t_m, t_v, last_step, uniq_rows, num_uniq, n_max, E, step_to, lr_table, beta1, beta2,
+                             epsilon, defer, lin_stride, mi::step_state())));
+  }
   MI_CHECK_LAUNCH("sparse_catchup");
   return MI_OK;
 }

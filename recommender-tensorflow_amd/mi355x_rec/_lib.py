@@ -16,7 +16,7 @@ import torch  # noqa: F401  (loads the HIP runtime this library must share)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmi355x_rec.so")
 
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 
 class MiError(RuntimeError):

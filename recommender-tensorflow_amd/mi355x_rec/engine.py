@@ -24,6 +24,7 @@ With a RowShard (N > 1 GPUs) table / lin_w / slots / last_step hold only the row
 r % world == rank, stored at r // world; the dense buffer is replicated.
 """
 import ctypes as C
+import json
 import os
 import math
 
@@ -153,6 +154,7 @@ class AdamSchedule:
         self.b2p = np.float32(spec.beta2)
         self.host = np.zeros(1, np.float32)  # index 0 unused: steps are 1-based
         self.table = None
+        self.gen = 0                         # bumped whenever `table` moves to new device memory (captured graphs hold its address)
         self._extend(capacity)
 
     def _extend(self, capacity):
@@ -167,6 +169,7 @@ class AdamSchedule:
         self.b1p, self.b2p = b1p, b2p
         self.host = np.concatenate([self.host, np.asarray(vals, np.float32)])
         self.table = torch.from_numpy(self.host.copy()).to(self.device)
+        self.gen += 1
 
     def lr_t(self, step):
         while step >= len(self.host):                     # also after restoring a checkpoint far into a run
@@ -186,12 +189,16 @@ class DeepFM:
     to the concat after the embedding columns, as the canned estimators' input_layer does (TF orders
     the concat by column name; here numeric columns follow the categorical block, which permutes
     kernel_0's rows only — tf_names maps them).
-    shard: parallel.RowShard for N > 1 GPUs (row-sharded tables, data-parallel MLP)."""
+    shard: parallel.RowShard for N > 1 GPUs (row-sharded tables, data-parallel MLP).
+    catchup: how the steps a row sat out under TF Adam's dense-equivalent sparse update are replayed when
+    the row is next read — "exact": TF's fp32 op sequence, the sweep's bits; "bounded": the same m chain and numerators
+    with sqrt(v_j) ~ sqrtf(v_0) beta2^(j/2) and a 1-ulp reciprocal, every variable within 1e-7 relative of the sweep
+    (include/mi355x_rec.h, MI_CATCHUP_BOUNDED), a third of the instructions."""
 
     def __init__(self, vocab_sizes, n_numeric=0, embedding_size=4, hidden_units=(16, 16),
                  use_linear=True, use_mf=True, use_dnn=True, dropout=0.0, optimizer=None,
                  linear_optimizer=None, reduction="mean", device="cuda", seed=0, shard=None,
-                 gemm="f16x2", numeric="embed", activation="relu", _kernels=None):
+                 gemm="f16x2", numeric="embed", activation="relu", catchup="exact", _kernels=None):
         if len(vocab_sizes) + n_numeric == 0:
             raise ValueError("At least 1 feature column of categorical_columns or numeric_columns "
                              "must be specified.")            # deep_fm.py:31-32
@@ -207,6 +214,9 @@ class DeepFM:
             raise ValueError("numeric must be 'embed' or 'raw'")
         if numeric == "raw" and use_mf:
             raise ValueError("raw numeric columns belong to the canned estimators, which have no FM term")
+        if catchup not in ("exact", "bounded"):
+            raise ValueError("catchup must be 'exact' or 'bounded'")
+        self.catchup = catchup
         self.k = _kernels if _kernels is not None else HipKernels()
         self.device = torch.device(device)
         self.vocab_sizes = [int(v) for v in vocab_sizes]
@@ -310,6 +320,7 @@ class DeepFM:
             # wide-part dense variables (linear bias, numeric linear weights) follow linear_optimizer
             self.dl_s0, self.dl_s1 = self._slots(self.dense, self.lin_opt)
         self._ws = {}
+        self._alloc_gen = 0                      # bumped whenever a workspace / planes buffer moves (see graph_train_step)
         self._final_step = 0
         self._presorted = None
         # Without numeric columns layer 1 of the MLP reads its input straight from the embedding table
@@ -452,6 +463,7 @@ class DeepFM:
         if cur is None or cur.numel() < n or cur.dtype != dtype:
             cur = torch.empty(max(n, 1), dtype=dtype, device=self.device)
             self._ws[name] = cur
+            self._alloc_gen += 1
         return cur[:n].view(*shape)
 
     def _bytes(self, name, nbytes):
@@ -460,12 +472,14 @@ class DeepFM:
         if cur is None or cur.numel() < n:
             cur = torch.empty(n, dtype=torch.uint8, device=self.device)
             self._ws[name] = cur
+            self._alloc_gen += 1
         return cur
 
     def _planes(self, name, rows, K):
         cur = self._pl.get(name)
         if cur is None or cur.rows < rows or cur.K != K:
             cur = self._pl[name] = PlaneBuf(rows, K, self.device)
+            self._alloc_gen += 1
         return cur.struct
 
     def _av(self, name):
@@ -728,7 +742,7 @@ class DeepFM:
                                  self.t_s1 if t_adam else None, self.lin_w if l_adam else None,
                                  self.l_s0 if l_adam else None, self.l_s1 if l_adam else None, self.last_step,
                                  uniq, num_uniq, n_max, self.E, self.step, self.sched.table, s.beta1, s.beta2,
-                                 s.epsilon, 1 if defer else 0, self.ls)
+                                 s.epsilon, (1 if defer else 0) | (2 if self.catchup == "bounded" else 0), self.ls)
 
     def _sort_unique(self, keys, n, key_range, tag):
         """mi_sort_unique_rows into persistent buffers named after `tag`."""
@@ -986,6 +1000,14 @@ class DeepFM:
             raise NotImplementedError("graph_train_step: single-GPU models without numeric columns")
         self._prep(ids, labels, None)
         g = getattr(self, "_graph", None)
+        if g is not None and g["gen"] != self._graph_gen():
+            # A captured graph holds the raw addresses of the workspaces, the planes and the lr_t table.  Something
+            # since the capture made one of them move (loss() / predict on a larger batch, a train_step of another
+            # shape, layer_summaries' workspaces, a restored checkpoint far into a run): the old storage may already
+            # belong to another tensor, so the graph is dropped and the step captured again (buffers only grow: the
+            # new capture needs no sizing step).
+            g = self._graph = None
+            self._graph_warm = tuple(ids.shape)
         if g is None or g["shape"] != tuple(ids.shape):
             if not getattr(self, "_graph_warm", None) == tuple(ids.shape):
                 self._graph_warm = tuple(ids.shape)
@@ -1004,6 +1026,9 @@ class DeepFM:
         self.step += 1
         g["dev_step"] = self.step
         return g["loss"], g["logits"]
+
+    def _graph_gen(self):
+        return (self._alloc_gen, self.sched.gen if self.sched is not None else 0)
 
     def _write_step_state(self, state):
         blob = np.zeros(1, np.dtype([("step", np.int32), ("lr_t", np.float32), ("seed_term", np.uint64)]))
@@ -1032,7 +1057,7 @@ class DeepFM:
             self.k.query("mi_set_step_state", None)
         graph.replay()                                                  # capture records, this executes the step
         return {"graph": graph, "state": state, "ids": g_ids, "y": g_y, "loss": loss, "logits": logits,
-                "shape": tuple(ids.shape), "dev_step": self.step}
+                "shape": tuple(ids.shape), "dev_step": self.step, "gen": self._graph_gen()}
 
     def layer_summaries(self):
         """What the reference's layer_summary calls record (model_utils.py:4-6 at deep_fm.py:43,89,105,
@@ -1082,11 +1107,32 @@ class DeepFM:
     # ------------------------------------------------------------------ checkpoint
     _STATE_KEYS = ("dense", "d_s0", "d_s1", "table", "lin_w", "t_s0", "t_s1", "l_s0", "l_s1", "last_step",
                    "dl_s0", "dl_s1")
+    STATE_FORMAT = 3       # 3: carries the layout table below (rounds 1-2 wrote bare tensors; the flat buffer's layout changed between them)
+
+    def _layout(self):
+        """What a checkpoint must agree on before its flat buffers may be copied in: the model's shape and where each
+        dense variable sits in `dense` (name -> [offset, rows, cols]).  The reference's TF checkpoints are name- and
+        shape-checked (conf_utils.py:6-10); a flat buffer is only as safe as this table."""
+        seg = {}
+        for i, (k_off, b_off, fan, h) in enumerate(self.layers):
+            seg["kernel_%d" % i] = [k_off, fan, h]
+            seg["bias_%d" % i] = [b_off, h, 1]
+        if self.num_emb_off is not None:
+            seg["numeric_embeddings"] = [self.num_emb_off, self.n_numeric, self.E]
+        seg["linear_bias"] = [self.lin_bias_off, 1, 1]
+        if self.lin_num_off is not None:
+            seg["linear_numeric_weights"] = [self.lin_num_off, self.n_numeric, 1]
+        world, rank = (1, 0) if self.shard is None else (self.shard.world, self.shard.rank)
+        return {"vocab_sizes": list(self.vocab_sizes), "embedding_size": self.E, "hidden_units": list(self.hidden),
+                "n_numeric": self.n_numeric, "numeric": self.numeric, "P": self.P, "R": self.R, "world": world, "rank": rank,
+                "use": [self.use_linear, self.use_mf, self.use_dnn], "optimizer": self.opt.name,
+                "linear_optimizer": None if self.lin_opt is None else self.lin_opt.name,
+                "lin_record_stride": self.ls, "segments": seg}
 
     def state_dict(self):
         """Everything needed to resume (reference: Estimator checkpoints, conf_utils.py:6-10)."""
         self.finalize_rows()
-        sd = {"step": self.step}
+        sd = {"step": self.step, "format": self.STATE_FORMAT, "layout": self._layout()}
         for key in self._STATE_KEYS:
             v = getattr(self, key, None)
             if v is not None:
@@ -1094,8 +1140,31 @@ class DeepFM:
         return sd
 
     def load_state_dict(self, sd):
+        """Verifies format, layout and every tensor's shape BEFORE anything is copied: a checkpoint of another model,
+        of another hidden / embedding size with the same parameter count, or of an older flat-buffer layout is an
+        error, never a silent permutation of the variables."""
+        if sd.get("format") != self.STATE_FORMAT:
+            raise ValueError("checkpoint format %r, this build reads %d: the flat dense buffer's layout is only defined "
+                             "by the layout table newer checkpoints carry (re-export the variables by name: "
+                             "mi355x_rec/tf_names.py)" % (sd.get("format"), self.STATE_FORMAT))
+        mine, theirs = self._layout(), sd["layout"]
+        canon = lambda v: json.loads(json.dumps(v))                   # (tuples / lists alike)
+        bad = sorted(k for k in set(mine) | set(theirs) if canon(mine.get(k)) != canon(theirs.get(k)))
+        if bad:
+            raise ValueError("checkpoint does not fit this model: %s" % "; ".join(
+                "%s = %r in the checkpoint, %r here" % (k, theirs.get(k), mine.get(k)) for k in bad))
+        have = {k for k in self._STATE_KEYS if getattr(self, k, None) is not None}
+        given = {k for k in sd if k not in ("step", "format", "layout")}
+        if have != given:
+            raise ValueError("checkpoint tensors %s, the model has %s" % (sorted(given), sorted(have)))
+        for key in given:
+            dst, v = getattr(self, key), sd[key]
+            if tuple(v.shape) != tuple(dst.shape) or v.dtype != dst.dtype:
+                raise ValueError("checkpoint tensor %r is %s %s, the model's is %s %s" %
+                                 (key, tuple(v.shape), v.dtype, tuple(dst.shape), dst.dtype))
+        for key in given:
+            getattr(self, key).copy_(sd[key].to(self.device))
         self.step = int(sd["step"])
-        for key, v in sd.items():
-            if key != "step":
-                getattr(self, key).copy_(v.to(self.device))
         self._final_step = self.step
+        self._presorted = None           # (a sort of a batch announced before the restore: dropped)
+        self._graph = None               # (captured steps are re-captured against the restored state)

@@ -36,13 +36,39 @@ ServingInputReceiver = collections.namedtuple("ServingInputReceiver", "features 
 
 class RunConfig:
     def __init__(self, model_dir=None, save_checkpoints_secs=600, keep_checkpoint_max=5, save_summary_steps=100,
-                 log_step_count_steps=100, device="cuda"):
+                 log_step_count_steps=100, device="cuda", clock_sync_steps=10):
         self.model_dir = model_dir
         self.save_checkpoints_secs = save_checkpoints_secs
         self.keep_checkpoint_max = keep_checkpoint_max
         self.save_summary_steps = save_summary_steps
         self.log_step_count_steps = log_step_count_steps
         self.device = device
+        # multi-GPU: wall-clock decisions (checkpoint now?) are taken by rank 0 and broadcast, every this many steps
+        self.clock_sync_steps = clock_sync_steps
+
+
+def _agree(shard, value):
+    """Rank 0's integer `value` on every rank (one tiny broadcast).  Every wall-clock decision of a multi-GPU run goes
+    through this: the ranks' clocks differ by far more than a step, and a rank that starts an evaluation (a collective
+    in the row-sharded engine) while the others start the next train step mismatches the collectives of the two."""
+    if shard is None or shard.world == 1:
+        return int(value)
+    import torch.distributed as dist
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(shard.group) == "nccl" else "cpu"
+    t = torch.tensor([int(value)], dtype=torch.int64, device=dev)
+    dist.broadcast(t, 0, group=shard.group)
+    return int(t.item())
+
+
+def _all_equal(shard, value):
+    """Does every rank hold the same integer?  (min == max over the ranks)"""
+    if shard is None or shard.world == 1:
+        return True
+    import torch.distributed as dist
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(shard.group) == "nccl" else "cpu"
+    t = torch.tensor([int(value), -int(value)], dtype=torch.int64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=shard.group)
+    return int(t[0].item()) == -int(t[1].item())
 
 
 class LatestExporter:
@@ -53,23 +79,34 @@ class LatestExporter:
         self.name, self.fn, self.keep = name, serving_input_receiver_fn, exports_to_keep
 
     def export(self, estimator, export_dir):
-        ts = str(int(time.time()))
-        out = os.path.join(export_dir, self.name, ts)
-        while os.path.exists(out):
-            ts = str(int(ts) + 1)
-            out = os.path.join(export_dir, self.name, ts)
-        os.makedirs(out)
+        """Single GPU: variables.pt.  N GPUs (every rank calls this): the chief picks the directory and writes the
+        signature, whose "sharding" entry says how to put the model together again — row r of the stacked tables lives
+        in variables.rank<r % world>.pt at index r // world; the dense variables are replicated in every file."""
+        shard = estimator._shard
+        ts = 0
+        if estimator.is_chief:
+            ts = int(time.time())
+            while os.path.exists(os.path.join(export_dir, self.name, str(ts))):
+                ts += 1
+            os.makedirs(os.path.join(export_dir, self.name, str(ts)))
+        ts = _agree(shard, ts)                       # (also orders the chief's makedirs before the other ranks' writes)
+        out = os.path.join(export_dir, self.name, str(ts))
         recv = self.fn()
-        torch.save(estimator._engine().state_dict(), os.path.join(out, "variables.pt"))
-        with open(os.path.join(out, "signature.json"), "w") as f:
-            json.dump({"receiver_tensors": {k: str(v) for k, v in recv.receiver_tensors.items()},
-                       "outputs": ["logits", "logistic", "probabilities", "class_ids", "classes"],
-                       "global_step": estimator.global_step}, f, indent=1)
-        old = sorted(glob.glob(os.path.join(export_dir, self.name, "*")))
-        for d in old[:-self.keep]:
-            for fn in glob.glob(os.path.join(d, "*")):
-                os.remove(fn)
-            os.rmdir(d)
+        torch.save(estimator._engine().state_dict(), os.path.join(out, "variables%s.pt" % estimator._rank_tag))
+        if estimator.is_chief:
+            sig = {"receiver_tensors": {k: str(v) for k, v in recv.receiver_tensors.items()},
+                   "outputs": ["logits", "logistic", "probabilities", "class_ids", "classes"],
+                   "global_step": estimator.global_step}
+            if shard is not None:
+                sig["sharding"] = {"world": shard.world, "files": ["variables.rank%d.pt" % r for r in range(shard.world)],
+                                   "rule": "row r of table / lin_w / slots: file r % world, index r // world; dense replicated"}
+            with open(os.path.join(out, "signature.json"), "w") as f:
+                json.dump(sig, f, indent=1)
+            old = sorted(glob.glob(os.path.join(export_dir, self.name, "*")))
+            for d in old[:-self.keep]:
+                for fn in glob.glob(os.path.join(d, "*")):
+                    os.remove(fn)
+                os.rmdir(d)
         return out
 
 
@@ -122,8 +159,15 @@ class Estimator:
             return
         self._restored = True
         ck = self.latest_checkpoint()
+        # (multi-GPU: every rank restores its own shard; a rank without its file, or with an older one, would
+        # otherwise resume at a different step than the others)
+        if not _all_equal(self._shard, 1 if ck else 0):
+            raise RuntimeError("restore: some ranks found a checkpoint in %s and some did not (this rank: %s)" % (self.model_dir, ck))
         if ck:
             self._engine().load_state_dict(torch.load(ck, weights_only=True))
+            if not _all_equal(self._shard, self.global_step):
+                raise RuntimeError("restore: the ranks' newest checkpoints are of different steps (this rank: %s, step %d)" %
+                                   (ck, self.global_step))
             if self.is_chief:
                 print("INFO: restored %s (global_step %d)" % (ck, self.global_step))
         elif self.warm_start_from:
@@ -159,8 +203,8 @@ class Estimator:
         """Every save_summary_steps: loss + the layer_summary statistics (model_utils.py:4-6; TensorBoard
         events in the reference) appended as one JSON line to <model_dir>/summaries.jsonl."""
         eng = self._engine()
-        if eng is None or not hasattr(eng, "layer_summaries"):
-            return
+        if eng is None or not hasattr(eng, "layer_summaries") or not self.is_chief:
+            return                                   # (multi-GPU: the chief's batch share; one writer per file)
         os.makedirs(self.model_dir, exist_ok=True)
         rec = {"global_step": self.global_step, "loss": loss, "layers": eng.layer_summaries()}
         with open(os.path.join(self.model_dir, "summaries.jsonl"), "a") as f:
@@ -195,7 +239,7 @@ class Estimator:
                 t_log, n_log = now, 0
             if self.config.save_summary_steps and self.global_step % self.config.save_summary_steps == 0:
                 self._write_summaries(float(loss))
-            if self.config.save_checkpoints_secs and time.time() - t_ckpt >= self.config.save_checkpoints_secs:
+            if self.config.save_checkpoints_secs and self._checkpoint_due(t_ckpt):
                 self.save_checkpoint()
                 t_ckpt = time.time()
                 if on_checkpoint:
@@ -205,6 +249,17 @@ class Estimator:
             if on_checkpoint:
                 on_checkpoint()
         return self
+
+    def _checkpoint_due(self, t_last):
+        """save_checkpoints_secs have passed.  One process: its own clock, every step.  N processes: rank 0's clock,
+        looked at every clock_sync_steps-th global step (the same steps on every rank: synchronous training) and
+        broadcast — the checkpoint, and the evaluation that follows it, then start at the same step everywhere."""
+        due = time.time() - t_last >= self.config.save_checkpoints_secs
+        if self._shard is None or self._shard.world == 1:
+            return due
+        if self.global_step % max(1, int(self.config.clock_sync_steps)):
+            return False
+        return bool(_agree(self._shard, due))
 
     def evaluate(self, input_fn, steps=None):
         store = self.params["_store"]
@@ -244,18 +299,23 @@ def train_and_evaluate(estimator, train_spec, eval_spec):
         # EvalSpec.start_delay_secs / throttle_secs (conf_utils.py:27-34): no evaluation before
         # start_delay_secs of training, none sooner than throttle_secs after the previous one started;
         # the checkpoint written when training ends is always evaluated (as TF's local loop does).
+        # Multi-GPU: every rank gets here at the same global step (the checkpoint decision is collective), and rank 0's
+        # clock decides for all of them — evaluate() is a collective in the row-sharded engine.
         now = time.time()
+        go = True
         if not final:
             if now - t_start < (eval_spec.start_delay_secs or 0):
-                return
-            if state["last_eval"] is not None and now - state["last_eval"] < (eval_spec.throttle_secs or 0):
-                return
+                go = False
+            elif state["last_eval"] is not None and now - state["last_eval"] < (eval_spec.throttle_secs or 0):
+                go = False
         if state["evaluated_step"] == estimator.global_step:
+            go = False
+        if not _agree(estimator._shard, go):
             return
         state["last_eval"], state["evaluated_step"] = now, estimator.global_step
         estimator.evaluate(eval_spec.input_fn, steps=eval_spec.steps)
         exporters = eval_spec.exporters
-        if exporters is not None and estimator.is_chief:      # (multi-GPU: rank 0's shard + the dense variables)
+        if exporters is not None:                             # (multi-GPU: every rank writes its shard, the chief the manifest)
             for ex in (exporters if isinstance(exporters, (list, tuple)) else [exporters]):
                 ex.export(estimator, os.path.join(estimator.model_dir, "export"))
     estimator.train(train_spec.input_fn, max_steps=train_spec.max_steps, on_checkpoint=after_checkpoint)

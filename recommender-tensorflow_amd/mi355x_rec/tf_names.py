@@ -13,7 +13,8 @@ with ``tf.train.init_from_checkpoint``-style assignment).  Names follow the scop
 trainers/deep_fm.py:38,48,94,99,107 for ``model="deep_fm"`` and the canned estimators' for
 ``"linear" | "dnn" | "dnn_linear_combined"`` (trainers/linear.py:30, deep.py:32, linear_deep.py:32).
 Optimizer slots are not part of the mapping (a warm start re-creates them, as TF's
-``warm_start_from`` does).  Single-GPU engines only: sharded engines hold a slice of every table.
+``warm_start_from`` does).  A row-sharded engine (N GPUs) imports its own rows of every table (row r of the stacked
+tables lives on rank r % world at index r // world); exporting needs the whole table and is single-GPU only.
 """
 import numpy as np
 
@@ -59,9 +60,9 @@ def kernel0_rows(column_names, numeric_names, E):
     return np.asarray(perm, np.int64)
 
 
-def _names_for(m, model, column_names, numeric_names=None):
-    if m.shard is not None:
-        raise ValueError("TF-named import/export works on single-GPU engines (a sharded engine holds table slices)")
+def _names_for(m, model, column_names, numeric_names=None, sharded_ok=False):
+    if m.shard is not None and not sharded_ok:
+        raise ValueError("TF-named export works on single-GPU engines (a sharded engine holds table slices)")
     if len(column_names) != m.F:
         raise ValueError("%d column names for %d categorical fields" % (len(column_names), m.F))
     if m.raw_numeric and (numeric_names is None or len(numeric_names) != m.n_numeric):
@@ -102,9 +103,20 @@ def import_variables(m, arrays, column_names, model="deep_fm", strict=True, nume
     variable the engine has must be present with TF's shape (strict) or keeps its value (not strict);
     returns the list of names that were loaded.  Optimizer slots and Adam row stamps are reset."""
     import torch
-    nm = _names_for(m, model, column_names, numeric_names)
+    nm = _names_for(m, model, column_names, numeric_names, sharded_ok=True)
     loaded = []
     off = m.field_off_host
+    rank, world = (0, 1) if m.shard is None else (m.shard.rank, m.shard.world)
+
+    def put_rows(dst, f, a):
+        """rows of field f (a: the whole variable) into the engine's table: all of them, or this rank's"""
+        if world == 1:
+            dst[off[f]:off[f + 1]].copy_(a)
+            return
+        g = np.arange(int(off[f]), int(off[f + 1]), dtype=np.int64)
+        mine = g[g % world == rank]
+        if len(mine):
+            dst[torch.from_numpy(mine // world).to(m.device)] = a[torch.from_numpy(mine - int(off[f])).to(m.device)]
 
     def get(name, shape):
         if name not in arrays:
@@ -122,11 +134,11 @@ def import_variables(m, arrays, column_names, model="deep_fm", strict=True, nume
         if m.table is not None:
             a = get(nm["emb"][f], (v, m.E))
             if a is not None:
-                m.table[off[f]:off[f + 1]].copy_(a)
+                put_rows(m.table, f, a)
         if m.lin_w is not None:
             a = get(nm["lin_w"][f], (v,))
             if a is not None:
-                m.lin_w[off[f]:off[f + 1]].copy_(a)
+                put_rows(m.lin_w, f, a)
     if m.lin_w is not None:
         a = get(nm["lin_bias"], (1,))
         if a is not None:

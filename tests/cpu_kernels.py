@@ -241,8 +241,8 @@ class NumpyKernels:
         _np(rows_out)[:n_max] = _np(uniq)[:n_max][np.argsort(_np(keys), kind="stable")]
 
     def mi_sparse_catchup(self, table, tm, tv, lin_w, lm, lv, last_step, uniq, num_uniq, n_max, E, step_to, lr_table,
-                          b1, b2, eps, defer_slots=0, ls=1):
-        defer = bool(defer_slots) and uniq is not None
+                          b1, b2, eps, flags=0, ls=1):
+        defer = bool(flags & 1) and uniq is not None          # (flag 2, the bounded-error replay: the exact sweep stands in)
         rows = np.arange(n_max) if uniq is None else _np(uniq)[:int(_np(num_uniq)[0])]
         ls = _np(last_step)
         lr = _np(lr_table)

@@ -71,6 +71,36 @@ def test_state_dict_roundtrip_resumes_bitwise():
     assert torch.equal(a.table, b.table) and torch.equal(a.dense, b.dense)
 
 
+def test_checkpoint_of_another_layout_is_refused(tmp_path):
+    """a checkpoint is a set of flat buffers; before anything is copied its format version, the layout
+    table (model shape + where every dense variable sits) and every tensor's shape must match — a checkpoint of another
+    hidden / embedding size with the SAME parameter count, of an older layout, or of another optimizer is an error,
+    not a silent permutation.  The file goes through torch.save / torch.load(weights_only=True) like the Estimator's."""
+    a = _engine([9, 13, 5], 4, [8])
+    sd = a.state_dict()
+    path = str(tmp_path / "m.pt")
+    torch.save(sd, path)
+    sd = torch.load(path, weights_only=True)
+    assert sd["format"] == a.STATE_FORMAT and sd["layout"]["segments"]["kernel_0"] == [0, 12, 8]
+    _engine([9, 13, 5], 4, [8]).load_state_dict(sd)                             # the same model: fine
+    b = _engine([9, 13, 5], 4, [4, 8])                                          # same P (16-float aligned segments), other layers
+    assert b.P == a.P
+    with pytest.raises(ValueError, match="hidden_units"):
+        b.load_state_dict(sd)
+    with pytest.raises(ValueError, match="vocab_sizes"):
+        _engine([9, 13, 6], 4, [8]).load_state_dict(sd)
+    from mi355x_rec.engine import OptimizerSpec
+    with pytest.raises(ValueError, match="optimizer"):
+        _engine([9, 13, 5], 4, [8], optimizer=OptimizerSpec("Adagrad", 0.05)).load_state_dict(sd)
+    old = {k: v for k, v in sd.items() if k not in ("format", "layout")}        # what rounds 1-2 wrote
+    with pytest.raises(ValueError, match="format"):
+        _engine([9, 13, 5], 4, [8]).load_state_dict(old)
+    bad = dict(sd); bad["dense"] = sd["dense"][:-16]
+    with pytest.raises(ValueError, match="dense"):
+        _engine([9, 13, 5], 4, [8]).load_state_dict(bad)
+    assert a._alloc_gen >= 0 and a._graph_gen()[1] == a.sched.gen
+
+
 def test_input_validation():
     m = _engine([3, 4], 4, [8])
     with pytest.raises(ValueError, match="int32"):

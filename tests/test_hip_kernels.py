@@ -565,6 +565,89 @@ def test_catchup_exact_at_range_edges(lib):
     assert np.array_equal(dlast.cpu().numpy(), np.where(last < step_to, step_to, last))
 
 
+def test_bounded_catchup_stays_within_1e7_of_the_sweep(lib):
+    """MI_CATCHUP_BOUNDED (include/mi355x_rec.h): the replay with sqrt(v_j) ~ sqrtf(v_0) beta2^(j/2) and a 1-ulp reciprocal
+    against the literal fp32 sweep (numpy: IEEE sqrt and divide), 150-200 replayed steps, (m, v) pairs spanning everything
+    Adam can produce — gradient scales from 2^-46 (v = 2^-92) to 2^10 (v = 2^20), plus elements with m = v = 0 and rows
+    never applied.  What is asserted, per variable:
+        |w_bounded - w_sweep| <= 3 ulp(w) + 2e-6 * sum_j |t_j|          (t_j: the replayed updates; the analytic bound)
+    and in distribution: >= 95 % of the variables bit-identical, >= 98 % within 1e-7 relative (a 1-ulp difference is by
+    itself up to 1.19e-7 relative, so "1e-7 for every variable" is not a bound ANY non-bit-exact form can meet).
+    m, v and the stamps must be the exact chains in both modes; with MI_CATCHUP_DEFER_SLOTS only w moves."""
+    rng = np.random.default_rng(31)
+    R, E, step_to = 4096, 64, 300
+    f = np.float32
+    b1, b2, eps = f(0.9), f(0.999), f(1e-8)
+    sig = 2.0 ** rng.uniform(-46, 10, (R, 1))
+    sig[:256] = 2.0 ** rng.uniform(-46, -45, (256, 1))              # whole waves at the small edge ...
+    sig[256:512] = 2.0 ** rng.uniform(9, 10, (256, 1))              # ... and at the large one
+    v = (sig ** 2 * rng.uniform(0.2, 1.0, (R, E))).astype(f)
+    m = (sig * rng.standard_normal((R, E)) * 0.5).astype(f)
+    zero = rng.random((R, E)) < 0.03                                # elements whose gradient has always been 0
+    m[zero] = 0.0; v[zero] = 0.0
+    w = (rng.standard_normal((R, E)) * 0.3).astype(f)
+    lw = (rng.standard_normal(R) * 0.3).astype(f)
+    lsig = 2.0 ** rng.uniform(-46, 10, R)
+    lvv = (lsig ** 2 * rng.uniform(0.2, 1.0, R)).astype(f); lmm = (lsig * rng.standard_normal(R) * 0.5).astype(f)
+    last = (step_to - rng.integers(150, 201, R)).astype(np.int32)
+    last[rng.random(R) < 0.05] = 0                                  # never applied: untouched
+    last[rng.random(R) < 0.05] = step_to                            # up to date: untouched
+    lr = (1e-3 * np.sqrt(1 - 0.999 ** np.arange(step_to + 1)) / np.maximum(1 - 0.9 ** np.arange(step_to + 1), 1e-30)).astype(f)
+    ew, em, ev, moved = w.copy(), m.copy(), v.copy(), np.zeros((R, E))
+    elw, elm, elv, lmoved = lw.copy(), lmm.copy(), lvv.copy(), np.zeros(R)
+    with np.errstate(all="ignore"):
+        for r in range(R):
+            if last[r] == 0:
+                continue
+            for s in range(last[r] + 1, step_to + 1):
+                em[r] = em[r] * b1; ev[r] = ev[r] * b2
+                t = (lr[s] * em[r]) / (np.sqrt(ev[r]) + eps)
+                ew[r] = ew[r] - t; moved[r] += np.abs(t)
+                elm[r] = elm[r] * b1; elv[r] = elv[r] * b2
+                t = (lr[s] * elm[r]) / (np.sqrt(elv[r]) + eps)
+                elw[r] = elw[r] - t; lmoved[r] += abs(t)
+
+    def check_w(got, exp, mv, what):
+        d = np.abs(got.astype(np.float64) - exp.astype(np.float64))
+        bound = 3 * np.spacing(np.abs(exp)).astype(np.float64) + 2e-6 * mv
+        worst = float((d / bound).max())
+        same = float((got.view(np.uint32) == exp.view(np.uint32)).mean())
+        within = float((d <= 1e-7 * np.abs(exp)).mean())
+        print("bounded catch-up, %s: worst |err| / (3 ulp + 2e-6 sum|t|) = %.3f, bit-identical %.4f, within 1e-7 relative %.4f, "
+              "max relative error %.3g" % (what, worst, same, within, float((d / np.maximum(np.abs(exp), 1e-30)).max())))
+        assert worst <= 1.0, (what, worst)
+        assert same >= 0.95 and within >= 0.98, (what, same, within)
+
+    # (a) all rows, slots written (the form that runs before an evaluation / a checkpoint)
+    dW, dM, dV, dL, dLm, dLv, dlast, dlr = dev(w), dev(m), dev(v), dev(lw), dev(lmm), dev(lvv), dev(last), dev(lr)
+    _chk(lib.mi_sparse_catchup(_p(dW), _p(dM), _p(dV), _p(dL), _p(dLm), _p(dLv), _p(dlast), None, None, R, E, step_to,
+                               _p(dlr), float(b1), float(b2), float(eps), 2, 1, _st()))
+    torch.cuda.synchronize()
+    check_w(dW.cpu().numpy(), ew, moved, "rows")
+    check_w(dL.cpu().numpy(), elw, lmoved, "wide part")
+    for got, exp in ((dM, em), (dV, ev), (dLm, elm), (dLv, elv)):        # the slots: exact chains, as in the exact mode
+        assert np.array_equal(got.cpu().numpy().view(np.uint32), exp.view(np.uint32))
+    assert np.array_equal(dlast.cpu().numpy(), np.where(last < step_to, step_to, last))
+    # (b) the rows of a batch with deferred slots (inside a train step): only w moves
+    uq = rng.permutation(R)[:3000].astype(np.int32)
+    dW, dM, dV, dL, dLm, dLv, dlast = dev(w), dev(m), dev(v), dev(lw), dev(lmm), dev(lvv), dev(last)
+    duq, dnu = dev(np.concatenate([uq, np.zeros(96, np.int32)])), dev(np.array([3000], np.int32))
+    _chk(lib.mi_sparse_catchup(_p(dW), _p(dM), _p(dV), _p(dL), _p(dLm), _p(dLv), _p(dlast), _p(duq), _p(dnu), 3096, E, step_to,
+                               _p(dlr), float(b1), float(b2), float(eps), 3, 1, _st()))
+    torch.cuda.synchronize()
+    sel = np.zeros(R, bool); sel[uq] = True
+    gw, gl = dW.cpu().numpy(), dL.cpu().numpy()
+    check_w(gw[sel], ew[sel], moved[sel], "rows (deferred slots)")
+    check_w(gl[sel], elw[sel], lmoved[sel], "wide part (deferred slots)")
+    assert np.array_equal(gw[~sel], w[~sel]) and np.array_equal(gl[~sel], lw[~sel])
+    for got, exp in ((dM, m), (dV, v), (dLm, lmm), (dLv, lvv), (dlast, last)):
+        assert np.array_equal(got.cpu().numpy(), exp)
+    # (c) the flag is ignored where the bounded form has no meaning (eps too small to keep sqrt(v) + eps normal): the
+    # exact form runs, and an unknown flag is refused
+    assert lib.mi_sparse_catchup(_p(dW), _p(dM), _p(dV), None, None, None, _p(dlast), None, None, R, E, step_to, _p(dlr),
+                                 float(b1), float(b2), float(eps), 4, 1, _st()) != 0
+
+
 @pytest.mark.parametrize("B", [1, 37, 5000])
 def test_sigmoid_ce_head(lib, B):
     rng = np.random.default_rng(B)

@@ -90,43 +90,95 @@ def _compare_vars(m, p, atol):
         assert np.max(np.abs(g["lin_num"] - p.lin_num)) < atol
 
 
-# Multi-step Adam trajectories amplify last-bit differences.  In the config-3-shaped case one unit's
-# pre-activation is 0 to within rounding (7e-9) at step 3: its relu mask — and with it that unit's
-# whole gradient — flips under ANY change of summation order (seen with the f16x2 split, and again
-# in fp32 mode when the wide part's field sum moved to its own kernel), after which TF-form Adam moves
-# the few weights whose gradient is near zero by ~lr per step whichever way the sign falls.  That
-# case is therefore held to the bound such a flip implies from step 1 on; what is not chaotic — one
-# step from identical parameters: logits AND every updated variable — is held tight in every case,
-# and the other cases are held tight over all five steps.
-@pytest.mark.parametrize("gemm", ["f16x2", "fp32", "f16x2+fm-fold"])
+def _device_relu_masks(m, B):
+    """Which hidden units the device's last train step let through (activation > 0), per hidden layer: read from the
+    stored activations — fp32, or the planes where a layer's output exists as planes only."""
+    out = []
+    for i, h in enumerate(m.hidden):
+        if i in m._acts_in_planes:
+            a = torch.empty(B, h, device="cuda")
+            m.k.mi_merge_rows(m._pl["x%dp" % (i + 1)].struct, B, h, a, h)
+        else:
+            a = m._ws["act%d" % i][:B * h].view(B, h)
+        out.append((a > 0).cpu().numpy())
+    return out
+
+
+# Multi-step Adam trajectories amplify last-bit differences: a hidden unit whose pre-activation is 0 to within the
+# rounding of its dot product (7e-9 at step 3 of the 4-field config-3-shaped case) lands on either side of relu
+# depending on summation order, and TF-form Adam then moves the few weights whose gradient is near zero by ~lr per
+# step whichever way the sign falls.  Round 3: the test no longer loosens its bars for that case (3e-4 / 3e-3 in round
+# 2).  The device's relu decisions are read back after each step and handed to the oracle (oracle.forward(relu_masks));
+# they may differ from the oracle's own sign test ONLY on units whose pre-activation is within 1e-6 of 0 — asserted —
+# and with both sides on the same branch every case is held to the standard bars over all five steps.
+@pytest.mark.parametrize("gemm", ["f16x2", "fp32", "f16x2+fm-fold", "f16x2+bounded"])
 @pytest.mark.parametrize("vocab,E,hidden,B,nn", CONFIGS)
 def test_adam_training_matches_oracle(vocab, E, hidden, B, nn, gemm, monkeypatch):
     """5 train steps with fresh batches (rows sit out steps, duplicates inside a batch): the lazy
     catch-up path must reproduce TF Adam's dense-equivalent sparse update.  "+fm-fold": the layer-1 data
-    gradient adds dlogit * sumv to d_concat once per example (MI_FOLD_FM=1) instead of the apply per entry."""
+    gradient adds dlogit * sumv to d_concat once per example (MI_FOLD_FM=1) instead of the apply per entry;
+    "+bounded": the bounded-error replay (MI_CATCHUP_BOUNDED) — same bars."""
     monkeypatch.setenv("MI_FOLD_FM", "1" if gemm.endswith("fm-fold") else "0")
+    catchup = "bounded" if gemm.endswith("bounded") else "exact"
     gemm = gemm.split("+")[0]
-    marginal = hidden == [512, 256, 128]
-    logit_tol, var_atol = (3e-4, 3e-3) if marginal else (5e-5, 2e-6)
+    logit_tol, var_atol = 5e-5, 2e-6
     p, ids, x, y = make_problem(3, vocab, E, hidden, B, n_numeric=nn)
-    m = _engine(vocab, E, hidden, nn, gemm=gemm)
+    m = _engine(vocab, E, hidden, nn, gemm=gemm, catchup=catchup)
     if gemm == "fp32":
         m.GAP_SORT_MIN = 1               # also exercise the sort-rows-by-staleness path of the catch-up
     m.load_oracle_params(p)
     st = O.TrainState(p, OO.Hyper("Adam", 0.001))
     rng = np.random.default_rng(0)
+    flipped = 0
     for step in range(5):
         ids_s = np.stack([rng.integers(0, v, B) for v in vocab], 1).astype(np.int32)
         ids_s[B // 2] = ids_s[0]
-        loss_o, logit_o = O.train_step(p, st, ids_s, y, x)
         loss_g, logit_g = m.train_step(dev(ids_s), dev(y), dev(x))
+        masks = _device_relu_masks(m, B)
+        pre = O.forward(p, ids_s, x)["pre"]
+        for mk, q in zip(masks, pre):
+            diff = mk != (q > 0)
+            flipped += int(diff.sum())
+            assert not diff.any() or float(np.abs(q[diff]).max()) < 1e-6, (step, float(np.abs(q[diff]).max()))
+        loss_o, logit_o = O.train_step(p, st, ids_s, y, x, relu_masks=masks)
         assert abs(loss_g.item() - float(loss_o)) / abs(float(loss_o)) < 2e-5, step
         assert max_err_scaled(logit_g.cpu().numpy(), logit_o) < logit_tol, step
         if step == 0:
             assert max_err_scaled(logit_g.cpu().numpy(), logit_o) < 5e-6
             _compare_vars(m, p, 2e-6)
+    assert flipped <= 4, flipped          # (a handful of marginal units at most)
     _compare_vars(m, p, var_atol)
     assert m.step == 5
+
+
+# A config-3-shaped problem (26 fields, E = 64, hidden [512, 256, 128]: the shape bench.py measures) whose trajectory
+# has NO marginal unit: seed 319 keeps every hidden pre-activation of all five steps at least 1e-6 away from 0 in the
+# oracle (4.0e-6 here; asserted below, so a change of the host's BLAS that moved it would be seen) — a relu decision
+# cannot depend on summation order, no mask is replayed, and every GEMM mode and both catch-up modes are held to the
+# standard bars.
+CONFIG3_SAFE_SEED = 319
+
+
+@pytest.mark.parametrize("gemm,catchup", [("f16x2", "exact"), ("fp32", "exact"), ("bf16x3", "exact"), ("f16x2", "bounded")])
+def test_config3_shape_trajectory_is_tight(gemm, catchup):
+    vocab, E, hidden, B = [40 + 3 * i for i in range(26)], 64, [512, 256, 128], 64
+    p, ids, x, y = make_problem(CONFIG3_SAFE_SEED, vocab, E, hidden, B)
+    m = _engine(vocab, E, hidden, gemm=gemm, catchup=catchup)
+    assert m.planes == (gemm == "f16x2")
+    m.load_oracle_params(p)
+    st = O.TrainState(p, OO.Hyper("Adam", 0.001))
+    rng = np.random.default_rng(CONFIG3_SAFE_SEED)
+    margin = np.inf
+    for step in range(5):
+        ids_s = np.stack([rng.integers(0, v, B) for v in vocab], 1).astype(np.int32)
+        ids_s[B // 2] = ids_s[0]
+        margin = min(margin, min(float(np.abs(q).min()) for q in O.forward(p, ids_s)["pre"]))
+        loss_o, logit_o = O.train_step(p, st, ids_s, y)
+        loss_g, logit_g = m.train_step(dev(ids_s), dev(y))
+        assert abs(loss_g.item() - float(loss_o)) / abs(float(loss_o)) < 2e-5, step
+        assert max_err_scaled(logit_g.cpu().numpy(), logit_o) < (5e-6 if step == 0 else 5e-5), step
+    assert margin >= 1e-6, margin
+    _compare_vars(m, p, 2e-6)
 
 
 @pytest.mark.parametrize("name,lr", [("Adagrad", 0.05), ("Ftrl", 0.1), ("RMSProp", 0.001), ("SGD", 0.05)])
@@ -349,6 +401,47 @@ def test_graph_train_step_replays_the_eager_step_bitwise(vocab, E, hidden, B):
             lg, gg = graph.graph_train_step(ids_s, ys)
         assert torch.equal(le, lg) and torch.equal(ge, gg), step
     assert graph._graph is not None and graph.step == eager.step == 9
+    for k in ("table", "t_s0", "t_s1", "lin_state", "dense", "d_s0", "d_s1"):
+        assert torch.equal(getattr(eager, k), getattr(graph, k)), k
+
+
+def test_graph_is_recaptured_when_its_buffers_moved():
+    """a captured step holds the raw addresses of the engine's workspaces, planes and lr_t table; a later
+    call that needs more room (loss() on a larger batch, a restored checkpoint, layer summaries) reallocates them and
+    the caching allocator may hand the old storage to someone else.  The engine counts reallocations and captures
+    again when the count moved: graph steps at B = 32, an evaluation at B = 4096, a checkpoint round trip, more graph
+    steps — bit for bit the eager sequence."""
+    from mi355x_rec.engine import OptimizerSpec
+    vocab, E, hidden, B = ML100K_VOCAB, 4, [16, 16], 32
+    p, ids, x, y = make_problem(21, vocab, E, hidden, B)
+    ms = []
+    for _ in range(2):
+        m = _engine(vocab, E, hidden, dropout=0.1, seed=3, optimizer=OptimizerSpec("Adam", 0.001))
+        m.load_oracle_params(p)
+        ms.append(m)
+    eager, graph = ms
+    rng = np.random.default_rng(5)
+    big = dev(np.stack([rng.integers(0, v, 4096) for v in vocab], 1).astype(np.int32))
+    big_y = dev((rng.random(4096) < 0.3).astype(np.uint8))
+    captures = []
+    for step in range(12):
+        ids_s = dev(np.stack([rng.integers(0, v, B) for v in vocab], 1).astype(np.int32))
+        ys = dev((rng.random(B) < 0.3).astype(np.uint8))
+        if step == 4:                                   # an evaluation on a larger batch: every workspace grows
+            g0 = graph._graph["graph"]
+            le, _ = eager.loss(big, big_y); lg, _ = graph.loss(big, big_y)
+            assert torch.equal(le, lg)
+            torch.empty(1 << 22, device="cuda").fill_(float("nan"))       # (whoever gets the old storage scribbles on it)
+        if step == 8:                                   # a checkpoint round trip drops the capture too
+            graph.load_state_dict(graph.state_dict())
+            assert graph._graph is None
+        le, ge = eager.train_step(ids_s, ys)
+        lg, gg = graph.graph_train_step(ids_s, ys)
+        assert torch.equal(le, lg) and torch.equal(ge, gg), step
+        captures.append(None if graph._graph is None else id(graph._graph["graph"]))
+        if step == 4:
+            assert graph._graph is not None and graph._graph["graph"] is not g0       # captured again, not replayed into freed memory
+    assert graph.step == eager.step == 12
     for k in ("table", "t_s0", "t_s1", "lin_state", "dense", "d_s0", "d_s1"):
         assert torch.equal(getattr(eager, k), getattr(graph, k)), k
 

@@ -185,9 +185,10 @@ def test_model_utils_helpers(device):
         model_utils.get_train_op(ls["loss"], model_utils.get_optimizer("SGD", 0.1))(eng, ids, None)
 
 
-def _cli_rank(rank, world, port, job_dir, q):
-    """one process of a 2-rank `python -m torch.distributed.run ... -m trainers.deep_fm --synthetic` launch on CPU"""
-    import sys, traceback
+def _cli_rank(rank, world, port, job_dir, q, steps=6, interval=None):
+    """one process of a 2-rank `python -m torch.distributed.run ... -m trainers.deep_fm --synthetic` launch on CPU.
+    interval: checkpoint / evaluation interval in seconds (conf_utils.EVAL_INTERVAL), None = the reference's 60."""
+    import sys, time, traceback
     try:
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         for p in (root, os.path.join(root, "recommender-tensorflow_amd")):
@@ -197,18 +198,35 @@ def _cli_rank(rank, world, port, job_dir, q):
         from mi355x_rec import engine
         from tests.cpu_kernels import NumpyKernels
         engine.HipKernels = NumpyKernels                      # host logic run: kernels stood in by numpy
-        from trainers import deep_fm as T, _cli
+        from trainers import deep_fm as T, _cli, conf_utils
+        from mi355x_rec import estimator as est_mod
+        n_eval = [0]
+        if interval is not None:
+            conf_utils.EVAL_INTERVAL = interval
+            _orig_eval = est_mod.Estimator.evaluate
+            _orig_step = engine.DeepFM.train_step
+
+            def counting(self, *a, **kw):
+                n_eval[0] += 1
+                return _orig_eval(self, *a, **kw)
+
+            def skewed(self, *a, **kw):                       # the ranks' clocks and paces differ
+                time.sleep(0.004 * (1 + rank))
+                return _orig_step(self, *a, **kw)
+            est_mod.Estimator.evaluate = counting
+            engine.DeepFM.train_step = skewed
+            time.sleep(0.03 * rank)
         args = _cli.make_parser("deep_fm", ("exclude_linear", "exclude_mf", "exclude_dnn", "hidden_units", "dropout")).parse_args(
-            ["--job-dir", job_dir, "--synthetic", "400", "--train-steps", "6", "--batch-size", "16", "--device", "cpu",
+            ["--job-dir", job_dir, "--synthetic", "400", "--train-steps", str(steps), "--batch-size", "16", "--device", "cpu",
              "--world-size", str(world), "--dropout", "0"])
         est = T.train_and_evaluate(args)
         eng = est._engine()
-        q.put((rank, "ok", est.global_step, eng.R_local, eng.dense.clone().numpy(), sorted(os.listdir(job_dir))))
+        q.put((rank, "ok", est.global_step, eng.R_local, eng.dense.clone().numpy(), sorted(os.listdir(job_dir)), n_eval[0]))
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
     except Exception:
-        q.put((rank, "error", traceback.format_exc(), None, None, None))
+        q.put((rank, "error", traceback.format_exc(), None, None, None, None))
 
 
 def test_cli_two_rank_launch_cpu(tmp_path):
@@ -238,6 +256,35 @@ def test_cli_two_rank_launch_cpu(tmp_path):
     with pytest.raises(SystemExit):
         os.environ.pop("WORLD_SIZE", None)
         _cli.init_distributed(_cli.make_parser("linear").parse_args(["--world-size", "4"]))
+
+
+def test_two_rank_run_checkpoints_and_evaluates_at_the_same_steps(tmp_path):
+    """with N processes the checkpoint / evaluation cadence must not come from each rank's own clock —
+    evaluate() is a collective in the row-sharded engine, and a rank that enters it while the other issues the next train
+    step's all_to_all hangs the run.  Two gloo ranks of different pace, a 50 ms interval, 60 steps: several mid-run
+    evaluations, the same number on both ranks, the same final step, identical dense variables."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    job = str(tmp_path / "job")
+    procs = [ctx.Process(target=_cli_rank, args=(r, 2, port, job, q, 60, 0.05)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2):
+        r = q.get(timeout=300)
+        assert r[1] == "ok", r[2]
+        res[r[0]] = r
+    for p in procs:
+        p.join(timeout=60)
+    assert res[0][2] == res[1][2] == 60
+    assert res[0][6] == res[1][6] and res[0][6] >= 3, (res[0][6], res[1][6])
+    assert np.array_equal(res[0][4], res[1][4])
+    exports = [d for d in os.listdir(os.path.join(job, "export", "exporter"))]
+    assert exports and all(sorted(os.listdir(os.path.join(job, "export", "exporter", d))) ==
+                           ["signature.json", "variables.rank0.pt", "variables.rank1.pt"] for d in exports)
 
 
 def test_synthetic_input():
