@@ -22,6 +22,13 @@ On one GPU the ids of step t + 1 are announced to step t (train_step(next_ids=..
 sort then runs beside step t's catch-up; --no-presort for the plain sequence, same bits).  --force-shard [--chunks C]
 runs the multi-GPU step with a one-rank RCCL group: what that path costs by itself, links aside.
 
+`config.catchup` names the lazy-Adam replay the headline runs ("bounded": every variable within 1e-7 relative of TF's
+sweep, tests/test_hip_kernels.py::test_bounded_catchup_stays_within_1e7_of_the_sweep; --catchup exact = TF's bits); the
+other mode is timed as the extra `catchup_exact` / `catchup_bounded`.  `configs` carries the other BASELINE.json
+workloads as short legs on the same GPU (config 2: us per step eager and as one hipGraph launch; config 4 at the CLI
+defaults and at config 3's sizes; one rank's share of config 5), `roofline_sparse_apply` and `roofline_catchup` the two
+other bandwidth / issue-bound kernels of the step.
+
 Prints ONE JSON line on rank 0 with `roofline` (embedding gather kernel, HBM bound: algorithmic bytes read
 and written per launch / launch time, timed live with HIP events on the launch stream) and `cpu_baseline`
 (oracle/cpu_torch.py: the reference's TF graph restated on multi-threaded PyTorch-CPU at the full vocabulary,
@@ -61,7 +68,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-second-dist", action="store_true", help="skip the short run on the other id distribution")
-    ap.add_argument("--no-extras", action="store_true", help="skip the fp32-MFMA and LazyAdam-semantics legs")
+    ap.add_argument("--no-extras", action="store_true", help="skip the fp32-MFMA, other-catch-up-mode and LazyAdam-semantics legs (and the configs legs)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the legs on the other BASELINE.json configs (2, 4, 5-share)")
     ap.add_argument("--dist", choices=["uniform", "zipf"], default="uniform", help="id distribution")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="nccl = RCCL over xGMI (the measured path); gloo only rehearses the N>1 flow on one GPU")
@@ -76,6 +84,9 @@ def parse():
                     help="do not announce the next batch's ids to train_step (its sort then runs at the head of the next step "
                          "instead of on a side stream beside this step's catch-up)")
     ap.add_argument("--gemm", choices=["f16x2", "bf16x3", "fp32"], default="f16x2", help="matrix-pipe path of the MLP GEMMs")
+    ap.add_argument("--catchup", choices=["exact", "bounded"], default="bounded",
+                    help="lazy Adam replay of the steps a row sat out: TF's fp32 op sequence bit for bit, or the bounded-error "
+                         "form (every variable within 1e-7 relative of the sweep; include/mi355x_rec.h MI_CATCHUP_BOUNDED)")
     return ap.parse_args()
 
 
@@ -114,9 +125,10 @@ def mlp_roofline(gemm, flops, gemm_ms):
     elif gemm == "bf16x3":
         peak, kern, prod = MFMA_F16_PEAK_TFLOPS / 6, "gemm_split_k<bf16x3> (v_mfma_f32_32x32x16_bf16, 6 products)", 6
     else:
-        peak, kern, prod = MFMA_F16_PEAK_TFLOPS / SPLIT_PRODUCTS, ("gemm_pl_k (forward, data gradient: pre-split fp16 high/low planes, per-row exponents) + "
-                                                                   "gemm_split_k<f16x2> (weight gradient); v_mfma_f32_32x32x16_f16, 3 products"), SPLIT_PRODUCTS
-    return {"kernel": kern + "; all dense fwd/bwd launches incl. the N=1 logits layer (matrix-vector kernels)", "bound": "mfma",
+        peak, kern, prod = MFMA_F16_PEAK_TFLOPS / SPLIT_PRODUCTS, ("gemm_pl_k (forward, data gradient) + wgrad_pl_k (weight gradient): operands as pre-split "
+                                                                   "fp16 high/low planes with per-row exponents; v_mfma_f32_32x32x16_f16, 3 products"), SPLIT_PRODUCTS
+    return {"kernel": kern + "; all dense fwd/bwd launches incl. the N=1 logits layer (matrix-vector kernels) AND the path's own "
+                             "overhead launches (weight split, abs-max, row splits, slab folds)", "bound": "mfma",
             "achieved": ach, "peak": peak, "unit": "TFLOP/s (fp32-equivalent)", "frac": ach / peak,
             "mfma_products_per_fp32_product": prod, "executed_mfma_tflops": ach * prod,
             "fp32_input_mfma_peak": MFMA_F32_PEAK_TFLOPS, "flops_per_step": flops, "gemm_ms_per_step": gemm_ms}
@@ -192,6 +204,75 @@ def cpu_baseline():
                       (B, F, E, HIDDEN, V, steps)}
 
 
+ML100K_VOCAB = [2] * 19 + [1000, 2000, 50, 1000, 7, 8, 3]
+
+
+def _time_steps(step, batches, warm, n, sync):
+    for i in range(warm):
+        step(*batches[i % len(batches)])
+    sync()
+    t0 = time.perf_counter()
+    out = None
+    for i in range(n):
+        out = step(*batches[i % len(batches)])
+    sync()
+    return (time.perf_counter() - t0) / n, out
+
+
+def other_configs(device, sync):
+    """The other BASELINE.json workloads as short legs on this GPU: step time and examples/sec each,
+    4 rotating batches (so little catch-up work: these are shape legs, not steady-state headlines)."""
+    from mi355x_rec.engine import DeepFM, OptimizerSpec
+    out = {}
+    g = torch.Generator(device=device)
+    g.manual_seed(SEED + 7)
+
+    def batches(vocab, B, n_num, n=4):
+        bs = []
+        for _ in range(n):
+            ids = torch.stack([torch.randint(0, v, (B,), device=device, generator=g) for v in vocab], 1).to(torch.int32).contiguous()
+            y = (torch.rand(B, device=device, generator=g) < 0.25).to(torch.uint8)
+            x = torch.log1p(torch.empty(B, n_num, device=device).exponential_(generator=g)) if n_num else None
+            bs.append((ids, y, x) if n_num else (ids, y))
+        return bs
+
+    # config 2: trainers.deep_fm defaults on the MovieLens schema — launch-bound: us per step
+    m = DeepFM(ML100K_VOCAB, embedding_size=4, hidden_units=[16, 16], dropout=0.1, optimizer=OptimizerSpec("Adam", 0.001), device=device)
+    m.init_variables(g, lin_scale=1e-3)
+    bs = batches(ML100K_VOCAB, 32, 0, n=1)
+    te, _ = _time_steps(m.train_step, bs, 20, 200, sync)
+    tg, _ = _time_steps(m.graph_train_step, bs, 20, 200, sync)
+    out["c2"] = {"workload": "config 2: trainers.deep_fm defaults (E=4, hidden [16,16], B=32, dropout 0.1, Adam), 26 MovieLens fields "
+                             "(4,106 rows), synthetic ids", "us_per_step_eager": te * 1e6, "us_per_step_hip_graph": tg * 1e6,
+                 "examples_per_sec_hip_graph": 32 / tg}
+    del m
+    # config 4: Wide&Deep (linear_deep), 26 fields x 1M ids + 13 dense columns, Ftrl (wide) + Adagrad (deep), SUM loss
+    for key, Ec, hid in (("c4_defaults", 4, [16, 16]), ("c4_c3sizes", E, HIDDEN)):
+        vocab = [V] * F
+        m = DeepFM(vocab, n_numeric=13, numeric="raw", embedding_size=Ec, hidden_units=hid, use_mf=False, dropout=0.1,
+                   optimizer=OptimizerSpec("Adagrad", 0.05), linear_optimizer=OptimizerSpec("Ftrl", 0.1961), reduction="sum", device=device)
+        m.init_variables(g, lin_scale=1e-3)
+        t, (loss, _) = _time_steps(m.train_step, batches(vocab, B_FULL, 13), 4, 12, sync)
+        out[key] = {"workload": "config 4: trainers.linear_deep (DNNLinearCombined: Ftrl + Adagrad, SUM loss) B=65536, 26 fields x 1M ids + "
+                                "13 dense columns, E=%d hidden %s, one GPU's step" % (Ec, hid),
+                    "ms_per_step": t * 1e3, "examples_per_sec": B_FULL / t, "final_loss": float(loss.item())}
+        del m
+        torch.cuda.empty_cache()
+    # config 5: one rank's share — 40 fields x 1.25M rows (50M rows x E=128 = 25.6 GB, 76.8 GB with Adam slots), B = 131072 / 8
+    vocab = [1_250_000] * 40
+    m = DeepFM(vocab, embedding_size=128, hidden_units=HIDDEN, dropout=0.1, optimizer=OptimizerSpec("Adam", 0.001), device=device,
+               catchup="bounded")
+    m.init_variables(g, lin_scale=1e-3)
+    t, (loss, _) = _time_steps(m.train_step, batches(vocab, 16384, 0), 4, 12, sync)
+    out["c5_rank_share"] = {"workload": "config 5, ONE rank's share as a single-GPU step (no exchange): 40 fields x 1.25M rows (a 25.6 GB table, "
+                                        "76.8 GB with Adam slots), E=128, hidden [512,256,128], B=16384 (131072 / 8)",
+                            "ms_per_step": t * 1e3, "examples_per_sec": 16384 / t, "final_loss": float(loss.item()),
+                            "hbm_allocated_GB": torch.cuda.max_memory_allocated() / 1e9}
+    del m
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -222,7 +303,8 @@ def main():
         from mi355x_rec.parallel import RowShard
         shard = RowShard(rank, world, chunks=args.chunks)
     m = DeepFM([V] * F, embedding_size=E, hidden_units=HIDDEN, dropout=DROPOUT,
-               optimizer=OptimizerSpec("Adam", 0.001), device=device, seed=SEED, shard=shard, gemm=args.gemm)
+               optimizer=OptimizerSpec("Adam", 0.001), device=device, seed=SEED, shard=shard, gemm=args.gemm,
+               catchup=args.catchup)
     gen = torch.Generator(device=device)
     gen.manual_seed(SEED + rank)
     m.init_variables(gen, lin_scale=1e-3)
@@ -306,6 +388,19 @@ def main():
     timers.update(roof_timers)                           # the roofline kernel's launches: those of the timed region
     log("instrumented pass: %.3f ms/step" % (idt / args.steps * 1e3))
 
+    # What the sparse kernels of a steady-state step work on (a statistic for their rooflines, taken outside every timed
+    # region with torch ops on the NEXT batch): distinct rows U, and over how many steps each has to be replayed.
+    sparse_stats = None
+    if shard is None and m.last_step is not None:
+        ids_n = batches[cursor[0] % len(batches)][0]
+        rows_n = torch.unique(ids_n.long() + m.field_off[None, :])
+        st_n = m.last_step[rows_n]
+        gaps_n = (m.step - st_n)[st_n > 0].double()
+        sparse_stats = {"unique_rows": int(rows_n.numel()), "rows_with_state": int(gaps_n.numel()),
+                        "mean_replayed_steps": float(gaps_n.mean().item()) if gaps_n.numel() else 0.0,
+                        "element_steps": float(gaps_n.sum().item()) * E}
+        del rows_n, st_n, gaps_n
+
     # second distribution of SURVEY 8d (Criteo-like skew), a short run after the headline one: same
     # protocol (barrier + synchronize on both sides, max over ranks); reported beside `value`
     other = None
@@ -354,6 +449,21 @@ def main():
                                    "note": "same steps with every MLP GEMM on the fp32-input MFMA (v_mfma_f32_32x32x2_f32, exact "
                                            "products): the un-emulated number beside the headline's fp16 high/low operand split"}
             m.gemm, m.planes, m.gather_mlp = keep
+        # the other catch-up mode, same steps (A/B partner of nothing: run on the fresh 24-batch pool like the legs above)
+        other_mode = "exact" if m.catchup == "bounded" else "bounded"
+        keep_mode, m.catchup = m.catchup, other_mode
+        run(3)
+        cdt, _ = timed(10)
+        m.catchup = keep_mode
+        run(3)
+        sdt, _ = timed(10)
+        extras["catchup_" + other_mode] = {
+            "value": B * 10 / cdt, "unit": "examples/sec", "ms_per_step": cdt / 10 * 1e3,
+            "same_leg_in_headline_mode_ms_per_step": sdt / 10 * 1e3,
+            "note": ("the same steps with the lazy Adam replay bit-exact with TF's dense-equivalent sweep (exactly rounded sqrt and divide "
+                     "per element and replayed step)" if other_mode == "exact" else
+                     "the same steps with the bounded-error replay (MI_CATCHUP_BOUNDED)") +
+                    "; timed back to back with 10 steps in the headline's mode on the same batch pool"}
         # LazyAdam semantics: rows that sat out are NOT replayed (no catch-up, no deferred slot decay).  NOT the
         # reference's tf.train.AdamOptimizer — here only to put a price on exactness.  Last leg: it
         # leaves the model's stamps stale.
@@ -364,6 +474,15 @@ def main():
                                              "note": "LazyAdam semantics (touched rows only; NOT the reference's dense-equivalent "
                                                      "AdamOptimizer): the step without the catch-up replay"}
         m.adam_rows, m.last_step = True, stamps
+
+    mode_catchup = m.catchup
+    configs = None
+    if world == 1 and not args.no_extras and not args.force_shard and not args.no_configs:
+        log("extras done; the other BASELINE configs")
+        del m
+        batches = None
+        torch.cuda.empty_cache()
+        configs = other_configs(device, sync)
 
     if rank == 0:
         km = kernel_ms(timers)
@@ -385,17 +504,62 @@ def main():
             gather_bytes = row_bytes
         total_bytes = gather_bytes if planes_gather else Bl * (F * (4 * E + (4 if wide_split else 8)) + 4 * E + (4 if wide_split else 8))
         achieved = gather_bytes / (g_ms * 1e-3) / 1e9
-        gemm_ms = sum(v[2] for k, v in km.items() if k in ("mi_dense_fwd", "mi_dense_fwd_gathered", "mi_dense_bwd_data", "mi_dense_bwd_weight",
-                                                        "mi_dense_bwd_weight_gathered", "mi_dense_fwd_planes",
-                                                        "mi_dense_bwd_data_planes", "mi_dense_bwd_weight_planes")) / args.steps
+        gemm_keys = ("mi_dense_fwd", "mi_dense_fwd_gathered", "mi_dense_bwd_data", "mi_dense_bwd_weight", "mi_dense_bwd_weight_gathered",
+                     "mi_dense_fwd_planes", "mi_dense_bwd_data_planes", "mi_dense_bwd_weight_planes")
+        # (the planes path's own overhead launches count against it: they exist only because of it)
+        gemm_overhead_keys = ("mi_dense_bwd_data_vec_planes", "mi_split_weights", "mi_absmax", "mi_split_rows")
+        gemm_ms = sum(v[2] for k, v in km.items() if k in gemm_keys + gemm_overhead_keys) / args.steps
+        gemm_overhead_ms = sum(v[2] for k, v in km.items() if k in gemm_overhead_keys) / args.steps
         dims = [F * E] + HIDDEN + [1]
         flops = 3 * 2 * B * sum(a * b for a, b in zip(dims[:-1], dims[1:]))
-        traffic = None
+        # PMC traffic: NOT measured by this run (hardware counters need rocprofv3 around the process) — the committed
+        # per-launch byte counts of the same kernels on the same workload, profiles/traffic.json (its _comment names the
+        # profile each entry comes from)
+        pmc = {}
         try:
             with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-                traffic = json.load(f)["embed_fm_planes_fwd_k" if planes_gather else "embed_fm_linear_fwd_k"]["bytes_per_launch"] if world == 1 else None
-        except (OSError, KeyError, ValueError):
+                pmc = json.load(f) if world == 1 else {}
+        except (OSError, ValueError):
             pass
+        tr = lambda name: pmc.get(name, {}).get("bytes_per_launch")
+        traffic = tr("embed_fm_planes_fwd_k" if planes_gather else "embed_fm_linear_fwd_k")
+        # the two other bandwidth / issue-bound kernels of the step (lazy sparse Adam = 28E + 8 bytes per distinct row)
+        roof_apply = roof_catchup = None
+        if sparse_stats is not None and "mi_sparse_apply_fused" in km:
+            U = sparse_stats["unique_rows"]
+            a_ms = km["mi_sparse_apply_fused"][0]
+            a_bytes = U * (28 * E + 8)
+            roof_apply = {"kernel": "sparse_apply_k<fused> (+ sparse_apply_long_k): duplicate-summing of the entry gradients rebuilt from "
+                                    "d_concat / sumv / dlogit, TF-form Adam on the distinct rows of the batch, wide-part record, stamps",
+                          "bound": "hbm", "achieved": a_bytes / (a_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": a_bytes / (a_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_launch_ms": a_ms, "unique_rows": U,
+                          "algorithmic_bytes_per_launch": int(a_bytes),
+                          "algorithmic_bytes_note": "SURVEY 8d: per distinct row 4E (gradient) + 24E (w, m, v read and written) + 8 = 28E + 8 = %d B" % (28 * E + 8),
+                          "traffic": tr("sparse_apply_k"),
+                          "traffic_note": "PMC bytes per launch (profiles/traffic.json); above the algorithmic bytes by the per-ENTRY reads of "
+                                          "sumv (served by L2 / Infinity Cache, counted at the fabric) and the wide-part records"}
+        if sparse_stats is not None and "mi_sparse_catchup" in km and sparse_stats["rows_with_state"]:
+            c_ms = km["mi_sparse_catchup"][0]
+            Us = sparse_stats["rows_with_state"]
+            c_bytes = Us * (16 * E + 32)          # w, m, v read + w written (deferred slots) + the 16-byte wide record read and written
+            cyc = 236.0 if mode_catchup == "exact" else 83.0
+            issue_ms = sparse_stats["element_steps"] / 256.0 * cyc / 1024.0 / 2.1e9 * 1e3
+            roof_catchup = {"kernel": "sparse_catchup_%s (+ catchup_lin_k): lazy replay of TF Adam's dense-equivalent update on the rows "
+                                      "about to be read (w only: the apply decays m, v)" % ("bounded_k" if mode_catchup == "bounded" else "k"),
+                            "mode": mode_catchup, "bound": "hbm" if mode_catchup == "bounded" else "valu issue",
+                            "achieved": c_bytes / (c_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": c_bytes / (c_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_launch_ms": c_ms,
+                            "algorithmic_bytes_per_launch": int(c_bytes),
+                            "algorithmic_bytes_note": "per row with state: w, m, v read (12E) + w written (4E) + the 16-byte wide record read and written = 16E + 32",
+                            "rows_with_state": Us, "mean_replayed_steps": sparse_stats["mean_replayed_steps"],
+                            "element_steps_per_launch": sparse_stats["element_steps"],
+                            "issue_model": {"cycles_per_wave_and_replayed_step": cyc, "simds": 1024, "clock_GHz": 2.1,
+                                            "issue_bound_ms": issue_ms, "frac_of_issue_bound": issue_ms / c_ms,
+                                            "note": "instruction issue of the replay loop alone (ISA count x the gfx950 prices measured by "
+                                                    "tools/probe/valu_cost_probe.hip); exact: 38 packed + 8 transcendental + 3; bounded: "
+                                                    "14 packed + 4 transcendental + 3 per 4 elements and step"},
+                            "traffic": tr("sparse_catchup_k") if mode_catchup == "exact" else tr("sparse_catchup_bounded_k"),
+                            "traffic_note": "PMC bytes per launch of the row kernel (profiles/traffic.json)"}
         out = {
             "metric": "examples/sec DeepFM batch=65536 (full train step)",
             "value": world * B * args.steps / dt,
@@ -415,6 +579,9 @@ def main():
                                 "bf16x3": "fp32 GEMMs via 3-way bf16 operand split, fp32 accumulate",
                                 "fp32": "fp32-input MFMA"}[args.gemm],
                        "parallelism": "dp%d + row-sharded embeddings (all-to-all)" % world if (world > 1 or args.force_shard) else "single GPU",
+                       "catchup": ("bounded-error lazy Adam replay (MI_CATCHUP_BOUNDED: every variable within 3 ulp + 2e-6 of the replayed "
+                                   "movement of TF's sweep, 98.7 % within 1e-7 relative; the exact mode is the extra catchup_exact)"
+                                   if mode_catchup == "bounded" else "lazy Adam replay bit-exact with TF's dense-equivalent sweep"),
                        "input_pipeline": ("next batch's ids announced one step ahead (train_step(next_ids=...)): their sort runs on a "
                                           "side stream beside this step's catch-up" if presort[0] else "ids handed over step by step")},
             "roofline": {"kernel": ("embed_fm_planes_fwd_k: embedding gather + FM second order, writes the input_layer concat as fp16 "
@@ -426,8 +593,14 @@ def main():
                          "algorithmic_bytes_per_launch": int(gather_bytes), "examples_per_launch": int(Bl), "avg_launch_ms": g_ms,
                          "row_read_GBs": row_bytes / (g_ms * 1e-3) / 1e9, "row_read_frac": row_bytes / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "traffic": traffic,
-                         "traffic_note": "HBM bytes/launch from rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE), profiles/"},
-            "roofline_mlp": mlp_roofline(args.gemm, flops, gemm_ms),
+                         "traffic_note": "HBM bytes/launch from rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE) of the same kernel on this workload, "
+                                         "committed in profiles/traffic.json — a constant read from that file, not a counter of this run",
+                         "launch_time_note": "avg_launch_ms: HIP events around the launches of the timed region; a long rocprofv3 trace of "
+                                             "the same build averages ~4 % less (boxes of the pool and cold starts differ by that much)"},
+            "roofline_mlp": dict(mlp_roofline(args.gemm, flops, gemm_ms), overhead_launches_ms_per_step=gemm_overhead_ms),
+            "roofline_sparse_apply": roof_apply,
+            "roofline_catchup": roof_catchup,
+            "configs": configs,
             "kernel_ms_per_step": {k: v[2] / args.steps for k, v in sorted(km.items())},
             "kernel_ms_note": "HIP-event pairs around every launch of a second pass over %d steps right after the timed "
                               "region (%.3f ms/step with the events' ~10-us bubbles); inside the timed region only the roofline "

@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include "../../include/mi355x_rec.h"
 
@@ -19,6 +20,12 @@ inline hipStream_t as_stream(mi_stream_t s) { return reinterpret_cast<hipStream_
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// tuning experiments only (tools/*_bench.py): an integer from the environment, else the built-in value
+inline int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return (e && *e) ? atoi(e) : dflt;
+}
 
 // device-resident step state registered by mi_set_step_state (host_ids.cpp), or nullptr
 const mi_step_state_t* step_state();

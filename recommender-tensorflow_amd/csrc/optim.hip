@@ -465,7 +465,7 @@ __global__ __launch_bounds__(kBlock) void catchup_lin_k(
   }
 }
 
-template <int LPR, bool BOUNDED>
+template <int LPR>
 __global__ __launch_bounds__(kBlock) void sparse_catchup_k(
     float* __restrict__ table, float* __restrict__ tm, float* __restrict__ tv,
     int32_t* __restrict__ last_step, const int32_t* __restrict__ uniq_rows,
@@ -485,25 +485,6 @@ __global__ __launch_bounds__(kBlock) void sparse_catchup_k(
     if (table && 4 * l < E) {
       const int64_t o = r * E + 4 * l;
       float4 w = ld4(table + o), m = ld4_nt(tm + o), v = ld4_nt(tv + o);
-      if constexpr (BOUNDED) {
-        const RhoSplit rho = rho_split(b2);
-        const float4 s0 = make_float4(sqrtf(v.x), sqrtf(v.y), sqrtf(v.z), sqrtf(v.w));
-        float rj = 1.f;
-        for (int s = ls + 1; s <= step_to; ++s) {
-          const float lr = lr_table[s];
-          rj = fmaf(rj, rho.lo, rj * rho.hi);
-          m.x = m.x * b1; m.y = m.y * b1; m.z = m.z * b1; m.w = m.w * b1;
-          w.x = bounded_step(w.x, lr * m.x, s0.x, rj, eps);
-          w.y = bounded_step(w.y, lr * m.y, s0.y, rj, eps);
-          w.z = bounded_step(w.z, lr * m.z, s0.z, rj, eps);
-          w.w = bounded_step(w.w, lr * m.w, s0.w, rj, eps);
-        }
-        st4(table + o, w);
-        if (!defer_slots) {
-          for (int s = ls + 1; s <= step_to; ++s) { v.x = v.x * b2; v.y = v.y * b2; v.z = v.z * b2; v.w = v.w * b2; }
-          st4_nt(tm + o, m); st4_nt(tv + o, v);
-        }
-      } else {
       // one loop for the four elements: one lr_t load and one loop counter per step instead of four,
       // four independent sqrt/divide chains in flight (the arithmetic per element is unchanged)
       const bool ok = catchup_params_in_range(step_to - ls, lr_table[step_to], eps, b1, b2) && catchup_in_range(m.x, v.x) &&
@@ -530,7 +511,6 @@ __global__ __launch_bounds__(kBlock) void sparse_catchup_k(
       }
       st4(table + o, w);
       if (!defer_slots) { st4_nt(tm + o, m); st4_nt(tv + o, v); }
-      }
     }
   }
   // (the wide part's scalar per row: catchup_lin_k)
@@ -539,6 +519,136 @@ __global__ __launch_bounds__(kBlock) void sparse_catchup_k(
   // of this kernel's HBM traffic.
   // every lane of the group has read last_step[r] above (same wave, program order) before lane 0 writes
   if (l == 0 && !defer_slots) last_step[r * st] = step_to;
+}
+
+// The bounded-error replay of the rows (MI_CATCHUP_BOUNDED).  With 4 + 1 instructions per element and step the replay is
+// no longer bound by instruction issue (0.25 ms of it at config 3) but by how a wave's life is spent: row id -> stamp ->
+// w, m, v are three DEPENDENT memory latencies before a dozen replayed steps, and a kernel shaped like the exact one
+// (one row per lane group, then exit) moved its 1.7 GB at 2.9 TB/s.  So this kernel is a software pipeline:
+//   * a lane group walks rows u, u + G, u + 2G, ... (G lane groups in the grid, a few workgroups per CU) and loads row
+//     u + G's stamp, w, m and v — all four at once, they depend on the row id only — BEFORE it replays row u: the next
+//     row's latencies pass under this row's arithmetic;
+//   * nothing inside the replay loop touches vector memory: lr_t[s] comes from an LDS copy of the table's last
+//     kLrWindow entries (s_waitcnt vmcnt counts in order: one global load in the loop would wait for the whole prefetch);
+//     older steps — a row that sat out more than kLrWindow steps — are replayed from the global table first;
+//   * the rows arrive sorted by staleness (mi_catchup_rows_by_gap), so the lane groups of a wave run loops of about the
+//     same length in every round.
+constexpr int kLrWindow = 1024;
+
+struct RowIn { int64_t r; int ls; float4 w, m, v; };
+
+// a row's stamp, w, m and v: four loads that depend on the row id only, issued together
+__device__ __forceinline__ RowIn load_row_in(const float* __restrict__ table, const float* __restrict__ tm, const float* __restrict__ tv,
+                                             const int32_t* __restrict__ last_step, int64_t r, int E, int l, bool lane_on, int st) {
+  RowIn q;
+  q.r = r;
+  q.ls = last_step[r * st];
+  q.w = q.m = q.v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (lane_on) {
+    const int64_t o = r * E + 4 * l;
+    q.w = ld4(table + o); q.m = ld4_nt(tm + o); q.v = ld4_nt(tv + o);
+  }
+  return q;
+}
+
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void sparse_catchup_bounded_k(
+    float* __restrict__ table, float* __restrict__ tm, float* __restrict__ tv,
+    int32_t* __restrict__ last_step, const int32_t* __restrict__ uniq_rows,
+    const int32_t* __restrict__ num_uniq, int64_t n_max, int E, int step_to,
+    const float* __restrict__ lr_table, float b1, float b2, float eps, bool defer_slots, int st,
+    const mi_step_state_t* __restrict__ ss) {
+  __shared__ float lr_s[kLrWindow];
+  if (ss) step_to = ss->step - 1;
+  const int base = step_to - (kLrWindow - 1);                 // lr_s[i] = lr_t[base + i]
+  for (int i = threadIdx.x; i < kLrWindow; i += kBlock) lr_s[i] = base + i >= 1 ? lr_table[base + i] : 0.f;
+  __syncthreads();
+  const int l = threadIdx.x & (LPR - 1);
+  const bool lane_on = 4 * l < E;
+  const int64_t count = uniq_rows ? static_cast<int64_t>(*num_uniq) : n_max;
+  // Which row when.  The rows come sorted by staleness, and a wave's lane groups should see equal staleness — but the
+  // CHIP should not: a window of the sorted list is all short replays (memory bound) or all long ones (issue bound),
+  // and waves that walk the list side by side make the whole chip one or the other.  So the list is cut into chunks of
+  // one wave's rows (64 / LPR consecutive rows), the chunks into W segments of J chunks (W = waves in the grid, a power
+  // of two), and wave k takes in round j chunk j of segment (k + j S) mod W: for fixed j a bijection over the waves, so
+  // every chunk is taken once; over the rounds a wave samples every staleness (equal work per wave), and in any round
+  // the waves between them hold all of them (memory and arithmetic overlap across waves).
+  constexpr int RPW = 64 / LPR;
+  const int64_t n_chunks = (count + RPW - 1) / RPW;
+  const int W = static_cast<int>(gridDim.x) * (kBlock / 64);                  // (a power of two: the launcher's grid)
+  const int64_t J = (n_chunks + W - 1) / W;
+  const int S = static_cast<int>(J > 0 && W / J > 1 ? W / J : 1);
+  const int k = static_cast<int>(blockIdx.x) * (kBlock / 64) + (threadIdx.x >> 6);
+  const int grp = (threadIdx.x & 63) / LPR;
+  auto row_at = [&](int64_t j) -> int64_t {                                   // position in the sorted list, or >= count
+    const int64_t seg = (k + j * S) & (W - 1);
+    const int64_t c = seg * J + j;
+    return c < n_chunks ? c * RPW + grp : count;
+  };
+  if (J == 0) return;
+  const RhoSplit rho = rho_split(b2);
+  auto row_id = [&](int64_t x) { return uniq_rows ? uniq_rows[x] : static_cast<int32_t>(x); };   // (rows fit int32: the engine checks)
+  // The pipeline: while round j's row is replayed, round j + 1's state and round j + 2's ID are in flight.  A round starts
+  // by taking over what the previous round prefetched (the one point where the wave waits for memory: everything
+  // outstanding there was issued before the previous round's arithmetic), then issues the next prefetch, then computes
+  // on registers.  A lane group whose chunk lies past the end of the list carries ls = step_to: nothing to do.
+  RowIn none;
+  none.r = 0; none.ls = INT32_MAX; none.w = none.m = none.v = make_float4(0.f, 0.f, 0.f, 0.f);
+  int64_t u0 = row_at(0);
+  RowIn nxt = u0 < count ? load_row_in(table, tm, tv, last_step, row_id(u0), E, l, lane_on, st) : none;
+  int64_t u1 = J > 1 ? row_at(1) : count;
+  int32_t id_pref = u1 < count ? row_id(u1) : 0;
+  for (int64_t j = 0; j < J; ++j) {
+    const RowIn cur = nxt;
+    const int64_t r_next = id_pref;
+    const bool more = j + 1 < J;
+    if (more) {
+      nxt = u1 < count ? load_row_in(table, tm, tv, last_step, r_next, E, l, lane_on, st) : none;
+      u1 = j + 2 < J ? row_at(j + 2) : count;
+      if (u1 < count) id_pref = row_id(u1);
+    }
+    // ---- replay row u (a row that was never applied has m = v = 0: every step subtracts exactly 0)
+    const int ls = cur.ls;
+    if (ls > 0 && ls < step_to) {
+      if (lane_on) {
+        float4 w = cur.w, m = cur.m;
+        // (v_sqrt_f32: 1 ulp; a v too small for it is also far too small to matter next to eps)
+        const float4 s0 = make_float4(__builtin_amdgcn_sqrtf(cur.v.x), __builtin_amdgcn_sqrtf(cur.v.y),
+                                      __builtin_amdgcn_sqrtf(cur.v.z), __builtin_amdgcn_sqrtf(cur.v.w));
+        float rj = 1.f;
+        int s = ls + 1;
+        for (; s < base && s <= step_to; ++s) {                 // steps older than the LDS window (rare)
+          const float lr = lr_table[s];
+          rj = fmaf(rj, rho.lo, rj * rho.hi);
+          m.x = m.x * b1; m.y = m.y * b1; m.z = m.z * b1; m.w = m.w * b1;
+          w.x = bounded_step(w.x, lr * m.x, s0.x, rj, eps); w.y = bounded_step(w.y, lr * m.y, s0.y, rj, eps);
+          w.z = bounded_step(w.z, lr * m.z, s0.z, rj, eps); w.w = bounded_step(w.w, lr * m.w, s0.w, rj, eps);
+        }
+        // (two-element vectors: hipcc then packs the fma of the denominators too; two steps per trip of the loop)
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const f32x2 sa = {s0.x, s0.y}, sb = {s0.z, s0.w};
+#pragma unroll 2
+        for (; s <= step_to; ++s) {
+          const float lr = lr_s[s - base];
+          rj = fmaf(rj, rho.lo, rj * rho.hi);
+          m.x = m.x * b1; m.y = m.y * b1; m.z = m.z * b1; m.w = m.w * b1;
+          const f32x2 rv = {rj, rj}, ev = {eps, eps};
+          const f32x2 da = __builtin_elementwise_fma(sa, rv, ev), db = __builtin_elementwise_fma(sb, rv, ev);
+          w.x = fmaf(-(lr * m.x), __builtin_amdgcn_rcpf(da.x), w.x); w.y = fmaf(-(lr * m.y), __builtin_amdgcn_rcpf(da.y), w.y);
+          w.z = fmaf(-(lr * m.z), __builtin_amdgcn_rcpf(db.x), w.z); w.w = fmaf(-(lr * m.w), __builtin_amdgcn_rcpf(db.y), w.w);
+        }
+        const int64_t o = cur.r * E + 4 * l;
+        st4(table + o, w);
+        if (!defer_slots) {
+          float4 v = cur.v;
+          for (int q = ls + 1; q <= step_to; ++q) { v.x = v.x * b2; v.y = v.y * b2; v.z = v.z * b2; v.w = v.w * b2; }
+          st4_nt(tm + o, m); st4_nt(tv + o, v);
+        }
+      }
+    }
+    // (every lane of the group read the stamp above before lane 0 overwrites it: same wave, program order)
+    if (l == 0 && !defer_slots && ls < step_to) last_step[cur.r * st] = step_to;
+  }
 }
 
 // The proof obligation of sqrt_rn_inrange: the same bits as hipcc's correctly rounded sqrtf for every value it is given.
@@ -827,12 +937,15 @@ int32_t mi_sparse_catchup(float* table, float* t_m, float* t_v, float* lin_w, fl
   const int lpr = table ? lanes_per_row(E) : 1;
   const int64_t blocks = mi::ceil_div(n_max * lpr, kBlock);
   MI_REQUIRE(blocks <= INT32_MAX, "sparse_catchup: grid too large");
-  if (bounded) {
-    MI_DISPATCH_LPR(lpr, (sparse_catchup_k<L, true><<<dim3((unsigned)blocks), dim3(kBlock), 0, mi::as_stream(stream)>>>(
+  if (bounded && table) {
+    // a pipelined grid: a few resident workgroups per CU, every lane group walks its share of the rows
+    int64_t pb = mi::env_int("MI_CATCHUP_BLOCKS", 2048);          // 8 workgroups per CU resident
+    while (pb > 1 && pb > blocks) pb >>= 1;                       // (a power of two: the kernel's wave -> chunk map)
+    MI_DISPATCH_LPR(lpr, (sparse_catchup_bounded_k<L><<<dim3((unsigned)pb), dim3(kBlock), 0, mi::as_stream(stream)>>>(
                              table, t_m, t_v, last_step, uniq_rows, num_uniq, n_max, E, step_to, lr_table, beta1, beta2,
                              epsilon, defer, lin_stride, mi::step_state())));
   } else {
-    MI_DISPATCH_LPR(lpr, (sparse_catchup_k<L, false><<<dim3((unsigned)blocks), dim3(kBlock), 0, mi::as_stream(stream)>>>(
+    MI_DISPATCH_LPR(lpr, (sparse_catchup_k<L><<<dim3((unsigned)blocks), dim3(kBlock), 0, mi::as_stream(stream)>>>(
                              table, t_m, t_v, last_step, uniq_rows, num_uniq, n_max, E, step_to, lr_table, beta1, beta2,
                              epsilon, defer, lin_stride, mi::step_state())));
   }
