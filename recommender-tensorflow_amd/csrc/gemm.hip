@@ -54,20 +54,8 @@ struct GemmArgs {
   const mi_step_state_t* st;   // device-resident step state of a captured step (seed += st->seed_term), or nullptr
 };
 
-// Counter-based dropout mask in 32-bit arithmetic only (64-bit multiplies are several quarter-rate
-// ops on CDNA; the first version cost 10 % of the layer-1 forward): one multiply-xorshift mixer over
-// (row, col, seed).  Element (row, col) of a layer's output is kept iff the top 24 bits of the hash
-// are below keep_prob * 2^24.  tests/util.py replays it on the host.
-__device__ __forceinline__ uint32_t mix32(uint32_t x) {
-  x ^= x >> 16; x *= 0x7feb352dU;
-  x ^= x >> 15; x *= 0x846ca68bU;
-  x ^= x >> 16;
-  return x;
-}
-__device__ __forceinline__ bool dropout_keep(uint64_t seed, uint32_t row, uint32_t col, uint32_t thresh) {
-  const uint32_t s = static_cast<uint32_t>(seed) ^ (static_cast<uint32_t>(seed >> 32) * 0xC2B2AE35U);
-  return (mix32((row * 0x9E3779B1U) ^ (col * 0x85EBCA77U) ^ s) >> 8) < thresh;
-}
+// Dropout mask: mi_drop_* of common.h (element (row, col) is kept iff its 16 bits of the pair hash are below
+// keep_prob * 2^16); the planes kernels (gemm_pl.hip) use the same functions, tests/util.py replays them on the host.
 
 // Stage one operand tile HBM -> registers.  Branch-free and consumer-free on purpose: an
 // out-of-range element reads the (always valid) first element of the buffer, and nothing touches
@@ -242,7 +230,7 @@ __device__ __forceinline__ void store_tile_c(const GemmArgs& a, const f32x16 (&a
   float* Cb = a.C;
   float mx = 0.f;
   if (a.epi == EPI_SLAB) Cb += static_cast<int64_t>(split) * a.M * a.ldc;
-  const uint32_t thresh = static_cast<uint32_t>(a.keep_prob * 16777216.0f);
+  const uint32_t thresh = mi_drop_thresh16(a.keep_prob);
   const uint64_t seed = a.seed + (a.st ? a.st->seed_term : 0ull);
 #pragma unroll
   for (int ni = 0; ni < 2; ++ni) {
@@ -259,7 +247,7 @@ __device__ __forceinline__ void store_tile_c(const GemmArgs& a, const f32x16 (&a
         if (a.epi == EPI_BIAS_ACT) {
           v += bv;
           v = act_apply(a.relu, v);
-          if (a.keep_prob < 1.f) v = dropout_keep(seed, row, col, thresh) ? v / a.keep_div : 0.f;
+          if (a.keep_prob < 1.f) v = mi_drop_keep_at(seed, row, col, thresh) ? v / a.keep_div : 0.f;
         } else if (a.epi == EPI_MASK) {
           if (a.mask_src) {
             const float x = a.mask_src[static_cast<int64_t>(row) * a.ldm + col];
@@ -519,7 +507,7 @@ __global__ __launch_bounds__(kThreads) void gemv_fwd_k(const float* __restrict__
   if (st) seed += st->seed_term;
   const int l = threadIdx.x & (kGvLanes - 1);
   const int64_t groups = static_cast<int64_t>(gridDim.x) * (kThreads / kGvLanes);
-  const uint32_t thresh = static_cast<uint32_t>(keep_prob * 16777216.0f);
+  const uint32_t thresh = mi_drop_thresh16(keep_prob);
   const float b0 = bias ? bias[0] : 0.f;
   float mx = 0.f;
   for (int64_t m0 = (static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x) / kGvLanes; m0 < M; m0 += 2 * groups) {
@@ -542,7 +530,7 @@ __global__ __launch_bounds__(kThreads) void gemv_fwd_k(const float* __restrict__
       if (m < M && l == 0) {
         float v = acc[j] + b0;
         v = act_apply(relu, v);
-        if (keep_prob < 1.f) v = dropout_keep(seed, static_cast<uint32_t>(m), 0u, thresh) ? v / keep_div : 0.f;
+        if (keep_prob < 1.f) v = mi_drop_keep_at(seed, static_cast<uint32_t>(m), 0u, thresh) ? v / keep_div : 0.f;
         Y[m * ldy] = v;
         mx = fmaxf(mx, fabsf(v));
       }

@@ -36,6 +36,7 @@
 #include "common.h"
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -57,7 +58,7 @@ struct PlArgs {
   int tiles_n;
   float* C; int64_t ldc;                                // fp32 result [M][N] or NULL
   char* Cp; int64_t bsc; int32_t* c_exp;                // planes of the result or NULL (one column tile only)
-  const float* bias; int relu; float keep_prob, keep_div; uint64_t seed;
+  const float* bias; int relu; float keep_prob, keep_div, keep_rcp; uint64_t seed;   // keep_rcp = RN(1 / keep_div), from the host
   const char* mask; int64_t bsm;                        // dgrad: planes of the stored activation (hi > 0 <=> active & kept)
   float* amax_c;                                        // abs-max vector of the result (the weight gradient's matrix-wide scales) or NULL
   // dgrad into the input_layer: the FM term's share of the concat gradient, added once here instead of once
@@ -73,18 +74,6 @@ __device__ __forceinline__ int pl_exp_for(float amax) {
   return max(-100, min(100, 141 - e));
 }
 
-__device__ __forceinline__ uint32_t pl_mix32(uint32_t x) {
-  x ^= x >> 16; x *= 0x7feb352dU;
-  x ^= x >> 15; x *= 0x846ca68bU;
-  x ^= x >> 16;
-  return x;
-}
-// the same counter-based mask as gemm.hip (tests/util.py replays it)
-__device__ __forceinline__ bool pl_dropout_keep(uint64_t seed, uint32_t row, uint32_t col, uint32_t thresh) {
-  const uint32_t s = static_cast<uint32_t>(seed) ^ (static_cast<uint32_t>(seed >> 32) * 0xC2B2AE35U);
-  return (pl_mix32((row * 0x9E3779B1U) ^ (col * 0x85EBCA77U) ^ s) >> 8) < thresh;
-}
-
 template <int N> __device__ __forceinline__ void pl_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // -DMI_PL_STAMPS: clock64() stamps at the phase boundaries of every k-step, from lane 0 of waves 0 (group 0) and 4
@@ -92,11 +81,15 @@ template <int N> __device__ __forceinline__ void pl_wait_vmcnt() { asm volatile(
 #ifdef MI_PL_STAMPS
 __device__ long long g_pl_stamps[32 * 2 * 128 * 8];
 #define PL_STAMP(slot) do { if (stamp_on && t < 128) g_pl_stamps[((stamp_wg * 2 + stamp_grp) * 128 + t) * 8 + (slot)] = clock64(); } while (0)
+// whole-workgroup marks in the unused slot 7 of rows 0..3: kernel entry, first k-step, end of the k loop, end of the epilogue
+#define PL_MARK(row) do { if (stamp_on) g_pl_stamps[((stamp_wg * 2 + stamp_grp) * 128 + (row)) * 8 + 7] = clock64(); } while (0)
 #else
 #define PL_STAMP(slot) do {} while (0)
+#define PL_MARK(row) do {} while (0)
 #endif
 
 template <int TN, int TM, int EPI>
+// (TN == 1: two workgroups share a CU — 4 waves per SIMD, at most 128 registers: said, not hoped)
 __global__ __launch_bounds__(PL_THREADS, 2) void gemm_pl_k(const PlArgs a) {
   // stage buffers: 4 where one workgroup per CU runs anyway (256 registers); 3 for the 128-column tile, whose
   // 128 registers and 72 KB let two workgroups share a CU (one stores its result while the other computes)
@@ -234,6 +227,13 @@ __global__ __launch_bounds__(PL_THREADS, 2) void gemm_pl_k(const PlArgs a) {
   };
   const bool g1 = __builtin_amdgcn_readfirstlane(wm) != 0;
 
+#ifdef MI_PL_STAMPS
+  // 32 workgroups spread over the grid (every generation of workgroups is sampled)
+  const int stamp_every = max(1, nb / 32);
+  const bool stamp_on = lane == 0 && (wv == 0 || wv == 4) && lid % stamp_every == 0 && lid / stamp_every < 32;
+  const int stamp_wg = lid / stamp_every, stamp_grp = wv >> 2;
+#endif
+  PL_MARK(0);
 #pragma unroll
   for (int s = 0; s < PL_NBUF; ++s) issue_share(min(s, nk - 1), s);
   pl_wait_vmcnt<LPS*(PL_NBUF - 1)>();                      // own share of stage 0
@@ -241,10 +241,7 @@ __global__ __launch_bounds__(PL_THREADS, 2) void gemm_pl_k(const PlArgs a) {
   if (g1) __builtin_amdgcn_s_barrier();                    // the stagger
   // (sched_barrier(0): hipcc otherwise moves register-only MFMAs across s_barrier, which would put both
   // groups' MFMAs into the same slot)
-#ifdef MI_PL_STAMPS
-  const bool stamp_on = lane == 0 && (wv == 0 || wv == 4) && lid < 32;
-  const int stamp_wg = lid, stamp_grp = wv >> 2;
-#endif
+  PL_MARK(1);
 #pragma unroll 1
   for (int t = 0; t < nk; ++t) {
     PL_STAMP(0);
@@ -268,6 +265,7 @@ __global__ __launch_bounds__(PL_THREADS, 2) void gemm_pl_k(const PlArgs a) {
     PL_STAMP(6);                                           // past the second barrier
   }
   if (!g1) __builtin_amdgcn_s_barrier();
+  PL_MARK(2);
 
   // ---------------------------------------------------------------- epilogue
   pl_wait_vmcnt<0>();                 // the tail's re-issued loads
@@ -289,9 +287,23 @@ __global__ __launch_bounds__(PL_THREADS, 2) void gemm_pl_k(const PlArgs a) {
   }
   __syncthreads();
 
-  const uint32_t thresh = static_cast<uint32_t>(a.keep_prob * 16777216.0f);
+  // The element loop.  Round 2's had the launch's (uniform) options as run-time tests per ELEMENT: hipcc emitted a scalar
+  // branch or two per element, which also fenced every element's LDS reads of its column factors behind an s_waitcnt of
+  // their own, a quarter-rate 32-bit multiply hash and an IEEE division behind a divergent branch — ~65 instructions per
+  // output (in-kernel marks, tools/gemm_pl_timeline.py: the epilogue was 18 % of the layer-1 forward's time and 65 % of
+  // the layer-2 data gradient's).  Now the options only select VALUES (no dropout: threshold 2^16 and divisor 1; no mask:
+  // an all-positive mask word), the per-element code is straight-line, and the uniform branches that remain are per group
+  // of four columns (hash / mask load / fp32 copy).
+  const bool drop = EPI == PL_FWD && a.keep_prob < 1.f;
+  const uint32_t thresh16 = drop ? mi_drop_thresh16(a.keep_prob) : 0x10000u;
   const uint64_t seed = a.seed + (a.st ? a.st->seed_term : 0ull);
   const int nw = wn * 32 * TN;                      // this wave's first column inside the tile
+  // (the hash of a column pair: (col >> 1) * MUL = pair_base + a compile-time multiple of MUL)
+  const uint32_t pair_base = static_cast<uint32_t>((n0 + nw + 4 * h) >> 1) * MI_DROP_PAIR_MUL;
+  const bool masked = EPI == PL_DGRAD && a.mask != nullptr;
+  const bool divide = drop || masked;
+  const float kd = divide ? a.keep_div : 1.f, kr = divide ? a.keep_rcp : 1.f;
+  const float relu_floor = a.relu ? 0.f : -__builtin_inff();
   float rmx[TM];
 #pragma unroll
   for (int y = 0; y < TM; ++y) {
@@ -305,46 +317,68 @@ __global__ __launch_bounds__(PL_THREADS, 2) void gemm_pl_k(const PlArgs a) {
     if constexpr (EPI == PL_DGRAD) {
       if (a.fold_s) { fgm = a.fold_g[mc]; fsm = a.fold_s + static_cast<int64_t>(mc) * a.fold_E; }
     }
+    const uint32_t rowkey = drop ? mi_drop_rowkey(seed, static_cast<uint32_t>(m)) : 0u;
+    // the 4 columns' factors of a group: one 16-byte LDS read each, for group gi + 1 while group gi is computed
+    auto col_of = [&](int gi) { return nw + (gi >> 2) * 32 + 8 * (gi & 3) + 4 * h; };
+    float4 fw_n = *reinterpret_cast<const float4*>(e_fw + col_of(0));
+    float4 b_n = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (EPI == PL_FWD) b_n = *reinterpret_cast<const float4*>(e_bias + col_of(0));
 #pragma unroll
-    for (int x = 0; x < TN; ++x) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int nl = nw + x * 32 + 8 * g + 4 * h;       // tile column of register 4 g
-        uint2 mk = make_uint2(0u, 0u);
-        float4 fs4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if constexpr (EPI == PL_DGRAD) {
-          if (fsm) fs4 = *reinterpret_cast<const float4*>(fsm + min(n0 + nl, a.N - 4) % a.fold_E);   // (4 columns stay inside a field: E % 4 == 0)
-          if (a.mask) {
-            const int gn = min(n0 + nl, a.N - 4);
-            mk = *reinterpret_cast<const uint2*>(a.mask + (gn >> 4) * a.bsm + static_cast<int64_t>(mc) * PL_ROWB + (gn & 15) * 2);
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int r = 4 * g + j;
-          float v = (acc[x][y][r] * fx) * e_fw[nl + j];
-          if constexpr (EPI == PL_FWD) {
-            v += e_bias[nl + j];
-            if (a.relu) v = fmaxf(v, 0.f);
-            if (a.keep_prob < 1.f)
-              v = pl_dropout_keep(seed, static_cast<uint32_t>(m), static_cast<uint32_t>(n0 + nl + j), thresh) ? v / a.keep_div : 0.f;
-          } else {
-            if (a.mask) {
-              const uint32_t w32 = (j < 2) ? mk.x : mk.y;
-              const uint32_t hbits = (j & 1) ? (w32 >> 16) : (w32 & 0xffffu);
-              // positive fp16 (sign clear, not zero): the unit was active and kept
-              v = (hbits != 0u && hbits < 0x8000u) ? v / a.keep_div : 0.f;
-            }
-            v += fgm * (j == 0 ? fs4.x : j == 1 ? fs4.y : j == 2 ? fs4.z : fs4.w);
-          }
-          if (n0 + nl + j >= a.N) v = 0.f;
-          acc[x][y][r] = v;
-          mx = fmaxf(mx, fabsf(v));
-        }
-        if (a.C)
-          *reinterpret_cast<float4*>(wreg + i * FS + (x * 32 + 8 * g + 4 * h) * 4) =
-              make_float4(acc[x][y][4 * g], acc[x][y][4 * g + 1], acc[x][y][4 * g + 2], acc[x][y][4 * g + 3]);
+    for (int gi = 0; gi < TN * 4; ++gi) {
+      const int x = gi >> 2, g = gi & 3;
+      const int nl = col_of(gi);                          // tile column of register 4 g
+      const float4 fw4 = fw_n, b4 = b_n;
+      if (gi + 1 < TN * 4) {
+        fw_n = *reinterpret_cast<const float4*>(e_fw + col_of(gi + 1));
+        if constexpr (EPI == PL_FWD) b_n = *reinterpret_cast<const float4*>(e_bias + col_of(gi + 1));
       }
+      // FWD: the two pair hashes of the group's 4 columns (0: every 16-bit half is below 2^16 — kept);
+      // DGRAD: the high plane of the stored activation, 4 x fp16 (positive <=> active and kept; no mask: all positive)
+      uint32_t w2[2] = {0u, 0u};
+      if constexpr (EPI == PL_DGRAD) {
+        w2[0] = w2[1] = 0x00010001u;
+        if (masked) {
+          const int gn = min(n0 + nl, a.N - 4);
+          const uint2 mk = *reinterpret_cast<const uint2*>(a.mask + (gn >> 4) * a.bsm + static_cast<int64_t>(mc) * PL_ROWB + (gn & 15) * 2);
+          w2[0] = mk.x; w2[1] = mk.y;
+        }
+      } else if (drop) {
+        const uint32_t pt = pair_base + static_cast<uint32_t>((x * 32 + 8 * g) >> 1) * MI_DROP_PAIR_MUL;
+        w2[0] = mi_drop_pairhash(rowkey, pt);
+        w2[1] = mi_drop_pairhash(rowkey, pt + MI_DROP_PAIR_MUL);
+      }
+      // (columns past N: their weight-row factor e_fw is 0 and their bias 0, so the value is exactly 0)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = 4 * g + j;
+        const float fwj = j == 0 ? fw4.x : j == 1 ? fw4.y : j == 2 ? fw4.z : fw4.w;
+        float v = (acc[x][y][r] * fx) * fwj;
+        const uint32_t bits16 = (j & 1) ? (w2[j >> 1] >> 16) : (w2[j >> 1] & 0xffffu);
+        if constexpr (EPI == PL_FWD) {
+          v += j == 0 ? b4.x : j == 1 ? b4.y : j == 2 ? b4.z : b4.w;
+          v = fmaxf(v, relu_floor);
+          v = bits16 < thresh16 ? mi_div_const(v, kd, kr) : 0.f;
+        } else {
+          // positive fp16 (sign clear, not zero): the unit was active and kept
+          v = (bits16 - 1u) < 0x7fffu ? mi_div_const(v, kd, kr) : 0.f;
+        }
+        acc[x][y][r] = v;
+      }
+      if constexpr (EPI == PL_DGRAD) {
+        if (fsm) {     // the FM term's share of the concat gradient (layer 1, MI_FOLD_FM=1): + dlogit[m] * sumv[m][n % E]
+          const float4 fs4 = *reinterpret_cast<const float4*>(fsm + min(n0 + nl, a.N - 4) % a.fold_E);   // (4 columns stay inside a field: E % 4 == 0)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float f = fgm * (j == 0 ? fs4.x : j == 1 ? fs4.y : j == 2 ? fs4.z : fs4.w);
+            acc[x][y][4 * g + j] = n0 + nl + j < a.N ? acc[x][y][4 * g + j] + f : 0.f;
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) mx = fmaxf(mx, fabsf(acc[x][y][4 * g + j]));
+      if (a.C)
+        *reinterpret_cast<float4*>(wreg + i * FS + (x * 32 + 8 * g + 4 * h) * 4) =
+            make_float4(acc[x][y][4 * g], acc[x][y][4 * g + 1], acc[x][y][4 * g + 2], acc[x][y][4 * g + 3]);
     }
     if (a.C) {
       // the wave's 32 rows x 32 TN columns went through its own LDS region: read them back row by row, so that
@@ -381,7 +415,13 @@ __global__ __launch_bounds__(PL_THREADS, 2) void gemm_pl_k(const PlArgs a) {
     const unsigned int bits = __float_as_uint(mx);
     if (bits > *reinterpret_cast<volatile unsigned int*>(slot)) atomicMax(slot, bits);
   }
-  if (!a.Cp) return;
+  if (!a.Cp) {
+#ifdef MI_PL_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    PL_MARK(3);
+    return;
+  }
 
   // ---- the result as planes: row exponent from the row's abs-max over ALL columns (tiles_n == 1) ----
 #pragma unroll
@@ -404,9 +444,13 @@ __global__ __launch_bounds__(PL_THREADS, 2) void gemm_pl_k(const PlArgs a) {
         uint32_t hb = __builtin_bit_cast(uint32_t, hh);
         if constexpr (EPI == PL_FWD) {
           // a positive value must stay positive in the high plane: the data gradient's relu/dropout mask
-          // reads "hi > 0" (only values below 2^-39 of the row maximum round to zero at all)
-          if (u0 > 0.f && (hb & 0xffffu) == 0u) hb |= 1u;
-          if (u1 > 0.f && (hb >> 16) == 0u) hb |= 0x10000u;
+          // reads "hi > 0" (only values below 2^-39 of the row maximum round to zero at all): high half =
+          // max(high half, u > 0) as ONE packed unsigned maximum — positive fp16 order like their bit patterns, and a
+          // negative half (sign bit set) is above 1 as an unsigned number, so it stays what it is.
+          const uint32_t nz = (u0 > 0.f ? 1u : 0u) | (u1 > 0.f ? 0x10000u : 0u);
+          typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+          const u16x2 mxv = __builtin_elementwise_max(__builtin_bit_cast(u16x2, hb), __builtin_bit_cast(u16x2, nz));
+          hb = __builtin_bit_cast(uint32_t, mxv);
           hh = __builtin_bit_cast(h16x2, hb);
         }
         const fl32x2 rr2 = {u0 - static_cast<float>(hh[0]), u1 - static_cast<float>(hh[1])};
@@ -445,6 +489,10 @@ __global__ __launch_bounds__(PL_THREADS, 2) void gemm_pl_k(const PlArgs a) {
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
+#ifdef MI_PL_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  PL_MARK(3);
 }
 
 // ---- fp32 rows -> planes (weights once per step; any buffer no kernel here produced) ---------------
@@ -570,7 +618,7 @@ __global__ __launch_bounds__(256) void split_rows_blk_k(const float* __restrict_
 // gradient takes planes).
 template <int LPR>
 __global__ __launch_bounds__(256) void vec_dgrad_planes_k(const float* __restrict__ dY, int64_t lddy, const float* __restrict__ W,
-                                                          const float* __restrict__ Xact, int64_t ldxa, float keep_div,
+                                                          const float* __restrict__ Xact, int64_t ldxa, float keep_div, float keep_rcp,
                                                           int64_t rows, int K, int rows_per_block, float* __restrict__ dX,
                                                           int64_t lddx, char* __restrict__ out, int64_t ldo_b,
                                                           int32_t* __restrict__ row_exp, float* __restrict__ amax_out) {
@@ -593,8 +641,9 @@ __global__ __launch_bounds__(256) void vec_dgrad_planes_k(const float* __restric
       float4 v = make_float4(g * w.x, g * w.y, g * w.z, g * w.w);
       if (Xact) {
         const float4 x = *reinterpret_cast<const float4*>(Xact + r * ldxa + k);
-        v.x = x.x > 0.f ? v.x / keep_div : 0.f; v.y = x.y > 0.f ? v.y / keep_div : 0.f;
-        v.z = x.z > 0.f ? v.z / keep_div : 0.f; v.w = x.w > 0.f ? v.w / keep_div : 0.f;
+        // (mi_div_const: the bits of '/', 3 instructions; the same masked division as gemm.hip's gemv_dgrad_k)
+        v.x = x.x > 0.f ? mi_div_const(v.x, keep_div, keep_rcp) : 0.f; v.y = x.y > 0.f ? mi_div_const(v.y, keep_div, keep_rcp) : 0.f;
+        v.z = x.z > 0.f ? mi_div_const(v.z, keep_div, keep_rcp) : 0.f; v.w = x.w > 0.f ? mi_div_const(v.w, keep_div, keep_rcp) : 0.f;
       }
       return v;
     };
@@ -798,6 +847,25 @@ __global__ __launch_bounds__(256) void merge_rows_k(const char* __restrict__ in,
   X[r * ldx + k] = v * pl_pow2(-row_exp[r]);
 }
 
+// The proof obligation of mi_div_const (common.h): the bits of x / d for every fp32 x.  One thread per bit pattern.
+// out[0] += mismatches, out[1] = max over the mismatching x of the bit pattern of |x|.
+__global__ __launch_bounds__(256) void selftest_div_k(float d, float r, uint32_t first_bits, int64_t count, unsigned long long* __restrict__ out) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  bool bad = false;
+  uint32_t ax = 0;
+  if (i < count) {
+    const float x = __uint_as_float(first_bits + static_cast<uint32_t>(i));
+    const float want = x / d, got = mi_div_const(x, d, r);
+    bad = __float_as_uint(want) != __float_as_uint(got) && !(want != want && got != got);   // (NaN payloads aside)
+    ax = __float_as_uint(x) & 0x7fffffffu;
+  }
+  const unsigned long long b = __ballot(bad);
+  if (b) {
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, static_cast<unsigned long long>(__popcll(b)));
+    if (bad) atomicMax(out + 1, static_cast<unsigned long long>(ax));
+  }
+}
+
 bool planes_ok(const mi_planes_t* p, int64_t rows, int K) {
   return p && p->data && p->row_exp && mi::aligned16(p->data) && p->blk_stride >= rows * PL_ROWB && (p->blk_stride & 63) == 0 && rows >= 0;
 }
@@ -807,8 +875,12 @@ int32_t launch_pl(PlArgs& a, hipStream_t st, const char* what) {
   // column tile: the narrowest that holds N (planes out needs all of N in one tile); row tile: 256 rows for
   // the narrower column tiles (same accumulator budget), 128 for 512 columns
   int tn = a.N <= 128 ? 1 : (a.N <= 256 ? 2 : 4);
-  if (a.N > 512) tn = 1;                              // fp32 result only: 128-column tiles, two workgroups per CU (measured:
-                                                      // layer-1 data gradient 426 us, 256 columns 467, 512 columns 520)
+  if (a.N > 512) tn = 2;                              // fp32 result only (layer-1 data gradient, 1664 columns): 256-column tiles.
+                                                      // Round 2 took 128 columns (two workgroups per CU: 426 us against 467 and 520
+                                                      // for 256 and 512); with round 3's epilogue 256 columns win although the 7th
+                                                      // column tile is half empty — isolated 340-350 us against 370-380, in the step
+                                                      // 0.482 against 0.509 ms for the three data gradients (in-kernel marks: the
+                                                      // 128-column kernel's k loop runs its matrix pipes at 35 %, this one's at 60 %)
   if (const char* e = getenv("MI_PL_TILE")) {         // tuning experiments (tools/gemm_pl_bench.py)
     const int v = atoi(e);
     if ((v == 1 || v == 2 || v == 4) && (!a.Cp || a.N <= 128 * v)) tn = v;
@@ -939,7 +1011,7 @@ int32_t mi_dense_fwd_planes(const mi_planes_t* X, const mi_planes_t* Wt, const f
   a.M = (int)M; a.N = N; a.K = K;
   a.C = Y; a.ldc = ldy;
   if (Yp) { a.Cp = static_cast<char*>(Yp->data); a.bsc = Yp->blk_stride; a.c_exp = Yp->row_exp; }
-  a.bias = bias; a.relu = relu; a.keep_prob = keep_prob; a.keep_div = keep_prob; a.seed = seed; a.st = mi::step_state();
+  a.bias = bias; a.relu = relu; a.keep_prob = keep_prob; a.keep_div = keep_prob; a.keep_rcp = 1.0f / keep_prob; a.seed = seed; a.st = mi::step_state();
   a.amax_c = amax_out;
   return launch_pl<PL_FWD>(a, mi::as_stream(stream), "dense_fwd_planes");
 }
@@ -964,7 +1036,7 @@ int32_t mi_dense_bwd_data_planes(const mi_planes_t* dY, const mi_planes_t* W, co
   a.M = (int)M; a.N = K; a.K = N;
   a.C = dX; a.ldc = lddx;
   if (dXp) { a.Cp = static_cast<char*>(dXp->data); a.bsc = dXp->blk_stride; a.c_exp = dXp->row_exp; }
-  a.keep_prob = keep_prob; a.keep_div = Xact ? keep_prob : 1.f;
+  a.keep_prob = keep_prob; a.keep_div = Xact ? keep_prob : 1.f; a.keep_rcp = 1.0f / a.keep_div;
   if (Xact) { a.mask = static_cast<const char*>(Xact->data); a.bsm = Xact->blk_stride; }
   a.amax_c = amax_out;
   if (fold_sumv) {
@@ -998,7 +1070,7 @@ int32_t mi_dense_bwd_data_vec_planes(const float* dY, int64_t lddy, const float*
   const int64_t nb = mi::ceil_div(M, rpb);
   MI_REQUIRE(nb <= INT32_MAX, "dense_bwd_data_vec_planes: grid too large");
 #define MI_VEC_DGRAD(L) vec_dgrad_planes_k<L><<<dim3((unsigned)nb), dim3(256), lds, mi::as_stream(stream)>>>( \
-      dY, lddy, W, Xact, ldxa, Xact ? keep_prob : 1.f, M, K, rpb, dX, lddx, static_cast<char*>(dXp->data), dXp->blk_stride, dXp->row_exp, amax_out)
+      dY, lddy, W, Xact, ldxa, Xact ? keep_prob : 1.f, Xact ? 1.0f / keep_prob : 1.f, M, K, rpb, dX, lddx, static_cast<char*>(dXp->data), dXp->blk_stride, dXp->row_exp, amax_out)
   switch (lpr) {
     case 4: MI_VEC_DGRAD(4); break;
     case 8: MI_VEC_DGRAD(8); break;
@@ -1008,6 +1080,19 @@ int32_t mi_dense_bwd_data_vec_planes(const float* dY, int64_t lddy, const float*
   }
 #undef MI_VEC_DGRAD
   MI_CHECK_LAUNCH("dense_bwd_data_vec_planes");
+  return MI_OK;
+}
+
+int32_t mi_selftest_div(float d, uint32_t first_bits, int64_t count, uint64_t* out, mi_stream_t stream) {
+  MI_REQUIRE(count >= 0 && static_cast<uint64_t>(first_bits) + static_cast<uint64_t>(count) <= (1ull << 32), "selftest_div: range leaves 32 bits");
+  MI_REQUIRE(d > 0.f, "selftest_div: d=%g", d);
+  if (count == 0) return MI_OK;
+  MI_REQUIRE(out, "selftest_div: null buffer");
+  const int64_t blocks = mi::ceil_div(count, 256);
+  MI_REQUIRE(blocks <= INT32_MAX, "selftest_div: grid too large");
+  selftest_div_k<<<dim3((unsigned)blocks), dim3(256), 0, mi::as_stream(stream)>>>(d, 1.0f / d, first_bits, count,
+                                                                                 reinterpret_cast<unsigned long long*>(out));
+  MI_CHECK_LAUNCH("selftest_div");
   return MI_OK;
 }
 

@@ -94,6 +94,7 @@ SIGNATURES = {
     "mi_dense_fwd_gathered": (_i32, [_p, _p, _p, _i32, _i32, _p, _p, _p, _i64, _i64, _i32, _i32, _f32, _u64, _amax, _p]),
     "mi_dense_bwd_weight_gathered": (_i32, [_p, _p, _p, _i32, _i32, _p, _i64, _p, _p, _i64, _i32, _p, _sz, _amax, _p]),
     "mi_selftest_sqrt": (_i32, [_u32, _i64, _p, _p]),
+    "mi_selftest_div": (_i32, [_f32, _u32, _i64, _p, _p]),
     "mi_catchup_gap_keys": (_i32, [_p, _p, _p, _i64, _i32, _p, _i32, _p]),
     "mi_catchup_rows_by_gap": (_i32, [_p, _p, _p, _i64, _i32, _i32, _p, _p, _sz, _p]),
     "mi_sparse_catchup": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p, _f32, _f32,

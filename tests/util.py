@@ -15,16 +15,27 @@ def _mix32(x):
 
 
 def dropout_mask(seed, M, N, keep):
-    """Host replica of gemm.hip's counter-based dropout mask: keep flag {0, 1} per element (kept values
-    are divided by keep, as tf.nn.dropout does)."""
+    """Host replica of the kernels' counter-based dropout mask (csrc/common.h, mi_drop_*): keep flag {0, 1} per element
+    (kept values are divided by keep, as tf.nn.dropout does).  Two decisions per 32-bit hash: element (row, col) is kept
+    iff its 16 bits of hash(row, col >> 1) — low half for an even column, high half for an odd one — are below keep * 2^16."""
+    u = np.uint32
     row = np.arange(M, dtype=np.uint32)[:, None]
     col = np.arange(N, dtype=np.uint32)[None, :]
     with np.errstate(over="ignore"):
-        s = np.uint32(seed & 0xFFFFFFFF) ^ (np.uint32((seed >> 32) & 0xFFFFFFFF) * np.uint32(0xC2B2AE35))
-        h = _mix32((row * np.uint32(0x9E3779B1)) ^ (col * np.uint32(0x85EBCA77)) ^ s)
-    thresh = np.uint32(np.float32(keep) * np.float32(16777216.0))
-    kept = (h >> np.uint32(8)) < thresh
-    return kept.astype(np.float32)
+        s = u(seed & 0xFFFFFFFF) ^ (u((seed >> 32) & 0xFFFFFFFF) * u(0xC2B2AE35))
+        rowkey = _mix32((row * u(0x9E3779B1)) ^ s)
+        x = rowkey + (col >> u(1)) * u(0x85EBCA77)
+        x = ~x + (x << u(15))
+        x = x ^ (x >> u(12))
+        x = x + (x << u(2))
+        x = x ^ (x >> u(4))
+        x = x + (x << u(3))
+        x = x ^ (x >> u(11))
+        x = x + (x << u(11))
+        x = x ^ (x >> u(16))
+    bits = np.where((col & u(1)) == 1, x >> u(16), x & u(0xFFFF))
+    thresh = u(np.float32(keep) * np.float32(65536.0))
+    return (bits < thresh).astype(np.float32)
 
 
 def make_problem(seed, vocab, E, hidden, B, n_numeric=0, lin_scale=0.05, dup=True, use_dnn=True):
