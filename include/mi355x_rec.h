@@ -339,9 +339,11 @@ int32_t mi_selftest_sqrt(uint32_t first_bits, int64_t count, uint64_t* mismatche
 
 /* Self-test of the GEMM epilogues' division by a host-known constant (tf.nn.dropout divides by keep_prob: deep_fm.py:102-103;
  * no reference analogue: the claim that the 3-instruction form q = x r; e = fma(-d, q, x); fma(e, r, q) with r = RN(1 / d)
- * returns the bits of x / d rests on it): for the `count` fp32 bit patterns x from first_bits on, out[0] += how many give
- * different bits than '/', out[1] = max(out[1], bit pattern of |x|) over those.  out: 2 x uint64 on the device, zeroed by
- * the caller.  The test sweeps all 2^32 patterns for the dropout rates in use and demands no mismatch with |x| >= 2^-100. */
+ * returns the bits of x / d rests on it): for the `count` fp32 bit patterns x from first_bits on, out[0] += how many with
+ * 2^-100 <= |x| <= 2^100 give different bits than '/', out[1] += how many of all of them do (below 2^-100 the residual of a
+ * quotient is not exactly representable any more, above 2^100 x r can overflow where x / d does not, and an infinite x gives
+ * inf - inf).  out: 2 x uint64 on the device, zeroed by the caller.  The test sweeps all 2^32 patterns for a set of dropout
+ * rates and demands out[0] == 0. */
 int32_t mi_selftest_div(float d, uint32_t first_bits, int64_t count, uint64_t* out, mi_stream_t stream);
 
 int32_t mi_sparse_catchup(float* table, float* t_m, float* t_v, float* lin_w, float* l_m, float* l_v,

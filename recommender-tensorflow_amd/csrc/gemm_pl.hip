@@ -323,6 +323,19 @@ __global__ __launch_bounds__(PL_THREADS, 2) void gemm_pl_k(const PlArgs a) {
     float4 fw_n = *reinterpret_cast<const float4*>(e_fw + col_of(0));
     float4 b_n = make_float4(0.f, 0.f, 0.f, 0.f);
     if constexpr (EPI == PL_FWD) b_n = *reinterpret_cast<const float4*>(e_bias + col_of(0));
+    // DGRAD: the mask words (high plane of the stored activation, 4 x fp16 per group) come from GLOBAL memory: fetched
+    // MK_AHEAD groups ahead — a group that loaded its own word and then waited for it paid a memory latency per group
+    // (in-kernel marks: the layer-2 data gradient's epilogue was 73 k cycles against 43 k for its k loop).
+    constexpr int MK_AHEAD = TN == 1 ? 2 : 4;           // (TN == 1 must stay within 128 registers: two workgroups per CU)
+    uint2 mkq[MK_AHEAD];
+    auto mask_word = [&](int gi) {
+      const int gn = min(n0 + col_of(gi), a.N - 4);
+      return *reinterpret_cast<const uint2*>(a.mask + (gn >> 4) * a.bsm + static_cast<int64_t>(mc) * PL_ROWB + (gn & 15) * 2);
+    };
+    if constexpr (EPI == PL_DGRAD) {
+#pragma unroll
+      for (int q = 0; q < MK_AHEAD; ++q) mkq[q] = (masked && q < TN * 4) ? mask_word(q) : make_uint2(0x00010001u, 0x00010001u);
+    }
 #pragma unroll
     for (int gi = 0; gi < TN * 4; ++gi) {
       const int x = gi >> 2, g = gi & 3;
@@ -333,15 +346,11 @@ __global__ __launch_bounds__(PL_THREADS, 2) void gemm_pl_k(const PlArgs a) {
         if constexpr (EPI == PL_FWD) b_n = *reinterpret_cast<const float4*>(e_bias + col_of(gi + 1));
       }
       // FWD: the two pair hashes of the group's 4 columns (0: every 16-bit half is below 2^16 — kept);
-      // DGRAD: the high plane of the stored activation, 4 x fp16 (positive <=> active and kept; no mask: all positive)
+      // DGRAD: the group's mask word (positive <=> active and kept; no mask: all positive)
       uint32_t w2[2] = {0u, 0u};
       if constexpr (EPI == PL_DGRAD) {
-        w2[0] = w2[1] = 0x00010001u;
-        if (masked) {
-          const int gn = min(n0 + nl, a.N - 4);
-          const uint2 mk = *reinterpret_cast<const uint2*>(a.mask + (gn >> 4) * a.bsm + static_cast<int64_t>(mc) * PL_ROWB + (gn & 15) * 2);
-          w2[0] = mk.x; w2[1] = mk.y;
-        }
+        w2[0] = mkq[gi % MK_AHEAD].x; w2[1] = mkq[gi % MK_AHEAD].y;
+        if (masked && gi + MK_AHEAD < TN * 4) mkq[gi % MK_AHEAD] = mask_word(gi + MK_AHEAD);
       } else if (drop) {
         const uint32_t pt = pair_base + static_cast<uint32_t>((x * 32 + 8 * g) >> 1) * MI_DROP_PAIR_MUL;
         w2[0] = mi_drop_pairhash(rowkey, pt);
@@ -848,21 +857,22 @@ __global__ __launch_bounds__(256) void merge_rows_k(const char* __restrict__ in,
 }
 
 // The proof obligation of mi_div_const (common.h): the bits of x / d for every fp32 x.  One thread per bit pattern.
-// out[0] += mismatches, out[1] = max over the mismatching x of the bit pattern of |x|.
+// out[0] += mismatches with 2^-100 <= |x| <= 2^100 (must be 0), out[1] += all mismatches (tiny x: the quotient's residual
+// is no longer exactly representable; huge x: x r overflows where x / d would not; infinities: inf - inf).
 __global__ __launch_bounds__(256) void selftest_div_k(float d, float r, uint32_t first_bits, int64_t count, unsigned long long* __restrict__ out) {
   const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
-  bool bad = false;
-  uint32_t ax = 0;
+  bool bad = false, in_range = false;
   if (i < count) {
     const float x = __uint_as_float(first_bits + static_cast<uint32_t>(i));
     const float want = x / d, got = mi_div_const(x, d, r);
     bad = __float_as_uint(want) != __float_as_uint(got) && !(want != want && got != got);   // (NaN payloads aside)
-    ax = __float_as_uint(x) & 0x7fffffffu;
+    const uint32_t ax = __float_as_uint(x) & 0x7fffffffu;
+    in_range = ax >= 0x0D800000u && ax <= 0x71800000u;                                         // 2^-100 .. 2^100
   }
-  const unsigned long long b = __ballot(bad);
-  if (b) {
-    if ((threadIdx.x & 63) == 0) atomicAdd(out, static_cast<unsigned long long>(__popcll(b)));
-    if (bad) atomicMax(out + 1, static_cast<unsigned long long>(ax));
+  const unsigned long long b_in = __ballot(bad && in_range), b_all = __ballot(bad);
+  if ((threadIdx.x & 63) == 0) {
+    if (b_in) atomicAdd(out, static_cast<unsigned long long>(__popcll(b_in)));
+    if (b_all) atomicAdd(out + 1, static_cast<unsigned long long>(__popcll(b_all)));
   }
 }
 

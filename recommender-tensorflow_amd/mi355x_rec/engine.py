@@ -495,7 +495,7 @@ class DeepFM:
         p = lambda n: None if n is None else ptr(self._av(n))
         return _lib.GemmAmax(p(a), p(b), p(out))
 
-    def _split_weights(self, train):
+    def _split_weights(self, train, amax=None):
         """Planes of every hidden layer's kernel in one launch per step: transposed (rows = output units) for
         the forward pass, as stored (rows = inputs) for the data gradient; one exponent for the whole
         parameter block, from its abs-max."""
@@ -507,6 +507,10 @@ class DeepFM:
         stamp = (self.step, self.dense._version)
         done = getattr(self, "_wsplit", None)
         if done is not None and done[:2] == stamp and (done[2] or not train) and not getattr(self, "_capturing", False):
+            ev = getattr(self, "_wsplit_event", None)
+            if ev is not None:            # launched ahead on the side stream (_split_weights_ahead): the GEMMs wait for it here
+                torch.cuda.current_stream().wait_event(ev)
+                self._wsplit_event = None
             return
         self._wsplit = stamp + (bool(train),)
         key = "wjobs_train" if train else "wjobs_eval"
@@ -519,8 +523,36 @@ class DeepFM:
                 if train:
                     jobs[i].w = self._planes("w%d" % i, fan, h)
             self._ws[key] = jobs
-        self.k.mi_absmax(self.dense, self.dnn_end, self._av("w"))
-        self.k.mi_split_weights(self.dense, jobs, len(hidden), self._av("w"))
+        amax = self._av("w") if amax is None else amax          # (an abs-max vector zeroed by the caller's stream)
+        self.k.mi_absmax(self.dense, self.dnn_end, amax)
+        self.k.mi_split_weights(self.dense, jobs, len(hidden), amax)
+
+    def _split_weights_ahead(self):
+        """The weight planes of a train step, started on a side stream at the HEAD of the step: they depend on the dense
+        variables only (final since the previous step's apply), while the step's first half — sort, catch-up, gather —
+        does not touch the MLP.  Two small latency-bound launches (abs-max, split: ~40 us at config 3) leave the critical
+        path; the first GEMM waits for their event (in _split_weights)."""
+        if not self.planes or self.device.type != "cuda" or getattr(self, "_capturing", False) or os.environ.get("MI_WSPLIT_AHEAD", "1") == "0":
+            return
+        side = self._ws.get("wsplit_stream")
+        if side is None:
+            side = self._ws["wsplit_stream"] = torch.cuda.Stream(device=self.device)
+        # (the planes' and job buffers must exist before another stream writes them: sized on this stream by an earlier step)
+        if "wjobs_train" not in self._ws:
+            return
+        main = torch.cuda.current_stream()
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            self._wsplit_event = None
+            # (its own abs-max vector: _forward zeroes the shared ones on the main stream meanwhile)
+            amax = self._ws.get("w_amax_ahead")
+            if amax is None:
+                amax = self._ws["w_amax_ahead"] = torch.zeros(_lib.AMAX_SLOTS, dtype=torch.float32, device=self.device)
+            amax.zero_()
+            self._split_weights(True, amax)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        self._wsplit_event = ev
 
     def _layer_seed(self, layer):
         rank = 0 if self.shard is None else self.shard.rank
@@ -808,6 +840,7 @@ class DeepFM:
             self._backward_dense(c, dlogit)
             self._apply(None, None, None, None, 0, None, None)
             return loss, logits
+        self._split_weights_ahead()
         # (1) which rows does this batch touch: sort + unique (TF: unique/unsorted_segment_sum)
         ps, self._presorted = getattr(self, "_presorted", None), None
         tag = "own"

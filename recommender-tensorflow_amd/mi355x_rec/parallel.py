@@ -186,6 +186,8 @@ def _sharded_step(m, ids, labels, x_num, train):
     n = B * F
     C = _n_chunks(m, B, train)
     Bc = B // C
+    if train and hasattr(m, "_split_weights_ahead"):
+        m._split_weights_ahead()            # the MLP's weight planes, on a side stream beside the routing
     slot, send_rows, sorted_entry, seg, send_counts, recv_counts = _route(m, ids, C)
     nsc = [sum(sc) for sc in send_counts]               # distinct requests of chunk c (all owners)
     uoff = [0]
