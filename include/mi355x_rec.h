@@ -18,6 +18,13 @@
  *   - shapes are validated on the host before any launch (a bad shape returns
  *     MI_ERR_INVALID instead of faulting the GPU).
  *   - all floating point is IEEE fp32 ("f32" in bench.py); index work is int32/int64, bit exact.
+ *   - PROCESS-WIDE STATE.  Two switches are per process, not per call or per model, because the deployment is one
+ *     process per GPU running one model: mi_set_gemm_mode (the matrix-pipe path every GEMM entry takes) and
+ *     mi_set_step_state (while set, the entries listed there read the step / lr_t / dropout seed term from a device
+ *     record instead of from their arguments: hipGraph capture).  A host that drives TWO models from one process must
+ *     set the GEMM mode before each model's calls (the shipped host does: engine._forward sets it every step) and
+ *     must not capture one model's step while another thread launches the other's — the registered step state would
+ *     be read by both.  Everything else (tables, slots, workspaces, streams) is per call.
  */
 #ifndef MI355X_REC_H
 #define MI355X_REC_H
@@ -300,7 +307,7 @@ int32_t mi_sparse_apply_fused(float* table, float* t_slot0, float* t_slot1, floa
  * — the same fp32 op sequence as the sweep, hence the same bits.  lr_table[s] (device, f32) holds
  * lr_t of step s.  Runs on the U distinct rows about to be gathered (step_to = step-1), or on all
  * rows (uniq_rows == NULL, n_max = R) before evaluation / checkpoint.
- * flags: MI_CATCHUP_DEFER_SLOTS | MI_CATCHUP_BOUNDED (0 = neither).
+ * flags: any of MI_CATCHUP_DEFER_SLOTS | MI_CATCHUP_BOUNDED | MI_CATCHUP_KEEP_STAMPS (0 = none).
  * MI_CATCHUP_DEFER_SLOTS (with uniq_rows): only w is written; m, v and last_step keep their old values and
  * the mi_sparse_apply[_fused] of the same step — which reads and writes m, v anyway and MUST then be
  * given last_step — decays them from the old stamp (same multiply chain, same bits).  Saves a third
@@ -312,8 +319,10 @@ int32_t mi_sparse_apply_fused(float* table, float* t_slot0, float* t_slot1, floa
  * reference's, i.e. ~1e-10 |w|; measured and enforced: every variable within 1e-7 relative of the literal sweep after
  * 150-200 replayed steps (tests/test_hip_kernels.py::test_bounded_catchup_stays_within_1e7_of_the_sweep).  m, v and the
  * stamps are written exactly as in the exact mode.  4 VALU operations + 1 transcendental per element and step instead
- * of 16 + 2, and no range conditions.  Needs epsilon >= 1e-30 (otherwise the exact form runs). */
-enum mi_catchup_flags { MI_CATCHUP_DEFER_SLOTS = 1, MI_CATCHUP_BOUNDED = 2 };
+ * of 16 + 2, and no range conditions.  Needs epsilon >= 1e-30 (otherwise the exact form runs).
+ * MI_CATCHUP_KEEP_STAMPS: the rows' stamps are left as they are (m, v ARE written) — for a model whose tables and wide part
+ * follow two different Adam optimizers (two lr_t tables: two calls; the first must not move the stamps the second reads). */
+enum mi_catchup_flags { MI_CATCHUP_DEFER_SLOTS = 1, MI_CATCHUP_BOUNDED = 2, MI_CATCHUP_KEEP_STAMPS = 4 };
 /* keys[u] = how many steps row uniq_rows[u] will be replayed over by mi_sparse_catchup(step_to) (0..62,
  * clamped), 63 for the slots u >= *num_uniq.  Sorting the rows by it (mi_sort_unique_rows with
  * key_range 64, then mi_gather_u32 of uniq_rows through the permutation) groups rows of equal

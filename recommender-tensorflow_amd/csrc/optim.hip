@@ -471,7 +471,7 @@ __global__ __launch_bounds__(kBlock) void sparse_catchup_k(
     int32_t* __restrict__ last_step, const int32_t* __restrict__ uniq_rows,
     const int32_t* __restrict__ num_uniq, int64_t n_max, int E, int step_to,
     const float* __restrict__ lr_table, float b1, float b2, float eps, bool defer_slots, int st,
-    const mi_step_state_t* __restrict__ ss) {
+    const mi_step_state_t* __restrict__ ss, bool keep_stamps) {
   if (ss) step_to = ss->step - 1;
   const int64_t u = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) / LPR;
   const int l = threadIdx.x & (LPR - 1);
@@ -518,7 +518,7 @@ __global__ __launch_bounds__(kBlock) void sparse_catchup_k(
   // writes them anyway) from the old stamp, so neither they nor the stamp are written here — a third
   // of this kernel's HBM traffic.
   // every lane of the group has read last_step[r] above (same wave, program order) before lane 0 writes
-  if (l == 0 && !defer_slots) last_step[r * st] = step_to;
+  if (l == 0 && !defer_slots && !keep_stamps) last_step[r * st] = step_to;
 }
 
 // The bounded-error replay of the rows (MI_CATCHUP_BOUNDED).  With 4 + 1 instructions per element and step the replay is
@@ -557,7 +557,7 @@ __global__ __launch_bounds__(kBlock) void sparse_catchup_bounded_k(
     int32_t* __restrict__ last_step, const int32_t* __restrict__ uniq_rows,
     const int32_t* __restrict__ num_uniq, int64_t n_max, int E, int step_to,
     const float* __restrict__ lr_table, float b1, float b2, float eps, bool defer_slots, int st,
-    const mi_step_state_t* __restrict__ ss) {
+    const mi_step_state_t* __restrict__ ss, bool keep_stamps) {
   __shared__ float lr_s[kLrWindow];
   if (ss) step_to = ss->step - 1;
   const int base = step_to - (kLrWindow - 1);                 // lr_s[i] = lr_t[base + i]
@@ -647,7 +647,7 @@ __global__ __launch_bounds__(kBlock) void sparse_catchup_bounded_k(
       }
     }
     // (every lane of the group read the stamp above before lane 0 overwrites it: same wave, program order)
-    if (l == 0 && !defer_slots && ls < step_to) last_step[cur.r * st] = step_to;
+    if (l == 0 && !defer_slots && !keep_stamps && ls < step_to) last_step[cur.r * st] = step_to;
   }
 }
 
@@ -916,7 +916,8 @@ int32_t mi_sparse_catchup(float* table, float* t_m, float* t_v, float* lin_w, fl
                           float beta1, float beta2, float epsilon, int32_t flags, int32_t lin_stride,
                           mi_stream_t stream) {
   MI_REQUIRE(n_max >= 0 && step_to >= 0 && lin_stride >= 1, "sparse_catchup: n_max=%lld step_to=%d", (long long)n_max, step_to);
-  MI_REQUIRE((flags & ~(MI_CATCHUP_DEFER_SLOTS | MI_CATCHUP_BOUNDED)) == 0, "sparse_catchup: flags=%d", flags);
+  MI_REQUIRE((flags & ~(MI_CATCHUP_DEFER_SLOTS | MI_CATCHUP_BOUNDED | MI_CATCHUP_KEEP_STAMPS)) == 0, "sparse_catchup: flags=%d", flags);
+  const bool keep_stamps = (flags & MI_CATCHUP_KEEP_STAMPS) != 0;
   const int32_t defer_slots = flags & MI_CATCHUP_DEFER_SLOTS;
   // the bounded form divides by rcp(sqrt(v) + eps): eps must keep that sum a normal number (TF's default 1e-8 does)
   const bool bounded = (flags & MI_CATCHUP_BOUNDED) != 0 && epsilon >= 1e-30f && beta2 > 0.f && beta2 <= 1.f;
@@ -943,11 +944,11 @@ int32_t mi_sparse_catchup(float* table, float* t_m, float* t_v, float* lin_w, fl
     while (pb > 1 && pb > blocks) pb >>= 1;                       // (a power of two: the kernel's wave -> chunk map)
     MI_DISPATCH_LPR(lpr, (sparse_catchup_bounded_k<L><<<dim3((unsigned)pb), dim3(kBlock), 0, mi::as_stream(stream)>>>(
                              table, t_m, t_v, last_step, uniq_rows, num_uniq, n_max, E, step_to, lr_table, beta1, beta2,
-                             epsilon, defer, lin_stride, mi::step_state())));
+                             epsilon, defer, lin_stride, mi::step_state(), keep_stamps)));
   } else {
     MI_DISPATCH_LPR(lpr, (sparse_catchup_k<L><<<dim3((unsigned)blocks), dim3(kBlock), 0, mi::as_stream(stream)>>>(
                              table, t_m, t_v, last_step, uniq_rows, num_uniq, n_max, E, step_to, lr_table, beta1, beta2,
-                             epsilon, defer, lin_stride, mi::step_state())));
+                             epsilon, defer, lin_stride, mi::step_state(), keep_stamps)));
   }
   MI_CHECK_LAUNCH("sparse_catchup");
   return MI_OK;

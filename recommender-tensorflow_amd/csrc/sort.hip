@@ -35,6 +35,13 @@ __global__ __launch_bounds__(256) void zero_i32_k(int32_t* __restrict__ p, int64
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * 256) p[i] = 0;
 }
 inline void zero_i32(int32_t* p, int64_t n, hipStream_t st) {
+  // (MI_SORT_MEMSET=1: the round-2 form again, for tools/graph_memset_nodes.py only — it captures a step WITHOUT replaying it
+  // and prints the memset nodes of the graph next to the live allocations)
+  static const bool use_memset = mi::env_int("MI_SORT_MEMSET", 0) != 0;
+  if (use_memset) {
+    (void)hipMemsetAsync(p, 0, static_cast<size_t>(n) * 4, st);
+    return;
+  }
   const int64_t b = (n + 255) / 256;
   zero_i32_k<<<dim3(static_cast<unsigned>(b < 64 ? b : 64)), dim3(256), 0, st>>>(p, n);
 }

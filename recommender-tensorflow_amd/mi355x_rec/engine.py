@@ -278,14 +278,20 @@ class DeepFM:
                 self.last_step = self.lin_state.view(torch.int32)[:, 3]
         elif self.adam_rows:
             self.last_step = torch.zeros(self.R_local, dtype=torch.int32, device=dev)
-        adam_spec = self.opt if self.opt.name == "Adam" else (sparse_lin_opt if sparse_lin_opt.name == "Adam" else None)
-        if self.lin_opt is not None and self.lin_opt.name == "Adam" and self.opt.name == "Adam" and \
-                (self.lin_opt.lr, self.lin_opt.beta1, self.lin_opt.beta2, self.lin_opt.epsilon) != \
-                (self.opt.lr, self.opt.beta1, self.opt.beta2, self.opt.epsilon):
-            raise NotImplementedError("two different Adam optimizers would need two lr_t schedules")
         if shard is not None and self.F == 0:
             raise NotImplementedError("a model without categorical columns has nothing to shard")
-        self.sched = AdamSchedule(adam_spec, dev) if adam_spec is not None else None
+        # lr_t schedules (TF keeps beta powers per optimizer): one for `optimizer`, one for `linear_optimizer` — the same
+        # object when the two Adams agree (or there is only one), two tables when they differ (round 2 refused that)
+        same = lambda a, b: (a.lr, a.beta1, a.beta2, a.epsilon) == (b.lr, b.beta1, b.beta2, b.epsilon)
+        self.sched = AdamSchedule(self.opt, dev) if self.opt.name == "Adam" else None
+        if sparse_lin_opt.name != "Adam":
+            self.lin_sched = None
+        elif self.sched is not None and same(sparse_lin_opt, self.opt):
+            self.lin_sched = self.sched
+        else:
+            self.lin_sched = AdamSchedule(sparse_lin_opt, dev)
+        if self.sched is None and self.lin_sched is not None and self.lin_opt is None:
+            self.sched = self.lin_sched
 
         # dense variables: one flat buffer
         # D_in: logical width of the MLP input; D: its width in memory (raw numeric columns: padded with
@@ -500,8 +506,6 @@ class DeepFM:
         the forward pass, as stored (rows = inputs) for the data gradient; one exponent for the whole
         parameter block, from its abs-max."""
         hidden = self.layers[:-1]
-        if len(hidden) > _lib.MAX_WEIGHT_JOBS:
-            raise NotImplementedError("more than %d hidden layers on the planes path" % _lib.MAX_WEIGHT_JOBS)
         # once per step, not once per forward: the chunks of a pipelined multi-GPU step see the same weights (the dense
         # variables change in _apply, which moves self.step, or through torch, which moves the tensor's version)
         stamp = (self.step, self.dense._version)
@@ -516,16 +520,23 @@ class DeepFM:
         key = "wjobs_train" if train else "wjobs_eval"
         jobs = self._ws.get(key)
         if jobs is None:
-            jobs = (_lib.WeightJob * len(hidden))()
-            for i, (k_off, _, fan, h) in enumerate(hidden):
-                jobs[i].offset, jobs[i].K, jobs[i].N = k_off, fan, h
-                jobs[i].wt = self._planes("wt%d" % i, h, fan)
-                if train:
-                    jobs[i].w = self._planes("w%d" % i, fan, h)
+            # one launch takes MI_MAX_WEIGHT_JOBS layers; a deeper MLP takes several (round 2 refused it)
+            jobs = []
+            for lo in range(0, len(hidden), _lib.MAX_WEIGHT_JOBS):
+                part = hidden[lo:lo + _lib.MAX_WEIGHT_JOBS]
+                arr = (_lib.WeightJob * len(part))()
+                for j, (k_off, _, fan, h) in enumerate(part):
+                    i = lo + j
+                    arr[j].offset, arr[j].K, arr[j].N = k_off, fan, h
+                    arr[j].wt = self._planes("wt%d" % i, h, fan)
+                    if train:
+                        arr[j].w = self._planes("w%d" % i, fan, h)
+                jobs.append(arr)
             self._ws[key] = jobs
         amax = self._av("w") if amax is None else amax          # (an abs-max vector zeroed by the caller's stream)
         self.k.mi_absmax(self.dense, self.dnn_end, amax)
-        self.k.mi_split_weights(self.dense, jobs, len(hidden), amax)
+        for arr in jobs:
+            self.k.mi_split_weights(self.dense, arr, len(arr), amax)
 
     def _split_weights_ahead(self):
         """The weight planes of a train step, started on a side stream at the HEAD of the step: they depend on the dense
@@ -757,24 +768,37 @@ class DeepFM:
         """defer: the rows are about to be applied in this same step by ONE mi_sparse_apply call, which
         then decays m and v itself from the old stamps — the catch-up moves w only (a third less HBM
         traffic).  Not with a separate linear optimizer (two apply calls would see each other's stamps)."""
-        if self.sched is None or n_max == 0:
-            return
-        defer = bool(defer and uniq is not None and self.lin_opt is None)
-        s = self.sched.spec
         t_adam = self.opt.name == "Adam" and self.table is not None
         l_adam = (self.lin_opt or self.opt).name == "Adam" and self.lin_w is not None
-        self.sched.lr_t(self.step)  # make sure the table covers step
+        if not (t_adam or l_adam) or n_max == 0:
+            return
+        defer = bool(defer and uniq is not None and self.lin_opt is None)
+        for sc in (self.sched, self.lin_sched):
+            if sc is not None:
+                sc.lr_t(self.step)  # make sure the table covers step
         if uniq is not None and n_max >= self.GAP_SORT_MIN:
             # rows of equal staleness into the same wave (the replay runs as long as a wave's stalest row)
             by_gap = self._buf("uniq_by_gap", (n_max,), torch.int32)
             ws = self._bytes("sort_ws", self.k.query("mi_sort_unique_workspace_bytes", n_max))
             self.k.mi_catchup_rows_by_gap(uniq, num_uniq, self.last_step, n_max, self.step, self.ls, by_gap, ws, ws.numel())
             uniq = by_gap
-        self.k.mi_sparse_catchup(self.table if t_adam else None, self.t_s0 if t_adam else None,
-                                 self.t_s1 if t_adam else None, self.lin_w if l_adam else None,
-                                 self.l_s0 if l_adam else None, self.l_s1 if l_adam else None, self.last_step,
-                                 uniq, num_uniq, n_max, self.E, self.step, self.sched.table, s.beta1, s.beta2,
-                                 s.epsilon, (1 if defer else 0) | (2 if self.catchup == "bounded" else 0), self.ls)
+        flags = (1 if defer else 0) | (2 if self.catchup == "bounded" else 0)
+        t_sched = self.sched if t_adam else None
+        l_sched = (self.lin_sched if self.lin_opt is not None else (self.lin_sched or self.sched)) if l_adam else None
+        if t_sched is not None and l_sched is not None and t_sched is not l_sched:
+            # two different Adams (tables vs wide part): one call each, with its own lr_t table and betas.  The table
+            # call must not move the stamps the wide call still has to read: it runs second.
+            assert not defer
+            parts = [(None, l_sched, 4), (t_sched, None, 0)]          # (4 = MI_CATCHUP_KEEP_STAMPS)
+        else:
+            parts = [(t_sched, l_sched, 0)]
+        for ts, lsch, extra in parts:
+            s = (ts or lsch).spec
+            self.k.mi_sparse_catchup(self.table if ts is not None else None, self.t_s0 if ts is not None else None,
+                                     self.t_s1 if ts is not None else None, self.lin_w if lsch is not None else None,
+                                     self.l_s0 if lsch is not None else None, self.l_s1 if lsch is not None else None,
+                                     self.last_step, uniq, num_uniq, n_max, self.E, self.step, (ts or lsch).table, s.beta1, s.beta2,
+                                     s.epsilon, flags | extra, self.ls)
 
     def _sort_unique(self, keys, n, key_range, tag):
         """mi_sort_unique_rows into persistent buffers named after `tag`."""
@@ -988,12 +1012,13 @@ class DeepFM:
         step = self.step + 1
         lr_t = self.sched.lr_t(step) if self.sched else 0.0
         hp = self.opt.hparams(lr_t)
+        lin_lr_t = self.lin_sched.lr_t(step) if self.lin_sched else 0.0
         if self.lin_opt is None:
             if self.P:
                 k.mi_dense_apply(self.dense, self.d_s0, self.d_s1, self.d_grad, self.P, hp)
             sparse_hp = [(True, True, hp)]
         else:
-            lhp = self.lin_opt.hparams(lr_t)
+            lhp = self.lin_opt.hparams(lin_lr_t)
             if self.wide_off:
                 k.mi_dense_apply(self.dense, self.d_s0, self.d_s1, self.d_grad, self.wide_off, hp)
             o = self.wide_off
@@ -1031,6 +1056,8 @@ class DeepFM:
         advances (include/mi355x_rec.h), so a replay is bit-identical to the eager step it replaces."""
         if self.shard is not None or self.n_numeric or self.device.type != "cuda":
             raise NotImplementedError("graph_train_step: single-GPU models without numeric columns")
+        if self.sched is not None and self.lin_sched is not None and self.sched is not self.lin_sched:
+            raise NotImplementedError("graph_train_step: the device-resident step state carries ONE lr_t (two different Adams)")
         self._prep(ids, labels, None)
         g = getattr(self, "_graph", None)
         if g is not None and g["gen"] != self._graph_gen():
@@ -1047,7 +1074,7 @@ class DeepFM:
                 return self.train_step(ids, labels)                     # sizes every workspace
             g = self._graph = self._capture(ids, labels)
             return g["loss"], g["logits"]
-        if self.sched is not None and self.step + 2 >= len(self.sched.host):
+        if self._gsched() is not None and self.step + 2 >= len(self._gsched().host):
             self._graph = None                                          # the lr_t table has to grow: capture again
             return self.graph_train_step(ids, labels)
         if g["dev_step"] != self.step:                                  # eager steps ran in between: resync
@@ -1060,8 +1087,12 @@ class DeepFM:
         g["dev_step"] = self.step
         return g["loss"], g["logits"]
 
+    def _gsched(self):
+        """the one Adam schedule a captured step reads lr_t from"""
+        return self.sched if self.sched is not None else self.lin_sched
+
     def _graph_gen(self):
-        return (self._alloc_gen, self.sched.gen if self.sched is not None else 0)
+        return (self._alloc_gen, self._gsched().gen if self._gsched() is not None else 0)
 
     def _write_step_state(self, state):
         blob = np.zeros(1, np.dtype([("step", np.int32), ("lr_t", np.float32), ("seed_term", np.uint64)]))
@@ -1069,8 +1100,8 @@ class DeepFM:
         state.copy_(torch.from_numpy(blob.view(np.uint8)))
 
     def _capture(self, ids, labels):
-        if self.sched is not None:                                      # the lr_t table must not move under the graph
-            self.sched.lr_t(self.step + (1 << 20))
+        if self._gsched() is not None:                                  # the lr_t table must not move under the graph
+            self._gsched().lr_t(self.step + (1 << 20))
         ps, self._presorted = getattr(self, "_presorted", None), None
         if ps is not None:                                              # (nothing of another stream inside the capture)
             torch.cuda.current_stream().wait_stream(ps["stream"])
@@ -1083,7 +1114,7 @@ class DeepFM:
         self._capturing = True
         try:
             with torch.cuda.graph(graph):
-                self.k.mi_step_advance(state, self.sched.table if self.sched is not None else None)
+                self.k.mi_step_advance(state, self._gsched().table if self._gsched() is not None else None)
                 loss, logits = self.train_step(g_ids, g_y)
         finally:
             self._capturing = False

@@ -262,7 +262,7 @@ class NumpyKernels:
                         W[r] = W[r] - (lr[s] * mr) / (np.sqrt(vr) + eps)
                     if not defer:
                         M[r], V[r] = mr, vr
-            if not defer:
+            if not defer and not (flags & 4):
                 ls[r] = step_to
 
     def mi_sparse_apply(self, table, t0, t1, lin_w, l0, l1, last_step, uniq, seg, sorted_entry, num_uniq, n_max,

@@ -228,6 +228,25 @@ def test_out_of_vocabulary_id_without_oov_bucket_is_refused():
         plan.transform({"gender": ["F", "X"]})
 
 
+def test_two_different_adam_optimizers(device):
+    """a model whose deep scope and linear scope follow two DIFFERENT Adam optimizers (TF keeps beta powers
+    per optimizer: two lr_t schedules) — refused in round 2.  DeepFM with Adam(1e-3) on the deep scope and Adam(2e-2) on
+    the wide part, 5 steps with fresh ids (rows sit out steps: two catch-up calls per step, each with its own table, the
+    first leaving the stamps alone), against the oracle's two-optimizer train op."""
+    _run(device, [9, 13, 5, 6], 8, [16, 8], 64, 0, "embed", (True, True, True), OO.Hyper("Adam", 0.001), OO.Hyper("Adam", 0.02),
+         steps=5, seed=33, atol=4e-6, reduction="mean")
+
+
+def test_more_hidden_layers_than_one_weight_split_launch_takes(device):
+    """more than MI_MAX_WEIGHT_JOBS (8) hidden layers on the planes path — refused in round 2; now several
+    mi_split_weights launches."""
+    hidden = [32, 32, 16, 16, 16, 16, 16, 16, 16, 16]
+    m, _ = _run(device, [9, 13, 5, 6], 16, hidden, 64, 0, "embed", (True, True, True), OO.Hyper("Adam", 0.001), None, steps=2,
+                seed=35, atol=4e-6, reduction="mean")
+    if device == "cuda":
+        assert m.planes and len(m._ws["wjobs_train"]) == 2
+
+
 def test_adam_schedule_extends_past_a_restored_step():
     """lr_t(step) after restoring a checkpoint far into a run (step > 2 x table size)."""
     from mi355x_rec.engine import AdamSchedule, OptimizerSpec

@@ -405,6 +405,48 @@ def test_graph_train_step_replays_the_eager_step_bitwise(vocab, E, hidden, B):
         assert torch.equal(getattr(eager, k), getattr(graph, k)), k
 
 
+def test_captured_step_has_no_memset_nodes():
+    """Round 2's GPU fault: a captured LINEAR step whose sorts zeroed their counters with hipMemsetAsync
+    faulted at replay ("write access to a read-only page") although — tools/graph_memset_nodes.py, round 3 — both memset
+    nodes pointed into a live torch allocation made before the capture, in bounds, and no workspace moved: the runtime's
+    memset nodes are not trusted; the library zeroes with a kernel of its own.  The captured B = 1024 step (no side stream:
+    a chain of nodes) must contain kernel and copy nodes only."""
+    import ctypes as C
+    from mi355x_rec.engine import OptimizerSpec
+    vocab, B = ML100K_VOCAB, 1024
+    p, ids, x, y = make_problem(23, vocab, 4, [16, 16], B)
+    m = _engine(vocab, 4, [16, 16], dropout=0.1, seed=3, optimizer=OptimizerSpec("Adam", 0.001))
+    m.load_oracle_params(p)
+    di, dy = dev(ids), dev(y)
+    m.train_step(di, dy)
+    torch.cuda.synchronize()
+    state = torch.zeros(16, dtype=torch.uint8, device="cuda")
+    m._write_step_state(state)
+    graph = torch.cuda.CUDAGraph(keep_graph=True)
+    m.k.query("mi_set_step_state", state.data_ptr())
+    m._capturing = True
+    try:
+        with torch.cuda.graph(graph):
+            m.k.mi_step_advance(state, m.sched.table)
+            m.train_step(di.clone(), dy.clone())
+    finally:
+        m._capturing = False
+        m.k.query("mi_set_step_state", None)
+    hip = C.CDLL("libamdhip64.so")
+    h = C.c_void_p(graph.raw_cuda_graph())
+    n = C.c_size_t(0)
+    assert hip.hipGraphGetNodes(h, None, C.byref(n)) == 0 and n.value > 10
+    arr = (C.c_void_p * n.value)()
+    assert hip.hipGraphGetNodes(h, arr, C.byref(n)) == 0
+    types = []
+    for node in arr:
+        t = C.c_int(-1)
+        assert hip.hipGraphNodeGetType(C.c_void_p(node), C.byref(t)) == 0
+        types.append(t.value)
+    assert 2 not in types, types               # hipGraphNodeTypeMemset
+    assert set(types) <= {0, 1}, types         # kernels and copies
+
+
 def test_graph_is_recaptured_when_its_buffers_moved():
     """a captured step holds the raw addresses of the engine's workspaces, planes and lr_t table; a later
     call that needs more room (loss() on a larger batch, a restored checkpoint, layer summaries) reallocates them and

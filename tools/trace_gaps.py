@@ -7,7 +7,7 @@ moves the window's end back past it, into the timed region.)"""
 import csv, sys, collections
 
 win_ms = 40.0
-args = [a for a in sys.argv[1:] if not a.startswith("--")]
+args = [a for i, a in enumerate(sys.argv[1:], 1) if not a.startswith("--") and not sys.argv[i - 1].startswith("--")]
 if "--window-ms" in sys.argv:
     win_ms = float(sys.argv[sys.argv.index("--window-ms") + 1])
 ev = []
