@@ -338,7 +338,9 @@ def main():
     # beside step t's VALU-bound catch-up (~14 small launch-bound kernels that leave most of the chip idle) instead of at
     # the head of step t + 1.  All of a step's work still happens inside the timed region — K timed steps run K sorts —
     # and the results are bitwise those of the plain sequence (tests/test_hip_model.py).  Single GPU only.
-    presort = [world == 1 and shard is None and not args.no_presort]
+    # (row-sharded step: the announced ids start the next batch's ROUTING — sorts, count exchange, split sizes to the host —
+    # beside this step's sparse apply instead: parallel._route_ahead)
+    presort = [not args.no_presort]
 
     def run(nsteps):
         out = None
@@ -590,8 +592,11 @@ def main():
                        "catchup": ("bounded-error lazy Adam replay (MI_CATCHUP_BOUNDED: every variable within 3 ulp + 2e-6 of the replayed "
                                    "movement of TF's sweep, 98.7 % within 1e-7 relative; the exact mode is the extra catchup_exact)"
                                    if mode_catchup == "bounded" else "lazy Adam replay bit-exact with TF's dense-equivalent sweep"),
-                       "input_pipeline": ("next batch's ids announced one step ahead (train_step(next_ids=...)): their sort runs on a "
-                                          "side stream beside this step's catch-up" if presort[0] else "ids handed over step by step")},
+                       "input_pipeline": (("next batch's ids announced one step ahead (train_step(next_ids=...)): " +
+                                           ("their routing (sorts, count exchange, split sizes to the host) runs on a side stream "
+                                            "beside this step's sparse apply" if shard is not None else
+                                            "their sort runs on a side stream beside this step's catch-up"))
+                                          if presort[0] else "ids handed over step by step")},
             "roofline": {"kernel": ("embed_fm_planes_fwd_k: embedding gather + FM second order, writes the input_layer concat as fp16 "
                                     "high/low planes with one exponent per example (the operand of the layer-1 GEMMs); the wide part's "
                                     "4-byte gathers run as linear_only_fwd_k on a side stream" if planes_gather else

@@ -800,14 +800,15 @@ class DeepFM:
                                      self.last_step, uniq, num_uniq, n_max, self.E, self.step, (ts or lsch).table, s.beta1, s.beta2,
                                      s.epsilon, flags | extra, self.ls)
 
-    def _sort_unique(self, keys, n, key_range, tag):
-        """mi_sort_unique_rows into persistent buffers named after `tag`."""
+    def _sort_unique(self, keys, n, key_range, tag, ws_name="sort_ws"):
+        """mi_sort_unique_rows into persistent buffers named after `tag` (ws_name: a workspace of its own for a sort that
+        runs on a side stream beside the main stream's)."""
         i32 = torch.int32
         sorted_entry = self._buf(tag + "_sorted", (n,), i32)
         uniq = self._buf(tag + "_uniq", (n,), i32)
         seg = self._buf(tag + "_seg", (n + 1,), i32)
         num_uniq = self._buf(tag + "_nu", (1,), i32)
-        ws = self._bytes("sort_ws", self.k.query("mi_sort_unique_workspace_bytes", n))
+        ws = self._bytes(ws_name, self.k.query("mi_sort_unique_workspace_bytes", n))
         self.k.mi_sort_unique_rows(keys, n, key_range, sorted_entry, uniq, seg, num_uniq, ws, ws.numel())
         return sorted_entry, uniq, seg, num_uniq
 
@@ -851,11 +852,37 @@ class DeepFM:
         """One optimizer.minimize(loss): returns (loss [1], logits [B]) device tensors, no host sync.
         next_ids (optional): the ids of the batch the NEXT call will be given — an input pipeline knows them (the
         reference prefetches its tf.data batches, ml_100k.py:42-61).  Their sort then runs beside this step's catch-up
-        (see _presort) instead of at the head of the next step.  Results are those of the plain sequence, bit for bit."""
+        (see _presort) instead of at the head of the next step.  Results are those of the plain sequence, bit for bit.
+        Three drivers share the kernels: this one dispatches — N > 1 GPUs: parallel.sharded_train_step; one GPU:
+        _train_step_single; one GPU as a hipGraph replay: graph_train_step (which captures _train_step_single)."""
         self._prep(ids, labels, x_num)
         if self.shard is not None:
             from . import parallel
-            return parallel.sharded_train_step(self, ids, labels, x_num)
+            return parallel.sharded_train_step(self, ids, labels, x_num, next_ids)
+        return self._train_step_single(ids, labels, x_num, next_ids)
+
+    def _take_presorted(self, ids):
+        """The sort of `ids` if the previous step was told about this very tensor (and it is unmodified), else None."""
+        ps, self._presorted = getattr(self, "_presorted", None), None
+        if ps is None:
+            return None
+        torch.cuda.current_stream().wait_stream(ps["stream"])           # (also before the workspace is reused)
+        if ps["ids"].data_ptr() == ids.data_ptr() and ps["ids"].shape == ids.shape and ps["version"] == ids._version:
+            return ps
+        return None
+
+    def _announce(self, ids, next_ids, x_num, tag):
+        """Start the next batch's sort on the side stream when it can pay (see _presort)."""
+        B = ids.shape[0]
+        if (next_ids is not None and self.device.type == "cuda" and B * self.F >= self.PRESORT_MIN and next_ids.shape == ids.shape
+                and B % 4096 == 0 and self.F <= 64 and hasattr(self.k, "mi_sort_unique_fields")   # (its own workspace)
+                and not getattr(self, "_capturing", False)):
+            self._prep(next_ids, None, x_num)
+            self._presort(next_ids, "own2" if tag == "own" else "own")
+
+    def _train_step_single(self, ids, labels, x_num, next_ids):
+        """The single-GPU step: sort/unique -> lazy Adam catch-up -> forward + head -> MLP backward -> dense apply +
+        fused sparse apply."""
         B = ids.shape[0]
         n = B * self.F
         if n == 0:                       # numeric columns only: no sparse variable exists
@@ -866,22 +893,10 @@ class DeepFM:
             return loss, logits
         self._split_weights_ahead()
         # (1) which rows does this batch touch: sort + unique (TF: unique/unsorted_segment_sum)
-        ps, self._presorted = getattr(self, "_presorted", None), None
-        tag = "own"
-        if ps is not None:
-            torch.cuda.current_stream().wait_stream(ps["stream"])       # (also before the workspace is reused below)
-            if ps["ids"].data_ptr() == ids.data_ptr() and ps["ids"].shape == ids.shape and ps["version"] == ids._version:
-                sorted_entry, uniq, seg, num_uniq = ps["sorted"]
-                tag = ps["tag"]
-            else:
-                ps = None
-        if ps is None:
-            sorted_entry, uniq, seg, num_uniq = self._sort_batch(ids, tag)
-        if (next_ids is not None and self.device.type == "cuda" and n >= self.PRESORT_MIN and next_ids.shape == ids.shape
-                and B % 4096 == 0 and self.F <= 64 and hasattr(self.k, "mi_sort_unique_fields")   # (its own workspace)
-                and not getattr(self, "_capturing", False)):
-            self._prep(next_ids, None, x_num)
-            self._presort(next_ids, "own2" if tag == "own" else "own")
+        ps = self._take_presorted(ids)
+        tag = ps["tag"] if ps is not None else "own"
+        sorted_entry, uniq, seg, num_uniq = ps["sorted"] if ps is not None else self._sort_batch(ids, tag)
+        self._announce(ids, next_ids, x_num, tag)
         # (2) TF Adam moved these rows on every step they sat out: replay that now
         if self.adam_rows and self.step > 0:
             self._catchup(uniq, num_uniq, n, defer=True)

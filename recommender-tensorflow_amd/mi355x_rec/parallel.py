@@ -52,18 +52,42 @@ class Comm:
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.direct = dist.get_backend(group) == "nccl"   # RCCL: device tensors go straight in
+        # A second communicator for the count exchange of a batch routed AHEAD (_route_ahead): RCCL runs a communicator's
+        # collectives in issue order on one stream, and that exchange waits for the next batch's sorts — on this step's
+        # communicator it would hold up this step's row exchanges behind them.  (Created by every rank, here, in the
+        # same order.)
+        ranks = dist.get_process_group_ranks(group if group is not None else dist.group.WORLD)
+        self.ahead_group = dist.new_group(ranks=ranks)
 
     def exchange_counts(self, counts_dev, C):
         """counts_dev [C * world] int32 (device): distinct requests of chunk c for rank j at c * world + j.
         One small all_to_all on the device buffers, then ONE device->host copy of both tables (the split
         sizes of all_to_all_single must be host integers): (send_counts[c][j], recv_counts[c][j])."""
+        return self.finish_counts(self.start_counts(counts_dev, C))
+
+    def start_counts(self, counts_dev, C, ahead=False):
+        """The count exchange WITHOUT the host wait: the all_to_all and an asynchronous copy of both tables into pinned
+        host memory are enqueued on the current stream; finish_counts() waits for the copy's event — immediately
+        (exchange_counts), or a step later, when the routing of the next batch was started ahead."""
         W = self.world
         send = counts_dev.view(C, W).t().contiguous().view(-1).to(torch.int64)       # [dest rank][chunk]
         if not self.direct:
             send = send.cpu()
         recv = torch.empty_like(send)
-        dist.all_to_all_single(recv, send, group=self.group)
-        both = torch.stack([send, recv]).cpu().tolist()                                # the step's one host sync
+        dist.all_to_all_single(recv, send, group=self.ahead_group if ahead else self.group)
+        both = torch.stack([send, recv])
+        if both.device.type != "cuda":
+            return {"host": both, "event": None, "C": C}
+        host = torch.empty(both.shape, dtype=both.dtype, pin_memory=True)
+        host.copy_(both, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return {"host": host, "event": ev, "C": C, "keep": both}
+
+    def finish_counts(self, pending):
+        if pending["event"] is not None:
+            pending["event"].synchronize()                                            # the step's one host sync
+        both, C, W = pending["host"].tolist(), pending["C"], self.world
         sc = [[int(both[0][j * C + c]) for j in range(W)] for c in range(C)]
         rc = [[int(both[1][j * C + c]) for j in range(W)] for c in range(C)]
         return sc, rc
@@ -141,30 +165,68 @@ def _n_chunks(m, B, train):
     return c
 
 
-def _route(m, ids, C):
+def _route(m, ids, C, tag="", ahead=False):
     """Plan the exchange for this batch, C chunks of B/C examples.  The entries are sorted by request key
     (chunk, owner, owner-local row); the DISTINCT keys are the requests that travel, in send order.  Returns
     (slot [B*F]: distinct request of every entry = slot of its row in the receive buffer, send_rows [U]: the
-    owner-local rows to ask for, the sort's (sorted_entry, seg_start) over the entries, send_counts[c][rank],
-    recv_counts[c][rank])."""
+    owner-local rows to ask for, the sort's (sorted_entry, seg_start) over the entries, and the pending count
+    exchange: Comm.finish_counts gives send_counts[c][rank], recv_counts[c][rank]).
+    tag / ahead: a second set of buffers and a sort workspace of its own, for the routing of the NEXT batch started on a
+    side stream while this step still uses the first set (_route_ahead)."""
     k, sh = m.k, m.shard
     comm = _comm(m)
     i32 = torch.int32
     B = ids.shape[0]
     n = B * m.F
     Rl = (m.R + sh.world - 1) // sh.world                     # rows per rank (upper bound): the key's row range
-    rows = m._buf("rows", (n,), i32)
+    rows = m._buf("rows" + tag, (n,), i32)
     k.mi_global_rows(ids, m.field_off, B, m.F, rows)
-    key = m._buf("route_key", (n,), i32)
+    key = m._buf("route_key" + tag, (n,), i32)
     k.mi_shard_keys(rows, n, sh.world, (n // C) if C > 1 else 0, Rl, key)
-    sorted_entry, uniq, seg, num_uniq = m._sort_unique(key, n, C * sh.world * Rl, "route")
-    send_rows = m._buf("send_rows", (n,), i32)
-    counts = m._buf("route_counts", (C * sh.world,), i32)
+    sorted_entry, uniq, seg, num_uniq = m._sort_unique(key, n, C * sh.world * Rl, "route" + tag,
+                                                       ws_name="sort_ws_ahead" if ahead else "sort_ws")
+    send_rows = m._buf("send_rows" + tag, (n,), i32)
+    counts = m._buf("route_counts" + tag, (C * sh.world,), i32)
     k.mi_route_requests(uniq, num_uniq, n, Rl, C * sh.world, send_rows, counts)
-    slot = m._buf("route_slot", (n,), i32)
+    slot = m._buf("route_slot" + tag, (n,), i32)
     k.mi_segment_slots(seg, sorted_entry, num_uniq, n, slot)
-    send_counts, recv_counts = comm.exchange_counts(counts, C)
-    return slot, send_rows, sorted_entry, seg, send_counts, recv_counts
+    return slot, send_rows, sorted_entry, seg, comm.start_counts(counts, C, ahead=ahead)
+
+
+def _route_ahead(m, next_ids, C):
+    """The routing of the NEXT batch — a pure function of its ids: a radix sort's worth of small kernels, the count
+    exchange (on a communicator of its own) and the copy of the split sizes to the host — started on a side stream at
+    the HEAD of this step, as soon as this step's own plan is on the host.  The next sharded_train_step picks it up if it
+    is given that very tensor, unmodified: its split sizes have then been on the host for a whole step — the host, which
+    enqueues a step in less time than the GPU takes to run it, never waits for them (started at the END of the step
+    the wait only moved: measured, no gain), and no routing sort stands at the head of the step.
+    Every rank must announce (or not announce) its next batch alike: the count exchange is a collective."""
+    side = m._ws.get("route_stream")
+    if side is None:
+        side = m._ws["route_stream"] = torch.cuda.Stream(device=m.device) if m.device.type == "cuda" else None
+    tag = "_b" if getattr(m, "_route_tag", "") == "" else ""      # the buffer set this step's plan does NOT live in
+    if side is None:
+        plan = _route(m, next_ids, C, tag, ahead=True)
+    else:
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            plan = _route(m, next_ids, C, tag, ahead=True)
+    m._routed = {"ids": next_ids, "version": next_ids._version, "plan": plan, "C": C, "tag": tag, "stream": side}
+
+
+def _take_route(m, ids, C):
+    """The plan _route_ahead made for exactly this tensor, or a fresh one."""
+    r, m._routed = getattr(m, "_routed", None), None
+    if r is not None:
+        if r["stream"] is not None:
+            torch.cuda.current_stream().wait_stream(r["stream"])
+        if C > 0 and r["ids"].data_ptr() == ids.data_ptr() and r["ids"].shape == ids.shape and r["version"] == ids._version and r["C"] == C:
+            m._route_tag = r["tag"]
+            m.route_ahead_hits = getattr(m, "route_ahead_hits", 0) + 1
+            return r["plan"]
+        _comm(m).finish_counts(r["plan"][4])          # (an announced batch that did not come: its exchange still completes)
+    m._route_tag = ""
+    return _route(m, ids, max(C, 1))
 
 
 def _zero_off(m):
@@ -174,7 +236,7 @@ def _zero_off(m):
     return z
 
 
-def _sharded_step(m, ids, labels, x_num, train):
+def _sharded_step(m, ids, labels, x_num, train, next_ids=None):
     """Forward (+ backward and apply when train) of one local batch on N ranks; see the module
     docstring.  Returns (this rank's share of the loss — already divided by the global batch —,
     local logits)."""
@@ -188,7 +250,11 @@ def _sharded_step(m, ids, labels, x_num, train):
     Bc = B // C
     if train and hasattr(m, "_split_weights_ahead"):
         m._split_weights_ahead()            # the MLP's weight planes, on a side stream beside the routing
-    slot, send_rows, sorted_entry, seg, send_counts, recv_counts = _route(m, ids, C)
+    # (an evaluation between two train steps plans into the first buffer set: a plan made ahead is dropped first)
+    slot, send_rows, sorted_entry, seg, pending = _take_route(m, ids, C if train else -1)
+    send_counts, recv_counts = comm.finish_counts(pending)
+    if train and next_ids is not None and next_ids.shape == ids.shape and not getattr(m, "_capturing", False):
+        _route_ahead(m, next_ids, C)
     nsc = [sum(sc) for sc in send_counts]               # distinct requests of chunk c (all owners)
     uoff = [0]
     for v in nsc:
@@ -300,6 +366,7 @@ def sharded_eval_step(m, ids, labels, x_num):
     return _sharded_step(m, ids, labels, x_num, False)
 
 
-def sharded_train_step(m, ids, labels, x_num):
-    """N-rank synchronous step.  Every rank must call it with the same local batch size."""
-    return _sharded_step(m, ids, labels, x_num, True)
+def sharded_train_step(m, ids, labels, x_num, next_ids=None):
+    """N-rank synchronous step.  Every rank must call it with the same local batch size — and, if it announces its
+    next batch (next_ids: see _route_ahead), every rank must."""
+    return _sharded_step(m, ids, labels, x_num, True, next_ids)

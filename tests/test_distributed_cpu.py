@@ -60,12 +60,17 @@ def _worker(rank, world, port, cfg, out_q, device="cpu", backend="gloo"):
         rng = np.random.default_rng(5)
         losses = []
         t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(device)
+        sl = slice(rank * B, (rank + 1) * B)
+        drawn = []
         for _ in range(steps):
             ids_s = _draw_ids(rng, vocab, B * world, extra)
             ids_s[1] = ids_s[0]
             ids_s[B % len(ids_s)] = ids_s[0]         # the same rows requested from both ranks
-            sl = slice(rank * B, (rank + 1) * B)
-            loss, logits = m.train_step(t(ids_s[sl]), t(y[sl]), t(None if x is None else x[sl]))
+            drawn.append(t(ids_s[sl]))
+        for s_i in range(steps):
+            # extra["announce"]: the next step's ids are handed over with this step's (parallel._route_ahead)
+            nxt = drawn[s_i + 1] if (extra.get("announce") and s_i + 1 < steps) else None
+            loss, logits = m.train_step(drawn[s_i], t(y[sl]), t(None if x is None else x[sl]), next_ids=nxt)
             tot = loss.detach().cpu().clone() if backend == "gloo" else loss.clone()
             dist.all_reduce(tot)
             losses.append((float(tot.item()), logits.cpu().numpy().copy()))
@@ -73,6 +78,7 @@ def _worker(rank, world, port, cfg, out_q, device="cpu", backend="gloo"):
                                     t(None if x is None else x[rank * B:(rank + 1) * B]))
         exported = m.export_numpy()
         exported["exchange"] = dict(m.last_exchange)            # of the eval step: one chunk
+        exported["route_ahead_hits"] = getattr(m, "route_ahead_hits", 0)
         out_q.put((rank, "ok", losses, exported, ev_logits.cpu().numpy().copy()))
         dist.barrier()
         dist.destroy_process_group()
@@ -136,6 +142,16 @@ CASES = [
 @pytest.mark.parametrize("cfg", CASES)
 def test_two_rank_step_equals_big_batch(cfg):
     check_against_big_batch(cfg, _run(cfg, 2), 2)
+
+
+def test_next_batch_routed_ahead_equals_big_batch():
+    """the routing of batch t + 1 (sorts, count exchange, split sizes to the host) is started during step t
+    when its ids are announced — the plan is picked up by the next call (every step but the first), results are those of
+    the plain sequence; an evaluation in between drops a plan made ahead instead of overwriting its buffers."""
+    cfg = ([9, 13, 5, 6], 8, [16, 8], 32, 0, "Adam", 0.001, 4, (True, True, True), 2, dict(announce=True))
+    res = _run(cfg, 2)
+    check_against_big_batch(cfg, res, 2)
+    assert all(res[r][1]["route_ahead_hits"] == 3 for r in range(2)), [res[r][1]["route_ahead_hits"] for r in range(2)]
 
 
 def test_four_rank_pipelined_step_equals_big_batch():
