@@ -36,6 +36,7 @@ if len(sys.argv) > 3:
                        "bench.py copies the entry of the roofline kernel into roofline.traffic"}
     for k, n, f, rd, w, wr in rows:
         base = k.split("<")[0]
-        if base in ("embed_fm_planes_fwd_k", "embed_fm_linear_fwd_k", "sparse_apply_k", "sparse_catchup_k", "catchup_lin_k") and base not in out:
+        if base in ("embed_fm_planes_fwd_k", "embed_fm_linear_fwd_k", "sparse_apply_k", "sparse_catchup_k", "sparse_catchup_bounded_k",
+                    "catchup_lin_k") and base not in out:
             out[base] = {"bytes_per_launch": int(rd + wr), "fetch_size_kib_raw": int(f), "write_size_kib": int(w)}
     json.dump(out, open(sys.argv[3], "w"), indent=2)
