@@ -663,7 +663,7 @@ def test_bounded_catchup_stays_within_1e7_of_the_sweep(lib):
     # (c) the flag is ignored where the bounded form has no meaning (eps too small to keep sqrt(v) + eps normal): the
     # exact form runs, and an unknown flag is refused
     assert lib.mi_sparse_catchup(_p(dW), _p(dM), _p(dV), None, None, None, _p(dlast), None, None, R, E, step_to, _p(dlr),
-                                 float(b1), float(b2), float(eps), 4, 1, _st()) != 0
+                                 float(b1), float(b2), float(eps), 8, 1, _st()) != 0
 
 
 @pytest.mark.parametrize("B", [1, 37, 5000])
