@@ -388,14 +388,14 @@ __device__ __forceinline__ bool catchup_params_in_range(int steps, float lr_last
 // this form keeps what is cheap to keep exact and approximates the rest with a stated bound:
 //   m_j = m_{j-1} * b1                 exactly the reference's chain (same bits)
 //   u_j = lr_t[s] * m_j                 exactly the reference's numerator (same bits)
-//   sqrt(v_j)  ~  s0 * rho_j            s0 = sqrtf(v_0) (correctly rounded, once per element), rho_j ~ beta2^(j/2): a per-ROW
+//   sqrt(v_j)  ~  s0 * rho_j            s0 = v_sqrt_f32(v_0) (1 ulp, once per element), rho_j ~ beta2^(j/2): a per-ROW
 //                                       scalar chain rho_j = rho_{j-1} * (rho_hi + rho_lo), rho_hi + rho_lo = sqrt(beta2) to
 //                                       2^-48 (no systematic drift; rounding noise <= sqrt(j) * 2^-24 rms)
 //   w_j = fma(-u_j, rcp(fma(s0, rho_j, eps)), w_{j-1})     v_rcp_f32: 1 ulp; ONE rounding of w per step, like the reference
 // Per element and step: 4 packed-able VALU operations + 1 transcendental instead of 16 + 2; no range conditions at all
 // (v = 0, denormal m, any gap: the same loop), so no wave ever falls back to a slow generic loop.
 // Error against the reference's literal fp32 sweep, per replayed step j of a row: the update t_j = u_j / (sqrt(v_j) + eps)
-// is reproduced to |t~_j / t_j - 1| <= (2 [v_rcp_f32: 1 ulp] + 1 [s0] + 1 [fma] + 2j [rho chain, worst case; ~sqrt(j)/2
+// is reproduced to |t~_j / t_j - 1| <= (2 [v_rcp_f32: 1 ulp] + 2 [s0] + 1 [fma] + 2j [rho chain, worst case; ~sqrt(j)/2
 // rms] + 3 [the reference's own sqrt, add and divide roundings] + j/2 [its v chain]) * 2^-24; the updates decay like
 // 0.9^j, so the sum over a replay is off by <~ 1e-6 of its FIRST update in the worst case and ~1e-7 of it typically —
 // of an update that is itself ~1e-3 |w|.  On top of that comes the rare step in which the difference moves RN(w - t)
