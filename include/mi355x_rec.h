@@ -77,6 +77,11 @@ int32_t mi_step_advance(mi_step_state_t* device_state, const float* lr_table, mi
  * tf.feature_column.categorical_column_with_hash_bucket applies (ml_100k.py:19,20,29,30). */
 uint64_t mi_fingerprint64(const void* data, size_t len);
 
+/* CRC-32C (Castagnoli) of len bytes, continuing from `crc` (0 to start; unmasked) — the checksum TensorFlow's tensor-bundle
+ * checkpoints carry per table block and per tensor (the files tf.estimator writes under conf_utils.py:6-10's RunConfig;
+ * read and written by mi355x_rec/tf_bundle.py).  Host function. */
+uint32_t mi_crc32c(const void* data, size_t len, uint32_t crc);
+
 /* id = Fingerprint64(decimal ASCII of v) mod num_buckets — hash_bucket column with an integer
  * dtype (user_id, item_id: ml_100k.py:19-20). */
 int32_t mi_hash_bucket_i64(const int64_t* values, int64_t n, int64_t num_buckets, int32_t* out_ids);

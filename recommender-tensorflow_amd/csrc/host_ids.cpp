@@ -184,6 +184,37 @@ const char* mi_build_info(void) {
   return info;
 }
 
+// CRC-32C (Castagnoli, reflected polynomial 0x82F63B78) — the checksum of TensorFlow's tensor-bundle checkpoint files
+// (block trailers of the .index table, one per tensor in the .data shards; conf_utils.py:6-10 configures the Estimator
+// that writes them).  Slicing-by-8 tables, built on first use; `crc` is the running value (0 to start), unmasked.
+uint32_t mi_crc32c(const void* data, size_t len, uint32_t crc) {
+  static uint32_t T[8][256];
+  static bool ready = false;
+  if (!ready) {
+    for (uint32_t i = 0; i < 256; ++i) {
+      uint32_t c = i;
+      for (int k = 0; k < 8; ++k) c = (c >> 1) ^ ((c & 1u) ? 0x82F63B78u : 0u);
+      T[0][i] = c;
+    }
+    for (uint32_t i = 0; i < 256; ++i)
+      for (int t = 1; t < 8; ++t) T[t][i] = (T[t - 1][i] >> 8) ^ T[0][T[t - 1][i] & 0xffu];
+    ready = true;
+  }
+  const uint8_t* p = static_cast<const uint8_t*>(data);
+  uint32_t c = ~crc;
+  while (len && (reinterpret_cast<uintptr_t>(p) & 7u)) { c = (c >> 8) ^ T[0][(c ^ *p++) & 0xffu]; --len; }
+  while (len >= 8) {
+    uint64_t w;
+    memcpy(&w, p, 8);
+    w ^= c;
+    c = T[7][w & 0xff] ^ T[6][(w >> 8) & 0xff] ^ T[5][(w >> 16) & 0xff] ^ T[4][(w >> 24) & 0xff] ^
+        T[3][(w >> 32) & 0xff] ^ T[2][(w >> 40) & 0xff] ^ T[1][(w >> 48) & 0xff] ^ T[0][(w >> 56) & 0xff];
+    p += 8; len -= 8;
+  }
+  while (len--) c = (c >> 8) ^ T[0][(c ^ *p++) & 0xffu];
+  return ~c;
+}
+
 uint64_t mi_fingerprint64(const void* data, size_t len) {
   return mi::farm::hash64(static_cast<const uint8_t*>(data), len);
 }

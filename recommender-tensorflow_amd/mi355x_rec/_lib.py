@@ -62,6 +62,7 @@ SIGNATURES = {
     "mi_set_step_state": (_i32, [_p]),
     "mi_step_advance": (_i32, [_p, _p, _p]),
     "mi_fingerprint64": (_u64, [_p, _sz]),
+    "mi_crc32c": (_u32, [_p, _sz, _u32]),
     "mi_hash_bucket_i64": (_i32, [_p, _i64, _i64, _p]),
     "mi_hash_bucket_bytes": (_i32, [_p, _p, _i64, _i64, _p]),
     "mi_bucketize_f32": (_i32, [_p, _i64, _p, _i32, _p]),

@@ -172,12 +172,29 @@ class Estimator:
                 print("INFO: restored %s (global_step %d)" % (ck, self.global_step))
         elif self.warm_start_from:
             import numpy as np
-            from . import tf_names
+            from . import tf_bundle, tf_names
             plan = self.params["_store"]["plan"]
-            with np.load(self.warm_start_from, allow_pickle=False) as z:
-                names = tf_names.import_variables(self._engine(), dict(z), [c.name for c in plan.categorical],
-                                                  model=self.params.get("tf_model", "deep_fm"),
-                                                  numeric_names=[c.name for c in plan.numeric])
+            cols, nums = [c.name for c in plan.categorical], [c.name for c in plan.numeric]
+            model = self.params.get("tf_model", "deep_fm")
+            if tf_bundle.is_bundle(self.warm_start_from):
+                # a TensorFlow checkpoint itself (model_dir or prefix): only the model's variables are read — not the
+                # optimizer slots, global_step, beta powers that the bundle also holds
+                nm = tf_names._names_for(self._engine(), model, cols, nums, sharded_ok=True)
+                flat = []
+
+                def walk(v):
+                    if isinstance(v, str):
+                        flat.append(v)
+                    elif isinstance(v, (list, tuple)):
+                        for q in v:
+                            walk(q)
+                walk(list(nm.values()))
+                have = tf_bundle.list_variables(self.warm_start_from)
+                arrays = tf_bundle.read_bundle(self.warm_start_from, names=[n for n in flat if n in have])
+            else:
+                with np.load(self.warm_start_from, allow_pickle=False) as z:
+                    arrays = dict(z)
+            names = tf_names.import_variables(self._engine(), arrays, cols, model=model, numeric_names=nums)
             print("INFO: warm-started %d variables from %s" % (len(names), self.warm_start_from))
 
     def save_checkpoint(self):

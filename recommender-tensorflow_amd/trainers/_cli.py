@@ -17,12 +17,16 @@ _COMMON = [
     ("--batch-size", dict(type=int, default=32, help="batch size (default: %(default)s)")),
     ("--train-steps", dict(type=int, default=20000, help="number of training steps (default: %(default)s)")),
     ("--device", dict(default="cuda", help="torch device of the MI355X to run on (default: %(default)s)")),
-    ("--warm-start-from", dict(default=None, help=".npz of TensorFlow-named variables (a dumped TF-1.12 checkpoint of "
-                                                   "the reference) to start from when job_dir has no checkpoint")),
+    ("--warm-start-from", dict(default=None, help="a TensorFlow checkpoint of the reference — its model_dir, a model.ckpt-N prefix, or "
+                                                   "an .npz dump of its variables by name — to start from when job_dir has no checkpoint")),
     ("--world-size", dict(type=int, default=None, help="number of MI355X (one process each): launch with `python -m "
                                                        "torch.distributed.run --nproc-per-node N -m trainers.<model> ...`; the flag "
                                                        "only checks the launch (default: WORLD_SIZE of the launcher, else 1)")),
     ("--hip-graph", dict(action="store_true", help="replay the train step as one hipGraph launch (launch-bound small batches)")),
+    ("--catchup", dict(choices=["exact", "bounded"], default="exact",
+                       help="Adam only: how the steps a table row sat out are replayed when it is next read — exact: TensorFlow's fp32 "
+                            "sequence bit for bit; bounded: every variable within 1e-7 relative of it (3 ulp + 2e-6 of the replayed "
+                            "movement), a third of the instructions (default: %(default)s)")),
     ("--synthetic", dict(type=int, default=None, metavar="N", help="train on N generated MovieLens-shaped examples (and evaluate on "
                                                                    "N/10) instead of --train-csv / --test-csv")),
 ]
@@ -95,6 +99,7 @@ def run(args, make_estimator):
     estimator.warm_start_from = getattr(args, "warm_start_from", None)
     estimator.params["_shard"] = shard
     estimator.params["hip_graph"] = bool(getattr(args, "hip_graph", False))
+    estimator.params["catchup"] = getattr(args, "catchup", "exact")
     train_spec = get_train_spec(get_input_fn(args.train_csv, batch_size=args.batch_size, seed=rank if world > 1 else None),
                                 args.train_steps)
     eval_spec = get_eval_spec(get_input_fn(args.test_csv, ModeKeys.EVAL, batch_size=args.batch_size),

@@ -29,7 +29,8 @@ def model_fn(features, labels, mode, params):
         return DeepFM(plan.vocab_sizes, n_numeric=len(plan.numeric), embedding_size=params.get("embedding_size", 4),
                       hidden_units=params.get("hidden_units", [16, 16]), use_linear=flags[0], use_mf=flags[1],
                       use_dnn=flags[2], dropout=params.get("dropout", 0), optimizer=opt, reduction="mean",
-                      device=device, seed=params.get("seed", 0), shard=shard, activation=activation)
+                      device=device, seed=params.get("seed", 0), shard=shard, activation=activation,
+                      catchup=params.get("catchup", "exact"))
 
     return run_batch(features, labels, mode, params, make)
 
