@@ -60,11 +60,15 @@ class Params:
 
 
 def init_params(rng, vocab_sizes, E, hidden_units, n_numeric=0, dtype=np.float32, lin_scale=0.0,
-                use_dnn=True, numeric="embed"):
+                use_dnn=True, numeric="embed", field_dims=None, wide_fields=None, deep_numeric=None):
     """TF initialisers: embeddings truncated_normal(0, 1/sqrt(E)) at 2 sigma,
     linear weights / biases zero, dense kernels glorot-uniform.  ``lin_scale`` > 0 replaces the
     zero linear init by N(0, lin_scale) so parity tests exercise that path with non-trivial data.
-    (TF's Philox stream is not reproducible; tests inject identical weights on both sides.)"""
+    (TF's Philox stream is not reproducible; tests inject identical weights on both sides.)
+    field_dims (canned DNNLinearCombinedClassifier with per-column embedding dimensions, or a column that only the
+    wide part uses: dimension 0): per-field embedding widths instead of one E; wide_fields: per-field flags, False = the
+    column is not in linear_feature_columns (its linear weights stay zero and are never touched); deep_numeric: per raw
+    numeric column, False = not in dnn_feature_columns (kernel_0 has no row for it)."""
     def trunc_normal(shape, std):
         x = rng.standard_normal(shape)
         bad = np.abs(x) > 2
@@ -77,13 +81,17 @@ def init_params(rng, vocab_sizes, E, hidden_units, n_numeric=0, dtype=np.float32
         lim = np.sqrt(6.0 / (fan_in + fan_out))
         return rng.uniform(-lim, lim, shape).astype(dtype)
 
-    emb = [trunc_normal((v, E), 1.0 / np.sqrt(E)) for v in vocab_sizes]
+    dims = [E] * len(vocab_sizes) if field_dims is None else [int(d) for d in field_dims]
+    emb = [trunc_normal((v, dd), 1.0 / np.sqrt(max(dd, 1))) for v, dd in zip(vocab_sizes, dims)]
     lin_w = [(rng.standard_normal(v) * lin_scale).astype(dtype) for v in vocab_sizes]
+    if wide_fields is not None:
+        lin_w = [w if on else np.zeros_like(w) for w, on in zip(lin_w, wide_fields)]
     lin_bias = np.zeros(1, dtype)
     d = len(vocab_sizes) + (n_numeric if numeric == "embed" else 0)
     mlp = []
     if use_dnn:
-        fan = d * E + (n_numeric if numeric == "raw" else 0)
+        n_raw = (n_numeric if deep_numeric is None else int(np.sum(deep_numeric))) if numeric == "raw" else 0
+        fan = (d * E if field_dims is None else sum(dims)) + n_raw
         for h in list(hidden_units) + [1]:
             mlp.append((glorot(fan, h, (fan, h)), np.zeros(h, dtype)))
             fan = h
@@ -101,7 +109,7 @@ ACTIVATIONS = {   # params["activation"] (deep_fm.py:22): name -> (f, f' express
 
 
 def forward(p, ids, x_num=None, use_linear=True, use_mf=True, use_dnn=True, dropout_masks=None, numeric="embed",
-            keep_prob=1.0, activation="relu", relu_masks=None):
+            keep_prob=1.0, activation="relu", relu_masks=None, wide_fields=None, deep_numeric=None, wide_numeric=None):
     """model_fn forward (deep_fm.py:36-115).  ids [B,F] per-field local ids; x_num [B,n_d].
     dropout_masks: per hidden layer, a [B,h] array of {0, 1} keep flags (TRAIN) or None; tf.layers.dropout
     (deep_fm.py:102-103) is tf.nn.dropout: div(x, keep_prob) * mask — a division, not a multiplication by 1/keep.
@@ -121,15 +129,23 @@ def forward(p, ids, x_num=None, use_linear=True, use_mf=True, use_dnn=True, drop
     if numeric == "raw" and use_mf:
         raise ValueError("raw numeric columns belong to the canned estimators, which have no FM term")
     c = {"ids": ids, "x_num": x_num, "flags": (use_linear, use_mf, use_dnn), "numeric": numeric, "keep_prob": keep_prob,
-         "activation": activation}
+         "activation": activation, "wide_fields": wide_fields, "widths": [a.shape[1] for a in p.emb],
+         "deep_numeric": deep_numeric, "wide_numeric": wide_numeric}
+    # the canned DNNLinearCombinedClassifier's general form: every column has its own embedding width, and
+    # the wide and the deep part each read their own subset of the columns
+    c["general"] = len(set(c["widths"])) > 1 or deep_numeric is not None or wide_numeric is not None
+    if c["general"] and (use_mf or (x_num is not None and numeric == "embed")):
+        raise ValueError("per-column widths / column subsets belong to the canned estimators (no FM term, raw numeric columns)")
     logits = np.zeros(B, dt)                                      # deep_fm.py:36
     if use_linear:                                                # deep_fm.py:37-44 linear_model
         lin = np.zeros(B, dt)
         for f in range(F):                                        # add_n over sorted columns
-            lin = lin + p.lin_w[f][ids[:, f]]
+            if wide_fields is None or wide_fields[f]:             # (a column of dnn_feature_columns only: no linear weight)
+                lin = lin + p.lin_w[f][ids[:, f]]
         if x_num is not None:
             for j in range(x_num.shape[1]):
-                lin = lin + x_num[:, j] * p.lin_num[j]
+                if wide_numeric is None or wide_numeric[j]:
+                    lin = lin + x_num[:, j] * p.lin_num[j]
         lin = lin + p.lin_bias[0]                                 # bias_add
         c["lin"] = lin
         logits = logits + lin
@@ -140,7 +156,7 @@ def forward(p, ids, x_num=None, use_linear=True, use_mf=True, use_dnn=True, drop
             parts += [x_num[:, j:j + 1] * p.num_emb[j][None, :] for j in range(x_num.shape[1])]
         d = len(parts)
         if x_num is not None and numeric == "raw":                # canned input_layer: the value itself
-            parts.append(x_num.astype(dt))
+            parts.append((x_num if deep_numeric is None else x_num[:, np.asarray(deep_numeric, bool)]).astype(dt))
         concat = np.concatenate(parts, 1)                         # [B, d*E (+ n_d raw)]
         c["concat"] = concat
     if use_mf:                                                    # deep_fm.py:76-90
@@ -237,6 +253,24 @@ def backward(p, c, d_logits, dropout_masks=None):
             d_net = d_pre @ k_i.T
         g_mlp = list(reversed(g_hidden)) + [g_last]
         d_concat = d_net
+    widths = c.get("widths") or []
+    if c.get("general"):
+        # per-field embedding widths / column subsets (canned estimators: no FM term, raw numeric columns): slices of d_concat
+        dense = []
+        for gk, gb in g_mlp:
+            dense += [gk, gb]
+        dense.append(d_logits.sum(keepdims=True) if use_linear else np.zeros(1, dt))
+        if x_num is not None:
+            g_lnum = ((d_logits[:, None] * x_num).sum(0) if use_linear else np.zeros_like(p.lin_num)).astype(dt)
+            if c.get("wide_numeric") is not None:
+                g_lnum[~np.asarray(c["wide_numeric"], bool)] = 0
+            dense.append(g_lnum)
+        offs = np.concatenate([[0], np.cumsum(widths)])
+        d_rows = [d_concat[:, offs[f]:offs[f + 1]] if d_concat is not None else np.zeros((B, widths[f]), dt) for f in range(F)]
+        d_lin = np.broadcast_to(d_logits[:, None], (B, F)).copy() if use_linear else None
+        if d_lin is not None and c.get("wide_fields") is not None:
+            d_lin[:, ~np.asarray(c["wide_fields"], bool)] = 0
+        return dense, d_rows, d_lin
     n_emb_num = 0 if (x_num is None or raw) else x_num.shape[1]    # numeric columns that own an embedding
     d = F + n_emb_num
     E = (c["concat"].shape[1] - (x_num.shape[1] if raw else 0)) // d if (use_mf or use_dnn) else 0
@@ -261,6 +295,8 @@ def backward(p, c, d_logits, dropout_masks=None):
         dense += ([] if raw else [g_num.astype(dt)]) + [g_lnum.astype(dt)]
     d_rows = g_v[:, :F, :] if g_v is not None else None
     d_lin = np.broadcast_to(d_logits[:, None], (B, F)).copy() if use_linear else None
+    if d_lin is not None and c.get("wide_fields") is not None:
+        d_lin[:, ~np.asarray(c["wide_fields"], bool)] = 0
     return dense, d_rows, d_lin
 
 
@@ -291,18 +327,19 @@ class TrainState:
 
 def train_step(p, st, ids, labels, x_num=None, use_linear=True, use_mf=True, use_dnn=True,
                reduction="mean", dropout_masks=None, global_batch=None, numeric="embed", keep_prob=1.0, activation="relu",
-               relu_masks=None):
+               relu_masks=None, wide_fields=None, deep_numeric=None, wide_numeric=None):
     """One optimizer.minimize(loss) (deep_fm.py:119-125 TRAIN branch): forward, head, backward,
     apply_gradients (dense vars: fused Apply*, embedding / linear tables: sparse apply with
     duplicate-summing), beta powers / global_step update.  Returns (loss, logits)."""
-    c = forward(p, ids, x_num, use_linear, use_mf, use_dnn, dropout_masks, numeric, keep_prob, activation, relu_masks)
+    c = forward(p, ids, x_num, use_linear, use_mf, use_dnn, dropout_masks, numeric, keep_prob, activation, relu_masks, wide_fields,
+                deep_numeric, wide_numeric)
     loss, d_logits, _, _ = head(c["logits"], labels, reduction, global_batch)
     dense_g, d_rows, d_lin = backward(p, c, d_logits, dropout_masks)
-    apply_gradients(p, st, ids, dense_g, d_rows, d_lin)
+    apply_gradients(p, st, ids, dense_g, d_rows, d_lin, wide_fields)
     return loss, c["logits"]
 
 
-def apply_gradients(p, st, ids, dense_g, d_rows, d_lin):
+def apply_gradients(p, st, ids, dense_g, d_rows, d_lin, wide_fields=None):
     hp, lhp = st.hp, st.lin_hp
     lr_t = st.powers.lr_t(hp.lr) if st.powers else None
     lin_lr_t = st.lin_powers.lr_t(lhp.lr) if st.lin_powers else None
@@ -313,9 +350,10 @@ def apply_gradients(p, st, ids, dense_g, d_rows, d_lin):
         else:
             opt.dense_apply(hp, var, s0, s1, g.reshape(var.shape).astype(var.dtype), lr_t)
     for f in range(F):
-        if d_rows is not None:
-            opt.sparse_apply(hp, p.emb[f], st.emb[f][0], st.emb[f][1], ids[:, f], d_rows[:, f, :], lr_t)
-        if d_lin is not None:
+        if d_rows is not None and p.emb[f].shape[1]:              # (width 0: the column is not in the deep part)
+            g_f = d_rows[f] if isinstance(d_rows, list) else d_rows[:, f, :]
+            opt.sparse_apply(hp, p.emb[f], st.emb[f][0], st.emb[f][1], ids[:, f], g_f, lr_t)
+        if d_lin is not None and (wide_fields is None or wide_fields[f]):
             w = p.lin_w[f][:, None]
             s0, s1 = st.lin[f][0][:, None], st.lin[f][1][:, None]
             opt.sparse_apply(lhp, w, s0, s1, ids[:, f], d_lin[:, f:f + 1], lin_lr_t)

@@ -20,10 +20,32 @@ def _linear_lr(n_columns):
 
 
 def _embedding_size(columns, default=4):
-    dims = {c.dimension for c in columns if isinstance(c, EmbeddingColumn)}
-    if len(dims) > 1:
-        raise NotImplementedError("all embedding columns must share one dimension on the HIP path")
-    return dims.pop() if dims else default
+    """Width of the fused table: the widest embedding column, in whole float4s (a narrower column — and a width that
+    is no multiple of 4 — uses its first `dimension` columns: engine.DeepFM field_dims)."""
+    dims = [c.dimension for c in columns if isinstance(c, EmbeddingColumn)]
+    return (max(dims) + 3) // 4 * 4 if dims else default
+
+
+def _name(c):
+    return (c.categorical_column if isinstance(c, EmbeddingColumn) else c).name
+
+
+def _subsets(plan, lin, dnn, lin_num, dnn_num):
+    """engine.DeepFM's column-subset arguments for the plan's field order: per categorical field its embedding dimension
+    (0: not in dnn_feature_columns) and whether linear_feature_columns has it; the same two flags per numeric column."""
+    dim = {_name(c): c.dimension for c in dnn if isinstance(c, EmbeddingColumn)}
+    wide = {_name(c) for c in lin}
+    deep_n, wide_n = {c.name for c in dnn_num}, {c.name for c in lin_num}
+    return dict(field_dims=[dim.get(c.name, 0) for c in plan.categorical],
+                wide_fields=[c.name in wide for c in plan.categorical],
+                deep_numeric=[c.name in deep_n for c in plan.numeric] if plan.numeric else None,
+                wide_numeric=[c.name in wide_n for c in plan.numeric] if plan.numeric else None)
+
+
+def _by_plan(plan, columns):
+    """the embedding columns in the plan's field order"""
+    by = {_name(c): c for c in columns}
+    return [by[c.name] for c in plan.categorical]
 
 
 def _split(columns):
@@ -56,7 +78,7 @@ class DNNClassifier(Estimator):
             return run_batch(features, labels, mode, params, lambda plan, dev, shard=None: DeepFM(
                 plan.vocab_sizes, n_numeric=len(plan.numeric), numeric="raw", embedding_size=E, hidden_units=hidden,
                 use_linear=False, use_mf=False, use_dnn=True, dropout=dropout or 0.0, optimizer=opt, reduction="sum",
-                device=dev, shard=shard))
+                device=dev, shard=shard, field_dims=[getattr(c, "dimension", E) for c in _by_plan(plan, cat)]))
         super().__init__(model_fn, model_dir, config, {"categorical_columns": cat, "numeric_columns": num,
                                                        "tf_model": "dnn"})
 
@@ -70,10 +92,14 @@ class DNNLinearCombinedClassifier(Estimator):
             raise ValueError("Either linear_feature_columns or dnn_feature_columns must be defined.")
         lin, lin_num = _split(lin_all)
         dnn, dnn_num = _split(dnn_all)
-        names = lambda cs: sorted((c.categorical_column if isinstance(c, EmbeddingColumn) else c).name for c in cs)
-        if lin_all and dnn_all and (names(lin) != names(dnn) or names(lin_num) != names(dnn_num)):
-            raise NotImplementedError("the HIP path shares one fused table and one numeric input: wide and deep parts "
-                                      "must use the same columns (as trainers/linear_deep.py does)")
+        for c in dnn:
+            if not isinstance(c, EmbeddingColumn):
+                raise ValueError("dnn_feature_columns takes embedding_column()s and numeric_column()s; wrap %r" % (_name(c),))
+        # the two lists are independent (linear_deep.py:32-39 happens to pass the same columns twice): the fused table
+        # holds the union of the categorical columns, each part reads its own subset (engine.DeepFM field_dims / ...)
+        union = {_name(c): c for c in lin}
+        union.update({_name(c): c for c in dnn})
+        union_num = {c.name: c for c in lin_num + dnn_num}
         E = _embedding_size(dnn)
         l_opt = linear_optimizer or OptimizerSpec("Ftrl", _linear_lr(len(lin_all)))
         d_opt = dnn_optimizer or OptimizerSpec("Adagrad", 0.05)
@@ -83,9 +109,11 @@ class DNNLinearCombinedClassifier(Estimator):
             return run_batch(features, labels, mode, params, lambda plan, dev, shard=None: DeepFM(
                 plan.vocab_sizes, n_numeric=len(plan.numeric), numeric="raw", embedding_size=E, hidden_units=hidden,
                 use_linear=bool(lin_all), use_mf=False, use_dnn=bool(dnn_all), dropout=dnn_dropout or 0.0, optimizer=d_opt,
-                linear_optimizer=l_opt if (lin_all and dnn_all) else None, reduction="sum", device=dev, shard=shard)
+                linear_optimizer=l_opt if (lin_all and dnn_all) else None, reduction="sum", device=dev, shard=shard,
+                **_subsets(plan, lin if lin_all else dnn, dnn, lin_num if lin_all else dnn_num, dnn_num))
                 if dnn_all else DeepFM(
                 plan.vocab_sizes, n_numeric=len(plan.numeric), numeric="raw", use_linear=True, use_mf=False, use_dnn=False,
                 optimizer=l_opt, reduction="sum", device=dev, shard=shard))
-        super().__init__(model_fn, model_dir, config, {"categorical_columns": lin or dnn, "numeric_columns": lin_num or dnn_num,
+        super().__init__(model_fn, model_dir, config, {"categorical_columns": list(union.values()),
+                                                       "numeric_columns": list(union_num.values()),
                                                        "tf_model": "dnn_linear_combined"})

@@ -190,6 +190,12 @@ class DeepFM:
     the concat by column name; here numeric columns follow the categorical block, which permutes
     kernel_0's rows only — tf_names maps them).
     shard: parallel.RowShard for N > 1 GPUs (row-sharded tables, data-parallel MLP).
+    field_dims / wide_fields (the canned DNNLinearCombinedClassifier with dnn_feature_columns != linear_feature_columns,
+    linear_deep.py:32-39 / SURVEY A.7; single GPU): per-field embedding dimensions (<= embedding_size; 0 = the column is
+    not in the deep part) and per-field flags "the column has a linear weight".  The fused [R, E] table keeps one E: a
+    narrower column uses the first field_dims[f] of them and its other columns — with the matching rows of kernel_0 — are
+    zero and stay zero under every optimizer here (their gradients are products with those zeros), which is the smaller
+    embedding exactly; the wide part runs on the wide columns' ids only.
     catchup: how the steps a row sat out under TF Adam's dense-equivalent sparse update are replayed when
     the row is next read — "exact": TF's fp32 op sequence, the sweep's bits; "bounded": the same m chain and numerators
     with sqrt(v_j) ~ sqrtf(v_0) beta2^(j/2) and a 1-ulp reciprocal, every variable within 1e-7 relative of the sweep
@@ -198,7 +204,8 @@ class DeepFM:
     def __init__(self, vocab_sizes, n_numeric=0, embedding_size=4, hidden_units=(16, 16),
                  use_linear=True, use_mf=True, use_dnn=True, dropout=0.0, optimizer=None,
                  linear_optimizer=None, reduction="mean", device="cuda", seed=0, shard=None,
-                 gemm="f16x2", numeric="embed", activation="relu", catchup="exact", _kernels=None):
+                 gemm="f16x2", numeric="embed", activation="relu", catchup="exact", field_dims=None, wide_fields=None,
+                 deep_numeric=None, wide_numeric=None, _kernels=None):
         if len(vocab_sizes) + n_numeric == 0:
             raise ValueError("At least 1 feature column of categorical_columns or numeric_columns "
                              "must be specified.")            # deep_fm.py:31-32
@@ -216,6 +223,30 @@ class DeepFM:
             raise ValueError("raw numeric columns belong to the canned estimators, which have no FM term")
         if catchup not in ("exact", "bounded"):
             raise ValueError("catchup must be 'exact' or 'bounded'")
+        self.field_dims = None if field_dims is None else [int(d) for d in field_dims]
+        self.wide_fields = None if (wide_fields is None or all(wide_fields)) else [bool(w) for w in wide_fields]
+        if self.field_dims is not None and all(d == int(embedding_size) for d in self.field_dims):
+            self.field_dims = None
+        if self.field_dims is not None or self.wide_fields is not None:
+            if shard is not None:
+                raise NotImplementedError("per-field embedding dimensions / a wide part on a subset of the columns: single GPU only")
+            if use_mf or (n_numeric and numeric == "embed"):
+                raise ValueError("field_dims / wide_fields belong to the canned estimators (no FM term, raw numeric columns)")
+            for v in (self.field_dims, self.wide_fields):
+                if v is not None and len(v) != len(vocab_sizes):
+                    raise ValueError("field_dims / wide_fields need one entry per categorical field")
+            if self.field_dims is not None and any(d < 0 or d > int(embedding_size) for d in self.field_dims):
+                raise ValueError("field_dims must lie in [0, embedding_size]")
+        flags = lambda v: None if (v is None or all(v)) else [bool(x) for x in v]
+        self.deep_numeric, self.wide_numeric = flags(deep_numeric), flags(wide_numeric)
+        if self.deep_numeric is not None or self.wide_numeric is not None:
+            if shard is not None:
+                raise NotImplementedError("numeric columns that only one of the wide / deep parts reads: single GPU only")
+            if numeric != "raw":
+                raise ValueError("deep_numeric / wide_numeric belong to the canned estimators (raw numeric columns)")
+            for v in (self.deep_numeric, self.wide_numeric):
+                if v is not None and len(v) != int(n_numeric):
+                    raise ValueError("deep_numeric / wide_numeric need one entry per numeric column")
         self.catchup = catchup
         self.k = _kernels if _kernels is not None else HipKernels()
         self.device = torch.device(device)
@@ -250,6 +281,14 @@ class DeepFM:
         dev = self.device
         self.field_off = torch.from_numpy(off[:-1].copy()).to(dev)
         self.R_local = self.R if shard is None else shard.local_rows(self.R)
+        self.wide_idx = self.wide_off_t = None                # the wide part's columns of ids / their field offsets
+        self.Fw = self.F
+        if self.wide_fields is not None:
+            wi = [f for f, on in enumerate(self.wide_fields) if on]
+            self.Fw = len(wi)
+            self.wide_idx = torch.tensor(wi, dtype=torch.int64, device=dev)
+            self.wide_off_t = torch.from_numpy(off[:-1][wi].copy()).to(dev)
+            self.wide_max_vocab = max([self.vocab_sizes[f] for f in wi] or [1])
 
         f32 = dict(dtype=torch.float32, device=dev)
         self.table = torch.zeros(self.R_local, self.E, **f32) if (self.use_emb and self.F) else None
@@ -300,6 +339,15 @@ class DeepFM:
         n_emb = self.F + (0 if self.raw_numeric else self.n_numeric)
         self.D_emb = n_emb * self.E if self.use_emb else 0
         self.D_in = self.D_emb + (self.n_numeric if (self.raw_numeric and self.use_dnn) else 0)
+        # rows of kernel_0 (as stored) that the LOGICAL input layer owns: all of them, or — with per-field embedding
+        # dimensions — the first field_dims[f] of every field's E rows (+ the raw numeric columns the deep part reads)
+        self._k0_rows = None
+        if self.use_dnn and (self.field_dims is not None or self.deep_numeric is not None):
+            rows = [f * self.E + j for f, d in enumerate(self.field_dims or [self.E] * self.F) for j in range(d)]
+            if self.raw_numeric:
+                rows += [self.D_emb + j for j in range(self.n_numeric) if self.deep_numeric is None or self.deep_numeric[j]]
+            self._k0_rows = np.asarray(rows, np.int64)
+            self.D_logical = len(rows)
         self.D = _align(self.D_in, 32) if (self.raw_numeric and self.use_dnn) else self.D_in
         self.layers = []                         # (kernel_off, bias_off, fan_in as stored, fan_out)
         o = 0
@@ -322,6 +370,18 @@ class DeepFM:
         self.dense = torch.zeros(self.P, **f32)
         self.d_grad = torch.zeros(self.P, **f32)
         self.d_s0, self.d_s1 = self._slots(self.dense, self.opt)
+        # slots of the flat buffer that belong to no variable of the model and must stay 0: kernel_0's rows of a raw
+        # numeric column the deep part does not read (their gradient x^T dY is not zero by itself) and the linear
+        # weight of one the wide part does not read.  Their gradients are cleared before the dense apply.
+        frozen = []
+        if self.deep_numeric is not None and self.use_dnn:
+            k_off, _, _, h0 = self.layers[0]
+            for j, on in enumerate(self.deep_numeric):
+                if not on:
+                    frozen += list(range(k_off + (self.D_emb + j) * h0, k_off + (self.D_emb + j + 1) * h0))
+        if self.wide_numeric is not None and self.lin_num_off is not None:
+            frozen += [self.lin_num_off + j for j, on in enumerate(self.wide_numeric) if not on]
+        self._frozen = torch.tensor(frozen, dtype=torch.int64, device=dev) if frozen else None
         if self.lin_opt is not None:
             # wide-part dense variables (linear bias, numeric linear weights) follow linear_optimizer
             self.dl_s0, self.dl_s1 = self._slots(self.dense, self.lin_opt)
@@ -408,17 +468,35 @@ class DeepFM:
         if self.table is not None:
             s = 1.0 / math.sqrt(self.E)
             torch.nn.init.trunc_normal_(self.table, 0.0, s, -2.0 * s, 2.0 * s, generator=g)
+            if self.field_dims is not None:          # a column of dimension d: N(0, 1/sqrt(d)) in its d columns, 0 in the rest
+                off = self.field_off_host
+                for f, d in enumerate(self.field_dims):
+                    blk = self.table[off[f]:off[f + 1]]
+                    if d:
+                        blk[:, :d].mul_(math.sqrt(self.E / d))
+                    blk[:, d:].zero_()
         if self.lin_w is not None and lin_scale:
             self.lin_w.normal_(0.0, lin_scale, generator=g)
+            if self.wide_fields is not None:
+                off = self.field_off_host
+                for f, on in enumerate(self.wide_fields):
+                    if not on:
+                        self.lin_w[off[f]:off[f + 1]].zero_()
         for i, (_, _, fan, h) in enumerate(self.layers):
-            fan_in = self.D_in if i == 0 else fan
+            fan_in = (self.D_logical if self._k0_rows is not None else self.D_in) if i == 0 else fan
             lim = math.sqrt(6.0 / (fan_in + h))
             self.kernel(i).uniform_(-lim, lim, generator=g)
-            if i == 0 and fan_in < fan:
+            if i == 0 and self._k0_rows is not None:
+                keep = torch.zeros(fan, dtype=torch.bool, device=self.device)
+                keep[torch.from_numpy(self._k0_rows).to(self.device)] = True
+                self.kernel(0)[~keep] = 0.0              # rows of the columns a narrower embedding does not have, and of the pad
+            elif i == 0 and fan_in < fan:
                 self.kernel(0)[fan_in:].zero_()            # rows of the zero pad columns
         if self.num_emb_off is not None:
             lim = math.sqrt(6.0 / (self.n_numeric + self.E))
             self._seg(self.dense, self.num_emb_off, (self.n_numeric, self.E)).uniform_(-lim, lim, generator=g)
+        if self._frozen is not None:
+            self.dense.index_fill_(0, self._frozen, 0.0)
 
     def _my_rows(self, a):
         """rows of a [R, ...] array that live on this rank, in local order"""
@@ -428,31 +506,52 @@ class DeepFM:
         """Copy an ``oracle.deepfm.Params`` (numpy) into the device buffers (tests / smoke)."""
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(self.device)
         if self.table is not None:
-            self.table.copy_(t(self._my_rows(np.concatenate(p.emb, 0))))
+            emb = p.emb
+            if self.field_dims is not None:              # narrower columns: zero-padded to E
+                emb = [np.pad(a, ((0, 0), (0, self.E - a.shape[1]))) for a in p.emb]
+            self.table.copy_(t(self._my_rows(np.concatenate(emb, 0))))
         if self.lin_w is not None:
             self.lin_w.copy_(t(self._my_rows(np.concatenate(p.lin_w, 0))))
         for i in range(len(self.layers)):
             k = self.kernel(i)
             k.zero_()
-            k[:p.mlp[i][0].shape[0]].copy_(t(p.mlp[i][0]))
+            if i == 0 and self._k0_rows is not None:
+                k[torch.from_numpy(self._k0_rows).to(self.device)] = t(p.mlp[0][0])
+            else:
+                k[:p.mlp[i][0].shape[0]].copy_(t(p.mlp[i][0]))
             self.bias(i).copy_(t(p.mlp[i][1]))
         self.dense[self.lin_bias_off] = float(p.lin_bias[0])
         if self.num_emb_off is not None:
             self._seg(self.dense, self.num_emb_off, (self.n_numeric, self.E)).copy_(t(p.num_emb))
         if self.lin_num_off is not None:
             self._seg(self.dense, self.lin_num_off, (self.n_numeric,)).copy_(t(p.lin_num))
+        if self._frozen is not None:
+            self.dense.index_fill_(0, self._frozen, 0.0)
 
     def export_numpy(self):
         """Variables as numpy arrays (after bringing Adam rows up to date).  Sparse variables are
         returned per field for a single GPU, as the local shard ("table", "lin_w_local") otherwise."""
         self.finalize_rows()
         rows = lambda i: self.D_in if i == 0 else self.layers[i][2]          # without the zero pad rows
-        out = {"mlp": [(self.kernel(i)[:rows(i)].cpu().numpy(), self.bias(i).cpu().numpy()) for i in range(len(self.layers))],
+
+        def kern(i):
+            if i == 0 and self._k0_rows is not None:                         # the logical input layer's rows only
+                return self.kernel(0)[torch.from_numpy(self._k0_rows).to(self.device)].cpu().numpy()
+            return self.kernel(i)[:rows(i)].cpu().numpy()
+        out = {"mlp": [(kern(i), self.bias(i).cpu().numpy()) for i in range(len(self.layers))],
                "lin_bias": self.dense[self.lin_bias_off:self.lin_bias_off + 1].cpu().numpy()}
         if self.shard is None:
             off = self.field_off_host
             sp = lambda a: [a[off[f]:off[f + 1]].cpu().numpy() for f in range(self.F)] if a is not None else None
             out.update(emb=sp(self.table), lin_w=sp(self.lin_w))
+            if self.wide_fields is not None and out["lin_w"] is not None:
+                # a column outside linear_feature_columns owns no linear weight: its slots of lin_w are never read (the
+                # sparse apply does write them — one kernel serves every row of the batch — and nothing looks)
+                out["lin_w"] = [a if on else None for a, on in zip(out["lin_w"], self.wide_fields)]
+            if self.field_dims is not None and out["emb"] is not None:
+                out["emb_padding_max_abs"] = max([float(np.abs(a[:, d:]).max()) if a[:, d:].size else 0.0
+                                                  for a, d in zip(out["emb"], self.field_dims)])
+                out["emb"] = [a[:, :d] for a, d in zip(out["emb"], self.field_dims)]
         else:
             out.update(table=None if self.table is None else self.table.cpu().numpy(),
                        lin_w_local=None if self.lin_w is None else self.lin_w.cpu().numpy())
@@ -593,6 +692,13 @@ class DeepFM:
         c = {"B": B}
         table, lin_w, field_off, rid = src if src is not None else (self.table, self.lin_w, self.field_off, ids)
         ls = self.ls if src is None else 1              # (rows received from their owners: plain arrays)
+        # the wide part's view of the batch: all columns, or (wide_fields) the wide columns' ids and field offsets
+        w_off, w_ids, Fw = field_off, rid, self.F
+        if self.wide_idx is not None:
+            w_ids = self._buf("wide_ids", (B, self.Fw), rid.dtype)
+            torch.index_select(rid, 1, self.wide_idx, out=w_ids)             # (a column copy: torch as plumbing)
+            w_off, Fw = self.wide_off_t, self.Fw
+            c["wide_ids"] = w_ids
         concat = sumv = fm = None
         ld = self.D
         gathered = self.gather_mlp
@@ -633,17 +739,25 @@ class DeepFM:
                 side = self._ws["side_stream"] = torch.cuda.Stream(device=self.device)
             side.wait_stream(torch.cuda.current_stream())        # the catch-up of these rows ran on the main stream
             with torch.cuda.stream(side):
-                k.tagged("mi_embed_fm_linear_fwd", "/wide")(None, lin_w, field_off, rid, B, F, self.E, None, 0, None,
+                k.tagged("mi_embed_fm_linear_fwd", "/wide")(None, lin_w, w_off, w_ids, B, Fw, self.E, None, 0, None,
                                                             None, lin, None, ls)
             c["lin_join"] = side
         elif pl_gather:
             k.mi_embed_fm_planes_fwd(table, field_off, rid, B, F, self.E, sumv, fm, self._planes("x0p", B, ld), rows_amax)
             if lin is not None:
-                k.tagged("mi_embed_fm_linear_fwd", "/wide")(None, lin_w, field_off, rid, B, F, self.E, None, 0, None, None, lin, None, ls)
+                k.tagged("mi_embed_fm_linear_fwd", "/wide")(None, lin_w, w_off, w_ids, B, Fw, self.E, None, 0, None, None, lin, None, ls)
         elif concat is not None or sumv is not None or lin is not None or rows_amax is not None:
             emb_on = self.use_emb
-            k.mi_embed_fm_linear_fwd(table if emb_on else None, lin_w if self.use_linear else None, field_off,
-                                     rid, B, F, self.E, concat if emb_on else None, ld, sumv, fm, lin, rows_amax, ls)
+            one_call = self.wide_idx is None                         # (a wide part on other columns: a call of its own)
+            if emb_on or one_call:
+                k.mi_embed_fm_linear_fwd(table if emb_on else None, lin_w if (self.use_linear and one_call) else None, field_off,
+                                         rid, B, F, self.E, concat if emb_on else None, ld, sumv, fm, lin if one_call else None,
+                                         rows_amax, ls)
+            if not one_call and lin is not None:
+                if Fw:
+                    k.mi_embed_fm_linear_fwd(None, lin_w, w_off, w_ids, B, Fw, self.E, None, 0, None, None, lin, None, ls)
+                else:
+                    lin.zero_()
         if self.n_numeric:
             wn = self._seg(self.dense, self.lin_num_off, (self.n_numeric,)) if self.use_linear else None
             if self.raw_numeric:
@@ -1028,6 +1142,8 @@ class DeepFM:
         lr_t = self.sched.lr_t(step) if self.sched else 0.0
         hp = self.opt.hparams(lr_t)
         lin_lr_t = self.lin_sched.lr_t(step) if self.lin_sched else 0.0
+        if self._frozen is not None:
+            self.d_grad.index_fill_(0, self._frozen, 0.0)
         if self.lin_opt is None:
             if self.P:
                 k.mi_dense_apply(self.dense, self.d_s0, self.d_s1, self.d_grad, self.P, hp)
@@ -1206,7 +1322,8 @@ class DeepFM:
                 "n_numeric": self.n_numeric, "numeric": self.numeric, "P": self.P, "R": self.R, "world": world, "rank": rank,
                 "use": [self.use_linear, self.use_mf, self.use_dnn], "optimizer": self.opt.name,
                 "linear_optimizer": None if self.lin_opt is None else self.lin_opt.name,
-                "lin_record_stride": self.ls, "segments": seg}
+                "lin_record_stride": self.ls, "segments": seg, "field_dims": self.field_dims, "wide_fields": self.wide_fields,
+                "deep_numeric": self.deep_numeric, "wide_numeric": self.wide_numeric}
 
     def state_dict(self):
         """Everything needed to resume (reference: Estimator checkpoints, conf_utils.py:6-10)."""

@@ -51,9 +51,12 @@ def kernel0_rows(column_names, numeric_names, E):
     """Canned estimators with raw numeric columns: TF's input_layer orders the concat by column name over
     ``<categorical>_embedding`` (E columns each) and the numeric keys (1 column each); the engine keeps
     the numeric columns after the categorical block.  Returns perm with
-    tf_kernel0[i] == engine_kernel0[perm[i]]."""
-    items = [(c + "_embedding", f * E, E) for f, c in enumerate(column_names)]
-    items += [(n, len(column_names) * E + j, 1) for j, n in enumerate(numeric_names)]
+    tf_kernel0[i] == engine_kernel0[perm[i]].  E: one width, or a list of per-column widths (0 = the column is not in
+    dnn_feature_columns); numeric_names: the numeric columns the deep part reads."""
+    dims = list(E) if isinstance(E, (list, tuple)) else [E] * len(column_names)
+    starts = np.concatenate([[0], np.cumsum(dims)]).astype(int)
+    items = [(c + "_embedding", int(starts[f]), dims[f]) for f, c in enumerate(column_names) if dims[f]]
+    items += [(n, int(starts[-1]) + j, 1) for j, n in enumerate(numeric_names)]
     perm = []
     for _, start, width in sorted(items):
         perm.extend(range(start, start + width))
@@ -71,28 +74,42 @@ def _names_for(m, model, column_names, numeric_names=None, sharded_ok=False):
                           numeric_names if m.raw_numeric else None)
 
 
+def _subsets(m, numeric_names):
+    """(per-column embedding widths, names of the numeric columns the deep part reads, flags of the numeric columns the
+    wide part reads) — the whole lists unless the engine was built with column subsets (engine.DeepFM field_dims,
+    wide_fields, deep_numeric, wide_numeric)."""
+    dims = getattr(m, "field_dims", None) or [m.E] * m.F
+    names = list(numeric_names or [])
+    dn, wn = getattr(m, "deep_numeric", None), getattr(m, "wide_numeric", None)
+    deep_names = [n for j, n in enumerate(names) if dn is None or dn[j]]
+    wide_num = [True] * len(names) if wn is None else list(wn)
+    return dims, deep_names, wide_num
+
+
 def export_variables(m, column_names, model="deep_fm", numeric_names=None):
     """Engine -> {TF variable name: ndarray} with TF's shapes (linear weights [vocab, 1], bias [1],
-    numeric embeddings [1, n_d, E] as deep_fm.py:64 creates them)."""
+    numeric embeddings [1, n_d, E] as deep_fm.py:64 creates them).  A column that only one of the wide / deep parts
+    reads has only that part's variable, an embedding column its own dimension."""
     nm = _names_for(m, model, column_names, numeric_names)
+    dims, deep_names, wide_num = _subsets(m, numeric_names)
     g = m.export_numpy()
     out = {}
     if g.get("emb") is not None:
-        out.update({n: a for n, a in zip(nm["emb"], g["emb"])})
+        out.update({n: a for n, a in zip(nm["emb"], g["emb"]) if a.shape[1]})
     if g.get("lin_w") is not None:
-        out.update({n: a.reshape(-1, 1) for n, a in zip(nm["lin_w"], g["lin_w"])})
+        out.update({n: a.reshape(-1, 1) for n, a in zip(nm["lin_w"], g["lin_w"]) if a is not None})
         out[nm["lin_bias"]] = g["lin_bias"].reshape(1)
     if m.use_dnn:
         for i, ((kn, bn), (k, b)) in enumerate(zip(nm["mlp"], g["mlp"])):
             if i == 0 and m.raw_numeric:
-                k = k[kernel0_rows(column_names, numeric_names, m.E)]
+                k = k[kernel0_rows(column_names, deep_names, dims)]
             out[kn], out[bn] = k, b
     if m.n_numeric:
         if nm["num_emb"] is not None:
             out[nm["num_emb"]] = g["num_emb"].reshape(1, m.n_numeric, m.E)
         if "lin_num" in g:
             if isinstance(nm["lin_num"], list):
-                out.update({n: g["lin_num"][j].reshape(1, 1) for j, n in enumerate(nm["lin_num"])})
+                out.update({n: g["lin_num"][j].reshape(1, 1) for j, n in enumerate(nm["lin_num"]) if wide_num[j]})
             else:
                 out[nm["lin_num"]] = g["lin_num"].reshape(-1, 1)
     return out
@@ -104,6 +121,8 @@ def import_variables(m, arrays, column_names, model="deep_fm", strict=True, nume
     returns the list of names that were loaded.  Optimizer slots and Adam row stamps are reset."""
     import torch
     nm = _names_for(m, model, column_names, numeric_names, sharded_ok=True)
+    dims, deep_names, wide_num = _subsets(m, numeric_names)
+    wide_f = getattr(m, "wide_fields", None)
     loaded = []
     off = m.field_off_host
     rank, world = (0, 1) if m.shard is None else (m.shard.rank, m.shard.world)
@@ -131,11 +150,13 @@ def import_variables(m, arrays, column_names, model="deep_fm", strict=True, nume
 
     for f in range(m.F):
         v = int(off[f + 1] - off[f])
-        if m.table is not None:
-            a = get(nm["emb"][f], (v, m.E))
+        if m.table is not None and dims[f]:
+            a = get(nm["emb"][f], (v, dims[f]))
             if a is not None:
+                if dims[f] < m.E:                                    # a narrower column: its first dims[f] columns
+                    a = torch.nn.functional.pad(a, (0, m.E - dims[f]))
                 put_rows(m.table, f, a)
-        if m.lin_w is not None:
+        if m.lin_w is not None and (wide_f is None or wide_f[f]):
             a = get(nm["lin_w"][f], (v,))
             if a is not None:
                 put_rows(m.lin_w, f, a)
@@ -146,13 +167,17 @@ def import_variables(m, arrays, column_names, model="deep_fm", strict=True, nume
     if m.use_dnn:
         for i, (kn, bn) in enumerate(nm["mlp"]):
             _, _, fan, h = m.layers[i]
-            rows = m.D_in if i == 0 else fan
+            k0 = getattr(m, "_k0_rows", None) if i == 0 else None   # (the logical input layer's rows of the stored kernel)
+            rows = len(k0) if k0 is not None else (m.D_in if i == 0 else fan)
             a, b = get(kn, (rows, h)), get(bn, (h,))
             if a is not None:
                 if i == 0 and m.raw_numeric:
-                    inv = torch.from_numpy(np.argsort(kernel0_rows(column_names, numeric_names, m.E))).to(m.device)
+                    inv = torch.from_numpy(np.argsort(kernel0_rows(column_names, deep_names, dims))).to(m.device)
                     a = a[inv]
-                m.kernel(i)[:rows].copy_(a)
+                if k0 is not None:
+                    m.kernel(0)[torch.from_numpy(k0).to(m.device)] = a
+                else:
+                    m.kernel(i)[:rows].copy_(a)
             if b is not None:
                 m.bias(i).copy_(b)
     if m.n_numeric:
@@ -164,7 +189,7 @@ def import_variables(m, arrays, column_names, model="deep_fm", strict=True, nume
             seg = m._seg(m.dense, m.lin_num_off, (m.n_numeric,))
             if isinstance(nm["lin_num"], list):
                 for j, n in enumerate(nm["lin_num"]):
-                    a = get(n, (1,))
+                    a = get(n, (1,)) if wide_num[j] else None
                     if a is not None:
                         seg[j:j + 1].copy_(a)
             else:

@@ -50,8 +50,9 @@ def _compare(m, p, atol):
     g = m.export_numpy()
     for f in range(len(p.emb)):
         if g.get("emb") is not None:
-            assert np.max(np.abs(g["emb"][f] - p.emb[f])) < atol, ("emb", f)
-        if g.get("lin_w") is not None:
+            assert g["emb"][f].shape == p.emb[f].shape
+            assert np.max(np.abs(g["emb"][f] - p.emb[f]), initial=0.0) < atol, ("emb", f)
+        if g.get("lin_w") is not None and g["lin_w"][f] is not None:       # (None: the column has no linear weight)
             assert np.max(np.abs(g["lin_w"][f] - p.lin_w[f])) < atol, ("lin_w", f)
     for i, (k, b) in enumerate(g["mlp"]):
         assert k.shape == p.mlp[i][0].shape
@@ -66,15 +67,19 @@ def _compare(m, p, atol):
 
 
 def _run(device, vocab, E, hidden, B, nn, numeric, flags, hp, lin_hp, dropout=0.0, steps=3, seed=21, atol=2e-5,
-         reduction="sum", activation="relu"):
+         reduction="sum", activation="relu", field_dims=None, wide_fields=None, deep_numeric=None, wide_numeric=None):
     ul, um, ud = flags
     rng0 = np.random.default_rng(seed)
-    p = O.init_params(rng0, vocab, E, hidden, n_numeric=nn, dtype=np.float32, lin_scale=0.05, use_dnn=ud, numeric=numeric)
+    p = O.init_params(rng0, vocab, E, hidden, n_numeric=nn, dtype=np.float32, lin_scale=0.05, use_dnn=ud, numeric=numeric,
+                      field_dims=field_dims, wide_fields=wide_fields, deep_numeric=deep_numeric)
+    if wide_numeric is not None:
+        p.lin_num[~np.asarray(wide_numeric, bool)] = 0
+    subsets = dict(field_dims=field_dims, wide_fields=wide_fields, deep_numeric=deep_numeric, wide_numeric=wide_numeric)
     p.lin_bias[:] = 0.1
     for _, b in p.mlp:
         b[:] = (rng0.standard_normal(b.shape) * 0.05).astype(np.float32)
     kw = dict(n_numeric=nn, numeric=numeric, embedding_size=E, hidden_units=hidden, use_linear=ul, use_mf=um, use_dnn=ud,
-              dropout=dropout, reduction=reduction, optimizer=_spec(hp.name, hp.lr), seed=3, activation=activation)
+              dropout=dropout, reduction=reduction, optimizer=_spec(hp.name, hp.lr), seed=3, activation=activation, **subsets)
     if lin_hp is not None:
         kw["linear_optimizer"] = _spec(lin_hp.name, lin_hp.lr)
     m = _engine(device, vocab, **kw)
@@ -90,7 +95,8 @@ def _run(device, vocab, E, hidden, B, nn, numeric, flags, hp, lin_hp, dropout=0.
         y = (rng.random(B) < 0.3).astype(np.uint8)
         masks = [dropout_mask(m._layer_seed(i), B, h, keep) for i, h in enumerate(hidden)] if (dropout and ud) else None
         lo, logit_o = O.train_step(p, st, ids, y, x, ul, um, ud, reduction, masks, numeric=numeric, keep_prob=keep,
-                                   activation=activation)
+                                   activation=activation, wide_fields=wide_fields, deep_numeric=deep_numeric,
+                                   wide_numeric=wide_numeric)
         lg, logit_g = m.train_step(_t(ids, device), _t(y, device), _t(x, device))
         assert abs(lg.item() - float(lo)) <= 2e-5 * abs(float(lo)) + 1e-6, step
         lo_a, lg_a = logit_o, logit_g.cpu().numpy()
@@ -216,6 +222,62 @@ def test_canned_estimators_accept_numeric_columns(device, monkeypatch):
     assert torch.equal(est2._engine().dense, eng.dense) and torch.equal(est2._engine().table, eng.table)
 
 
+def test_combined_classifier_with_independent_column_lists(device, monkeypatch):
+    """DNNLinearCombinedClassifier whose two column lists differ — a crossed-style column only the wide
+    part has, an embedding column only the deep part has, embedding dimensions 6 and 3 (no multiples of 4), a numeric
+    column per part — through the Estimator surface: the engine gets the union with per-part subsets, a TF-named export
+    holds exactly the variables TF would create (shapes included) and round-trips into a fresh estimator."""
+    if device == "cpu":
+        from mi355x_rec import engine
+        from tests.cpu_kernels import NumpyKernels
+        monkeypatch.setattr(engine, "HipKernels", NumpyKernels)
+    from mi355x_rec import feature_column as fc, tf_names
+    from mi355x_rec.canned import DNNLinearCombinedClassifier
+    from mi355x_rec.estimator import RunConfig
+    a, b, c = (fc.categorical_column_with_identity("a", 5), fc.categorical_column_with_identity("b", 7),
+               fc.categorical_column_with_hash_bucket("c", 11))
+    age, inc = fc.numeric_column("age"), fc.numeric_column("inc")
+    make = lambda: DNNLinearCombinedClassifier(model_dir=None, linear_feature_columns=[a, c, age],
+                                               dnn_feature_columns=[fc.embedding_column(a, 6), fc.embedding_column(b, 3), inc],
+                                               dnn_hidden_units=[8], dnn_dropout=0.1, config=RunConfig(device=device))
+    est = make()
+    rng = np.random.default_rng(2)
+    B = 16
+    feats = {"a": rng.integers(0, 5, B), "b": rng.integers(0, 7, B), "c": ["%05d" % z for z in rng.integers(0, 99999, B)],
+             "age": rng.random(B).astype(np.float32), "inc": rng.random(B).astype(np.float32)}
+    labels = rng.random(B) < 0.4
+    for _ in range(3):
+        spec = est.model_fn(feats, labels, "train", est.params)
+    assert np.isfinite(float(spec.loss))
+    eng = est._engine()
+    plan = est.params["_store"]["plan"]
+    names, nnames = [x.name for x in plan.categorical], [x.name for x in plan.numeric]
+    assert names == ["a", "b", "c"] and nnames == ["age", "inc"]
+    assert eng.E == 8 and eng.field_dims == [6, 3, 0] and eng.wide_fields == [True, False, True]
+    assert eng.deep_numeric == [False, True] and eng.wide_numeric == [True, False]
+    dump = tf_names.export_variables(eng, names, "dnn_linear_combined", nnames)
+    pre = "dnn/input_from_feature_columns/input_layer/"
+    assert sorted(dump) == sorted([pre + "a_embedding/embedding_weights", pre + "b_embedding/embedding_weights",
+                                   "linear/linear_model/a/weights", "linear/linear_model/c/weights",
+                                   "linear/linear_model/age/weights", "linear/linear_model/bias_weights",
+                                   "dnn/hiddenlayer_0/kernel", "dnn/hiddenlayer_0/bias", "dnn/logits/kernel", "dnn/logits/bias"])
+    assert dump[pre + "a_embedding/embedding_weights"].shape == (5, 6) and dump[pre + "b_embedding/embedding_weights"].shape == (7, 3)
+    assert dump["dnn/hiddenlayer_0/kernel"].shape == (6 + 3 + 1, 8)
+    # TF's input_layer order: a_embedding (6), b_embedding (3), inc; the engine's stored rows: a at 0..5, b at 8..10, inc at 25
+    ek = eng.kernel(0).cpu().numpy()
+    k0 = dump["dnn/hiddenlayer_0/kernel"]
+    assert np.array_equal(k0[:6], ek[0:6]) and np.array_equal(k0[6:9], ek[8:11]) and np.array_equal(k0[9], ek[3 * 8 + 1])
+    assert float(np.abs(ek[6:8]).max()) == 0.0 and float(np.abs(ek[11:25]).max()) == 0.0     # rows of no variable
+    assert float(np.abs(dump["linear/linear_model/c/weights"]).max()) > 0.0                   # (Ftrl moved the wide-only column)
+    est2 = make()
+    est2.model_fn(feats, labels, "_build", est2.params)
+    e2 = est2._engine()
+    tf_names.import_variables(e2, dump, names, "dnn_linear_combined", numeric_names=nnames)
+    p1 = est.model_fn(feats, None, "infer", est.params).predictions["logits"]
+    p2 = est2.model_fn(feats, None, "infer", est2.params).predictions["logits"]
+    assert torch.equal(torch.as_tensor(p1), torch.as_tensor(p2))
+
+
 def test_out_of_vocabulary_id_without_oov_bucket_is_refused():
     """a vocabulary column with num_oov_buckets=0 emits default_value=-1 for unknown values; the
     kernels index rows unchecked, so the host refuses such ids before they reach the device."""
@@ -245,6 +307,35 @@ def test_more_hidden_layers_than_one_weight_split_launch_takes(device):
                 seed=35, atol=4e-6, reduction="mean")
     if device == "cuda":
         assert m.planes and len(m._ws["wjobs_train"]) == 2
+
+
+def test_wide_and_deep_parts_on_different_columns_with_per_column_dimensions(device):
+    """VERDICT r2 (8), the last refusals: DNNLinearCombinedClassifier(linear_feature_columns != dnn_feature_columns) with
+    embedding columns of different dimensions (linear_deep.py:32-39 passes two independent lists).  Six
+    categorical columns: dimensions 8 / 4 / 8 / 0 (wide only) / 4 / 8, of which columns 1 and 4 are deep only; three
+    numeric columns: one in both parts, one wide only, one deep only.  Ftrl on the linear scope, Adagrad on the dnn
+    scope, dropout; 4 steps against the oracle, which holds the ragged variables as TF does."""
+    vocab = [9, 13, 5, 6, 7, 11]
+    dims = [8, 4, 8, 0, 4, 8]
+    wide = [True, False, True, True, False, True]
+    m, p = _run(device, vocab, 8, [16, 8], 64, 3, "raw", (True, False, True), ADAGRAD, _ftrl(4 + 2), dropout=0.1, steps=4,
+                seed=41, field_dims=dims, wide_fields=wide, deep_numeric=[True, False, True], wide_numeric=[True, True, False])
+    g = m.export_numpy()
+    assert [a.shape[1] for a in g["emb"]] == dims and g["emb_padding_max_abs"] == 0.0
+    assert g["mlp"][0][0].shape == (sum(dims) + 2, 16)
+    assert [a is None for a in g["lin_w"]] == [not w for w in wide]
+    k0 = m.kernel(0).cpu().numpy()
+    logical = np.zeros(k0.shape[0], bool); logical[m._k0_rows] = True
+    assert float(np.abs(k0[~logical]).max()) == 0.0           # rows of no variable stayed zero through the training
+    assert float(g["lin_num"][2]) == 0.0
+
+
+def test_wide_and_deep_column_subsets_same_adam(device):
+    """... and with ONE Adam for everything (a DeepFM-less model_fn of the same shape, lazily replayed rows): the wide
+    part's kernel runs on its own columns' ids, the catch-up and the apply on every row of the batch."""
+    vocab = [9, 13, 5, 6]
+    _run(device, vocab, 8, [16], 48, 0, "raw", (True, False, True), OO.Hyper("Adam", 0.001), None, steps=5, seed=43, atol=4e-6,
+         field_dims=[8, 4, 0, 8], wide_fields=[False, True, True, True], reduction="mean")
 
 
 def test_adam_schedule_extends_past_a_restored_step():
