@@ -47,7 +47,7 @@ enum mi_status {
 };
 
 /* ---- library ---------------------------------------------------------------------------- */
-int32_t mi_abi_version(void);       /* bumps when a signature changes (currently 16) */
+int32_t mi_abi_version(void);       /* bumps when a signature changes (currently 17) */
 const char* mi_last_error(void);    /* thread-local, never NULL */
 const char* mi_build_info(void);    /* "gfx950 hipcc <ver>" */
 
@@ -179,11 +179,14 @@ int32_t mi_embed_fm_linear_bwd(const float* d_concat, int64_t ld_dconcat, const 
  *   d_concat[b - b0, f*E:(f+1)*E] + d_logit_fm[b - b0] * (sumv[b - b0,:] - rows[u,:])
  * and out_lin[u] = sum of d_logit_lin[b - b0]; rows [*,E] = the exchange's receive buffer (slot u), the
  * per-example arrays belong to examples b0.. (one chunk).  Segments longer than 48 entries are summed by a
- * workgroup in fixed slices, like mi_sparse_apply's. */
+ * workgroup in fixed slices, like mi_sparse_apply's.
+ * out_row0 (0 <= out_row0 <= u_begin): the request that row 0 of out_rows / out_lin holds — request u is written at
+ * row u - out_row0.  0: the out buffers are the whole send buffer; u_begin: they start at this range (a rank's
+ * requests to ITSELF are summed straight into the buffer its own sparse apply reads, no exchange in between). */
 int32_t mi_entry_grads_segsum(const float* rows, const int32_t* seg_start, const int32_t* sorted_entry, int64_t u_begin,
                               int64_t u_count, const float* d_concat, int64_t ld_dconcat, const float* sumv,
                               const float* d_logit_fm, const float* d_logit_lin, int64_t b0, int32_t F, int32_t E,
-                              float* out_rows, float* out_lin, mi_stream_t stream);
+                              float* out_rows, float* out_lin, int64_t out_row0, mi_stream_t stream);
 
 /* (a4) backward of the numeric embedding: dV[j,e] = sum_b x[b,j]*g[b,j,e] with
  * g = d_concat + d_logit_fm*(sumv - concat);  dw_num[j] = sum_b d_logit_lin[b]*x[b,j].
@@ -226,8 +229,12 @@ int32_t mi_sort_unique_fields(const int32_t* ids, const int64_t* field_off, int6
 /* Routing helpers of the row-sharded multi-GPU path (row r lives on rank r % world as local row
  * r / world; the reference's own multi-worker mode is TF's parameter-server placement of whole
  * variables, distributed.md:58-82 — see DESIGN.md "Multi-GPU").
- *   mi_shard_keys     : keys[i] = ((i / entries_per_chunk) * world + rows[i] % world) * rows_per_rank + rows[i] / world
+ *   mi_shard_keys     : keys[i] = ((i / entries_per_chunk) * world + pos(rows[i] % world)) * rows_per_rank + rows[i] / world
  *                       (chunk-major request key of a pipelined step; entries_per_chunk == 0: one chunk).
+ *                       pos: the owner's place in the send order — the rank itself (self_rank = -1), or, with
+ *                       self_rank >= 0, the other ranks in rank order and the asking rank LAST (o -> o below
+ *                       self_rank, o - 1 above, world - 1 for self_rank): a rank's requests to itself then end every
+ *                       chunk's run, outside the part an all-to-all with a zero self split ships.
  *                       mi_sort_unique_rows of the keys orders the entries by (chunk, owner, row); its unique
  *                       keys are the DISTINCT rows each chunk needs from each owner — what travels.
  *   mi_route_requests : per distinct request u < *num_uniq: send_rows[u] = owner-local row;
@@ -237,7 +244,7 @@ int32_t mi_sort_unique_fields(const int32_t* ids, const int64_t* field_off, int6
  *                       slot in the exchange buffer)
  *   mi_gather_u32     : out[i] = src[idx[i]] for 4-byte elements (int32 ids or f32 values) */
 int32_t mi_shard_keys(const int32_t* rows, int64_t n, int32_t world, int64_t entries_per_chunk, int64_t rows_per_rank,
-                      int32_t* keys, mi_stream_t stream);
+                      int32_t self_rank, int32_t* keys, mi_stream_t stream);
 int32_t mi_route_requests(const int32_t* uniq_keys, const int32_t* num_uniq, int64_t n_max, int64_t rows_per_rank,
                           int32_t n_groups, int32_t* send_rows, int32_t* counts, mi_stream_t stream);
 int32_t mi_segment_slots(const int32_t* seg_start, const int32_t* sorted_entry, const int32_t* num_uniq, int64_t n,

@@ -856,9 +856,11 @@ int32_t mi_sparse_apply_fused(float* table, float* t_slot0, float* t_slot1, floa
 int32_t mi_entry_grads_segsum(const float* rows, const int32_t* seg_start, const int32_t* sorted_entry, int64_t u_begin,
                               int64_t u_count, const float* d_concat, int64_t ld_dconcat, const float* sumv,
                               const float* d_logit_fm, const float* d_logit_lin, int64_t b0, int32_t F, int32_t E,
-                              float* out_rows, float* out_lin, mi_stream_t stream) {
+                              float* out_rows, float* out_lin, int64_t out_row0, mi_stream_t stream) {
   MI_REQUIRE(u_begin >= 0 && u_count >= 0 && u_begin + u_count <= INT32_MAX && F > 0 && b0 >= 0, "entry_grads_segsum: u_begin=%lld u_count=%lld",
              (long long)u_begin, (long long)u_count);
+  MI_REQUIRE(out_row0 >= 0 && out_row0 <= u_begin, "entry_grads_segsum: out_row0=%lld must lie in [0, u_begin=%lld]", (long long)out_row0,
+             (long long)u_begin);
   if (u_count == 0) return MI_OK;
   MI_REQUIRE(seg_start && sorted_entry && (out_rows || out_lin), "entry_grads_segsum: null buffer");
   MI_REQUIRE(!out_rows || (E >= 4 && E <= 256 && (E & 3) == 0 && mi::aligned16(out_rows) && (d_concat || d_logit_fm)),
@@ -874,9 +876,14 @@ int32_t mi_entry_grads_segsum(const float* rows, const int32_t* seg_start, const
   ApplyArgs a{};
   a.table = out_rows ? const_cast<float*>(rows) : nullptr;     // read only: w of d fm / d v = sumv - w
   if (out_rows && !rows) a.table = out_rows;                    // (no FM term: w is never read; any valid pointer turns the row part on)
-  a.lin_w = out_lin ? out_lin : nullptr;                        // (non-null turns the linear part on; never read)
+  a.lin_w = out_lin;                                            // (non-null turns the linear part on; never read)
   a.seg_start = seg_start; a.sorted_entry = sorted_entry;
-  a.E = E; a.out_rows = out_rows; a.out_lin = out_lin; a.u_begin = (int)u_begin; a.u_count = (int)u_count; a.ls = 1;
+  // request u is written at row u - out_row0 of the out buffers (the kernels index by u: the bases are moved back; only
+  // u >= u_begin >= out_row0 is ever touched)
+  a.E = E;
+  a.out_rows = out_rows ? reinterpret_cast<float*>(reinterpret_cast<uintptr_t>(out_rows) - static_cast<uintptr_t>(out_row0) * E * sizeof(float)) : nullptr;
+  a.out_lin = out_lin ? reinterpret_cast<float*>(reinterpret_cast<uintptr_t>(out_lin) - static_cast<uintptr_t>(out_row0) * sizeof(float)) : nullptr;
+  a.u_begin = (int)u_begin; a.u_count = (int)u_count; a.ls = 1;
   const Hp h{};
   MI_DISPATCH_LPR(lpr, (sparse_apply_k<L, true, true><<<dim3((unsigned)blocks), dim3(kBlock), 0, mi::as_stream(stream)>>>(a, h, fg)));
   MI_CHECK_LAUNCH("entry_grads_segsum");

@@ -576,14 +576,19 @@ namespace {
 // request key of entry i for row r: ((chunk * world + owner) * rows_per_rank + local row); sorting by it
 // (mi_sort_unique_rows) orders the entries by (chunk, owner, row) and its unique keys are the DISTINCT rows
 // a chunk needs from an owner: a row asked for by many entries of a batch crosses the link once.
+// self_rank >= 0: the owners are numbered with the asking rank itself LAST (owner o -> o for o < self, o - 1 for
+// o > self, world - 1 for self): a rank's requests to itself then sit at the end of every chunk's run — outside the
+// part of the buffers the all-to-all ships, which skips the self piece (its split size is 0).
 __global__ __launch_bounds__(kBlock) void shard_keys_k(const int32_t* __restrict__ rows, int64_t n, int world,
-                                                       int64_t entries_per_chunk, int64_t rows_per_rank,
+                                                       int64_t entries_per_chunk, int64_t rows_per_rank, int self_rank,
                                                        int32_t* __restrict__ keys) {
   const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
   if (i >= n) return;
   const int32_t r = rows[i];
   const int64_t chunk = entries_per_chunk > 0 ? i / entries_per_chunk : 0;
-  keys[i] = static_cast<int32_t>((chunk * world + r % world) * rows_per_rank + r / world);
+  int o = r % world;
+  if (self_rank >= 0) o = o == self_rank ? world - 1 : (o > self_rank ? o - 1 : o);
+  keys[i] = static_cast<int32_t>((chunk * world + o) * rows_per_rank + r / world);
 }
 
 // per distinct request u: the owner-local row to ask for, and the request counts per (chunk, owner) group.
@@ -639,15 +644,16 @@ __global__ __launch_bounds__(kBlock) void gather_u32_k(const uint32_t* __restric
 extern "C" {
 
 int32_t mi_shard_keys(const int32_t* rows, int64_t n, int32_t world, int64_t entries_per_chunk, int64_t rows_per_rank,
-                      int32_t* keys, mi_stream_t stream) {
-  MI_REQUIRE(n >= 0 && world > 0 && entries_per_chunk >= 0 && rows_per_rank > 0, "shard_keys: n=%lld world=%d", (long long)n, world);
+                      int32_t self_rank, int32_t* keys, mi_stream_t stream) {
+  MI_REQUIRE(n >= 0 && world > 0 && entries_per_chunk >= 0 && rows_per_rank > 0 && self_rank >= -1 && self_rank < world,
+             "shard_keys: n=%lld world=%d self_rank=%d", (long long)n, world, self_rank);
   if (n == 0) return MI_OK;
   MI_REQUIRE(rows && keys, "shard_keys: null buffer");
   const int64_t chunks = entries_per_chunk > 0 ? mi::ceil_div(n, entries_per_chunk) : 1;
   MI_REQUIRE(chunks * world * rows_per_rank <= INT32_MAX, "shard_keys: %lld chunks x %d ranks x %lld rows per rank does not fit an int32 key",
              (long long)chunks, world, (long long)rows_per_rank);
   shard_keys_k<<<dim3((unsigned)mi::ceil_div(n, kBlock)), dim3(kBlock), 0, mi::as_stream(stream)>>>(rows, n, world, entries_per_chunk,
-                                                                                                   rows_per_rank, keys);
+                                                                                                   rows_per_rank, self_rank, keys);
   MI_CHECK_LAUNCH("shard_keys");
   return MI_OK;
 }

@@ -16,7 +16,7 @@ import torch  # noqa: F401  (loads the HIP runtime this library must share)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmi355x_rec.so")
 
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 
 class MiError(RuntimeError):
@@ -73,7 +73,7 @@ SIGNATURES = {
     "mi_numeric_raw_bwd_workspace_bytes": (_sz, [_i64, _i32]),
     "mi_numeric_raw_bwd": (_i32, [_p, _p, _i64, _i32, _p, _p, _sz, _p]),
     "mi_embed_fm_linear_bwd": (_i32, [_p, _i64, _p, _i64, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p, _p, _p]),
-    "mi_entry_grads_segsum": (_i32, [_p, _p, _p, _i64, _i64, _p, _i64, _p, _p, _p, _i64, _i32, _i32, _p, _p, _p]),
+    "mi_entry_grads_segsum": (_i32, [_p, _p, _p, _i64, _i64, _p, _i64, _p, _p, _p, _i64, _i32, _i32, _p, _p, _i64, _p]),
     "mi_numeric_embed_bwd_workspace_bytes": (_sz, [_i64, _i32, _i32]),
     "mi_numeric_embed_bwd": (_i32, [_p, _p, _i64, _p, _i64, _i64, _p, _p, _p, _i64, _i32, _i32, _p,
                                     _p, _p, _sz, _p]),
@@ -82,7 +82,7 @@ SIGNATURES = {
     "mi_sort_unique_fields": (_i32, [_p, _p, _i64, _i32, _i64, _p, _p, _p, _p, _p, _sz, _p]),
     "mi_sort_unique_rows": (_i32, [_p, _i64, _i64, _p, _p, _p, _p, _p, _sz, _p]),
     "mi_global_rows": (_i32, [_p, _p, _i64, _i32, _p, _p]),
-    "mi_shard_keys": (_i32, [_p, _i64, _i32, _i64, _i64, _p, _p]),
+    "mi_shard_keys": (_i32, [_p, _i64, _i32, _i64, _i64, _i32, _p, _p]),
     "mi_route_requests": (_i32, [_p, _p, _i64, _i64, _i32, _p, _p, _p]),
     "mi_segment_slots": (_i32, [_p, _p, _p, _i64, _p, _p]),
     "mi_axpy": (_i32, [_p, _p, _i64, _f32, _p]),

@@ -58,11 +58,15 @@ class Comm:
         # same order.)
         ranks = dist.get_process_group_ranks(group if group is not None else dist.group.WORLD)
         self.ahead_group = dist.new_group(ranks=ranks)
+        # send order of the owners (mi_shard_keys, self_rank): the other ranks in rank order, this rank LAST
+        self.pos_of_rank = [j if j < self.rank else (self.world - 1 if j == self.rank else j - 1) for j in range(self.world)]
+        self._pos_dev = {}
 
     def exchange_counts(self, counts_dev, C):
-        """counts_dev [C * world] int32 (device): distinct requests of chunk c for rank j at c * world + j.
-        One small all_to_all on the device buffers, then ONE device->host copy of both tables (the split
-        sizes of all_to_all_single must be host integers): (send_counts[c][j], recv_counts[c][j])."""
+        """counts_dev [C * world] int32 (device): distinct requests of chunk c for the owner at send position p
+        (pos_of_rank) at c * world + p.  One small all_to_all on the device buffers, then ONE device->host copy of both
+        tables (the split sizes of all_to_all_single must be host integers): (send_counts[c][j], recv_counts[c][j]),
+        j = rank."""
         return self.finish_counts(self.start_counts(counts_dev, C))
 
     def start_counts(self, counts_dev, C, ahead=False):
@@ -70,7 +74,10 @@ class Comm:
         host memory are enqueued on the current stream; finish_counts() waits for the copy's event — immediately
         (exchange_counts), or a step later, when the routing of the next batch was started ahead."""
         W = self.world
-        send = counts_dev.view(C, W).t().contiguous().view(-1).to(torch.int64)       # [dest rank][chunk]
+        pos = self._pos_dev.get(counts_dev.device)
+        if pos is None:
+            pos = self._pos_dev[counts_dev.device] = torch.tensor(self.pos_of_rank, dtype=torch.int64, device=counts_dev.device)
+        send = counts_dev.view(C, W).index_select(1, pos).t().contiguous().view(-1).to(torch.int64)   # [dest rank][chunk]
         if not self.direct:
             send = send.cpu()
         recv = torch.empty_like(send)
@@ -95,7 +102,11 @@ class Comm:
     def all_to_all(self, out, inp, out_counts, in_counts, async_op=False):
         """Rows (dim 0) of `inp`, split by in_counts, go to the ranks; `out` receives out_counts rows.
         async_op (RCCL only): returns a handle whose wait() orders the current stream after the
-        exchange; the buffers must stay untouched until then."""
+        exchange; the buffers must stay untouched until then.  The step's exchanges carry nothing from a rank to
+        itself (split size 0 at its own index: those rows never leave the device, see _sharded_step); with one rank
+        there is nothing to exchange at all."""
+        if self.world == 1:
+            return None
         if self.direct:
             return dist.all_to_all_single(out, inp, list(out_counts), list(in_counts), group=self.group,
                                           async_op=async_op) if async_op else \
@@ -167,7 +178,8 @@ def _n_chunks(m, B, train):
 
 def _route(m, ids, C, tag="", ahead=False):
     """Plan the exchange for this batch, C chunks of B/C examples.  The entries are sorted by request key
-    (chunk, owner, owner-local row); the DISTINCT keys are the requests that travel, in send order.  Returns
+    (chunk, owner, owner-local row) — owners in send order: the other ranks by rank, this rank last; the DISTINCT keys
+    are the requests, in send order (a chunk's requests to the rank itself end its run and stay on the device).  Returns
     (slot [B*F]: distinct request of every entry = slot of its row in the receive buffer, send_rows [U]: the
     owner-local rows to ask for, the sort's (sorted_entry, seg_start) over the entries, and the pending count
     exchange: Comm.finish_counts gives send_counts[c][rank], recv_counts[c][rank]).
@@ -182,7 +194,7 @@ def _route(m, ids, C, tag="", ahead=False):
     rows = m._buf("rows" + tag, (n,), i32)
     k.mi_global_rows(ids, m.field_off, B, m.F, rows)
     key = m._buf("route_key" + tag, (n,), i32)
-    k.mi_shard_keys(rows, n, sh.world, (n // C) if C > 1 else 0, Rl, key)
+    k.mi_shard_keys(rows, n, sh.world, (n // C) if C > 1 else 0, Rl, sh.rank, key)
     sorted_entry, uniq, seg, num_uniq = m._sort_unique(key, n, C * sh.world * Rl, "route" + tag,
                                                        ws_name="sort_ws_ahead" if ahead else "sort_ws")
     send_rows = m._buf("send_rows" + tag, (n,), i32)
@@ -255,6 +267,7 @@ def _sharded_step(m, ids, labels, x_num, train, next_ids=None):
     send_counts, recv_counts = comm.finish_counts(pending)
     if train and next_ids is not None and next_ids.shape == ids.shape and not getattr(m, "_capturing", False):
         _route_ahead(m, next_ids, C)
+    me = m.shard.rank
     nsc = [sum(sc) for sc in send_counts]               # distinct requests of chunk c (all owners)
     uoff = [0]
     for v in nsc:
@@ -265,13 +278,28 @@ def _sharded_step(m, ids, labels, x_num, train, next_ids=None):
     for v in nrc:
         roff.append(roff[-1] + v)
     nr = roff[-1]
-    m.last_exchange = {"entries": n, "requests_sent": U, "requests_received": nr}    # (tests / bench: the dedup's effect)
+    # A rank's requests to ITSELF never leave the device.  They end every chunk's run on both sides (mi_shard_keys:
+    # self last; recv_ids / the owners' buffers: sources in rank order, self last), the exchanges get split size 0 at
+    # the rank's own index and ship the runs' heads; the tails are served in place: the owner's gather writes them
+    # straight into the receive buffer, the requester's segment sum straight into the buffer its own apply reads.
+    # (Through RCCL the self piece was a device copy at ~1.1 TB/s: 0.74 ms of the one-rank step, 1/8 of it at 8 ranks.)
+    n_self = [sc[me] for sc in send_counts]
+    for c in range(C):
+        if recv_counts[c][me] != n_self[c]:
+            raise RuntimeError("count exchange: rank %d sends itself %d requests but receives %d" % (me, n_self[c], recv_counts[c][me]))
+    sc0 = [[0 if j == me else v for j, v in enumerate(sc)] for sc in send_counts]
+    rc0 = [[0 if j == me else v for j, v in enumerate(rc)] for rc in recv_counts]
+    umid = [uoff[c + 1] - n_self[c] for c in range(C)]  # chunk c: requests [uoff[c], umid[c]) travel, [umid[c], uoff[c+1]) are its own
+    rmid = [roff[c + 1] - n_self[c] for c in range(C)]  # owner side: [roff[c], rmid[c]) arrived, [rmid[c], roff[c+1]) are its own
+    m.last_exchange = {"entries": n, "requests_sent": U, "requests_received": nr, "requests_to_self": sum(n_self)}    # (tests / bench)
 
     # requests to their owners (small), then the owners' bookkeeping for the WHOLE step: which rows are
     # touched, and TF Adam's catch-up on them before any of them is read
     recv_ids = m._buf("recv_ids", (max(nr, 1),), i32)[:nr]
     for c in range(C):
-        comm.all_to_all(recv_ids[roff[c]:roff[c + 1]], send_rows[uoff[c]:uoff[c + 1]], recv_counts[c], send_counts[c])
+        comm.all_to_all(recv_ids[roff[c]:rmid[c]], send_rows[uoff[c]:umid[c]], rc0[c], sc0[c])
+        if n_self[c]:
+            recv_ids[rmid[c]:roff[c + 1]].copy_(send_rows[umid[c]:uoff[c + 1]])
     book = None
     if train and nr > 0:
         book = m._sort_unique(recv_ids, nr, m.R_local, "own")     # (sorted_entry, uniq, seg, num_uniq)
@@ -283,18 +311,23 @@ def _sharded_step(m, ids, labels, x_num, train, next_ids=None):
     got_rows = m._buf("got_rows", (max(U, 1), E)) if m.use_emb else None
     got_lin = m._buf("got_lin", (max(U, 1),)) if m.use_linear else None
 
+    def gather(ids_, n_, rows_out, lin_out):
+        if n_ > 0:
+            k.mi_gather_rows(m.table if m.use_emb else None, m.lin_w if m.use_linear else None, ids_, n_, E,
+                             rows_out if m.use_emb else None, lin_out if m.use_linear else None, m.ls)
+
     def serve(c):
-        """owners gather chunk c's rows and send them back; returns the exchange handles"""
-        lo, hi = roff[c], roff[c + 1]
+        """owners gather chunk c's rows and send them back (their own requests: straight into the receive buffer);
+        returns the exchange handles"""
+        lo, mid, hi = roff[c], rmid[c], roff[c + 1]
+        ulo, um, uhi = uoff[c], umid[c], uoff[c + 1]
         hs = []
+        gather(recv_ids[lo:mid], mid - lo, own_rows[lo:mid] if m.use_emb else None, own_lin[lo:mid] if m.use_linear else None)
         if m.use_emb:
-            k.mi_gather_rows(m.table, m.lin_w if m.use_linear else None, recv_ids[lo:hi], hi - lo, E, own_rows[lo:hi],
-                             own_lin[lo:hi] if m.use_linear else None, m.ls)
-            hs.append(comm.all_to_all(got_rows[uoff[c]:uoff[c + 1]], own_rows[lo:hi], send_counts[c], recv_counts[c], True))
-        elif m.use_linear:
-            k.mi_gather_rows(None, m.lin_w, recv_ids[lo:hi], hi - lo, E, None, own_lin[lo:hi], m.ls)
+            hs.append(comm.all_to_all(got_rows[ulo:um], own_rows[lo:mid], sc0[c], rc0[c], True))
         if m.use_linear:
-            hs.append(comm.all_to_all(got_lin[uoff[c]:uoff[c + 1]], own_lin[lo:hi], send_counts[c], recv_counts[c], True))
+            hs.append(comm.all_to_all(got_lin[ulo:um], own_lin[lo:mid], sc0[c], rc0[c], True))
+        gather(recv_ids[mid:hi], hi - mid, got_rows[um:uhi] if m.use_emb else None, got_lin[um:uhi] if m.use_linear else None)
         return hs
 
     d_rows = m._buf("d_rows", (max(U, 1), E)) if (train and m.use_emb) else None      # one row per distinct request, send order
@@ -333,18 +366,22 @@ def _sharded_step(m, ids, labels, x_num, train, next_ids=None):
                 acc.copy_(m.d_grad)
             else:
                 k.mi_axpy(acc, m.d_grad, m.P, 1.0)
-        # the chunk's entry gradients summed per distinct request, written at the request's send slot
-        ulo, uhi = uoff[c], uoff[c + 1]
-        if uhi > ulo:
-            k.mi_entry_grads_segsum(got_rows if m.use_mf else None, seg, sorted_entry, ulo, uhi - ulo,
-                                    d_concat if m.use_emb else None, m.D, cc["sumv"] if m.use_mf else None,
-                                    dlogit if m.use_mf else None, dlogit if m.use_linear else None, c * Bc, F, E,
-                                    d_rows, d_lin)
-        lo, hi = roff[c], roff[c + 1]
+        # the chunk's entry gradients summed per distinct request, written at the request's send slot — those of the
+        # rank's own rows straight into the buffer its apply reads
+        ulo, um, uhi = uoff[c], umid[c], uoff[c + 1]
+        lo, mid, hi = roff[c], rmid[c], roff[c + 1]
+        for u0, cnt, o_rows, o_lin, row0 in ((ulo, um - ulo, d_rows, d_lin, 0),
+                                            (um, uhi - um, r_rows[mid:hi] if m.use_emb else None,
+                                             r_lin[mid:hi] if m.use_linear else None, um)):
+            if cnt > 0:
+                k.mi_entry_grads_segsum(got_rows if m.use_mf else None, seg, sorted_entry, u0, cnt,
+                                        d_concat if m.use_emb else None, m.D, cc["sumv"] if m.use_mf else None,
+                                        dlogit if m.use_mf else None, dlogit if m.use_linear else None, c * Bc, F, E,
+                                        o_rows, o_lin, row0)
         if m.use_emb:
-            grad_h.append(comm.all_to_all(r_rows[lo:hi], d_rows[ulo:uhi], recv_counts[c], send_counts[c], True))
+            grad_h.append(comm.all_to_all(r_rows[lo:mid], d_rows[ulo:um], rc0[c], sc0[c], True))
         if m.use_linear:
-            grad_h.append(comm.all_to_all(r_lin[lo:hi], d_lin[ulo:uhi], recv_counts[c], send_counts[c], True))
+            grad_h.append(comm.all_to_all(r_lin[lo:mid], d_lin[ulo:um], rc0[c], sc0[c], True))
     m._chunk = 0
     if C > 1:
         logits, loss = logits_all, (loss_all if loss is not None else None)

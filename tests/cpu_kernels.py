@@ -36,10 +36,13 @@ class NumpyKernels:
     def mi_global_rows(self, ids, field_off, B, F, rows):
         _np(rows)[:] = (_np(ids).astype(np.int64) + _np(field_off)[None, :]).reshape(-1)
 
-    def mi_shard_keys(self, rows, n, world, entries_per_chunk, rows_per_rank, keys):
+    def mi_shard_keys(self, rows, n, world, entries_per_chunk, rows_per_rank, self_rank, keys):
         r = _np(rows)[:n].astype(np.int64)
         chunk = (np.arange(n) // entries_per_chunk) if entries_per_chunk > 0 else 0
-        _np(keys)[:n] = (chunk * world + r % world) * rows_per_rank + r // world
+        o = r % world
+        if self_rank >= 0:
+            o = np.where(o == self_rank, world - 1, np.where(o > self_rank, o - 1, o))
+        _np(keys)[:n] = (chunk * world + o) * rows_per_rank + r // world
 
     def mi_route_requests(self, uniq, num_uniq, n_max, rows_per_rank, n_groups, send_rows, counts):
         U = int(_np(num_uniq)[0])
@@ -54,7 +57,7 @@ class NumpyKernels:
             _np(slot)[se[sg[u]:sg[u + 1]]] = u
 
     def mi_entry_grads_segsum(self, rows, seg, sorted_entry, u_begin, u_count, d_concat, ldd, sumv, dlf, dll, b0, F, E,
-                              out_rows, out_lin):
+                              out_rows, out_lin, out_row0=0):
         sg, se = _np(seg), _np(sorted_entry)
         for u in range(u_begin, u_begin + u_count):
             g = np.zeros(E, np.float32)
@@ -71,9 +74,9 @@ class NumpyKernels:
                 if out_lin is not None:
                     gl = gl + _np(dll)[b]
             if out_rows is not None:
-                _np(out_rows)[u] = g
+                _np(out_rows)[u - out_row0] = g
             if out_lin is not None:
-                _np(out_lin)[u] = gl
+                _np(out_lin)[u - out_row0] = gl
 
     def mi_axpy(self, y, x, n, alpha):
         _np(y)[:n] += np.float32(alpha) * _np(x)[:n]
