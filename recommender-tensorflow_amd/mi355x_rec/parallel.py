@@ -99,7 +99,7 @@ class Comm:
         rc = [[int(both[1][j * C + c]) for j in range(W)] for c in range(C)]
         return sc, rc
 
-    def all_to_all(self, out, inp, out_counts, in_counts, async_op=False):
+    def all_to_all(self, out, inp, out_counts, in_counts, async_op=False, ahead=False):
         """Rows (dim 0) of `inp`, split by in_counts, go to the ranks; `out` receives out_counts rows.
         async_op (RCCL only): returns a handle whose wait() orders the current stream after the
         exchange; the buffers must stay untouched until then.  The step's exchanges carry nothing from a rank to
@@ -107,14 +107,14 @@ class Comm:
         there is nothing to exchange at all."""
         if self.world == 1:
             return None
+        group = self.ahead_group if ahead else self.group      # (ahead: the next batch's id exchange, see _own_ahead)
         if self.direct:
-            return dist.all_to_all_single(out, inp, list(out_counts), list(in_counts), group=self.group,
+            return dist.all_to_all_single(out, inp, list(out_counts), list(in_counts), group=group,
                                           async_op=async_op) if async_op else \
-                dist.all_to_all_single(out, inp, list(out_counts), list(in_counts), group=self.group)
+                dist.all_to_all_single(out, inp, list(out_counts), list(in_counts), group=group)
         else:
             o = torch.empty(out.shape, dtype=out.dtype)
-            dist.all_to_all_single(o, inp.detach().cpu().contiguous(), list(out_counts), list(in_counts),
-                                   group=self.group)
+            dist.all_to_all_single(o, inp.detach().cpu().contiguous(), list(out_counts), list(in_counts), group=group)
             out.copy_(o)
 
     def all_reduce(self, t):
@@ -202,7 +202,60 @@ def _route(m, ids, C, tag="", ahead=False):
     k.mi_route_requests(uniq, num_uniq, n, Rl, C * sh.world, send_rows, counts)
     slot = m._buf("route_slot" + tag, (n,), i32)
     k.mi_segment_slots(seg, sorted_entry, num_uniq, n, slot)
-    return slot, send_rows, sorted_entry, seg, comm.start_counts(counts, C, ahead=ahead)
+    return {"slot": slot, "send_rows": send_rows, "sorted_entry": sorted_entry, "seg": seg, "C": C, "tag": tag,
+            "pending": comm.start_counts(counts, C, ahead=ahead)}
+
+
+def _finish_plan(m, plan):
+    """The plan's split sizes on the host (Comm.finish_counts: the step's one host wait) and what follows from them:
+    where every chunk's requests sit in the buffers of both sides.
+    A rank's requests to ITSELF never leave the device.  They end every chunk's run on both sides (mi_shard_keys: self
+    last; the owners' buffers: sources in rank order, self last), the exchanges get split size 0 at the rank's own index
+    and ship the runs' heads; the tails are served in place: the owner's gather writes them straight into the receive
+    buffer, the requester's segment sum straight into the buffer its own apply reads.  (Through RCCL the self piece was
+    a device copy at ~1.1 TB/s: 0.74 ms of the one-rank step, 1/8 of it at 8 ranks.)"""
+    if "uoff" in plan:
+        return plan
+    me, C = m.shard.rank, plan["C"]
+    send_counts, recv_counts = _comm(m).finish_counts(plan.pop("pending"))
+    uoff, roff = [0], [0]
+    for c in range(C):
+        uoff.append(uoff[-1] + sum(send_counts[c]))       # distinct requests of chunk c (all owners)
+        roff.append(roff[-1] + sum(recv_counts[c]))       # requests chunk c brings this owner
+    n_self = [sc[me] for sc in send_counts]
+    for c in range(C):
+        if recv_counts[c][me] != n_self[c]:
+            raise RuntimeError("count exchange: rank %d sends itself %d requests but receives %d" % (me, n_self[c], recv_counts[c][me]))
+    plan.update(uoff=uoff, roff=roff, n_self=n_self,
+                sc0=[[0 if j == me else v for j, v in enumerate(sc)] for sc in send_counts],
+                rc0=[[0 if j == me else v for j, v in enumerate(rc)] for rc in recv_counts],
+                # chunk c: requests [uoff[c], umid[c]) travel, [umid[c], uoff[c+1]) are the rank's own;
+                # owner side: [roff[c], rmid[c]) arrived, [rmid[c], roff[c+1]) are its own
+                umid=[uoff[c + 1] - n_self[c] for c in range(C)], rmid=[roff[c + 1] - n_self[c] for c in range(C)])
+    return plan
+
+
+def _owners_side(m, plan, train, ahead=False):
+    """Requests to their owners (small), then — for a train step — which rows this owner's step touches (sort + unique
+    of everything it was asked for: the sparse apply's segments and the catch-up's row list).  ahead: on the second
+    communicator, into the plan's own buffer set (see _own_ahead)."""
+    if "recv_ids" in plan:
+        return plan
+    comm = _comm(m)
+    tag, C = plan["tag"], plan["C"]
+    uoff, roff, umid, rmid = plan["uoff"], plan["roff"], plan["umid"], plan["rmid"]
+    nr = roff[-1]
+    recv_ids = m._buf("recv_ids" + tag, (max(nr, 1),), torch.int32)[:nr]
+    send_rows = plan["send_rows"]
+    for c in range(C):
+        comm.all_to_all(recv_ids[roff[c]:rmid[c]], send_rows[uoff[c]:umid[c]], plan["rc0"][c], plan["sc0"][c], ahead=ahead)
+        if plan["n_self"][c]:
+            recv_ids[rmid[c]:roff[c + 1]].copy_(send_rows[umid[c]:uoff[c + 1]])
+    plan["recv_ids"] = recv_ids
+    plan["book"] = None
+    if train and nr > 0:        # (sorted_entry, uniq, seg, num_uniq)
+        plan["book"] = m._sort_unique(recv_ids, nr, m.R_local, "own" + tag, ws_name="sort_ws_ahead" if ahead else "sort_ws")
+    return plan
 
 
 def _route_ahead(m, next_ids, C):
@@ -226,6 +279,27 @@ def _route_ahead(m, next_ids, C):
     m._routed = {"ids": next_ids, "version": next_ids._version, "plan": plan, "C": C, "tag": tag, "stream": side}
 
 
+def _own_ahead(m):
+    """Second half of the routing ahead, at the END of a step's enqueue: the host takes the next batch's split sizes (the
+    event it would otherwise wait for at the head of the next step — the GPU is at the same point of its queue either
+    way) and enqueues, on the side stream and the second communicator, the next batch's id exchange and the owners' sort
+    of the requests they receive.  Both depend on ids only; the next step then starts with the catch-up."""
+    r = getattr(m, "_routed", None)
+    if r is None:
+        return
+    plan = _finish_plan(m, r["plan"])
+    if r["stream"] is None:
+        _owners_side(m, plan, True, ahead=True)
+    else:
+        # beside this step's sparse apply (HBM-bound, 0.6 ms), not beside the weight-gradient GEMMs the host's enqueue
+        # would otherwise put it next to: their grids are whole waves of workgroups over the 256 CUs, and a sort kernel
+        # on a few CUs costs them a third wave (kernel trace: wgrad_pl_k 298 -> 341 us, the layer-1 data gradient 335 -> 354)
+        if r.get("gate") is not None:
+            r["stream"].wait_event(r["gate"])
+        with torch.cuda.stream(r["stream"]):
+            _owners_side(m, plan, True, ahead=True)
+
+
 def _take_route(m, ids, C):
     """The plan _route_ahead made for exactly this tensor, or a fresh one."""
     r, m._routed = getattr(m, "_routed", None), None
@@ -236,7 +310,7 @@ def _take_route(m, ids, C):
             m._route_tag = r["tag"]
             m.route_ahead_hits = getattr(m, "route_ahead_hits", 0) + 1
             return r["plan"]
-        _comm(m).finish_counts(r["plan"][4])          # (an announced batch that did not come: its exchange still completes)
+        _finish_plan(m, r["plan"])                    # (an announced batch that did not come: its exchange still completes)
     m._route_tag = ""
     return _route(m, ids, max(C, 1))
 
@@ -263,48 +337,20 @@ def _sharded_step(m, ids, labels, x_num, train, next_ids=None):
     if train and hasattr(m, "_split_weights_ahead"):
         m._split_weights_ahead()            # the MLP's weight planes, on a side stream beside the routing
     # (an evaluation between two train steps plans into the first buffer set: a plan made ahead is dropped first)
-    slot, send_rows, sorted_entry, seg, pending = _take_route(m, ids, C if train else -1)
-    send_counts, recv_counts = comm.finish_counts(pending)
+    plan = _finish_plan(m, _take_route(m, ids, C if train else -1))
     if train and next_ids is not None and next_ids.shape == ids.shape and not getattr(m, "_capturing", False):
         _route_ahead(m, next_ids, C)
-    me = m.shard.rank
-    nsc = [sum(sc) for sc in send_counts]               # distinct requests of chunk c (all owners)
-    uoff = [0]
-    for v in nsc:
-        uoff.append(uoff[-1] + v)
-    U = uoff[-1]
-    nrc = [sum(rc) for rc in recv_counts]
-    roff = [0]
-    for v in nrc:
-        roff.append(roff[-1] + v)
-    nr = roff[-1]
-    # A rank's requests to ITSELF never leave the device.  They end every chunk's run on both sides (mi_shard_keys:
-    # self last; recv_ids / the owners' buffers: sources in rank order, self last), the exchanges get split size 0 at
-    # the rank's own index and ship the runs' heads; the tails are served in place: the owner's gather writes them
-    # straight into the receive buffer, the requester's segment sum straight into the buffer its own apply reads.
-    # (Through RCCL the self piece was a device copy at ~1.1 TB/s: 0.74 ms of the one-rank step, 1/8 of it at 8 ranks.)
-    n_self = [sc[me] for sc in send_counts]
-    for c in range(C):
-        if recv_counts[c][me] != n_self[c]:
-            raise RuntimeError("count exchange: rank %d sends itself %d requests but receives %d" % (me, n_self[c], recv_counts[c][me]))
-    sc0 = [[0 if j == me else v for j, v in enumerate(sc)] for sc in send_counts]
-    rc0 = [[0 if j == me else v for j, v in enumerate(rc)] for rc in recv_counts]
-    umid = [uoff[c + 1] - n_self[c] for c in range(C)]  # chunk c: requests [uoff[c], umid[c]) travel, [umid[c], uoff[c+1]) are its own
-    rmid = [roff[c + 1] - n_self[c] for c in range(C)]  # owner side: [roff[c], rmid[c]) arrived, [rmid[c], roff[c+1]) are its own
-    m.last_exchange = {"entries": n, "requests_sent": U, "requests_received": nr, "requests_to_self": sum(n_self)}    # (tests / bench)
+    slot, sorted_entry, seg = plan["slot"], plan["sorted_entry"], plan["seg"]
+    uoff, roff, umid, rmid, sc0, rc0 = plan["uoff"], plan["roff"], plan["umid"], plan["rmid"], plan["sc0"], plan["rc0"]
+    U, nr = uoff[-1], roff[-1]
+    m.last_exchange = {"entries": n, "requests_sent": U, "requests_received": nr, "requests_to_self": sum(plan["n_self"])}
 
-    # requests to their owners (small), then the owners' bookkeeping for the WHOLE step: which rows are
-    # touched, and TF Adam's catch-up on them before any of them is read
-    recv_ids = m._buf("recv_ids", (max(nr, 1),), i32)[:nr]
-    for c in range(C):
-        comm.all_to_all(recv_ids[roff[c]:rmid[c]], send_rows[uoff[c]:umid[c]], rc0[c], sc0[c])
-        if n_self[c]:
-            recv_ids[rmid[c]:roff[c + 1]].copy_(send_rows[umid[c]:uoff[c + 1]])
-    book = None
-    if train and nr > 0:
-        book = m._sort_unique(recv_ids, nr, m.R_local, "own")     # (sorted_entry, uniq, seg, num_uniq)
-        if m.adam_rows and m.step > 0:
-            m._catchup(book[1], book[3], nr, defer=True)
+    # requests to their owners, the owners' bookkeeping for the WHOLE step (done ahead if the batch was announced), and
+    # TF Adam's catch-up on the rows this step touches, before any of them is read
+    _owners_side(m, plan, train)
+    recv_ids, book = plan["recv_ids"], plan["book"]
+    if book is not None and m.adam_rows and m.step > 0:
+        m._catchup(book[1], book[3], nr, defer=True)
 
     own_rows = m._buf("own_rows", (max(nr, 1), E))[:nr] if m.use_emb else None
     own_lin = m._buf("own_lin", (max(nr, 1),))[:nr] if m.use_linear else None
@@ -391,11 +437,16 @@ def _sharded_step(m, ids, labels, x_num, train, next_ids=None):
         m.d_grad.copy_(acc)
     comm.all_reduce(m.d_grad)                                   # dense gradients: SUM over ranks
     _wait(grad_h)
+    r = getattr(m, "_routed", None)
+    if r is not None and r["stream"] is not None:
+        r["gate"] = torch.cuda.Event()
+        r["gate"].record()                                      # (the next batch's owner-side work starts here: _own_ahead)
     if book is not None:
         bs_entry, buniq, bseg, bnum = book
         m._apply(buniq, bseg, bs_entry, bnum, nr, r_rows, r_lin)
     else:
         m._apply(None, None, None, None, 0, None, None)
+    _own_ahead(m)
     return loss, logits
 
 
