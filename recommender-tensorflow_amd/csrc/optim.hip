@@ -942,12 +942,15 @@ int32_t mi_sparse_catchup(float* table, float* t_m, float* t_v, float* lin_w, fl
         bounded);
     MI_CHECK_LAUNCH("sparse_catchup(wide part)");
   }
+  // the wide part alone (two Adams, or its replay on a stream of its own): the row kernel would only write the stamps —
+  // nothing at all when those are deferred or kept
+  if (!table && (defer || keep_stamps)) return MI_OK;
   const int lpr = table ? lanes_per_row(E) : 1;
   const int64_t blocks = mi::ceil_div(n_max * lpr, kBlock);
   MI_REQUIRE(blocks <= INT32_MAX, "sparse_catchup: grid too large");
   if (bounded && table) {
     // a pipelined grid: a few resident workgroups per CU, every lane group walks its share of the rows
-    int64_t pb = mi::env_int("MI_CATCHUP_BLOCKS", 2048);          // 8 workgroups per CU resident
+    int64_t pb = mi::env_int("MI_CATCHUP_BLOCKS", 1024);          // 4 workgroups per CU resident: half the wave slots stay free for the side streams' small kernels (A/B on one box, 3 x alternating: 2.864 vs 2.881 ms per step at 2048)
     while (pb > 1 && pb > blocks) pb >>= 1;                       // (a power of two: the kernel's wave -> chunk map)
     MI_DISPATCH_LPR(lpr, (sparse_catchup_bounded_k<L><<<dim3((unsigned)pb), dim3(kBlock), 0, mi::as_stream(stream)>>>(
                              table, t_m, t_v, last_step, uniq_rows, num_uniq, n_max, E, step_to, lr_table, beta1, beta2,

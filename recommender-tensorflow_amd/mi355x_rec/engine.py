@@ -720,8 +720,7 @@ class DeepFM:
         # (3.9 vs 4.9 TB/s of row bytes).  On a single GPU they run as their own kernel on a side stream
         # under the matrix-bound layer-1 GEMM instead; the head joins the two streams.
         # (from a few thousand examples on: below that a fork / join costs more than the 4-byte gathers it hides)
-        side_lin = (src is None and self.device.type == "cuda" and self.use_emb and self.use_linear and self.use_dnn
-                    and self.n_numeric == 0 and F > 0 and B >= 4096)
+        side_lin = src is None and self._wide_on_side_stream(B)
         c["lin_join"] = None
         if F == 0:
             # numeric columns only (deep_fm.py:57-70 allows it): the sums start from zero (memsets)
@@ -734,10 +733,8 @@ class DeepFM:
             elif concat is not None or sumv is not None or rows_amax is not None:
                 k.mi_embed_fm_linear_fwd(table, None, field_off, rid, B, F, self.E, concat, ld, sumv, fm, None,
                                          rows_amax, 1)
-            side = self._ws.get("side_stream")
-            if side is None:
-                side = self._ws["side_stream"] = torch.cuda.Stream(device=self.device)
-            side.wait_stream(torch.cuda.current_stream())        # the catch-up of these rows ran on the main stream
+            side = self._side_stream()
+            side.wait_stream(torch.cuda.current_stream())        # (w_ids; the wide part's own catch-up is on this stream already)
             with torch.cuda.stream(side):
                 k.tagged("mi_embed_fm_linear_fwd", "/wide")(None, lin_w, w_off, w_ids, B, Fw, self.E, None, 0, None,
                                                             None, lin, None, ls)
@@ -878,10 +875,11 @@ class DeepFM:
 
     GAP_SORT_MIN = 16384      # entries from which sorting the touched rows by staleness pays for itself
 
-    def _catchup(self, uniq, num_uniq, n_max, defer=False):
+    def _catchup(self, uniq, num_uniq, n_max, defer=False, by_gap=None):
         """defer: the rows are about to be applied in this same step by ONE mi_sparse_apply call, which
         then decays m and v itself from the old stamps — the catch-up moves w only (a third less HBM
-        traffic).  Not with a separate linear optimizer (two apply calls would see each other's stamps)."""
+        traffic).  Not with a separate linear optimizer (two apply calls would see each other's stamps).
+        by_gap: the rows already in staleness order (made ahead by _presort)."""
         t_adam = self.opt.name == "Adam" and self.table is not None
         l_adam = (self.lin_opt or self.opt).name == "Adam" and self.lin_w is not None
         if not (t_adam or l_adam) or n_max == 0:
@@ -891,28 +889,50 @@ class DeepFM:
             if sc is not None:
                 sc.lr_t(self.step)  # make sure the table covers step
         if uniq is not None and n_max >= self.GAP_SORT_MIN:
-            # rows of equal staleness into the same wave (the replay runs as long as a wave's stalest row)
-            by_gap = self._buf("uniq_by_gap", (n_max,), torch.int32)
-            ws = self._bytes("sort_ws", self.k.query("mi_sort_unique_workspace_bytes", n_max))
-            self.k.mi_catchup_rows_by_gap(uniq, num_uniq, self.last_step, n_max, self.step, self.ls, by_gap, ws, ws.numel())
-            uniq = by_gap
+            uniq = by_gap if by_gap is not None else self._rows_by_gap(uniq, num_uniq, n_max, self.step)
         flags = (1 if defer else 0) | (2 if self.catchup == "bounded" else 0)
         t_sched = self.sched if t_adam else None
         l_sched = (self.lin_sched if self.lin_opt is not None else (self.lin_sched or self.sched)) if l_adam else None
+        side = None
         if t_sched is not None and l_sched is not None and t_sched is not l_sched:
             # two different Adams (tables vs wide part): one call each, with its own lr_t table and betas.  The table
             # call must not move the stamps the wide call still has to read: it runs second.
             assert not defer
             parts = [(None, l_sched, 4), (t_sched, None, 0)]          # (4 = MI_CATCHUP_KEEP_STAMPS)
+        elif (defer and t_sched is not None and l_sched is not None and self.shard is None and self.device.type == "cuda"
+              and self._wide_on_side_stream(n_max // max(self.F, 1)) and os.environ.get("MI_LIN_SIDE", "1") == "1"):
+            # deferred: neither call writes a stamp or touches the other's state — the wide part's 16-byte records
+            # (scattered, latency-bound: 0.08 ms) are replayed on the stream that will run the wide part's forward,
+            # beside the row kernel; the head joins that stream before anything else reads them
+            parts = [(None, l_sched, 0), (t_sched, None, 0)]
+            side = self._side_stream()
+            side.wait_stream(torch.cuda.current_stream())
         else:
             parts = [(t_sched, l_sched, 0)]
-        for ts, lsch, extra in parts:
+        for i, (ts, lsch, extra) in enumerate(parts):
             s = (ts or lsch).spec
-            self.k.mi_sparse_catchup(self.table if ts is not None else None, self.t_s0 if ts is not None else None,
-                                     self.t_s1 if ts is not None else None, self.lin_w if lsch is not None else None,
-                                     self.l_s0 if lsch is not None else None, self.l_s1 if lsch is not None else None,
-                                     self.last_step, uniq, num_uniq, n_max, self.E, self.step, (ts or lsch).table, s.beta1, s.beta2,
-                                     s.epsilon, flags | extra, self.ls)
+            call = lambda: self.k.mi_sparse_catchup(
+                self.table if ts is not None else None, self.t_s0 if ts is not None else None,
+                self.t_s1 if ts is not None else None, self.lin_w if lsch is not None else None,
+                self.l_s0 if lsch is not None else None, self.l_s1 if lsch is not None else None,
+                self.last_step, uniq, num_uniq, n_max, self.E, self.step, (ts or lsch).table, s.beta1, s.beta2,
+                s.epsilon, flags | extra, self.ls)
+            if side is not None and i == 0:
+                with torch.cuda.stream(side):
+                    call()
+            else:
+                call()
+
+    def _side_stream(self):
+        side = self._ws.get("side_stream")
+        if side is None:
+            side = self._ws["side_stream"] = torch.cuda.Stream(device=self.device)
+        return side
+
+    def _wide_on_side_stream(self, B):
+        """the wide part's forward of a B-example single-GPU batch runs as its own kernel on the side stream (_forward)"""
+        return (self.device.type == "cuda" and self.use_emb and self.use_linear and self.use_dnn and self.n_numeric == 0
+                and self.F > 0 and B >= 4096)
 
     def _sort_unique(self, keys, n, key_range, tag, ws_name="sort_ws"):
         """mi_sort_unique_rows into persistent buffers named after `tag` (ws_name: a workspace of its own for a sort that
@@ -948,10 +968,18 @@ class DeepFM:
         return self._sort_unique(rows, n, self.R, tag)
 
     def _presort(self, next_ids, tag):
-        """The sort of the NEXT batch, on a side stream, enqueued right before this step's catch-up: a pure function of
-        next_ids (no model state), made of ~14 small launches that are bound by launch latency and leave most of the
-        chip idle (0.17 ms at config 3) — beside the VALU-bound catch-up they cost nothing.  The result is used by the
-        next train_step if it is given that very tensor, unmodified; otherwise it is dropped."""
+        """The sort of the NEXT batch and the order its catch-up will walk its rows in (by staleness), on a side stream,
+        enqueued right before this step's catch-up: ~20 small launches that are bound by launch latency and leave most of
+        the chip idle (0.17 + 0.11 ms at config 3 alone).  Beside the catch-up — whose resident workgroups fill the CUs:
+        the side kernels get the slots its waves free, the sort ends about when the catch-up does, at +35 us for it — and
+        the gather (HBM-bound, short-lived workgroups), where the staleness order lands.  (Measured alternatives, kernel
+        timelines of tools/step_timeline.py: beside the sparse apply the apply takes 713 us instead of 631 and the
+        one-workgroup scan waits 350 us for a slot; beside the MLP's GEMMs, whose grids are whole waves of workgroups over
+        the 256 CUs, those lose 5-15 %.)  The sort is a pure function of next_ids.  The staleness order reads the rows'
+        stamps BEFORE this step's apply has written this batch's: a row of both batches is filed under the gap it had
+        before (its real gap is 0) — the order only decides which rows share a wave, the catch-up kernels read every row's
+        stamp themselves.  (Each stamp is read once: mi_catchup_rows_by_gap materialises its keys before it counts them.)
+        The result is used by the next train_step if it is given that very tensor, unmodified; otherwise it is dropped."""
         side = self._ws.get("presort_stream")
         if side is None:
             side = self._ws["presort_stream"] = torch.cuda.Stream(device=self.device)
@@ -959,8 +987,22 @@ class DeepFM:
         side.wait_stream(main)                       # next_ids exists, this step's own sort has left the shared workspace
         with torch.cuda.stream(side):
             out = self._sort_batch(next_ids, tag, side=True)
+            by_gap = None
+            n = next_ids.shape[0] * self.F
+            if self.adam_rows and n >= self.GAP_SORT_MIN and os.environ.get("MI_BYGAP_AHEAD", "1") == "1":
+                by_gap = self._rows_by_gap(out[1], out[3], n, self.step + 1, tag + "_ahead", side=True)
         # (the tensor itself is kept: while it is alive its memory cannot come back as another batch's)
-        self._presorted = {"ids": next_ids, "version": next_ids._version, "tag": tag, "sorted": out, "stream": side}
+        self._presorted = {"ids": next_ids, "version": next_ids._version, "tag": tag, "sorted": out, "stream": side,
+                           "by_gap": by_gap, "by_gap_step": self.step + 1}
+
+    def _rows_by_gap(self, uniq, num_uniq, n_max, step_to, tag="", side=False):
+        """rows of equal staleness into the same wave (the replay runs as long as a wave's stalest row)"""
+        by_gap = self._buf("uniq_by_gap" + tag, (n_max,), torch.int32)
+        ws = self._bytes("gap_ws" + tag, self.k.query("mi_sort_unique_workspace_bytes", n_max))
+        f = self.k.tagged("mi_catchup_rows_by_gap", "/next batch, side stream") if (side and hasattr(self.k, "tagged")) else \
+            self.k.mi_catchup_rows_by_gap
+        f(uniq, num_uniq, self.last_step, n_max, step_to, self.ls, by_gap, ws, ws.numel())
+        return by_gap
 
     def train_step(self, ids, labels, x_num=None, next_ids=None):
         """One optimizer.minimize(loss): returns (loss [1], logits [B]) device tensors, no host sync.
@@ -1010,10 +1052,11 @@ class DeepFM:
         ps = self._take_presorted(ids)
         tag = ps["tag"] if ps is not None else "own"
         sorted_entry, uniq, seg, num_uniq = ps["sorted"] if ps is not None else self._sort_batch(ids, tag)
-        self._announce(ids, next_ids, x_num, tag)
+        self._announce(ids, next_ids, x_num, tag)       # the next batch's sort, beside the catch-up (see _presort)
         # (2) TF Adam moved these rows on every step they sat out: replay that now
         if self.adam_rows and self.step > 0:
-            self._catchup(uniq, num_uniq, n, defer=True)
+            by_gap = ps["by_gap"] if (ps is not None and ps.get("by_gap_step") == self.step) else None
+            self._catchup(uniq, num_uniq, n, defer=True, by_gap=by_gap)
         # (3) forward + head
         c = self._forward(ids, x_num, True)
         logits, loss, dlogit = self._head(c, labels, True)
