@@ -54,6 +54,7 @@ HBM_MEASURED_GBS = 6290.0
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
 MFMA_F16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense f16/bf16 MFMA (no sparsity)
 SPLIT_PRODUCTS = 3            # f16x2 split: MFMA products issued per fp32 product
+SUSTAINED_F16_EXECUTED_TFLOPS = 1050.0   # executed f16 MFMA TFLOP/s this chip sustains on live (random) operands: power-limited, profiles/r03_gemm_power_limit.md
 
 F, V, E, HIDDEN, B_FULL = 26, 1_000_000, 64, [512, 256, 128], 65536
 DROPOUT = 0.1
@@ -131,7 +132,12 @@ def mlp_roofline(gemm, flops, gemm_ms):
                              "overhead launches (weight split, abs-max, row splits, slab folds)", "bound": "mfma",
             "achieved": ach, "peak": peak, "unit": "TFLOP/s (fp32-equivalent)", "frac": ach / peak,
             "mfma_products_per_fp32_product": prod, "executed_mfma_tflops": ach * prod,
-            "fp32_input_mfma_peak": MFMA_F32_PEAK_TFLOPS, "flops_per_step": flops, "gemm_ms_per_step": gemm_ms}
+            "fp32_input_mfma_peak": MFMA_F32_PEAK_TFLOPS, "flops_per_step": flops, "gemm_ms_per_step": gemm_ms,
+            # (f16 split paths) what this chip sustains on live operands under its power management — a constant from
+            # profiles/r03_gemm_power_limit.md (tools/probe/gemm4w_probe.hip: the same loop at 82 % matrix duty, the clock
+            # falls to 1.3 GHz; 2.0 GHz and 1.67 PF on all-zero operands), not a measurement of this run
+            "sustained_executed_peak_tflops": SUSTAINED_F16_EXECUTED_TFLOPS if prod in (3, 6) else None,
+            "frac_of_sustained": (ach * prod / SUSTAINED_F16_EXECUTED_TFLOPS) if prod in (3, 6) else None}
 
 
 def cpu_model():
