@@ -13,6 +13,7 @@
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int THREADS = 256, ROWB = 64, BK = 16;
 constexpr int XT = 8, YT = 2;                         // per wave: 8 x 32 columns, 2 x 32 examples
@@ -24,7 +25,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 
 struct Frags { f16x8 ah[XT], al[XT], bh[YT], bl[YT]; };
 
-template <bool STORE>
+template <bool STORE, int ORDER>
 __global__ __launch_bounds__(THREADS, 1) void gemm4w_k(const char* __restrict__ A, int64_t bsa, const char* __restrict__ B, int64_t bsb,
                                                        int M, int N, int K, float* __restrict__ C, float* __restrict__ sink, long long* clk) {
   __shared__ __attribute__((aligned(1024))) char smem[NBUF * STAGE];
@@ -53,6 +54,11 @@ __global__ __launch_bounds__(THREADS, 1) void gemm4w_k(const char* __restrict__ 
   const int offA = (wn * 32 * XT + i) * ROWB;
   const int offB = (BN + wm * 32 * YT + i) * ROWB;
 
+  // ORDER 2: the same loop — same loads, same number of flops and accumulator registers — issued as v_mfma_f32_16x16x32_f16
+  // (two per 32x32x16, on the same operand registers: the RESULT IS NOT A GEMM, only the energy is meant)
+  f32x4 acc4[ORDER == 2 ? 4 * XT * YT : 1];
+#pragma unroll
+  for (int q = 0; q < (ORDER == 2 ? 4 * XT * YT : 1); ++q) acc4[q] = f32x4{0.f, 0.f, 0.f, 0.f};
   f32x16 acc[XT][YT];
 #pragma unroll
   for (int x = 0; x < XT; ++x)
@@ -80,7 +86,16 @@ __global__ __launch_bounds__(THREADS, 1) void gemm4w_k(const char* __restrict__ 
     const int kt = min(tt + NBUF, nk - 1);
 #pragma unroll
     for (int idx = 0; idx < NM; ++idx) {
-      const int pr = idx / (XT * YT), x = (idx % (XT * YT)) / YT, y = idx % YT;
+      // ORDER 0: product-major (an accumulator's three products are XT YT MFMAs apart); ORDER 1: column-tile-major (a
+      // column tile's 3 YT MFMAs back to back: the weight operand changes twice per six MFMAs instead of every second one)
+      const int pr = ORDER == 0 ? idx / (XT * YT) : (idx % (3 * YT)) / YT;
+      const int x = ORDER == 0 ? (idx % (XT * YT)) / YT : idx / (3 * YT);
+      const int y = idx % YT;
+      if constexpr (ORDER == 2) {
+        const int q = 4 * (x * YT + y) + 2 * (pr & 1);
+        acc4[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pr == 0 ? cur.al[x] : cur.ah[x], pr == 1 ? cur.bl[y] : cur.bh[y], acc4[q], 0, 0, 0);
+        acc4[q + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pr == 1 ? cur.bl[y] : cur.bh[y], pr == 0 ? cur.al[x] : cur.ah[x], acc4[q + 1], 0, 0, 0);
+      } else
       acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pr == 0 ? cur.al[x] : cur.ah[x], pr == 1 ? cur.bl[y] : cur.bh[y], acc[x][y], 0, 0, 0);
       // 30 side instructions over 48 MFMAs: the 20 reads first (their data is needed at the top of the next
       // iteration), the 10 DMA pieces after
@@ -142,6 +157,9 @@ __global__ __launch_bounds__(THREADS, 1) void gemm4w_k(const char* __restrict__ 
       for (int y = 0; y < YT; ++y)
 #pragma unroll
         for (int r = 0; r < 16; ++r) s += acc[x][y][r];
+    if constexpr (ORDER == 2)
+#pragma unroll
+      for (int q = 0; q < 4 * XT * YT; ++q) s += acc4[q][0] + acc4[q][1] + acc4[q][2] + acc4[q][3];
     sink[blockIdx.x * THREADS + t] = s;
   }
   if (t == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1)) {
@@ -172,15 +190,19 @@ int main() {
   const dim3 grid(M / BM), blk(THREADS);
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   std::vector<float> hcheck(static_cast<size_t>(M) * N);
-  for (int pass = 0; pass < 3; ++pass) {
-    const int store = pass == 1;
+  for (int pass = 0; pass < 5; ++pass) {
+    const int store = pass == 1, order = pass == 3 ? 1 : pass == 4 ? 2 : 0;   // pass 3: column-tile-major MFMA order, zero operands again? no: live operands restored
     // pass 2: the same loop on ALL-ZERO operands (after the check below has its outputs): same instructions, same
     // bytes, no toggling in the multipliers — what the clock does then says whether the limit is power
+    if (pass == 3) { CK(hipMemcpy(dA, ha.data(), abytes, hipMemcpyHostToDevice)); CK(hipMemcpy(dB, hb.data(), bbytes, hipMemcpyHostToDevice)); }
     if (pass == 2) { CK(hipMemcpy(hcheck.data(), dC, hcheck.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemset(dA, 0, abytes)); CK(hipMemset(dB, 0, bbytes)); }
 
     auto launch = [&]() {
-      if (store) gemm4w_k<true><<<grid, blk>>>(dA, (int64_t)N * ROWB, dB, (int64_t)M * ROWB, M, N, K, dC, sink, clk);
-      else gemm4w_k<false><<<grid, blk>>>(dA, (int64_t)N * ROWB, dB, (int64_t)M * ROWB, M, N, K, dC, sink, clk);
+      if (order == 2) gemm4w_k<false, 2><<<grid, blk>>>(dA, (int64_t)N * ROWB, dB, (int64_t)M * ROWB, M, N, K, dC, sink, clk);
+      else if (order) { if (store) gemm4w_k<true, 1><<<grid, blk>>>(dA, (int64_t)N * ROWB, dB, (int64_t)M * ROWB, M, N, K, dC, sink, clk);
+        else gemm4w_k<false, 1><<<grid, blk>>>(dA, (int64_t)N * ROWB, dB, (int64_t)M * ROWB, M, N, K, dC, sink, clk); }
+      else if (store) gemm4w_k<true, 0><<<grid, blk>>>(dA, (int64_t)N * ROWB, dB, (int64_t)M * ROWB, M, N, K, dC, sink, clk);
+      else gemm4w_k<false, 0><<<grid, blk>>>(dA, (int64_t)N * ROWB, dB, (int64_t)M * ROWB, M, N, K, dC, sink, clk);
     };
     for (int w = 0; w < 3; ++w) launch();
     CK(hipDeviceSynchronize());
@@ -193,7 +215,7 @@ int main() {
     const double us = ms / reps * 1e3;
     const double flop = 3.0 * 2.0 * M * N * K;
     printf("%s: %.1f us per launch, %.0f TF/s executed (%.2f of 2500), prologue %lld cycles, k loop %lld cycles = %.0f per k-step (48 MFMAs = 1536)\n",
-           pass == 2 ? "zero operands   " : store ? "with fp32 store " : "loop only       ", us, flop / us * 1e-6, flop / us * 1e-6 / 2500.0, hc[0], hc[1], (double)hc[1] / nk);
+           pass == 4 ? "16x16x32 shape  " : pass == 3 ? "tile-major order" : pass == 2 ? "zero operands   " : store ? "with fp32 store " : "loop only       ", us, flop / us * 1e-6, flop / us * 1e-6 / 2500.0, hc[0], hc[1], (double)hc[1] / nk);
     // wall_clock64: 100 MHz.  First and last workgroup of the grid: their prologue + loop in wall time, the shader clock that implies, when the last one started
     printf("   workgroup 0: %.1f us wall for %lld cycles = %.2f GHz; last workgroup: %.1f us wall for %lld cycles = %.2f GHz, started %.1f us after the first\n",
            hc[2] / 100.0, hc[0] + hc[1], (hc[0] + hc[1]) / (hc[2] / 100.0) * 1e-3, hc[6] / 100.0, hc[4] + hc[5], (hc[4] + hc[5]) / (hc[6] / 100.0) * 1e-3,
