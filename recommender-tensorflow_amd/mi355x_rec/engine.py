@@ -968,14 +968,14 @@ class DeepFM:
         return self._sort_unique(rows, n, self.R, tag)
 
     def _presort(self, next_ids, tag):
-        """The sort of the NEXT batch and the order its catch-up will walk its rows in (by staleness), on a side stream,
-        enqueued right before this step's catch-up: ~20 small launches that are bound by launch latency and leave most of
-        the chip idle (0.17 + 0.11 ms at config 3 alone).  Beside the catch-up — whose resident workgroups fill the CUs:
-        the side kernels get the slots its waves free, the sort ends about when the catch-up does, at +35 us for it — and
-        the gather (HBM-bound, short-lived workgroups), where the staleness order lands.  (Measured alternatives, kernel
-        timelines of tools/step_timeline.py: beside the sparse apply the apply takes 713 us instead of 631 and the
-        one-workgroup scan waits 350 us for a slot; beside the MLP's GEMMs, whose grids are whole waves of workgroups over
-        the 256 CUs, those lose 5-15 %.)  The sort is a pure function of next_ids.  The staleness order reads the rows'
+        """The sort of the NEXT batch, on a side stream, enqueued right before this step's catch-up: ~14 small launches
+        that are bound by launch latency and leave most of the chip idle (0.17 ms at config 3 alone).  Beside the catch-up
+        — whose resident workgroups fill half the wave slots: the sort ends about when the catch-up does, at +35 us for it.
+        (Measured alternatives, kernel timelines of tools/step_timeline.py: beside the sparse apply the apply takes 713 us
+        instead of 631 and the one-workgroup scan waits 350 us for a slot; beside the MLP's big GEMMs, whose grids are whole
+        waves of workgroups over the 256 CUs, those lose 5-15 %; after the head, beside the small layer-2 / layer-3 kernels of the backward: +0.03 ms per step, A/B on one
+        box.)  The sort is a pure function of next_ids.  The order the
+        next catch-up will walk the rows in (by staleness) follows later in the step: _by_gap_ahead.  It reads the rows'
         stamps BEFORE this step's apply has written this batch's: a row of both batches is filed under the gap it had
         before (its real gap is 0) — the order only decides which rows share a wave, the catch-up kernels read every row's
         stamp themselves.  (Each stamp is read once: mi_catchup_rows_by_gap materialises its keys before it counts them.)
@@ -987,13 +987,26 @@ class DeepFM:
         side.wait_stream(main)                       # next_ids exists, this step's own sort has left the shared workspace
         with torch.cuda.stream(side):
             out = self._sort_batch(next_ids, tag, side=True)
-            by_gap = None
-            n = next_ids.shape[0] * self.F
-            if self.adam_rows and n >= self.GAP_SORT_MIN and os.environ.get("MI_BYGAP_AHEAD", "1") == "1":
-                by_gap = self._rows_by_gap(out[1], out[3], n, self.step + 1, tag + "_ahead", side=True)
         # (the tensor itself is kept: while it is alive its memory cannot come back as another batch's)
         self._presorted = {"ids": next_ids, "version": next_ids._version, "tag": tag, "sorted": out, "stream": side,
-                           "by_gap": by_gap, "by_gap_step": self.step + 1}
+                           "by_gap": None, "by_gap_step": None}
+
+    def _by_gap_ahead(self):
+        """Second half of _presort, enqueued after the head: the staleness order of the next batch's rows, on the same side
+        stream, behind this step's forward.  There — the logits layer, the head and the small layer-3 kernels, ~0.15 ms in
+        which most of the chip idles — it costs nothing; right after the sort it ran beside the gather (HBM-bound: 176 ->
+        231 us) and the layer-1 forward GEMM (310 -> 374 us: kernel timelines, tools/step_timeline.py)."""
+        ps = self._presorted
+        if ps is None or not self.adam_rows or os.environ.get("MI_BYGAP_AHEAD", "1") != "1":
+            return
+        n = ps["ids"].shape[0] * self.F
+        if n < self.GAP_SORT_MIN:
+            return
+        side = ps["stream"]
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            ps["by_gap"] = self._rows_by_gap(ps["sorted"][1], ps["sorted"][3], n, self.step + 1, ps["tag"] + "_ahead", side=True)
+        ps["by_gap_step"] = self.step + 1
 
     def _rows_by_gap(self, uniq, num_uniq, n_max, step_to, tag="", side=False):
         """rows of equal staleness into the same wave (the replay runs as long as a wave's stalest row)"""
@@ -1060,6 +1073,7 @@ class DeepFM:
         # (3) forward + head
         c = self._forward(ids, x_num, True)
         logits, loss, dlogit = self._head(c, labels, True)
+        self._by_gap_ahead()
         # (4) backward through the MLP (+ numeric embeddings)
         d_concat = self._backward_dense(c, dlogit, fold_fm=True)
         # (5) sparse apply on the unique rows; the per-entry row gradients (deep_fm.py:54,81-87,39

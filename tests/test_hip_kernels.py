@@ -715,6 +715,53 @@ def test_route_requests_counts_runs_of_sorted_keys(lib, U, n_groups, Rl):
     assert np.array_equal(counts.cpu().numpy(), np.bincount(keys // Rl, minlength=n_groups))
 
 
+@pytest.mark.parametrize("world,self_rank,chunks", [(1, 0, 1), (8, -1, 1), (8, 3, 2), (4, 0, 4), (5, 4, 1)])
+def test_shard_keys_number_the_asking_rank_last(lib, world, self_rank, chunks):
+    """mi_shard_keys: key = ((chunk * world + pos(owner)) * rows_per_rank + local row), owner = row % world; pos is the
+    rank itself (self_rank = -1) or — self_rank >= 0 — the other ranks in rank order with the asking rank LAST, so that a
+    rank's requests to itself end every chunk's run (they never enter an exchange: DESIGN section 4)."""
+    rng = np.random.default_rng(world * 10 + chunks)
+    R, n = 100003, 4096 * chunks
+    rows = rng.integers(0, R, n).astype(np.int32)
+    Rl = (R + world - 1) // world
+    epc = n // chunks if chunks > 1 else 0
+    keys = torch.empty(n, dtype=torch.int32, device="cuda")
+    _chk(lib.mi_shard_keys(_p(dev(rows)), n, world, epc, Rl, self_rank, _p(keys), _st()))
+    o = rows.astype(np.int64) % world
+    if self_rank >= 0:
+        o = np.where(o == self_rank, world - 1, np.where(o > self_rank, o - 1, o))
+    chunk = (np.arange(n) // epc) if epc else 0
+    assert np.array_equal(keys.cpu().numpy(), ((chunk * world + o) * Rl + rows // world).astype(np.int32))
+    assert lib.mi_shard_keys(_p(dev(rows)), n, world, epc, Rl, world, _p(keys), _st()) != 0       # self_rank outside [-1, world)
+
+
+def test_entry_grads_segsum_writes_a_range_at_its_own_base(lib):
+    """mi_entry_grads_segsum(out_row0): request u is written at row u - out_row0 of the out buffers — a rank's requests to
+    itself are summed straight into the buffer its own apply reads.  The same range written both ways gives the same bits,
+    rows outside the range are not touched, and a base past the range's start is refused."""
+    rng = np.random.default_rng(77)
+    B, F, E = 512, 5, 16
+    n = B * F
+    rows = rng.integers(0, 300, n).astype(np.int32)                 # ~300 distinct requests, segments of ~8 entries
+    key = dev(rows)
+    se = torch.empty(n, dtype=torch.int32, device="cuda"); uq = torch.empty(n, dtype=torch.int32, device="cuda")
+    sg = torch.empty(n + 1, dtype=torch.int32, device="cuda"); nu = torch.empty(1, dtype=torch.int32, device="cuda")
+    ws = torch.empty(int(lib.mi_sort_unique_workspace_bytes(n)) + 256, dtype=torch.uint8, device="cuda")
+    _chk(lib.mi_sort_unique_rows(_p(key), n, 300, _p(se), _p(uq), _p(sg), _p(nu), _p(ws), ws.numel(), _st()))
+    U = int(nu.item())
+    d_concat = dev(rng.standard_normal((B, F * E)).astype(np.float32))
+    dl = dev(rng.standard_normal(B).astype(np.float32))
+    full_r = torch.full((U, E), 7.0, device="cuda"); full_l = torch.full((U,), 7.0, device="cuda")
+    _chk(lib.mi_entry_grads_segsum(None, _p(sg), _p(se), 0, U, _p(d_concat), F * E, None, None, _p(dl), 0, F, E, _p(full_r), _p(full_l), 0, _st()))
+    u0, cnt = U // 3, U // 2
+    part_r = torch.full((cnt + 2, E), 7.0, device="cuda"); part_l = torch.full((cnt + 2,), 7.0, device="cuda")
+    _chk(lib.mi_entry_grads_segsum(None, _p(sg), _p(se), u0, cnt, _p(d_concat), F * E, None, None, _p(dl), 0, F, E, _p(part_r), _p(part_l), u0, _st()))
+    assert torch.equal(part_r[:cnt], full_r[u0:u0 + cnt]) and torch.equal(part_l[:cnt], full_l[u0:u0 + cnt])
+    assert float(part_r[cnt:].min()) == 7.0 and float(part_l[cnt:].min()) == 7.0
+    assert lib.mi_entry_grads_segsum(None, _p(sg), _p(se), u0, cnt, _p(d_concat), F * E, None, None, _p(dl), 0, F, E, _p(part_r), _p(part_l),
+                                     u0 + 1, _st()) != 0
+
+
 def test_binary_predictions_match_oracle(lib):
     """mi_binary_predictions: get_binary_predictions / get_binary_losses (model_utils.py:9-36) per example."""
     rng = np.random.default_rng(5)
