@@ -395,6 +395,20 @@ def main():
     timers, m.timers = m.timers, None
     timers.update(roof_timers)                           # the roofline kernel's launches: those of the timed region
     log("instrumented pass: %.3f ms/step" % (idt / args.steps * 1e3))
+    # The roofline kernel once more WITHOUT the next batch's sort running beside it: in the timed region that sort (a side
+    # stream's small kernels, started beside the catch-up) ends under the gather and shares HBM with it; a few steps with
+    # the batches handed over one by one (the sort then runs at the head of the step, on the step's stream) give the
+    # kernel's own launch time.  Not part of `value`.
+    alone_ms = None
+    if presort[0] and shard is None:
+        presort[0] = False
+        run(3)
+        m.timers, m.k.timer_only = {}, roof_keys
+        timed(min(args.steps, 20))
+        at, m.timers, m.k.timer_only = m.timers, None, None
+        presort[0] = True
+        ak = kernel_ms(at)
+        alone_ms = next((v[0] for k, v in ak.items() if k in roof_keys), None)
 
     # What the sparse kernels of a steady-state step work on (a statistic for their rooflines, taken outside every timed
     # region with torch ops on the NEXT batch): distinct rows U, and over how many steps each has to be replayed.
@@ -616,6 +630,11 @@ def main():
                          "frac_of_measured_copy_peak": achieved / HBM_MEASURED_GBS,
                          "algorithmic_bytes_per_launch": int(gather_bytes), "examples_per_launch": int(Bl), "avg_launch_ms": g_ms,
                          "row_read_GBs": row_bytes / (g_ms * 1e-3) / 1e9, "row_read_frac": row_bytes / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "avg_launch_ms_without_side_stream": alone_ms,
+                         "frac_without_side_stream": (gather_bytes / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if alone_ms else None,
+                         "side_stream_note": ("in the timed region the next batch's sort (side stream, started beside the catch-up) ends "
+                                              "under this kernel and shares HBM with it; *_without_side_stream: the same launches over a "
+                                              "few steps whose batches were handed over one by one — the kernel by itself") if alone_ms else None,
                          "traffic": traffic,
                          "traffic_note": "HBM bytes/launch from rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE) of the same kernel on this workload, "
                                          "committed in profiles/traffic.json — a constant read from that file, not a counter of this run",

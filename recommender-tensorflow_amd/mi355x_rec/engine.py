@@ -1106,8 +1106,11 @@ class DeepFM:
         _, _, fan, h = self.layers[i]
         return B % 32 == 0 and fan % 128 == 0 and h % 128 == 0 and hasattr(self.k, "mi_dense_bwd_weight_planes")
 
-    def _backward_dense(self, c, dlogit, fold_fm=False):
+    def _backward_dense(self, c, dlogit, fold_fm=False, on_d_concat=None):
         """Fills self.d_grad (dense gradients) and returns d_concat [B, D] (or None).
+        on_d_concat (the row-sharded step): called with d_concat as soon as the input layer's DATA gradient is enqueued —
+        which then runs BEFORE that layer's weight gradient (both need only dY of layer 1): the requester-side segment sums
+        and the gradient exchange start there and travel under the largest weight-gradient GEMM and the dense all-reduce.
         fold_fm: the layer-1 data gradient may add the FM term's dlogit * sumv to d_concat (once per example
         instead of once per entry in the fused sparse apply); c["fm_folded"] tells whether it did.  Taken only
         with MI_FOLD_FM=1: it removes the apply's per-entry sumv reads (0.44 GB of 3.7 GB at config 3) but those
@@ -1131,17 +1134,21 @@ class DeepFM:
                 dyn = "dy%d" % i if i < nh else None
                 ga_w = self._ga("x%d" % i, dyn, None) if dyn else None
                 ga_d = self._ga(dyn, "w", "dy%d" % (i - 1) if i else None) if (dyn or i) else None
-                if self._wgrad_planes_ok(B, i):
-                    k.mi_dense_bwd_weight_planes(self._pl["x%dp" % i].struct, self._pl["dy%dp" % i].struct,
-                                                 self.kernel(i, self.d_grad), self.bias(i, self.d_grad), B, h, fan, ws,
-                                                 ws.numel(), ga_w)
-                elif i == 0 and c["gathered"]:
-                    k.mi_dense_bwd_weight_gathered(c["g_table"], c["g_off"], c["ids"], self.F, self.E, dy, lddy,
-                                                   self.kernel(0, self.d_grad), self.bias(0, self.d_grad), B, h, ws,
-                                                   ws.numel(), ga_w)
-                else:
-                    k.mi_dense_bwd_weight(x, ldx, dy, lddy, self.kernel(i, self.d_grad), self.bias(i, self.d_grad), B,
-                                          h, fan, ws, ws.numel(), ga_w)
+                def weight_gradient(i=i, fan=fan, h=h, x=x, ldx=ldx, dy=dy, lddy=lddy, ga_w=ga_w):
+                    if self._wgrad_planes_ok(B, i):
+                        k.mi_dense_bwd_weight_planes(self._pl["x%dp" % i].struct, self._pl["dy%dp" % i].struct,
+                                                     self.kernel(i, self.d_grad), self.bias(i, self.d_grad), B, h, fan, ws,
+                                                     ws.numel(), ga_w)
+                    elif i == 0 and c["gathered"]:
+                        k.mi_dense_bwd_weight_gathered(c["g_table"], c["g_off"], c["ids"], self.F, self.E, dy, lddy,
+                                                       self.kernel(0, self.d_grad), self.bias(0, self.d_grad), B, h, ws,
+                                                       ws.numel(), ga_w)
+                    else:
+                        k.mi_dense_bwd_weight(x, ldx, dy, lddy, self.kernel(i, self.d_grad), self.bias(i, self.d_grad), B,
+                                              h, fan, ws, ws.numel(), ga_w)
+                data_first = i == 0 and on_d_concat is not None
+                if not data_first:
+                    weight_gradient()
                 dx = self._buf("dact%d" % i, (B, fan))
                 if self.planes and i < nh:
                     # dY of this layer is at hand as planes ("dy<i>p": written by the layer above); the mask is
@@ -1177,6 +1184,9 @@ class DeepFM:
                     if self.planes and i == nh and i > 0:
                         # the logits layer's matrix-vector data gradient writes fp32: split it for the layer below
                         k.mi_split_rows(dx, fan, B, fan, 0, self._planes("dy%dp" % (i - 1), B, fan), self._av("dy%d" % (i - 1)))
+                if data_first:
+                    on_d_concat(dx)
+                    weight_gradient()
                 dy, lddy = dx, fan
             d_concat = dy
         if self.n_numeric and self.raw_numeric:

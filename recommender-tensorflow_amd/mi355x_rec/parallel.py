@@ -406,28 +406,35 @@ def _sharded_step(m, ids, labels, x_num, train, next_ids=None):
                     k.mi_axpy(loss_all, loss, 1, 1.0)
         if not train:
             continue
-        d_concat = m._backward_dense(cc, dlogit)
+        def send_gradients(d_concat, c=c, cc=cc, dlogit=dlogit):
+            """the chunk's entry gradients summed per distinct request, written at the request's send slot — those of the
+            rank's own rows straight into the buffer its apply reads — and the exchange started"""
+            ulo, um, uhi = uoff[c], umid[c], uoff[c + 1]
+            lo, mid, hi = roff[c], rmid[c], roff[c + 1]
+            for u0, cnt, o_rows, o_lin, row0 in ((ulo, um - ulo, d_rows, d_lin, 0),
+                                                (um, uhi - um, r_rows[mid:hi] if m.use_emb else None,
+                                                 r_lin[mid:hi] if m.use_linear else None, um)):
+                if cnt > 0:
+                    k.mi_entry_grads_segsum(got_rows if m.use_mf else None, seg, sorted_entry, u0, cnt,
+                                            d_concat if m.use_emb else None, m.D, cc["sumv"] if m.use_mf else None,
+                                            dlogit if m.use_mf else None, dlogit if m.use_linear else None, c * Bc, F, E,
+                                            o_rows, o_lin, row0)
+            if m.use_emb:
+                grad_h.append(comm.all_to_all(r_rows[lo:mid], d_rows[ulo:um], rc0[c], sc0[c], True))
+            if m.use_linear:
+                grad_h.append(comm.all_to_all(r_lin[lo:mid], d_lin[ulo:um], rc0[c], sc0[c], True))
+
+        # (with an MLP the gradients leave as soon as the input layer's data gradient is enqueued — before its weight
+        # gradient, the step's largest GEMM, and under it; without one there is only the wide part's dlogit)
+        sent = []
+        m._backward_dense(cc, dlogit, on_d_concat=(lambda d: (send_gradients(d), sent.append(1))) if m.use_dnn else None)
+        if not sent:
+            send_gradients(None)
         if C > 1:
             if c == 0:
                 acc.copy_(m.d_grad)
             else:
                 k.mi_axpy(acc, m.d_grad, m.P, 1.0)
-        # the chunk's entry gradients summed per distinct request, written at the request's send slot — those of the
-        # rank's own rows straight into the buffer its apply reads
-        ulo, um, uhi = uoff[c], umid[c], uoff[c + 1]
-        lo, mid, hi = roff[c], rmid[c], roff[c + 1]
-        for u0, cnt, o_rows, o_lin, row0 in ((ulo, um - ulo, d_rows, d_lin, 0),
-                                            (um, uhi - um, r_rows[mid:hi] if m.use_emb else None,
-                                             r_lin[mid:hi] if m.use_linear else None, um)):
-            if cnt > 0:
-                k.mi_entry_grads_segsum(got_rows if m.use_mf else None, seg, sorted_entry, u0, cnt,
-                                        d_concat if m.use_emb else None, m.D, cc["sumv"] if m.use_mf else None,
-                                        dlogit if m.use_mf else None, dlogit if m.use_linear else None, c * Bc, F, E,
-                                        o_rows, o_lin, row0)
-        if m.use_emb:
-            grad_h.append(comm.all_to_all(r_rows[lo:mid], d_rows[ulo:um], rc0[c], sc0[c], True))
-        if m.use_linear:
-            grad_h.append(comm.all_to_all(r_lin[lo:mid], d_lin[ulo:um], rc0[c], sc0[c], True))
     m._chunk = 0
     if C > 1:
         logits, loss = logits_all, (loss_all if loss is not None else None)
