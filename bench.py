@@ -81,6 +81,9 @@ def parse():
                     help="N = 1 only: run the row-sharded multi-GPU step with a one-rank RCCL group (every all_to_all is a "
                          "copy to self) — what the sharded step's own machinery costs next to the single-GPU step")
     ap.add_argument("--chunks", type=int, default=None, help="pipeline depth of the row-sharded step (default: parallel.py's)")
+    ap.add_argument("--chunk-compute", type=int, choices=[0, 1], default=None,
+                    help="row-sharded step: 1 = every chunk runs its own forward / backward, 0 = only the exchanges and the embedding-side "
+                         "kernels are chunked (default: parallel.RowShard's — 0 from 8 ranks on)")
     ap.add_argument("--no-presort", action="store_true",
                     help="do not announce the next batch's ids to train_step (its sort then runs at the head of the next step "
                          "instead of on a side stream beside this step's catch-up)")
@@ -307,7 +310,8 @@ def main():
     shard = None
     if world > 1 or args.force_shard:
         from mi355x_rec.parallel import RowShard
-        shard = RowShard(rank, world, chunks=args.chunks)
+        shard = RowShard(rank, world, chunks=args.chunks,
+                         chunk_compute=None if args.chunk_compute is None else bool(args.chunk_compute))
     m = DeepFM([V] * F, embedding_size=E, hidden_units=HIDDEN, dropout=DROPOUT,
                optimizer=OptimizerSpec("Adam", 0.001), device=device, seed=SEED, shard=shard, gemm=args.gemm,
                catchup=args.catchup)

@@ -682,10 +682,12 @@ class DeepFM:
         self.k.timers = v
 
     # ------------------------------------------------------------------ forward
-    def _forward(self, ids, x_num, train, src=None):
+    def _forward(self, ids, x_num, train, src=None, pieces=None):
         """ids [B,F] int32; returns the logit components and caches activations for the backward.
         src = (table, lin_w, field_off, ids) overrides where rows are read from (sharded path: the
-        rows received from their owners, addressed by slot)."""
+        rows received from their owners, addressed by slot).
+        pieces (sharded path): [(b0, b1, ready)] — the embedding-side kernels run once per range of examples, each after
+        ready() has ordered the stream behind that range's row exchange; the MLP runs once, on the whole batch."""
         k = self.k
         B = ids.shape[0]
         self._last_B = B
@@ -740,21 +742,39 @@ class DeepFM:
                                                             None, lin, None, ls)
             c["lin_join"] = side
         elif pl_gather:
-            k.mi_embed_fm_planes_fwd(table, field_off, rid, B, F, self.E, sumv, fm, self._planes("x0p", B, ld), rows_amax)
-            if lin is not None:
-                k.tagged("mi_embed_fm_linear_fwd", "/wide")(None, lin_w, w_off, w_ids, B, Fw, self.E, None, 0, None, None, lin, None, ls)
+            x0p = self._planes("x0p", B, ld)
+            for b0, b1, ready in (pieces or [(0, B, None)]):
+                if ready is not None:
+                    ready()
+                sl = slice(b0, b1)
+                # (rows b0.. of a k-block-major planes matrix: every block's rows are contiguous, 64 B each)
+                xp_ = x0p if (b0 == 0 and b1 == B) else _lib.Planes(x0p.data + 64 * b0, x0p.row_exp + 4 * b0, x0p.blk_stride)
+                k.mi_embed_fm_planes_fwd(table, field_off, rid[sl], b1 - b0, F, self.E, None if sumv is None else sumv[sl],
+                                         None if fm is None else fm[sl], xp_, rows_amax)
+                if lin is not None:
+                    k.tagged("mi_embed_fm_linear_fwd", "/wide")(None, lin_w, w_off, w_ids[sl], b1 - b0, Fw, self.E, None, 0, None, None,
+                                                                lin[sl], None, ls)
         elif concat is not None or sumv is not None or lin is not None or rows_amax is not None:
             emb_on = self.use_emb
             one_call = self.wide_idx is None                         # (a wide part on other columns: a call of its own)
-            if emb_on or one_call:
-                k.mi_embed_fm_linear_fwd(table if emb_on else None, lin_w if (self.use_linear and one_call) else None, field_off,
-                                         rid, B, F, self.E, concat if emb_on else None, ld, sumv, fm, lin if one_call else None,
-                                         rows_amax, ls)
-            if not one_call and lin is not None:
-                if Fw:
-                    k.mi_embed_fm_linear_fwd(None, lin_w, w_off, w_ids, B, Fw, self.E, None, 0, None, None, lin, None, ls)
-                else:
-                    lin.zero_()
+            for b0, b1, ready in (pieces or [(0, B, None)]):
+                if ready is not None:
+                    ready()
+                sl = slice(b0, b1)
+                v = lambda t: None if t is None else t[sl]
+                if emb_on or one_call:
+                    k.mi_embed_fm_linear_fwd(table if emb_on else None, lin_w if (self.use_linear and one_call) else None, field_off,
+                                             rid[sl], b1 - b0, F, self.E, v(concat) if emb_on else None, ld, v(sumv), v(fm),
+                                             v(lin) if one_call else None, rows_amax, ls)
+                if not one_call and lin is not None:
+                    if Fw:
+                        k.mi_embed_fm_linear_fwd(None, lin_w, w_off, w_ids[sl], b1 - b0, Fw, self.E, None, 0, None, None, lin[sl], None, ls)
+                    else:
+                        lin[sl].zero_()
+        elif pieces:
+            for _, _, ready in pieces:           # (nothing reads the rows here, but the exchanges must be joined)
+                if ready is not None:
+                    ready()
         if self.n_numeric:
             wn = self._seg(self.dense, self.lin_num_off, (self.n_numeric,)) if self.use_linear else None
             if self.raw_numeric:

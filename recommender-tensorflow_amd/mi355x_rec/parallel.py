@@ -32,12 +32,19 @@ import torch.distributed as dist
 
 
 class RowShard:
-    def __init__(self, rank, world, group=None, chunks=None):
-        """chunks: pipeline depth of a train step (None: chosen from the batch and world size, see _n_chunks)."""
+    def __init__(self, rank, world, group=None, chunks=None, chunk_compute=None):
+        """chunks: pipeline depth of a train step (None: chosen from the batch and world size, see _n_chunks).
+        chunk_compute: True — every chunk runs its own forward / backward (the exchanges of one chunk travel under the
+        whole compute of its neighbours; the MLP's GEMMs shrink to a chunk's examples); False — only the exchanges and
+        the embedding-side kernels are chunked, the MLP runs once on the whole batch (the row exchange travels under the
+        owners' gathers and the requester's embedding kernels, the gradient exchange under the input layer's weight
+        gradient); None: False from 8 ranks on (7 links per rank: the exchanges are short against the step), True below
+        (exchange-bound: as much compute as possible beside the links)."""
         if not (0 <= rank < world):
             raise ValueError("rank %d not in [0, %d)" % (rank, world))
         self.rank, self.world, self.group = int(rank), int(world), group
         self.chunks = chunks
+        self.chunk_compute = (self.world < 8) if chunk_compute is None else bool(chunk_compute)
         self.comm = None
 
     def local_rows(self, R):
@@ -386,61 +393,85 @@ def _sharded_step(m, ids, labels, x_num, train, next_ids=None):
     slot2 = slot.view(B, F)
     zero_off = _zero_off(m)
 
-    rows_h = serve(0)
     grad_h = []
-    loss = logits = None
-    for c in range(C):
-        nxt = serve(c + 1) if c + 1 < C else []          # on the links while chunk c computes
-        _wait(rows_h)
-        rows_h = nxt
-        sl = slice(c * Bc, (c + 1) * Bc)
-        m._chunk = c
-        cc = m._forward(ids[sl], None if x_num is None else x_num[sl], train, (got_rows, got_lin, zero_off, slot2[sl]))
-        logits, loss, dlogit = m._head(cc, None if labels is None else labels[sl], train, global_batch=B * m.shard.world)
-        if C > 1:
-            logits_all[sl].copy_(logits)
-            if loss is not None:
-                if c == 0:
-                    loss_all.copy_(loss)
-                else:
-                    k.mi_axpy(loss_all, loss, 1, 1.0)
-        if not train:
-            continue
-        def send_gradients(d_concat, c=c, cc=cc, dlogit=dlogit):
-            """the chunk's entry gradients summed per distinct request, written at the request's send slot — those of the
-            rank's own rows straight into the buffer its apply reads — and the exchange started"""
-            ulo, um, uhi = uoff[c], umid[c], uoff[c + 1]
-            lo, mid, hi = roff[c], rmid[c], roff[c + 1]
-            for u0, cnt, o_rows, o_lin, row0 in ((ulo, um - ulo, d_rows, d_lin, 0),
-                                                (um, uhi - um, r_rows[mid:hi] if m.use_emb else None,
-                                                 r_lin[mid:hi] if m.use_linear else None, um)):
-                if cnt > 0:
-                    k.mi_entry_grads_segsum(got_rows if m.use_mf else None, seg, sorted_entry, u0, cnt,
-                                            d_concat if m.use_emb else None, m.D, cc["sumv"] if m.use_mf else None,
-                                            dlogit if m.use_mf else None, dlogit if m.use_linear else None, c * Bc, F, E,
-                                            o_rows, o_lin, row0)
-            if m.use_emb:
-                grad_h.append(comm.all_to_all(r_rows[lo:mid], d_rows[ulo:um], rc0[c], sc0[c], True))
-            if m.use_linear:
-                grad_h.append(comm.all_to_all(r_lin[lo:mid], d_lin[ulo:um], rc0[c], sc0[c], True))
 
-        # (with an MLP the gradients leave as soon as the input layer's data gradient is enqueued — before its weight
-        # gradient, the step's largest GEMM, and under it; without one there is only the wide part's dlogit)
+    def send_gradients(c, d_concat, cc, dlogit, b0):
+        """chunk c's entry gradients summed per distinct request, written at the request's send slot — those of the
+        rank's own rows straight into the buffer its apply reads — and the exchange started.  (d_concat, sumv, dlogit
+        belong to examples b0.. of the local batch.)"""
+        ulo, um, uhi = uoff[c], umid[c], uoff[c + 1]
+        lo, mid, hi = roff[c], rmid[c], roff[c + 1]
+        for u0, cnt, o_rows, o_lin, row0 in ((ulo, um - ulo, d_rows, d_lin, 0),
+                                            (um, uhi - um, r_rows[mid:hi] if m.use_emb else None,
+                                             r_lin[mid:hi] if m.use_linear else None, um)):
+            if cnt > 0:
+                k.mi_entry_grads_segsum(got_rows if m.use_mf else None, seg, sorted_entry, u0, cnt,
+                                        d_concat if m.use_emb else None, m.D, cc["sumv"] if m.use_mf else None,
+                                        dlogit if m.use_mf else None, dlogit if m.use_linear else None, b0, F, E,
+                                        o_rows, o_lin, row0)
+        if m.use_emb:
+            grad_h.append(comm.all_to_all(r_rows[lo:mid], d_rows[ulo:um], rc0[c], sc0[c], True))
+        if m.use_linear:
+            grad_h.append(comm.all_to_all(r_lin[lo:mid], d_lin[ulo:um], rc0[c], sc0[c], True))
+
+    def backward(cc, dlogit, chunks, b0):
+        """MLP backward of the examples b0..; the gradients of `chunks` leave as soon as the input layer's data gradient
+        is enqueued — before its weight gradient, the step's largest GEMM, and under it (without an MLP there is only
+        the FM term's / the wide part's dlogit)"""
         sent = []
-        m._backward_dense(cc, dlogit, on_d_concat=(lambda d: (send_gradients(d), sent.append(1))) if m.use_dnn else None)
+
+        def go(d_concat):
+            for c in chunks:
+                send_gradients(c, d_concat, cc, dlogit, b0)
+            sent.append(1)
+        m._backward_dense(cc, dlogit, on_d_concat=go if m.use_dnn else None)
         if not sent:
-            send_gradients(None)
-        if C > 1:
-            if c == 0:
-                acc.copy_(m.d_grad)
-            else:
-                k.mi_axpy(acc, m.d_grad, m.P, 1.0)
+            go(None)
+
+    loss = logits = None
+    if C > 1 and not m.shard.chunk_compute:
+        # chunked exchanges, ONE forward / backward: every chunk's rows are served at once (gather, exchange, gather, ...),
+        # the embedding-side kernels of chunk c wait for its exchange only, the MLP sees the whole batch
+        handles = [serve(c) for c in range(C)]
+        pieces = [(c * Bc, (c + 1) * Bc, (lambda c=c: _wait(handles[c]))) for c in range(C)]
+        m._chunk = 0
+        cc = m._forward(ids, x_num, train, (got_rows, got_lin, zero_off, slot2), pieces=pieces)
+        logits, loss, dlogit = m._head(cc, labels, train, global_batch=B * m.shard.world)
+        if train:
+            backward(cc, dlogit, range(C), 0)
+        C_acc = 1
+    else:
+        C_acc = C
+        rows_h = serve(0)
+        for c in range(C):
+            nxt = serve(c + 1) if c + 1 < C else []          # on the links while chunk c computes
+            _wait(rows_h)
+            rows_h = nxt
+            sl = slice(c * Bc, (c + 1) * Bc)
+            m._chunk = c
+            cc = m._forward(ids[sl], None if x_num is None else x_num[sl], train, (got_rows, got_lin, zero_off, slot2[sl]))
+            logits, loss, dlogit = m._head(cc, None if labels is None else labels[sl], train, global_batch=B * m.shard.world)
+            if C > 1:
+                logits_all[sl].copy_(logits)
+                if loss is not None:
+                    if c == 0:
+                        loss_all.copy_(loss)
+                    else:
+                        k.mi_axpy(loss_all, loss, 1, 1.0)
+            if not train:
+                continue
+            backward(cc, dlogit, [c], c * Bc)
+            if C > 1:
+                if c == 0:
+                    acc.copy_(m.d_grad)
+                else:
+                    k.mi_axpy(acc, m.d_grad, m.P, 1.0)
     m._chunk = 0
-    if C > 1:
+    if C_acc > 1:
         logits, loss = logits_all, (loss_all if loss is not None else None)
     if not train:
         return loss, logits
-    if C > 1:
+    if C_acc > 1:
         m.d_grad.copy_(acc)
     comm.all_reduce(m.d_grad)                                   # dense gradients: SUM over ranks
     _wait(grad_h)

@@ -53,7 +53,7 @@ def _worker(rank, world, port, cfg, out_q, device="cpu", backend="gloo"):
         p, ids, x, y = _problem(cfg, world)
         lin_opt = OptimizerSpec(*extra["lin_opt"]) if "lin_opt" in extra else None
         m = DeepFM(vocab, n_numeric=nn, embedding_size=E, hidden_units=hidden, use_linear=flags[0], use_mf=flags[1],
-                   use_dnn=flags[2], optimizer=OptimizerSpec(opt_name, lr), device=device, shard=RowShard(rank, world, chunks=chunks),
+                   use_dnn=flags[2], optimizer=OptimizerSpec(opt_name, lr), device=device, shard=RowShard(rank, world, chunks=chunks, chunk_compute=extra.get("chunk_compute")),
                    numeric=extra.get("numeric", "embed"), linear_optimizer=lin_opt, reduction=extra.get("reduction", "mean"),
                    _kernels=kernels)
         m.load_oracle_params(p)
@@ -152,6 +152,24 @@ def test_next_batch_routed_ahead_equals_big_batch():
     res = _run(cfg, 2)
     check_against_big_batch(cfg, res, 2)
     assert all(res[r][1]["route_ahead_hits"] == 3 for r in range(2)), [res[r][1]["route_ahead_hits"] for r in range(2)]
+
+
+@pytest.mark.parametrize("cfg", [
+    ([9, 13, 5, 6], 8, [16, 8], 32, 0, "Adam", 0.001, 3, (True, True, True), 4, dict(chunk_compute=False, announce=True)),
+    ([11, 5, 9], 4, [12], 16, 2, "Adam", 0.001, 2, (True, True, True), 2, dict(chunk_compute=False)),          # numeric columns
+    ([7, 6, 5], 4, [], 16, 0, "Ftrl", 0.1, 2, (True, False, False), 2, dict(chunk_compute=False)),              # wide part only
+    ([9, 13, 5, 6], 8, [16, 8], 16, 3, "Adagrad", 0.05, 2, (True, False, True), 2,
+     dict(numeric="raw", lin_opt=("Ftrl", 0.2), reduction="sum", chunk_compute=False))])
+def test_chunked_exchanges_one_forward_equals_big_batch(cfg):
+    """RowShard(chunk_compute=False) — the default from 8 ranks on: the exchanges and the embedding-side kernels run per
+    chunk (every chunk's rows served at once, a chunk's embedding kernels behind its own exchange), the MLP once on the
+    whole batch, the gradient exchange started from inside the backward (after the input layer's data gradient)."""
+    check_against_big_batch(cfg, _run(cfg, 2), 2)
+
+
+def test_four_rank_chunked_exchanges_one_forward():
+    cfg = ([9, 13, 5, 6], 8, [16, 8], 16, 0, "Adam", 0.001, 3, (True, True, True), 2, dict(chunk_compute=False))
+    check_against_big_batch(cfg, _run(cfg, 4), 4)
 
 
 def test_four_rank_pipelined_step_equals_big_batch():

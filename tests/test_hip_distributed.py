@@ -17,13 +17,17 @@ pytestmark = pytest.mark.gpu
                                  # BASELINE config 5's model shape: 40 fields, E=128, [512,256,128], row-sharded, pipelined
                                  ([13] * 40, 128, [512, 256, 128], 128, 0, "Adam", 0.001, 2, (True, True, True), 2),
                                  # BASELINE config 4's model: Wide&Deep + raw numeric columns, Ftrl + Adagrad, SUM loss
-                                 CASES[7]])
+                                 CASES[7],
+                                 # chunked exchanges, one forward / backward (the default from 8 ranks on), config-5 shape
+                                 ([13] * 40, 128, [512, 256, 128], 128, 0, "Adam", 0.001, 2, (True, True, True), 2, dict(chunk_compute=False)),
+                                 ([50, 30, 20, 40], 64, [64, 32], 256, 0, "Adam", 0.001, 3, (True, True, True), 2,
+                                  dict(chunk_compute=False, announce=True))])
 def test_two_ranks_one_gpu_gloo(cfg):
     check_against_big_batch(cfg, _run(cfg, 2, device="cuda", backend="gloo"), 2, tol=3.0)
 
 
-@pytest.mark.parametrize("chunks", [1, 3])
-def test_single_rank_rccl_path(chunks):
+@pytest.mark.parametrize("chunks,chunk_compute", [(1, True), (3, True), (3, False)])
+def test_single_rank_rccl_path(chunks, chunk_compute):
     """chunks = 3: the asynchronous all_to_all handles of the pipelined step on RCCL's own stream"""
-    cfg = ([50, 30, 20, 40], 16, [32, 16], 96, 0, "Adam", 0.001, 3, (True, True, True), chunks)
+    cfg = ([50, 30, 20, 40], 16, [32, 16], 96, 0, "Adam", 0.001, 3, (True, True, True), chunks, dict(chunk_compute=chunk_compute))
     check_against_big_batch(cfg, _run(cfg, 1, device="cuda", backend="nccl"), 1, tol=3.0)
