@@ -47,7 +47,7 @@ enum mi_status {
 };
 
 /* ---- library ---------------------------------------------------------------------------- */
-int32_t mi_abi_version(void);       /* bumps when a signature changes (currently 17) */
+int32_t mi_abi_version(void);       /* bumps when a signature changes (currently 18) */
 const char* mi_last_error(void);    /* thread-local, never NULL */
 const char* mi_build_info(void);    /* "gfx950 hipcc <ver>" */
 
@@ -127,11 +127,15 @@ int32_t mi_embed_fm_linear_fwd(const float* table, const float* lin_w, const int
  * the layer-1 GEMMs mi_dense_fwd_planes / mi_dense_bwd_weight_planes.  One exponent per example, from the
  * example's abs-max over all F*E values (the lane group that gathers an example holds all its rows in
  * registers).  Also sumv / fm as above and amax_rows.  E a multiple of 16 and >= 32, F <= 48; the wide part
- * is mi_embed_fm_linear_fwd(table = NULL). */
+ * is mi_embed_fm_linear_fwd(table = NULL).
+ * x_num [B, n_numeric], tail_cols (0: none): the canned estimators' raw numeric columns (linear_deep.py:32-39 with
+ * numeric_column()s in dnn_feature_columns) — the values themselves follow the embedding columns as columns
+ * F*E .. F*E + tail_cols of the concat (n_numeric values, then zeros; tail_cols a multiple of 16, at most 4 E), under the
+ * example's one exponent: the fp32 concat, its abs-max pass and its split into planes are never made. */
 struct mi_planes;
 int32_t mi_embed_fm_planes_fwd(const float* table, const int64_t* field_off, const int32_t* ids, int64_t B, int32_t F,
                                int32_t E, float* sumv, float* fm, const struct mi_planes* concat, float* amax_rows,
-                               mi_stream_t stream);
+                               const float* x_num, int32_t n_numeric, int32_t tail_cols, mi_stream_t stream);
 
 /* Owner-side half of the row-sharded path (multi-GPU): out_rows[i,:] = table[rows[i],:],
  * out_lin[i] = lin_w[rows[i] * lin_stride].  rows [n] int32 local row ids; table (with out_rows) or lin_w

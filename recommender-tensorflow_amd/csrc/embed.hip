@@ -133,7 +133,7 @@ template <int LPR, int FC>
 __global__ __launch_bounds__(kBlock) void embed_fm_planes_fwd_k(
     const float* __restrict__ table, const int64_t* __restrict__ field_off, const int32_t* __restrict__ ids, int64_t B,
     int F, int E, float* __restrict__ sumv, float* __restrict__ fm, char* __restrict__ planes, int64_t ldp_b,
-    int32_t* __restrict__ row_exp, float* __restrict__ amax_rows) {
+    int32_t* __restrict__ row_exp, float* __restrict__ amax_rows, const float* __restrict__ x_num, int nd, int tail_cols) {
   static_assert(LPR >= 8, "planes gather: E >= 32");
   const int64_t g = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) / LPR;
   const int l = threadIdx.x & (LPR - 1);
@@ -168,6 +168,24 @@ __global__ __launch_bounds__(kBlock) void embed_fm_planes_fwd_k(
       mx = fmaxf(fmaxf(mx, fmaxf(fabsf(r[f].x), fabsf(r[f].y))), fmaxf(fabsf(r[f].z), fabsf(r[f].w)));
     }
   }
+  // The canned estimators' raw numeric columns: the values themselves follow the embedding columns in the
+  // input_layer concat — columns F E .. F E + tail_cols of the planes (nd values, then zeros: whole k-tiles).  They share
+  // the example's exponent, so they join its abs-max; the FM sums above do not see them (no FM term there).
+  constexpr int kTailMax = 4;                      // float4 per lane: tail_cols <= 16 LPR
+  float4 tv[kTailMax];
+#pragma unroll
+  for (int c = 0; c < kTailMax; ++c) {
+    tv[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int col = c * 4 * LPR + 4 * l;
+    if (col < tail_cols && valid) {
+      const float* xr = x_num + b * nd;
+      if (col < nd) tv[c].x = xr[col];
+      if (col + 1 < nd) tv[c].y = xr[col + 1];
+      if (col + 2 < nd) tv[c].z = xr[col + 2];
+      if (col + 3 < nd) tv[c].w = xr[col + 3];
+      mx = fmaxf(fmaxf(mx, fmaxf(fabsf(tv[c].x), fabsf(tv[c].y))), fmaxf(fabsf(tv[c].z), fabsf(tv[c].w)));
+    }
+  }
   float t = ((__fmul_rn(s.x, s.x) - q.x) + (__fmul_rn(s.y, s.y) - q.y)) +
             ((__fmul_rn(s.z, s.z) - q.z) + (__fmul_rn(s.w, s.w) - q.w));
   t = group_sum<LPR>(t);
@@ -183,24 +201,28 @@ __global__ __launch_bounds__(kBlock) void embed_fm_planes_fwd_k(
       if (fm) fm[b] = 0.5f * t;
       row_exp[b] = sx;
     }
+    // 4 k of one example: 8 bytes of the high plane, 8 of the low one, in k-block (k >> 4) at planes + (k >> 4) * ldp_b
+    auto store4 = [&](int k, const float4& v) {
+      const e_f32x2 u01 = {v.x * sc, v.y * sc}, u23 = {v.z * sc, v.w * sc};
+      const e_h16x2 h01 = __builtin_convertvector(u01, e_h16x2), h23 = __builtin_convertvector(u23, e_h16x2);
+      const e_f32x2 d01 = {u01[0] - static_cast<float>(h01[0]), u01[1] - static_cast<float>(h01[1])};
+      const e_f32x2 d23 = {u23[0] - static_cast<float>(h23[0]), u23[1] - static_cast<float>(h23[1])};
+      const e_h16x2 l01 = __builtin_convertvector(d01, e_h16x2), l23 = __builtin_convertvector(d23, e_h16x2);
+      char* d = planes + b * 64 + (k & 15) * 2 + (k >> 4) * ldp_b;
+      // (tried here, no gain: non-temporal stores, 0.188 vs 0.175 ms per launch; a DPP quad exchange so that every
+      // lane stores a whole 16-byte piece of the block instead of two 8-byte halves, 0.168-0.176 vs 0.166-0.18)
+      *reinterpret_cast<uint2*>(d) = make_uint2(__builtin_bit_cast(uint32_t, h01), __builtin_bit_cast(uint32_t, h23));
+      *reinterpret_cast<uint2*>(d + 32) = make_uint2(__builtin_bit_cast(uint32_t, l01), __builtin_bit_cast(uint32_t, l23));
+    };
     if (lane_on) {
-      char* prow = planes + b * 64 + (eo & 15) * 2;      // k-block major: block (k >> 4) at planes + (k >> 4) * ldp_b
 #pragma unroll
-      for (int f = 0; f < FC; ++f) {
-        if (f < F) {
-          const int k = f * E + eo;
-          const e_f32x2 u01 = {r[f].x * sc, r[f].y * sc}, u23 = {r[f].z * sc, r[f].w * sc};
-          const e_h16x2 h01 = __builtin_convertvector(u01, e_h16x2), h23 = __builtin_convertvector(u23, e_h16x2);
-          const e_f32x2 d01 = {u01[0] - static_cast<float>(h01[0]), u01[1] - static_cast<float>(h01[1])};
-          const e_f32x2 d23 = {u23[0] - static_cast<float>(h23[0]), u23[1] - static_cast<float>(h23[1])};
-          const e_h16x2 l01 = __builtin_convertvector(d01, e_h16x2), l23 = __builtin_convertvector(d23, e_h16x2);
-          char* d = prow + (k >> 4) * ldp_b;
-          // (tried here, no gain: non-temporal stores, 0.188 vs 0.175 ms per launch; a DPP quad exchange so that every
-          // lane stores a whole 16-byte piece of the block instead of two 8-byte halves, 0.168-0.176 vs 0.166-0.18)
-          *reinterpret_cast<uint2*>(d) = make_uint2(__builtin_bit_cast(uint32_t, h01), __builtin_bit_cast(uint32_t, h23));
-          *reinterpret_cast<uint2*>(d + 32) = make_uint2(__builtin_bit_cast(uint32_t, l01), __builtin_bit_cast(uint32_t, l23));
-        }
-      }
+      for (int f = 0; f < FC; ++f)
+        if (f < F) store4(f * E + eo, r[f]);
+    }
+#pragma unroll
+    for (int c = 0; c < kTailMax; ++c) {
+      const int col = c * 4 * LPR + 4 * l;
+      if (col < tail_cols) store4(F * E + col, tv[c]);
     }
   }
   if (amax_rows) mi_amax_publish(amax_rows, mx);
@@ -479,7 +501,7 @@ int32_t mi_embed_fm_linear_fwd(const float* table, const float* lin_w, const int
 
 int32_t mi_embed_fm_planes_fwd(const float* table, const int64_t* field_off, const int32_t* ids, int64_t B, int32_t F,
                                int32_t E, float* sumv, float* fm, const mi_planes_t* concat, float* amax_rows,
-                               mi_stream_t stream) {
+                               const float* x_num, int32_t n_numeric, int32_t tail_cols, mi_stream_t stream) {
   if (int32_t rc = check_E("embed_fm_planes_fwd", E)) return rc;
   MI_REQUIRE(B >= 0 && F > 0, "embed_fm_planes_fwd: B=%lld F=%d", (long long)B, F);
   if ((E & 15) || E < 32 || F > 48) {
@@ -490,14 +512,20 @@ int32_t mi_embed_fm_planes_fwd(const float* table, const int64_t* field_off, con
   MI_REQUIRE(concat->blk_stride >= B * 64 && (concat->blk_stride & 63) == 0 && mi::aligned16(concat->data) && mi::aligned16(table) &&
                  (!sumv || mi::aligned16(sumv)), "embed_fm_planes_fwd: planes block stride / alignment");
   MI_REQUIRE(!fm || sumv, "embed_fm_planes_fwd: fm needs sumv");
+  MI_REQUIRE(tail_cols >= 0 && (tail_cols & 15) == 0 && n_numeric >= 0 && n_numeric <= tail_cols && (tail_cols == 0 || x_num),
+             "embed_fm_planes_fwd: %d numeric columns in a tail of %d (whole 16-k blocks, x_num given)", n_numeric, tail_cols);
   if (B == 0) return MI_OK;
   const int lpr = lanes_per_row(E);
+  if (tail_cols > 4 * E) {                       // (the kernel holds 4 float4 of tail per lane: 16 lpr >= 4 E columns)
+    mi::set_error("embed_fm_planes_fwd: a tail of %d columns needs E >= %d (E=%d)", tail_cols, tail_cols / 4, E);
+    return MI_ERR_UNSUPPORTED;
+  }
   const int64_t blocks = mi::ceil_div(B * lpr, kBlock);
   MI_REQUIRE(blocks <= INT32_MAX, "embed_fm_planes_fwd: grid too large");
   char* pd = static_cast<char*>(concat->data);
   const dim3 g((unsigned)blocks), blk(kBlock);
   hipStream_t st = mi::as_stream(stream);
-#define MI_PL_GATHER(L, FCAP) embed_fm_planes_fwd_k<L, FCAP><<<g, blk, 0, st>>>(table, field_off, ids, B, F, E, sumv, fm, pd, concat->blk_stride, concat->row_exp, amax_rows)
+#define MI_PL_GATHER(L, FCAP) embed_fm_planes_fwd_k<L, FCAP><<<g, blk, 0, st>>>(table, field_off, ids, B, F, E, sumv, fm, pd, concat->blk_stride, concat->row_exp, amax_rows, x_num, n_numeric, tail_cols)
   if (F <= 32) {
     switch (lpr) {
       case 8: MI_PL_GATHER(8, 32); break;

@@ -348,7 +348,10 @@ class DeepFM:
                 rows += [self.D_emb + j for j in range(self.n_numeric) if self.deep_numeric is None or self.deep_numeric[j]]
             self._k0_rows = np.asarray(rows, np.int64)
             self.D_logical = len(rows)
-        self.D = _align(self.D_in, 32) if (self.raw_numeric and self.use_dnn) else self.D_in
+        # (wide input layers — config 4 at config 3's sizes, 1664 + 13 columns: to a multiple of 128, the k-tile of the planes
+        # weight gradient; with the gather writing the numeric columns into the planes itself, see pl_numeric below)
+        d_align = 128 if (self.D_in >= 512 and use_dnn and len(hidden_units) > 0 and int(hidden_units[0]) % 128 == 0) else 32
+        self.D = _align(self.D_in, d_align) if (self.raw_numeric and self.use_dnn) else self.D_in
         self.layers = []                         # (kernel_off, bias_off, fan_in as stored, fan_out)
         o = 0
         if self.use_dnn:
@@ -421,6 +424,11 @@ class DeepFM:
         self.pl_gather_ok = self.E % 16 == 0 and self.E >= 32 and self.F <= 48
         if self.planes and self.gather_mlp and not self.pl_gather_ok:
             self.gather_mlp = False
+        # raw numeric columns (canned Wide&Deep, config 4) on the planes path: the gather writes them into the planes as
+        # the concat's tail, under the example's exponent — no fp32 concat, no abs-max pass over it, no split
+        # (config 4 at config 3's sizes: 0.36 + 0.12 ms of a 3.0 ms step, and the fp32 concat's 0.47 GB written)
+        self.pl_numeric = bool(self.planes and self.raw_numeric and self.use_dnn and self.F > 0 and self.pl_gather_ok and
+                               0 < self.D - self.F * self.E <= 4 * self.E and getattr(self.k, "supports_planes", False))
 
     # ------------------------------------------------------------------ variables
     def _slots(self, like, spec):
@@ -704,9 +712,10 @@ class DeepFM:
         concat = sumv = fm = None
         ld = self.D
         gathered = self.gather_mlp
+        no_concat = gathered or self.pl_numeric          # layer 1 reads the rows / the planes the gather wrote
         F = self.F
         if self.use_emb:
-            concat = None if gathered else self._buf("concat", (B, ld))
+            concat = None if no_concat else self._buf("concat", (B, ld))
             sumv = self._buf("sumv", (B, self.E)) if self.use_mf else None
             fm = self._buf("fm", (B,)) if self.use_mf else None
         elif self.raw_numeric and self.use_dnn:
@@ -715,9 +724,10 @@ class DeepFM:
         f16 = self.gemm == "f16x2" and self.use_dnn
         if f16:
             self._amax.zero_()
-        rows_amax = self._av("x0") if (f16 and gathered) else None
+        rows_amax = self._av("x0") if (f16 and no_concat) else None
         # planes path, layer 1: the gather itself writes the concat as planes (one exponent per example)
-        pl_gather = self.planes and gathered and self.pl_gather_ok
+        pl_gather = self.planes and no_concat and self.pl_gather_ok
+        tail = (x_num, self.n_numeric, self.D - F * self.E) if self.pl_numeric else (None, 0, 0)
         # The wide part's 4-byte weight gathers drag a whole sector each through the row-gather kernel
         # (3.9 vs 4.9 TB/s of row bytes).  On a single GPU they run as their own kernel on a side stream
         # under the matrix-bound layer-1 GEMM instead; the head joins the two streams.
@@ -731,7 +741,7 @@ class DeepFM:
                     t.zero_()
         elif side_lin:
             if pl_gather:
-                k.mi_embed_fm_planes_fwd(table, field_off, rid, B, F, self.E, sumv, fm, self._planes("x0p", B, ld), rows_amax)
+                k.mi_embed_fm_planes_fwd(table, field_off, rid, B, F, self.E, sumv, fm, self._planes("x0p", B, ld), rows_amax, *tail)
             elif concat is not None or sumv is not None or rows_amax is not None:
                 k.mi_embed_fm_linear_fwd(table, None, field_off, rid, B, F, self.E, concat, ld, sumv, fm, None,
                                          rows_amax, 1)
@@ -750,7 +760,8 @@ class DeepFM:
                 # (rows b0.. of a k-block-major planes matrix: every block's rows are contiguous, 64 B each)
                 xp_ = x0p if (b0 == 0 and b1 == B) else _lib.Planes(x0p.data + 64 * b0, x0p.row_exp + 4 * b0, x0p.blk_stride)
                 k.mi_embed_fm_planes_fwd(table, field_off, rid[sl], b1 - b0, F, self.E, None if sumv is None else sumv[sl],
-                                         None if fm is None else fm[sl], xp_, rows_amax)
+                                         None if fm is None else fm[sl], xp_, rows_amax,
+                                         None if tail[0] is None else tail[0][sl], tail[1], tail[2])
                 if lin is not None:
                     k.tagged("mi_embed_fm_linear_fwd", "/wide")(None, lin_w, w_off, w_ids[sl], b1 - b0, Fw, self.E, None, 0, None, None,
                                                                 lin[sl], None, ls)
@@ -778,8 +789,10 @@ class DeepFM:
         if self.n_numeric:
             wn = self._seg(self.dense, self.lin_num_off, (self.n_numeric,)) if self.use_linear else None
             if self.raw_numeric:
-                # canned input_layer: the values themselves (+ zero pad) follow the embedding columns
-                k.mi_numeric_raw_fwd(x_num, wn, B, self.n_numeric, concat, ld, self.D_emb, ld - self.D_emb, lin)
+                # canned input_layer: the values themselves (+ zero pad) follow the embedding columns (pl_numeric: the
+                # gather has written them into the planes; what is left here is the wide part's x . w)
+                if concat is not None or lin is not None:
+                    k.mi_numeric_raw_fwd(x_num, wn, B, self.n_numeric, concat, ld, self.D_emb, ld - self.D_emb, lin)
             else:
                 V = self._seg(self.dense, self.num_emb_off, (self.n_numeric, self.E))
                 k.mi_numeric_embed_fwd(x_num, V, wn, B, self.n_numeric, self.E, concat, ld, F * self.E, sumv, fm, lin)
@@ -789,7 +802,7 @@ class DeepFM:
         if self.use_dnn:
             x, ldx = concat, ld
             if f16:
-                if not gathered:
+                if not no_concat:
                     k.mi_absmax(concat, B * ld, self._av("x0"))
                 if not self.planes:
                     # one bound for every layer's weights: the abs-max over the whole MLP parameter block
@@ -1164,6 +1177,9 @@ class DeepFM:
                                                        self.kernel(0, self.d_grad), self.bias(0, self.d_grad), B, h, ws,
                                                        ws.numel(), ga_w)
                     else:
+                        if x is None:     # (pl_numeric, a batch the planes weight gradient does not take: the concat back in fp32)
+                            x = self._buf("concat", (B, ldx))
+                            k.mi_merge_rows(self._pl["x0p"].struct, B, ldx, x, ldx)
                         k.mi_dense_bwd_weight(x, ldx, dy, lddy, self.kernel(i, self.d_grad), self.bias(i, self.d_grad), B,
                                               h, fan, ws, ws.numel(), ga_w)
                 data_first = i == 0 and on_d_concat is not None

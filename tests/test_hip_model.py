@@ -308,14 +308,18 @@ def test_config4_full_size_properties():
     ids = torch.randint(0, V, (B, F), device="cuda", dtype=torch.int32, generator=g)
     x = torch.log1p(-torch.log(torch.rand(B, ND, device="cuda", generator=g).clamp_min(1e-12)))   # log1p(Exp(1)), SURVEY 8d
     y = (torch.rand(B, device="cuda", generator=g) < 0.25).to(torch.uint8)
-    assert m.D_in == F * E + ND and m.D == 1696 and m.lin_opt.name == "Ftrl"
+    assert m.D_in == F * E + ND and m.D == 1792 and m.pl_numeric and m.lin_opt.name == "Ftrl"    # (the planes weight gradient's k-tile)
     table0, lin0 = m.table.clone(), m.lin_w.clone()
     rows = ids.long() + m.field_off[None, :]
     loss0 = m.loss(ids, y, x)[0].item()          # (the returned tensor is workspace the next step overwrites)
-    concat = m._ws["concat"][:B * m.D].view(B, m.D)
+    # the input_layer concat exists as planes only (the gather writes embedding rows, the numeric values and the zero pad
+    # under one exponent per example: engine.pl_numeric): back to fp32, every value within 2^-21 of its example's maximum
+    concat = torch.empty(B, m.D, device="cuda")
+    m.k.mi_merge_rows(m._pl["x0p"].struct, B, m.D, concat, m.D)
     sel = torch.arange(0, B, 1009, device="cuda")
-    assert torch.equal(concat[sel, :F * E].reshape(-1, F, E), m.table[rows[sel]])      # exact-copy gather
-    assert torch.equal(concat[sel, F * E:F * E + ND], x[sel])                            # the values themselves
+    want = torch.cat([m.table[rows[sel]].reshape(len(sel), F * E), x[sel]], 1)
+    bound = want.abs().max(1, keepdim=True).values * 2.0 ** -21
+    assert bool(((concat[sel, :F * E + ND] - want).abs() <= bound).all())                # the rows and the values themselves
     assert float(concat[:, F * E + ND:].abs().max()) == 0.0                             # zero pad
     losses = _props_after_steps(m, ids, y, x, table0, rows)
     assert losses[0] == pytest.approx(loss0, rel=2e-2)     # (the training forward drops 10 % of the units)

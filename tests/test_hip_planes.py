@@ -264,31 +264,48 @@ def test_planes_entries_refuse_bad_shapes(lib):
         _chk(lib.mi_dense_fwd_planes(xp2.ref, w2.ref, None, None, 0, yp.ref, 64, 1024, 32, 0, 1.0, 0, None, _st()))
 
 
-@pytest.mark.parametrize("E,F,B", [(64, 26, 300), (128, 40, 65), (32, 5, 129), (48, 3, 17)])
-def test_embed_fm_planes_fwd(lib, E, F, B):
+@pytest.mark.parametrize("E,F,B,nd,tail", [(64, 26, 300, 0, 0), (128, 40, 65, 0, 0), (32, 5, 129, 0, 0), (48, 3, 17, 0, 0),
+                                           (64, 26, 300, 13, 32), (64, 26, 129, 13, 128), (32, 5, 65, 16, 16), (48, 3, 17, 1, 16),
+                                           (128, 7, 33, 40, 64)])
+def test_embed_fm_planes_fwd(lib, E, F, B, nd, tail):
     """the gather that writes the concat as planes: same bits as mi_split_rows of the materialised concat;
-    sumv / fm equal to the fp32 gather kernel's."""
+    sumv / fm equal to the fp32 gather kernel's.  nd / tail: the canned estimators' raw numeric columns — nd values and
+    tail - nd zero columns after the embedding columns, under the example's one exponent (an example whose largest value
+    is a numeric column takes its exponent from it)."""
     rng = np.random.default_rng(E + F + B)
     vocab = rng.integers(2, 50, F)
     off = np.concatenate([[0], np.cumsum(vocab)]).astype(np.int64)
     table = rng.standard_normal((int(off[-1]), E)).astype(np.float32)
     table[:3] *= np.float32(2.0 ** -20)
     ids = np.stack([rng.integers(0, v, B) for v in vocab], 1).astype(np.int32)
+    x = None
+    if nd:
+        x = rng.standard_normal((B, nd)).astype(np.float32)
+        x[::3] *= np.float32(40.0)                       # every third example: a numeric column is the largest value
+        x[1::7] *= np.float32(2.0 ** -12)
     t, fo, di = dev(table), dev(off[:-1].copy()), dev(ids)
-    cp = PB(lib, B, F * E, pad=1)
+    dx = dev(x) if nd else None
+    cp = PB(lib, B, F * E + tail, pad=1)
     sumv = torch.empty(B, E, device="cuda"); fm = torch.empty(B, device="cuda"); amax = torch.zeros(64, device="cuda")
     _chk(lib.mi_embed_fm_planes_fwd(t.data_ptr(), fo.data_ptr(), di.data_ptr(), B, F, E, sumv.data_ptr(), fm.data_ptr(), cp.ref,
-                                    amax.data_ptr(), _st()))
+                                    amax.data_ptr(), dx.data_ptr() if nd else None, nd, tail, _st()))
     concat = torch.empty(B, F * E, device="cuda"); sumv2 = torch.empty(B, E, device="cuda"); fm2 = torch.empty(B, device="cuda")
     _chk(lib.mi_embed_fm_linear_fwd(t.data_ptr(), None, fo.data_ptr(), di.data_ptr(), B, F, E, concat.data_ptr(), F * E,
                                     sumv2.data_ptr(), fm2.data_ptr(), None, None, 1, _st()))
     rows = ids.astype(np.int64) + off[:-1][None, :]
     assert np.array_equal(concat.cpu().numpy(), table[rows].reshape(B, F * E))
-    hb, he = host_planes(concat.cpu().numpy())
+    full = concat.cpu().numpy()
+    if tail:
+        full = np.concatenate([full, x, np.zeros((B, tail - nd), np.float32)], 1)
+    hb, he = host_planes(full)
     assert np.array_equal(cp.exp.cpu().numpy(), he)
     assert np.array_equal(cp.bits(), hb)
     assert torch.equal(sumv, sumv2) and torch.equal(fm, fm2)
-    assert float(amax.max()) == float(np.abs(table[rows]).max())
+    assert float(amax.max()) == float(np.abs(full).max())
+    if tail:      # refused: a tail that is no whole number of k-blocks, more numeric columns than the tail holds, a tail wider than 4 E
+        assert lib.mi_embed_fm_planes_fwd(t.data_ptr(), fo.data_ptr(), di.data_ptr(), B, F, E, None, None, cp.ref, None, dx.data_ptr(), nd, tail + 8, _st()) != 0
+        assert lib.mi_embed_fm_planes_fwd(t.data_ptr(), fo.data_ptr(), di.data_ptr(), B, F, E, None, None, cp.ref, None, dx.data_ptr(), tail + 1, tail, _st()) != 0
+        assert lib.mi_embed_fm_planes_fwd(t.data_ptr(), fo.data_ptr(), di.data_ptr(), B, F, E, None, None, cp.ref, None, dx.data_ptr(), nd, 4 * E + 16, _st()) != 0
 
 
 def test_split_weights_one_launch(lib):

@@ -28,6 +28,16 @@ def run(name, m, B, n_num, vocab, steps=20):
         l, _ = m.train_step(*bs[i % 4])
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
     losses.append(l.item())
+    if os.environ.get("MI_BREAKDOWN"):
+        # per-entry HIP-event times of a few more steps (each launch bracketed: ~10 us of bubble per launch)
+        m.timers = {}
+        for i in range(6):
+            m.train_step(*bs[i % 4])
+        torch.cuda.synchronize()
+        tm, m.timers = m.timers, None
+        rows = sorted(((sum(s_.elapsed_time(e_) for s_, e_ in ev) / 6, k_, len(ev) // 6) for k_, ev in tm.items()), reverse=True)
+        for ms, k_, cnt in rows:
+            print("    %-44s %7.3f ms/step  (%d launches)" % (k_, ms, cnt))
     assert all(map(lambda v: v == v and abs(v) < 1e9, losses)), losses
     print("%-8s B=%6d F=%2d E=%3d  %.3f ms/step  %.2f M examples/s  loss %.5f -> %.5f  mem %.1f GB" % (
         name, B, F, m.E, dt * 1e3, B / dt / 1e6, losses[0], losses[-1], torch.cuda.max_memory_allocated() / 1e9))
