@@ -551,7 +551,7 @@ __device__ __forceinline__ RowIn load_row_in(const float* __restrict__ table, co
   return q;
 }
 
-template <int LPR>
+template <int LPR, bool DEEP>
 __global__ __launch_bounds__(kBlock) void sparse_catchup_bounded_k(
     float* __restrict__ table, float* __restrict__ tm, float* __restrict__ tv,
     int32_t* __restrict__ last_step, const int32_t* __restrict__ uniq_rows,
@@ -594,19 +594,8 @@ __global__ __launch_bounds__(kBlock) void sparse_catchup_bounded_k(
   // on registers.  A lane group whose chunk lies past the end of the list carries ls = step_to: nothing to do.
   RowIn none;
   none.r = 0; none.ls = INT32_MAX; none.w = none.m = none.v = make_float4(0.f, 0.f, 0.f, 0.f);
-  int64_t u0 = row_at(0);
-  RowIn nxt = u0 < count ? load_row_in(table, tm, tv, last_step, row_id(u0), E, l, lane_on, st) : none;
-  int64_t u1 = J > 1 ? row_at(1) : count;
-  int32_t id_pref = u1 < count ? row_id(u1) : 0;
-  for (int64_t j = 0; j < J; ++j) {
-    const RowIn cur = nxt;
-    const int64_t r_next = id_pref;
-    const bool more = j + 1 < J;
-    if (more) {
-      nxt = u1 < count ? load_row_in(table, tm, tv, last_step, r_next, E, l, lane_on, st) : none;
-      u1 = j + 2 < J ? row_at(j + 2) : count;
-      if (u1 < count) id_pref = row_id(u1);
-    }
+  // the replay of one row from registers (the state a round took over)
+  auto replay = [&](const RowIn& cur) {
     // ---- replay row u (a row that was never applied has m = v = 0: every step subtracts exactly 0)
     const int ls = cur.ls;
     if (ls > 0 && ls < step_to) {
@@ -648,6 +637,65 @@ __global__ __launch_bounds__(kBlock) void sparse_catchup_bounded_k(
     }
     // (every lane of the group read the stamp above before lane 0 overwrites it: same wave, program order)
     if (l == 0 && !defer_slots && !keep_stamps && ls < step_to) last_step[cur.r * st] = step_to;
+  };
+  if constexpr (!DEEP) {
+  int64_t u0 = row_at(0);
+  RowIn nxt = u0 < count ? load_row_in(table, tm, tv, last_step, row_id(u0), E, l, lane_on, st) : none;
+  int64_t u1 = J > 1 ? row_at(1) : count;
+  int32_t id_pref = u1 < count ? row_id(u1) : 0;
+  for (int64_t j = 0; j < J; ++j) {
+    const RowIn cur = nxt;
+    const int64_t r_next = id_pref;
+    const bool more = j + 1 < J;
+    if (more) {
+      nxt = u1 < count ? load_row_in(table, tm, tv, last_step, r_next, E, l, lane_on, st) : none;
+      u1 = j + 2 < J ? row_at(j + 2) : count;
+      if (u1 < count) id_pref = row_id(u1);
+    }
+    replay(cur);
+  }
+  } else {
+  // Two rounds' state in flight: twice the bytes per wave on the wire for the same number of resident waves.
+  //  * Every load is UNCONDITIONAL — a lane group past the end of the list, or a lane past the row's end, loads a valid
+  //    address it does not use (position count - 1 / the row's first floats; without a row list the stamps stand in for
+  //    it): with loads under branches hipcc's wait-count bookkeeping gives up and drains the pipeline (s_waitcnt vmcnt(0))
+  //    every round.
+  //  * The three buffers ROTATE through an unrolled loop — a register copy of a state still in flight would wait for it.
+  //  * The ID of round j + 3's row is loaded BEFORE round j + 2's state, so that waiting for it a round later does not
+  //    wait for that state: vmcnt counts in order.
+  const int64_t last_pos = count - 1;                        // (count >= 1 here: J > 0)
+  const int col = lane_on ? 4 * l : 0;
+  const int32_t* id_list = uniq_rows ? uniq_rows : last_step;
+  const bool has_list = uniq_rows != nullptr;
+  auto id_at = [&](int64_t jj) -> int32_t {                  // row of round jj (clamped into the list)
+    const int64_t u = row_at(jj < J ? jj : J - 1);
+    const int64_t pos = u < count ? u : last_pos;
+    const int32_t v = id_list[pos];
+    return has_list ? v : static_cast<int32_t>(pos);
+  };
+  auto on_at = [&](int64_t jj) -> bool { return jj < J && row_at(jj) < count; };
+  auto state_of = [&](int32_t id, bool on) -> RowIn {
+    RowIn q;
+    q.r = id;
+    const int stamp = last_step[static_cast<int64_t>(id) * st];
+    const int64_t o = static_cast<int64_t>(id) * E + col;
+    q.w = ld4(table + o); q.m = ld4_nt(tm + o); q.v = ld4_nt(tv + o);
+    q.ls = on ? stamp : INT32_MAX;
+    return q;
+  };
+  RowIn sa = state_of(id_at(0), on_at(0)), sb = state_of(id_at(1), on_at(1)), sc;
+  int32_t id_next = id_at(2);
+  auto round = [&](const RowIn& x, RowIn& z, int64_t j) {    // consume round j's state x, fill z with round j + 2's
+    const int32_t id_a = id_next;
+    id_next = id_at(j + 3);
+    z = state_of(id_a, on_at(j + 2));
+    replay(x);
+  };
+  for (int64_t j = 0; j < J; j += 3) {                       // (rounds past J - 1 are off: they load and do nothing)
+    round(sa, sc, j);
+    round(sb, sa, j + 1);
+    round(sc, sb, j + 2);
+  }
   }
 }
 
@@ -952,9 +1000,19 @@ int32_t mi_sparse_catchup(float* table, float* t_m, float* t_v, float* lin_w, fl
     // a pipelined grid: a few resident workgroups per CU, every lane group walks its share of the rows
     int64_t pb = mi::env_int("MI_CATCHUP_BLOCKS", 1024);          // 4 workgroups per CU resident: half the wave slots stay free for the side streams' small kernels (A/B on one box, 3 x alternating: 2.864 vs 2.881 ms per step at 2048)
     while (pb > 1 && pb > blocks) pb >>= 1;                       // (a power of two: the kernel's wave -> chunk map)
-    MI_DISPATCH_LPR(lpr, (sparse_catchup_bounded_k<L><<<dim3((unsigned)pb), dim3(kBlock), 0, mi::as_stream(stream)>>>(
-                             table, t_m, t_v, last_step, uniq_rows, num_uniq, n_max, E, step_to, lr_table, beta1, beta2,
-                             epsilon, defer, lin_stride, mi::step_state(), keep_stamps)));
+    // MI_CATCHUP_DEPTH=2: two rounds' row state in flight per lane group instead of one (see the kernel).  Alone on the
+    // GPU it is the faster kernel (tools/catchup_bench.py: 0.450 -> 0.411 ms at 1,024 workgroups, 0.398 at 2,048); inside
+    // the step it is not (A/B on one box, three alternating runs: 2.82-2.96 vs 2.84-2.95 ms) — it finishes earlier against
+    // the next batch's sort on the side stream, more of which then lands on the gather (189-216 -> 247-269 us).  Default 1.
+    if (mi::env_int("MI_CATCHUP_DEPTH", 1) >= 2) {
+      MI_DISPATCH_LPR(lpr, (sparse_catchup_bounded_k<L, true><<<dim3((unsigned)pb), dim3(kBlock), 0, mi::as_stream(stream)>>>(
+                               table, t_m, t_v, last_step, uniq_rows, num_uniq, n_max, E, step_to, lr_table, beta1, beta2,
+                               epsilon, defer, lin_stride, mi::step_state(), keep_stamps)));
+    } else {
+      MI_DISPATCH_LPR(lpr, (sparse_catchup_bounded_k<L, false><<<dim3((unsigned)pb), dim3(kBlock), 0, mi::as_stream(stream)>>>(
+                               table, t_m, t_v, last_step, uniq_rows, num_uniq, n_max, E, step_to, lr_table, beta1, beta2,
+                               epsilon, defer, lin_stride, mi::step_state(), keep_stamps)));
+    }
   } else {
     MI_DISPATCH_LPR(lpr, (sparse_catchup_k<L><<<dim3((unsigned)blocks), dim3(kBlock), 0, mi::as_stream(stream)>>>(
                              table, t_m, t_v, last_step, uniq_rows, num_uniq, n_max, E, step_to, lr_table, beta1, beta2,
