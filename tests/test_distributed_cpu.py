@@ -172,6 +172,21 @@ def test_four_rank_chunked_exchanges_one_forward():
     check_against_big_batch(cfg, _run(cfg, 4), 4)
 
 
+@pytest.mark.parametrize("cfg", [
+    ([19, 23, 17, 29], 8, [16, 8], 16, 0, "Adam", 0.001, 3, (True, True, True), 2, dict(announce=True)),
+    # BASELINE config 4's model (Wide&Deep, raw numeric columns, Ftrl + Adagrad, SUM loss) — its 8-GPU form
+    ([19, 23, 17, 29], 8, [16, 8], 16, 3, "Adagrad", 0.05, 3, (True, False, True), 2,
+     dict(numeric="raw", lin_opt=("Ftrl", 0.2), reduction="sum", announce=True))])
+def test_eight_rank_default_step_equals_big_batch(cfg):
+    """world 8, as the driver's 8-GPU bench runs it: RowShard's defaults from 8 ranks on (chunked exchanges, one MLP pass),
+    two chunks, the next batch announced (routing and owner-side sort ahead, on the second communicator) — every rank asks
+    7 peers and itself, its own requests last in every chunk."""
+    res = _run(cfg, 8)
+    check_against_big_batch(cfg, res, 8)
+    assert all(res[r][1]["route_ahead_hits"] == 2 for r in range(8))
+    assert all(res[r][1]["exchange"]["requests_to_self"] <= res[r][1]["exchange"]["requests_sent"] for r in range(8))
+
+
 def test_four_rank_pipelined_step_equals_big_batch():
     """world 4 (keys chunk * 4 + owner, 4-way splits, some empty): the pipelined step in 2 chunks"""
     cfg = ([9, 13, 5, 6], 8, [16, 8], 16, 0, "Adam", 0.001, 3, (True, True, True), 2)
