@@ -144,6 +144,20 @@ def test_wide_deep_two_optimizers_with_numeric_columns(device):
     assert float(m.kernel(0)[m.D_in:].abs().max()) == 0.0     # ... whose kernel rows stay zero
 
 
+def test_wide_deep_numeric_columns_written_into_the_planes(device):
+    """... at an embedding size the planes gather takes (E = 32): on the GPU the numeric values and the zero pad are written
+    into the planes by the gather itself (engine.pl_numeric: no fp32 concat); 131 -> 160 input columns are no whole k-tile
+    of the planes weight gradient, so layer 1's weight gradient gets the concat back through mi_merge_rows.  (On the CPU
+    stand-ins the same model runs on the fp32 concat.)"""
+    vocab = [9, 13, 5, 6]
+    m, p = _run(device, vocab, 32, [64, 32], 96, 3, "raw", (True, False, True), ADAGRAD, _ftrl(len(vocab) + 3), dropout=0.1, seed=29,
+                atol=4e-6)
+    assert m.D_in == 4 * 32 + 3 and m.D == 160
+    if device == "cuda":
+        assert m.pl_numeric and "concat" in m._ws              # (the fallback weight gradient's fp32 copy)
+    assert float(m.kernel(0)[m.D_in:].abs().max()) == 0.0
+
+
 def test_deepfm_two_optimizers_numeric_embeddings_follow_the_deep_optimizer(device):
     """A DeepFM handed a linear_optimizer: numeric_embeddings (deep_fm.py:64) is an input-layer variable,
     not a linear_model one — it must take `optimizer`, only lin_w / bias / numeric linear weights take

@@ -21,7 +21,11 @@ pytestmark = pytest.mark.gpu
                                  # chunked exchanges, one forward / backward (the default from 8 ranks on), config-5 shape
                                  ([13] * 40, 128, [512, 256, 128], 128, 0, "Adam", 0.001, 2, (True, True, True), 2, dict(chunk_compute=False)),
                                  ([50, 30, 20, 40], 64, [64, 32], 256, 0, "Adam", 0.001, 3, (True, True, True), 2,
-                                  dict(chunk_compute=False, announce=True))])
+                                  dict(chunk_compute=False, announce=True)),
+                                 # config 4's model with the numeric columns written into the planes by the gather (E = 32),
+                                 # the embedding-side kernels in two pieces
+                                 ([50, 30, 20, 40], 32, [64, 32], 128, 3, "Adagrad", 0.05, 2, (True, False, True), 2,
+                                  dict(numeric="raw", lin_opt=("Ftrl", 0.2), reduction="sum", chunk_compute=False))])
 def test_two_ranks_one_gpu_gloo(cfg):
     check_against_big_batch(cfg, _run(cfg, 2, device="cuda", backend="gloo"), 2, tol=3.0)
 
