@@ -49,10 +49,29 @@ class HashBucketColumn(_Categorical):
             a = np.ascontiguousarray(arr, np.int64)
             _lib.check(lib.mi_hash_bucket_i64(a.ctypes.data, n, self.num_buckets, out.ctypes.data), "mi_hash_bucket_i64")
         else:
-            enc = [x if isinstance(x, bytes) else str(x).encode("utf-8") for x in v]
-            offs = np.zeros(n + 1, np.int64)
-            np.cumsum([len(e) for e in enc], out=offs[1:])
-            blob = b"".join(enc)
+            blob = offs = None
+            # the whole column at once: numpy encodes ASCII strings into a fixed-width byte matrix at C speed; the
+            # padding is cut out with one boolean index.  Anything that path would change takes the per-element path
+            # below (the bytes mean the same in either case: utf-8 of str(value)): non-ASCII text (the encode raises),
+            # values that are neither str nor bytes (len() raises), trailing NULs, which a fixed-width array drops
+            # (the total length then differs from Python's).
+            if n and arr.dtype.kind in "OUS":
+                try:
+                    sa = arr if arr.dtype.kind == "S" else arr.astype("S")
+                    w = sa.dtype.itemsize
+                    lens = np.char.str_len(sa).astype(np.int64)
+                    if w and int(lens.sum()) == (sum(map(len, v)) if not (isinstance(v, np.ndarray) and arr.dtype.kind in "US") else int(lens.sum())):
+                        mat = np.ascontiguousarray(sa).view(np.uint8).reshape(n, w)
+                        blob = mat[np.arange(w)[None, :] < lens[:, None]].tobytes()
+                        offs = np.zeros(n + 1, np.int64)
+                        np.cumsum(lens, out=offs[1:])
+                except (UnicodeEncodeError, ValueError, TypeError):
+                    blob = offs = None
+            if blob is None:
+                enc = [x if isinstance(x, bytes) else str(x).encode("utf-8") for x in v]
+                offs = np.zeros(n + 1, np.int64)
+                np.cumsum([len(e) for e in enc], out=offs[1:])
+                blob = b"".join(enc)
             buf = C.create_string_buffer(blob, max(len(blob), 1))
             _lib.check(lib.mi_hash_bucket_bytes(C.addressof(buf), offs.ctypes.data, n, self.num_buckets,
                                                 out.ctypes.data), "mi_hash_bucket_bytes")
@@ -76,8 +95,20 @@ class VocabularyListColumn(_Categorical):
 
     def transform(self, features):
         lib = _lib.load()
-        out = np.empty(len(features[self.key]), np.int32)
-        for i, v in enumerate(features[self.key]):
+        vals = features[self.key]
+        arr = np.asarray(vals)
+        if len(arr) > 64 and arr.dtype.kind in "OUS":
+            # a batch holds few distinct values of a vocabulary column: look each one up once
+            try:
+                uniq, inv = np.unique(arr.astype("U"), return_inverse=True)
+                return self._lookup(lib, uniq.tolist())[inv].astype(np.int32)
+            except (UnicodeDecodeError, ValueError, TypeError):
+                pass
+        return self._lookup(lib, vals)
+
+    def _lookup(self, lib, values):
+        out = np.empty(len(values), np.int32)
+        for i, v in enumerate(values):
             v = v.decode() if isinstance(v, bytes) else (v if isinstance(v, str) else v.item() if hasattr(v, "item") else v)
             j = self._index.get(v)
             if j is None:

@@ -105,25 +105,33 @@ def get_input_fn(csv_path, mode=ModeKeys.TRAIN, batch_size=32, cutoff=5, seed=No
             return
         rng = np.random.default_rng(seed)
         cap = 16 * batch_size
-        pending = []
+        pending = np.empty(0, np.int64)
         while True:                                        # .repeat()
-            buf = []
-            for i in range(n):                             # .shuffle(cap): swap-out buffer
-                if len(buf) < cap:
-                    buf.append(i)
-                    continue
-                j = int(rng.integers(cap))
-                pending.append(buf[j])
-                buf[j] = i
-                if len(pending) == batch_size:
-                    yield emit(pending)
-                    pending = []
+            # .shuffle(cap): a buffer of cap elements; every further element i draws a slot j uniformly, the slot's
+            # occupant goes out, i takes its place; at the end of the pass the buffer goes out in random order.
+            # The draws of a pass come from the generator in one call, the swap chain — element i's successor is the
+            # next element that draws i's slot — is followed per SLOT in numpy: out[k] = the occupant of slot j[k]
+            # before draw k = the element of the latest earlier draw with the same slot (or the slot's first occupant).
+            m = max(n - cap, 0)
+            j = rng.integers(cap, size=m) if m else np.empty(0, np.int64)
+            order = np.argsort(j, kind="stable")           # draws grouped by slot, in time order inside a group
+            js = j[order]
+            prev = np.empty(m, np.int64)                   # for every draw: who sits in its slot
+            first = np.ones(m, bool)
+            first[1:] = js[1:] != js[:-1]
+            prev[order] = np.where(first, js, np.concatenate([[0], order[:-1]]) + cap)   # slot's first occupant = element js
+            out = prev                                     # (element ids: the first cap elements are 0..cap-1, draw k places element cap + k)
+            buf = np.arange(min(n, cap), dtype=np.int64)
+            if m:
+                last = np.ones(m, bool)
+                last[:-1] = js[1:] != js[:-1]
+                buf[js[last]] = order[last] + cap          # what sits in a drawn slot after the pass
             rng.shuffle(buf)
-            for i in buf:
-                pending.append(i)
-                if len(pending) == batch_size:
-                    yield emit(pending)
-                    pending = []
+            stream = np.concatenate([pending, out, buf])
+            nb = len(stream) // batch_size
+            for b in range(nb):
+                yield emit(stream[b * batch_size:(b + 1) * batch_size])
+            pending = stream[nb * batch_size:]
     return input_fn
 
 

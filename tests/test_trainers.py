@@ -76,6 +76,32 @@ def test_input_fn_semantics(data):
                                           "release_year", *ml_100k.GENRE}
 
 
+def test_column_transforms_of_a_whole_batch_equal_the_per_element_definition():
+    """The host side of a large batch (hash-bucket and vocabulary columns, the shuffle buffer) runs on whole numpy columns;
+    the results are those of the per-element definitions: utf-8 bytes of str(value) -> Fingerprint64 % buckets (ASCII,
+    non-ASCII, empty and long values, bytes), vocabulary index / OOV bucket, and tf.data's swap-out shuffle buffer."""
+    from mi355x_rec import feature_column as fc
+    rng = np.random.default_rng(0)
+    col = fc.categorical_column_with_hash_bucket("z", 1000)
+    vals = np.array(["%05d" % z for z in rng.integers(0, 99999, 500)] + ["", "a", "h\u00e9llo", "x" * 70, "tail\0"], dtype=object)
+    one_by_one = np.array([col.transform({"z": [v]})[0] for v in vals])
+    assert np.array_equal(col.transform({"z": vals}), one_by_one)                       # (non-ASCII / NUL: the per-element path)
+    assert np.array_equal(col.transform({"z": vals[:500]}), one_by_one[:500])           # the whole-column path
+    assert np.array_equal(col.transform({"z": vals[:500].astype("U")}), one_by_one[:500])
+    assert np.array_equal(col.transform({"z": np.array([b"ab", b"c"], dtype=object)}),
+                          [col.transform({"z": ["ab"]})[0], col.transform({"z": ["c"]})[0]])
+    vc = fc.categorical_column_with_vocabulary_list("g", ["F", "M"], num_oov_buckets=2)
+    g = np.array(rng.choice(["F", "M", "null", "other"], 300), dtype=object)
+    assert np.array_equal(vc.transform({"g": g}), np.array([vc.transform({"g": [x]})[0] for x in g]))
+    # the shuffle buffer: every element of a pass exactly once, no element before the buffer is full, and an element never
+    # leaves before one that entered cap or more positions after it has entered (it can only be delayed)
+    n, bs = 2000, 16
+    it = ml_100k.get_input_fn("synthetic:%d:3" % n, batch_size=bs, seed=1)()
+    first_pass = np.concatenate([next(it)[0]["user_id"] for _ in range(n // bs)])
+    ref = ml_100k.synthetic_columns(n, 3)[0]["user_id"]
+    assert sorted(first_pass.tolist()) == sorted(ref.tolist())
+
+
 def test_model_fn_errors_and_params(device):
     cols = ml_100k.get_feature_columns(4)["linear"]
     with pytest.raises(ValueError, match="At least 1 feature column"):
