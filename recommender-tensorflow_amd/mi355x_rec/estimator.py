@@ -239,7 +239,7 @@ class Estimator:
         n_log = 0
         done = 0
         loss = None
-        for features, labels in input_fn():
+        for features, labels in self._grouped(input_fn()):
             self._first_call(features, labels, ModeKeys.TRAIN)
             if max_steps is not None and self.global_step >= max_steps:
                 break
@@ -266,6 +266,44 @@ class Estimator:
             if on_checkpoint:
                 on_checkpoint()
         return self
+
+    GROUP_ROWS = 2048         # small batches: this many examples' id transforms in one call (see _grouped)
+
+    def _grouped(self, it):
+        """The training batches of `it`, unchanged — but batches of a few dozen examples (the reference's default is 32)
+        are drawn GROUP_ROWS examples at a time, and the group's concatenated columns ride along in params["_ahead"]: the
+        engine's run_batch then transforms the ids of the whole group in one call and copies them to the device once (the
+        per-call overhead of 26 column transforms and three host-to-device copies is what a 32-example step costs on the
+        host; the transforms are stateless, so the order of results is that of the batches).  A model_fn that does not look
+        at params["_ahead"] sees exactly what it always saw."""
+        import itertools
+        it = iter(it)
+        first = next(it, None)
+        if first is None:
+            return
+        try:
+            B = len(first[1])
+        except TypeError:
+            B = 0
+        k = self.GROUP_ROWS // B if 0 < B <= self.GROUP_ROWS // 4 else 1
+        it = itertools.chain([first], it)
+        if k <= 1 or not isinstance(first[0], dict):
+            self.params.pop("_ahead", None)
+            yield from it
+            return
+        while True:
+            grp = list(itertools.islice(it, k))
+            if not grp:
+                break
+            feats = {key: np.concatenate([np.asarray(f[key]) for f, _ in grp]) for key in grp[0][0]}
+            group = {"features": feats, "labels": np.concatenate([np.asarray(l).reshape(-1) for _, l in grp])}
+            lo = 0
+            for f, l in grp:
+                n = len(l)
+                self.params["_ahead"] = {"features": f, "group": group, "rows": (lo, lo + n)}
+                lo += n
+                yield f, l
+        self.params.pop("_ahead", None)
 
     def _checkpoint_due(self, t_last):
         """save_checkpoints_secs have passed.  One process: its own clock, every step.  N processes: rank 0's clock,

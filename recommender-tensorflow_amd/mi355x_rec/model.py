@@ -53,13 +53,27 @@ def run_batch(features, labels, mode, params, make_engine):
     if mode == "_build":
         return None
     plan, eng = store["plan"], store["engine"]
-    ids_np, x_np = plan.transform(features)
     dev = eng.device
-    ids = torch.from_numpy(ids_np).to(dev)
-    x = torch.from_numpy(x_np).to(dev) if x_np is not None else None
-    y = None
-    if labels is not None:
-        y = torch.from_numpy(np.ascontiguousarray(np.asarray(labels).reshape(-1)).astype(np.uint8)).to(dev)
+    ahead = params.get("_ahead")
+    if ahead is not None and mode == ModeKeys.TRAIN and ahead.get("features") is features:
+        # small batches (Estimator.train groups them): the id transforms of a whole group of batches were done in one
+        # call and copied to the device once; this batch is rows lo..hi of the group
+        g = ahead["group"]
+        if "ids" not in g:
+            ids_np, x_np = plan.transform(g["features"])
+            g["ids"] = torch.from_numpy(ids_np).to(dev)
+            g["x"] = torch.from_numpy(x_np).to(dev) if x_np is not None else None
+            g["y"] = torch.from_numpy(np.ascontiguousarray(np.asarray(g["labels"]).reshape(-1)).astype(np.uint8)).to(dev)
+        lo, hi = ahead["rows"]
+        ids, y = g["ids"][lo:hi], g["y"][lo:hi]
+        x = g["x"][lo:hi] if g["x"] is not None else None
+    else:
+        ids_np, x_np = plan.transform(features)
+        ids = torch.from_numpy(ids_np).to(dev)
+        x = torch.from_numpy(x_np).to(dev) if x_np is not None else None
+        y = None
+        if labels is not None:
+            y = torch.from_numpy(np.ascontiguousarray(np.asarray(labels).reshape(-1)).astype(np.uint8)).to(dev)
 
     # multi-GPU: a rank's loss is its SHARE of the global-batch mean (already divided by the global batch); times
     # world = the mean over its own examples — what is logged, and, with every rank evaluating the same batches,

@@ -160,6 +160,27 @@ def test_train_and_evaluate_end_to_end(device, data, trainer, extra, capsys):
     assert first["probabilities"].shape == (2,)
 
 
+def test_grouped_id_transforms_leave_the_training_unchanged(device, data, monkeypatch):
+    """Estimator.train draws small batches 2,048 examples at a time and has their ids transformed in one call (the host
+    cost of a 32-example step): the batches, their order and the trained variables are those of the batch-by-batch loop."""
+    from mi355x_rec.estimator import Estimator
+    fixed = lambda path, mode="train", batch_size=32, seed=None: ml_100k.get_input_fn(path, mode, batch_size=batch_size, seed=5)
+    monkeypatch.setattr(_cli, "get_input_fn", fixed)             # (one process shuffles with a fresh seed per run)
+    finals = []
+    for rows in (Estimator.GROUP_ROWS, 0):
+        monkeypatch.setattr(Estimator, "GROUP_ROWS", rows)
+        job = str(data / ("job_g%d" % rows))
+        argv = ["--train-csv", str(data / "train.csv"), "--test-csv", str(data / "test.csv"), "--job-dir", job,
+                "--train-steps", "70", "--batch-size", "32", "--device", device, "--hidden-units", "8", "8", "--dropout", "0.1"]
+        opt = ("exclude_linear", "exclude_mf", "exclude_dnn", "hidden_units", "dropout")
+        est = deep_fm.train_and_evaluate(_cli.make_parser("deep_fm", opt).parse_args(argv))
+        assert est.global_step == 70
+        finals.append(est._engine().export_numpy())
+    a, b = finals
+    assert all(np.array_equal(x, y) for x, y in zip(a["emb"], b["emb"])) and all(np.array_equal(x, y) for x, y in zip(a["lin_w"], b["lin_w"]))
+    assert all(np.array_equal(ka, kb) and np.array_equal(ba, bb) for (ka, ba), (kb, bb) in zip(a["mlp"], b["mlp"]))
+
+
 def test_warm_start_from_tf_named_variables(device, data, capsys):
     """--warm-start-from: a dump of TensorFlow-named variables (the reference's checkpoint scopes) seeds a
     fresh job; evaluating before any further step reproduces the donor's metrics."""

@@ -13,7 +13,7 @@ _write_csv(d / "train.csv", 20000, 1); _write_csv(d / "test.csv", 2000, 2)
 opt = ("exclude_linear", "exclude_mf", "exclude_dnn", "hidden_units", "dropout")
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
 args = _cli.make_parser("deep_fm", opt).parse_args(["--train-csv", str(d / "train.csv"), "--test-csv", str(d / "test.csv"),
-                                                     "--job-dir", str(d / "job"), "--train-steps", str(steps)])
+                                                     "--job-dir", str(d / "job"), "--train-steps", str(steps)] + sys.argv[2:])
 t0 = time.time()
 est = deep_fm.train_and_evaluate(args)
 dt = time.time() - t0
