@@ -17,7 +17,12 @@
  *   - scratch space is an explicit caller-sized workspace: ask mi_*_workspace_bytes() first.
  *   - shapes are validated on the host before any launch (a bad shape returns
  *     MI_ERR_INVALID instead of faulting the GPU).
- *   - all floating point is IEEE fp32 ("f32" in bench.py); index work is int32/int64, bit exact.
+ *   - variables, activations, gradients and results are IEEE fp32, and so is every accumulation; index work is
+ *     int32/int64, bit exact.  ONE family of entries feeds the matrix pipe something other than fp32 operands: the
+ *     *_planes entries (and the other GEMM entries in gemm mode 1) split each fp32 operand into fp16 high + low parts
+ *     (~22 significant bits per row-scaled operand; three exact 16-bit products per fp32 product, the lo*lo term
+ *     dropped, fp32 accumulate) — fp32-LEVEL results (row-relative error < 1e-5, enforced in tests/test_hip_planes.py),
+ *     not IEEE fp32 products.  mi_set_gemm_mode(0) runs the same GEMMs on the fp32-input MFMA (exact products).
  *   - PROCESS-WIDE STATE.  Two switches are per process, not per call or per model, because the deployment is one
  *     process per GPU running one model: mi_set_gemm_mode (the matrix-pipe path every GEMM entry takes) and
  *     mi_set_step_state (while set, the entries listed there read the step / lr_t / dropout seed term from a device
@@ -332,8 +337,10 @@ int32_t mi_sparse_apply_fused(float* table, float* t_slot0, float* t_slot1, floa
  * logits, not bit equality): m_j and lr_t[s] * m_j are still the reference's chain, bit for bit; sqrt(v_j) is taken as
  * sqrtf(v_0) * beta2^(j/2) (a per-row scalar chain with a two-float multiplier) and the division as v_rcp_f32 (1 ulp),
  * w is rounded once per step like the reference's.  Every replayed update is within a few 2^-24 (relative) of the
- * reference's, i.e. ~1e-10 |w|; measured and enforced: every variable within 1e-7 relative of the literal sweep after
- * 150-200 replayed steps (tests/test_hip_kernels.py::test_bounded_catchup_stays_within_1e7_of_the_sweep).  m, v and the
+ * reference's, i.e. ~1e-10 |w|.  Enforced against the literal sweep after 150-200 replayed steps, for EVERY variable:
+ * |w - w_sweep| <= 3 ulp(w) + 2e-6 * sum_j |t_j| (t_j: the replayed updates) — and in distribution >= 95 % of the variables
+ * bit-identical, >= 98 % within 1e-7 relative (measured 96.7 % / 98.7 %; a 1-ulp difference alone is up to 1.19e-7, so
+ * "1e-7 for every variable" is NOT claimed): tests/test_hip_kernels.py::test_bounded_catchup_stays_within_its_bound_of_the_sweep.  m, v and the
  * stamps are written exactly as in the exact mode.  4 VALU operations + 1 transcendental per element and step instead
  * of 16 + 2, and no range conditions.  Needs epsilon >= 1e-30 (otherwise the exact form runs).
  * MI_CATCHUP_KEEP_STAMPS: the rows' stamps are left as they are (m, v ARE written) — for a model whose tables and wide part

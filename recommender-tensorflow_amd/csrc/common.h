@@ -21,11 +21,18 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
-// tuning experiments only (tools/*_bench.py): an integer from the environment, else the built-in value
+// Tuning switches (MI_PL_TILE, MI_WGRAD_TILE, MI_WGRAD_PL, MI_CATCHUP_BLOCKS, MI_CATCHUP_DEPTH, MI_SORT_MEMSET): read from the
+// environment ONLY in the tools' build of the library (`make tuning` -> tools/probe/libmi355x_rec_tuning.so, -DMI_TUNING; the
+// tools/*_bench.py scripts load that file).  The shipped libmi355x_rec.so has no environment switch: env_int is the
+// built-in value, and the measured-and-dropped variants behind the switches are dead code the compiler removes.
+#ifdef MI_TUNING
 inline int env_int(const char* name, int dflt) {
   const char* e = getenv(name);
   return (e && *e) ? atoi(e) : dflt;
 }
+#else
+constexpr int env_int(const char*, int dflt) { return dflt; }
+#endif
 
 // device-resident step state registered by mi_set_step_state (host_ids.cpp), or nullptr
 const mi_step_state_t* step_state();

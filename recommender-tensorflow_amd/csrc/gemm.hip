@@ -898,10 +898,9 @@ static int32_t bwd_weight_impl(const float* X, int64_t ldx, const float* dY, int
 
 
 // two kernels: wgrad_pl.hip (LDS-DMA staging, transposed LDS reads; N = 128 / 256 / 512) and, for the other whole-tile
-// shapes, gemm_wgrad_pl_k (register staging).  MI_WGRAD_PL=0 forces the second (A/B runs).
+// shapes, gemm_wgrad_pl_k (register staging).  (MI_WGRAD_PL=0 in the tools' build forces the second: A/B runs.)
 static bool wgrad_plan(int64_t M, int32_t N, int32_t K, mi::WgradPlPlan* p) {
-  const char* e = getenv("MI_WGRAD_PL");          // (read per call: the tests switch it)
-  return !(e && e[0] == '0') && mi::wgrad_pl_plan(M, N, K, p);
+  return mi::env_int("MI_WGRAD_PL", 1) != 0 && mi::wgrad_pl_plan(M, N, K, p);
 }
 
 size_t mi_dense_bwd_weight_planes_workspace_bytes(int64_t M, int32_t N, int32_t K) {

@@ -374,7 +374,7 @@ __global__ __launch_bounds__(PL_THREADS, 2) void gemm_pl_k(const PlArgs a) {
         acc[x][y][r] = v;
       }
       if constexpr (EPI == PL_DGRAD) {
-        if (fsm) {     // the FM term's share of the concat gradient (layer 1, MI_FOLD_FM=1): + dlogit[m] * sumv[m][n % E]
+        if (fsm) {     // the FM term's share of the concat gradient (layer 1, engine.DeepFM.FOLD_FM): + dlogit[m] * sumv[m][n % E]
           const float4 fs4 = *reinterpret_cast<const float4*>(fsm + min(n0 + nl, a.N - 4) % a.fold_E);   // (4 columns stay inside a field: E % 4 == 0)
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
@@ -891,8 +891,7 @@ int32_t launch_pl(PlArgs& a, hipStream_t st, const char* what) {
                                                       // column tile is half empty — isolated 340-350 us against 370-380, in the step
                                                       // 0.482 against 0.509 ms for the three data gradients (in-kernel marks: the
                                                       // 128-column kernel's k loop runs its matrix pipes at 35 %, this one's at 60 %)
-  if (const char* e = getenv("MI_PL_TILE")) {         // tuning experiments (tools/gemm_pl_bench.py)
-    const int v = atoi(e);
+  if (const int v = mi::env_int("MI_PL_TILE", 0)) {   // tuning experiments (tools/gemm_pl_bench.py, the tools' build only)
     if ((v == 1 || v == 2 || v == 4) && (!a.Cp || a.N <= 128 * v)) tn = v;
   }
   // 256-row tiles for the narrower column tiles — unless that leaves CUs without a workgroup (a chunk of a multi-GPU

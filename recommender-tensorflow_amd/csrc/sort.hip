@@ -37,8 +37,7 @@ __global__ __launch_bounds__(256) void zero_i32_k(int32_t* __restrict__ p, int64
 inline void zero_i32(int32_t* p, int64_t n, hipStream_t st) {
   // (MI_SORT_MEMSET=1: the round-2 form again, for tools/graph_memset_nodes.py only — it captures a step WITHOUT replaying it
   // and prints the memset nodes of the graph next to the live allocations)
-  static const bool use_memset = mi::env_int("MI_SORT_MEMSET", 0) != 0;
-  if (use_memset) {
+  if (mi::env_int("MI_SORT_MEMSET", 0) != 0) {          // (the tools' build only: the shipped library cannot reach hipMemsetAsync)
     (void)hipMemsetAsync(p, 0, static_cast<size_t>(n) * 4, st);
     return;
   }

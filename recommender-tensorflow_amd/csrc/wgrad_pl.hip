@@ -313,8 +313,7 @@ bool wgrad_pl_plan(int64_t M, int N, int K, WgradPlPlan* p) {
   // (32 KB of operands per k-step instead of 40 KB for the same MFMAs, a half-empty last feature tile at K = 1664) —
   // measured slower, 469 vs 451 us on the layer-1 shape: the loop is not bound by operand bytes.
   if (p->tn == 4) {
-    const char* e = getenv("MI_WGRAD_TILE");
-    if (e && e[0] == '2') { p->tn = 2; p->tm = 4; p->tiles_n = 2; }
+    if (env_int("MI_WGRAD_TILE", 512) == 256) { p->tn = 2; p->tm = 4; p->tiles_n = 2; }      // (the tools' build only)
   }
   if (K % 128 != 0) return false;
   p->tiles_k = static_cast<int>(ceil_div(K, 64 * p->tm));      // (the last tile may be half empty)

@@ -198,8 +198,9 @@ class DeepFM:
     embedding exactly; the wide part runs on the wide columns' ids only.
     catchup: how the steps a row sat out under TF Adam's dense-equivalent sparse update are replayed when
     the row is next read — "exact": TF's fp32 op sequence, the sweep's bits; "bounded": the same m chain and numerators
-    with sqrt(v_j) ~ sqrtf(v_0) beta2^(j/2) and a 1-ulp reciprocal, every variable within 1e-7 relative of the sweep
-    (include/mi355x_rec.h, MI_CATCHUP_BOUNDED), a third of the instructions."""
+    with sqrt(v_j) ~ sqrtf(v_0) beta2^(j/2) and a 1-ulp reciprocal: every variable within 3 ulp + 2e-6 of the movement the
+    replay covers (98.7 % of them within 1e-7 relative of the sweep, 96.7 % bit-identical; include/mi355x_rec.h,
+    MI_CATCHUP_BOUNDED), a third of the instructions."""
 
     def __init__(self, vocab_sizes, n_numeric=0, embedding_size=4, hidden_units=(16, 16),
                  use_linear=True, use_mf=True, use_dnn=True, dropout=0.0, optimizer=None,
@@ -650,7 +651,7 @@ class DeepFM:
         variables only (final since the previous step's apply), while the step's first half — sort, catch-up, gather —
         does not touch the MLP.  Two small latency-bound launches (abs-max, split: ~40 us at config 3) leave the critical
         path; the first GEMM waits for their event (in _split_weights)."""
-        if not self.planes or self.device.type != "cuda" or getattr(self, "_capturing", False) or os.environ.get("MI_WSPLIT_AHEAD", "1") == "0":
+        if not self.planes or self.device.type != "cuda" or getattr(self, "_capturing", False) or not self.WSPLIT_AHEAD:
             return
         side = self._ws.get("wsplit_stream")
         if side is None:
@@ -907,6 +908,13 @@ class DeepFM:
         self._final_step = self.step
 
     GAP_SORT_MIN = 16384      # entries from which sorting the touched rows by staleness pays for itself
+    # Scheduling choices of the single-GPU step, as class attributes (no environment switches in the product; bench.py
+    # --engine-opt NAME=0/1 flips one for an A/B run; every combination gives the same bits but FOLD_FM, which moves one
+    # addition — tests/test_hip_model.py runs both):
+    WSPLIT_AHEAD = True       # weight planes of the step made on a side stream at its head (_split_weights_ahead)
+    LIN_SIDE = True           # the wide part's catch-up on the wide part's stream, beside the row kernel (_catchup)
+    BYGAP_AHEAD = True        # the next batch's staleness order made a step ahead (_by_gap_ahead)
+    FOLD_FM = False           # layer-1 data gradient adds dlogit * sumv to d_concat once per example (_backward_dense)
 
     def _catchup(self, uniq, num_uniq, n_max, defer=False, by_gap=None):
         """defer: the rows are about to be applied in this same step by ONE mi_sparse_apply call, which
@@ -933,7 +941,7 @@ class DeepFM:
             assert not defer
             parts = [(None, l_sched, 4), (t_sched, None, 0)]          # (4 = MI_CATCHUP_KEEP_STAMPS)
         elif (defer and t_sched is not None and l_sched is not None and self.shard is None and self.device.type == "cuda"
-              and self._wide_on_side_stream(n_max // max(self.F, 1)) and os.environ.get("MI_LIN_SIDE", "1") == "1"):
+              and self._wide_on_side_stream(n_max // max(self.F, 1)) and self.LIN_SIDE):
             # deferred: neither call writes a stamp or touches the other's state — the wide part's 16-byte records
             # (scattered, latency-bound: 0.08 ms) are replayed on the stream that will run the wide part's forward,
             # beside the row kernel; the head joins that stream before anything else reads them
@@ -1030,7 +1038,7 @@ class DeepFM:
         which most of the chip idles — it costs nothing; right after the sort it ran beside the gather (HBM-bound: 176 ->
         231 us) and the layer-1 forward GEMM (310 -> 374 us: kernel timelines, tools/step_timeline.py)."""
         ps = self._presorted
-        if ps is None or not self.adam_rows or os.environ.get("MI_BYGAP_AHEAD", "1") != "1":
+        if ps is None or not self.adam_rows or not self.BYGAP_AHEAD:
             return
         n = ps["ids"].shape[0] * self.F
         if n < self.GAP_SORT_MIN:
@@ -1146,7 +1154,7 @@ class DeepFM:
         and the gradient exchange start there and travel under the largest weight-gradient GEMM and the dense all-reduce.
         fold_fm: the layer-1 data gradient may add the FM term's dlogit * sumv to d_concat (once per example
         instead of once per entry in the fused sparse apply); c["fm_folded"] tells whether it did.  Taken only
-        with MI_FOLD_FM=1: it removes the apply's per-entry sumv reads (0.44 GB of 3.7 GB at config 3) but those
+        with DeepFM.FOLD_FM: it removes the apply's per-entry sumv reads (0.44 GB of 3.7 GB at config 3) but those
         come from L2 / Infinity Cache, and the data gradient's epilogue pays as much as the apply saves (DESIGN)."""
         k = self.k
         B = c["B"]
@@ -1199,7 +1207,7 @@ class DeepFM:
                     # (the fp32 copy only where something reads it: d_concat, or a weight gradient on fp32 operands)
                     need_f = i == 0 or not (direct and self._wgrad_planes_ok(B, i - 1))
                     fold = (fold_fm and i == 0 and self.use_mf and self.n_numeric == 0 and fan == self.F * self.E
-                            and c["sumv"] is not None and os.environ.get("MI_FOLD_FM", "0") == "1")
+                            and c["sumv"] is not None and self.FOLD_FM)
                     c["fm_folded"] = c.get("fm_folded", False) or fold
                     k.mi_dense_bwd_data_planes(self._planes("dy%dp" % i, B, h), self._pl["w%d" % i].struct, xa,
                                                dx if need_f else None, fan,

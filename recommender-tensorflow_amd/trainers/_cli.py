@@ -25,8 +25,8 @@ _COMMON = [
     ("--hip-graph", dict(action="store_true", help="replay the train step as one hipGraph launch (launch-bound small batches)")),
     ("--catchup", dict(choices=["exact", "bounded"], default="exact",
                        help="Adam only: how the steps a table row sat out are replayed when it is next read — exact: TensorFlow's fp32 "
-                            "sequence bit for bit; bounded: every variable within 1e-7 relative of it (3 ulp + 2e-6 of the replayed "
-                            "movement), a third of the instructions (default: %(default)s)")),
+                            "sequence bit for bit; bounded: every variable within 3 ulp + 2e-6 of the movement the replay covers (98.7 %% of "
+                            "them within 1e-7 relative of the sweep), a third of the instructions (default: %(default)s)")),
     ("--synthetic", dict(type=int, default=None, metavar="N", help="train on N generated MovieLens-shaped examples (and evaluate on "
                                                                    "N/10) instead of --train-csv / --test-csv")),
 ]

@@ -583,37 +583,7 @@ def test_catchup_exact_at_range_edges(lib):
     assert np.array_equal(dlast.cpu().numpy(), np.where(last < step_to, step_to, last))
 
 
-@pytest.mark.parametrize("use_list,defer", [(True, 1), (True, 0), (False, 0)])
-def test_bounded_catchup_two_deep_pipeline_gives_the_same_bits(lib, monkeypatch, use_list, defer):
-    """MI_CATCHUP_DEPTH=2 (two rounds of row state in flight, unconditional clamped loads, rotating buffers: optim.hip) is
-    another schedule of the same arithmetic: w, m, v and the stamps come out bit for bit as from the default kernel —
-    with a row list (ragged tail: rounds past the list's end load clamped addresses and do nothing) and over all rows."""
-    rng = np.random.default_rng(7)
-    R, E, step_to = 5000, 64, 120
-    f = np.float32
-    w = (rng.standard_normal((R, E)) * 0.3).astype(f)
-    m = (rng.standard_normal((R, E)) * 1e-3).astype(f)
-    v = (rng.uniform(1e-9, 1e-6, (R, E))).astype(f)
-    last = (step_to - rng.integers(0, 60, R)).astype(np.int32)
-    last[rng.random(R) < 0.05] = 0
-    rows = np.sort(rng.choice(R, 3111, replace=False)).astype(np.int32)          # (3111: no whole number of waves' rows)
-    lr = (1e-3 * np.sqrt(1 - 0.999 ** np.arange(step_to + 1)) / np.maximum(1 - 0.9 ** np.arange(step_to + 1), 1e-30)).astype(f)
-    outs = []
-    for depth in ("1", "2"):
-        monkeypatch.setenv("MI_CATCHUP_DEPTH", depth)
-        dW, dM, dV, dlast, dlr, drows = dev(w), dev(m), dev(v), dev(last), dev(lr), dev(rows)
-        dn = dev(np.array([len(rows)], np.int32))
-        _chk(lib.mi_sparse_catchup(_p(dW), _p(dM), _p(dV), None, None, None, _p(dlast), _p(drows) if use_list else None,
-                                   _p(dn) if use_list else None, len(rows) if use_list else R, E, step_to, _p(dlr), 0.9, 0.999, 1e-8,
-                                   2 | defer, 1, _st()))
-        torch.cuda.synchronize()
-        outs.append([t.cpu().numpy() for t in (dW, dM, dV, dlast)])
-    for a, b in zip(*outs):
-        assert np.array_equal(a.view(np.uint32) if a.dtype == np.float32 else a, b.view(np.uint32) if b.dtype == np.float32 else b)
-    assert not np.array_equal(outs[0][0], w)                                     # (something was replayed)
-
-
-def test_bounded_catchup_stays_within_1e7_of_the_sweep(lib):
+def test_bounded_catchup_stays_within_its_bound_of_the_sweep(lib):
     """MI_CATCHUP_BOUNDED (include/mi355x_rec.h): the replay with sqrt(v_j) ~ sqrtf(v_0) beta2^(j/2) and a 1-ulp reciprocal
     against the literal fp32 sweep (numpy: IEEE sqrt and divide), 150-200 replayed steps, (m, v) pairs spanning everything
     Adam can produce — gradient scales from 2^-46 (v = 2^-92) to 2^10 (v = 2^20), plus elements with m = v = 0 and rows

@@ -340,15 +340,15 @@ def test_split_weights_one_launch(lib):
         assert np.array_equal(pw.data.cpu().numpy()[:, :k, :16].transpose(1, 0, 2).reshape(k, -1)[:, :n].view(np.float16), hi)
 
 
-@pytest.mark.parametrize("kernel", ["lds-dma", "register-staged"])
+# (N = 128 / 256 / 512 with K a multiple of 128: the LDS-DMA kernel, wgrad_pl.hip; every other whole-tile shape — N = 384,
+# 640 here — the register-staged one, gemm_wgrad_pl.inc.  The shipped library has no switch between them.)
 @pytest.mark.parametrize("M,N,K,bias", [(4096, 128, 256, True), (8192, 512, 1664, True), (1024, 256, 512, False), (32, 128, 128, True),
-                                        (2080, 256, 384, True), (4096, 384, 128, True)])
-def test_dense_bwd_weight_planes_against_fp64(lib, M, N, K, bias, kernel, monkeypatch):
+                                        (2080, 256, 384, True), (4096, 384, 128, True), (2080, 640, 256, True), (32, 384, 128, False)])
+def test_dense_bwd_weight_planes_against_fp64(lib, M, N, K, bias):
     """dW = X^T dY and db = colsum(dY) from planes whose rows span 2^-20 .. 1 (examples with tiny gradients next
     to large ones): error relative to the rms of the exact result at fp32 level, like the fp32-operand entry;
     twice the same bits (fixed-order split-K)."""
     from mi355x_rec import _lib as L
-    monkeypatch.setenv("MI_WGRAD_PL", "1" if kernel == "lds-dma" else "0")    # (N = 384 takes the register-staged kernel either way)
     rng = np.random.default_rng(M + N + K)
     X = np.maximum(rows_spread(rng, M, K, -6), 0).astype(np.float32)
     dY = (rows_spread(rng, M, N, -20) * 1e-4).astype(np.float32)
@@ -385,14 +385,13 @@ def test_dense_bwd_weight_planes_refuses_ragged_shapes(lib):
                                               C.byref(ga), _st()) != 0
 
 
-@pytest.mark.parametrize("kernel", ["lds-dma", "register-staged"])
-def test_weight_gradient_keeps_fp16_subnormal_operands(lib, kernel, monkeypatch):
+@pytest.mark.parametrize("N", [128, 384])              # the LDS-DMA kernel / the register-staged kernel
+def test_weight_gradient_keeps_fp16_subnormal_operands(lib, N):
     """An example 2^-30 below the matrices' abs-max reaches the matrix pipe as fp16 SUBNORMAL values (the per-example
     factor 2^d brings its rows to matrix-wide scales).  The MFMA must not flush them: with one such example
     carrying all of the signal, dW is its outer product (exact here: powers of two)."""
     from mi355x_rec import _lib as L
-    monkeypatch.setenv("MI_WGRAD_PL", "1" if kernel == "lds-dma" else "0")
-    M, N, K = 32, 128, 128
+    M, K = 32, 128
     X = np.zeros((M, K), np.float32); dY = np.zeros((M, N), np.float32)
     X[0, :] = 1.0                       # example 0: full-size activations, a gradient 2^-30 below the batch maximum
     dY[0, :] = 2.0 ** -30
