@@ -975,15 +975,17 @@ class DeepFM:
         return (self.device.type == "cuda" and self.use_emb and self.use_linear and self.use_dnn and self.n_numeric == 0
                 and self.F > 0 and B >= 4096)
 
-    def _sort_unique(self, keys, n, key_range, tag, ws_name="sort_ws"):
+    def _sort_unique(self, keys, n, key_range, tag, ws_name="sort_ws", cap=None):
         """mi_sort_unique_rows into persistent buffers named after `tag` (ws_name: a workspace of its own for a sort that
-        runs on a side stream beside the main stream's)."""
+        runs on a side stream beside the main stream's).  cap: allocate for that many keys (a count that varies from step
+        to step must not reallocate between the collectives of a multi-GPU step)."""
         i32 = torch.int32
-        sorted_entry = self._buf(tag + "_sorted", (n,), i32)
-        uniq = self._buf(tag + "_uniq", (n,), i32)
-        seg = self._buf(tag + "_seg", (n + 1,), i32)
+        cap = max(n, cap or 0)
+        sorted_entry = self._buf(tag + "_sorted", (cap,), i32)[:n]
+        uniq = self._buf(tag + "_uniq", (cap,), i32)[:n]
+        seg = self._buf(tag + "_seg", (cap + 1,), i32)[:n + 1]
         num_uniq = self._buf(tag + "_nu", (1,), i32)
-        ws = self._bytes(ws_name, self.k.query("mi_sort_unique_workspace_bytes", n))
+        ws = self._bytes(ws_name, self.k.query("mi_sort_unique_workspace_bytes", cap))
         self.k.mi_sort_unique_rows(keys, n, key_range, sorted_entry, uniq, seg, num_uniq, ws, ws.numel())
         return sorted_entry, uniq, seg, num_uniq
 
@@ -1289,18 +1291,24 @@ class DeepFM:
         self.step = step
 
     # ------------------------------------------------------------------ replayable step (hipGraph)
-    def graph_train_step(self, ids, labels):
-        """train_step as ONE hipGraph launch (single GPU, no numeric columns): the launch-bound small-batch
+    def graph_ok(self):
+        """a captured step exists for this model: single GPU, at most ONE Adam schedule (the device-resident step state
+        carries one lr_t)"""
+        return (self.shard is None and self.device.type == "cuda" and
+                not (self.sched is not None and self.lin_sched is not None and self.sched is not self.lin_sched))
+
+    def graph_train_step(self, ids, labels, x_num=None):
+        """train_step as ONE hipGraph launch (single GPU; numeric columns are a third input copy): the launch-bound small-batch
         configurations (trainers.deep_fm's defaults: B = 32, ~50 launches) pay one graph launch instead of ~50
         kernel launches.  The first call runs eagerly (it sizes the workspaces), the second captures, later
         calls copy the batch into the captured buffers and replay.  Per-step scalars — global step, Adam's lr_t,
         the dropout seeds — live in a device-resident step state that the captured mi_step_advance node
         advances (include/mi355x_rec.h), so a replay is bit-identical to the eager step it replaces."""
-        if self.shard is not None or self.n_numeric or self.device.type != "cuda":
-            raise NotImplementedError("graph_train_step: single-GPU models without numeric columns")
-        if self.sched is not None and self.lin_sched is not None and self.sched is not self.lin_sched:
+        if self.shard is not None or self.device.type != "cuda":
+            raise NotImplementedError("graph_train_step: single-GPU models")
+        if not self.graph_ok():
             raise NotImplementedError("graph_train_step: the device-resident step state carries ONE lr_t (two different Adams)")
-        self._prep(ids, labels, None)
+        self._prep(ids, labels, x_num)
         g = getattr(self, "_graph", None)
         if g is not None and g["gen"] != self._graph_gen():
             # A captured graph holds the raw addresses of the workspaces, the planes and the lr_t table.  Something
@@ -1313,17 +1321,19 @@ class DeepFM:
         if g is None or g["shape"] != tuple(ids.shape):
             if not getattr(self, "_graph_warm", None) == tuple(ids.shape):
                 self._graph_warm = tuple(ids.shape)
-                return self.train_step(ids, labels)                     # sizes every workspace
-            g = self._graph = self._capture(ids, labels)
+                return self.train_step(ids, labels, x_num)              # sizes every workspace
+            g = self._graph = self._capture(ids, labels, x_num)
             return g["loss"], g["logits"]
         if self._gsched() is not None and self.step + 2 >= len(self._gsched().host):
             self._graph = None                                          # the lr_t table has to grow: capture again
-            return self.graph_train_step(ids, labels)
+            return self.graph_train_step(ids, labels, x_num)
         if g["dev_step"] != self.step:                                  # eager steps ran in between: resync
             self._write_step_state(g["state"])
             g["dev_step"] = self.step
         g["ids"].copy_(ids)
         g["y"].copy_(labels)
+        if x_num is not None:
+            g["x"].copy_(x_num)
         g["graph"].replay()
         self.step += 1
         g["dev_step"] = self.step
@@ -1341,7 +1351,7 @@ class DeepFM:
         blob["step"] = self.step
         state.copy_(torch.from_numpy(blob.view(np.uint8)))
 
-    def _capture(self, ids, labels):
+    def _capture(self, ids, labels, x_num=None):
         if self._gsched() is not None:                                  # the lr_t table must not move under the graph
             self._gsched().lr_t(self.step + (1 << 20))
         ps, self._presorted = getattr(self, "_presorted", None), None
@@ -1350,6 +1360,7 @@ class DeepFM:
         state = torch.zeros(16, dtype=torch.uint8, device=self.device)
         self._write_step_state(state)
         g_ids, g_y = ids.clone(), labels.clone()
+        g_x = None if x_num is None else x_num.clone()
         graph = torch.cuda.CUDAGraph()
         torch.cuda.synchronize()
         self.k.query("mi_set_step_state", state.data_ptr())
@@ -1357,12 +1368,12 @@ class DeepFM:
         try:
             with torch.cuda.graph(graph):
                 self.k.mi_step_advance(state, self._gsched().table if self._gsched() is not None else None)
-                loss, logits = self.train_step(g_ids, g_y)
+                loss, logits = self.train_step(g_ids, g_y, g_x)
         finally:
             self._capturing = False
             self.k.query("mi_set_step_state", None)
         graph.replay()                                                  # capture records, this executes the step
-        return {"graph": graph, "state": state, "ids": g_ids, "y": g_y, "loss": loss, "logits": logits,
+        return {"graph": graph, "state": state, "ids": g_ids, "y": g_y, "x": g_x, "loss": loss, "logits": logits,
                 "shape": tuple(ids.shape), "dev_step": self.step, "gen": self._graph_gen()}
 
     def layer_summaries(self):

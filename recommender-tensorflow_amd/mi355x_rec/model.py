@@ -11,6 +11,9 @@ from .feature_column import FieldPlan
 from .metrics import metrics_from_counters
 
 
+GRAPH_AUTO_MAX_BATCH = 1024      # from here on nothing in a step is launch-bound (bench.py: the replay is 1-6 % behind eager at B = 65536)
+
+
 def binary_predictions(logits, kernels):
     """logits [B] -> the head's PREDICT dict (same keys as the TF head): mi_binary_predictions."""
     x = logits.reshape(-1).contiguous()
@@ -80,8 +83,13 @@ def run_batch(features, labels, mode, params, make_engine):
     # the eval loss
     rescale = (lambda l: l * float(eng.shard.world)) if (eng.shard is not None and eng.reduction == "mean") else (lambda l: l)
     if mode == ModeKeys.TRAIN:
-        if params.get("hip_graph") and x is None and eng.shard is None and eng.device.type == "cuda":
-            loss, logits = eng.graph_train_step(ids, y)      # the whole step as one hipGraph launch (small batches)
+        # the whole step as ONE hipGraph launch — bit for bit the eager step (tests/test_hip_model.py) — where a step is
+        # launch-bound: "auto" (the default) takes it for batches of <= GRAPH_AUTO_MAX_BATCH examples on a single GPU
+        # (trainers.deep_fm at the reference's defaults, B = 32: 2-2.5x the eager rate), "on" / True always, "off" never
+        hg = params.get("hip_graph", "auto")
+        graph = hg in (True, "on") or (hg == "auto" and ids.shape[0] <= GRAPH_AUTO_MAX_BATCH)
+        if graph and eng.device.type == "cuda" and hasattr(eng, "graph_ok") and eng.graph_ok():
+            loss, logits = eng.graph_train_step(ids, y, x)
         else:
             loss, logits = eng.train_step(ids, y, x)
         return EstimatorSpec(mode, predictions=None, loss=rescale(loss), train_op=eng.step)

@@ -32,8 +32,14 @@ import torch.distributed as dist
 
 
 class RowShard:
-    def __init__(self, rank, world, group=None, chunks=None, chunk_compute=None):
+    def __init__(self, rank, world, group=None, chunks=None, chunk_compute=None, route_ahead=None):
         """chunks: pipeline depth of a train step (None: chosen from the batch and world size, see _n_chunks).
+        route_ahead: True (default) — an announced next batch is routed during this step, on a side stream and a SECOND
+        RCCL communicator (see Comm / _route_ahead); False — the whole step runs on ONE communicator and one stream
+        order: no second communicator is created, every collective of a step is issued in program order (the
+        conservative form for a first run on new hardware: two communicators progressing concurrently on two streams
+        can deadlock if a device-synchronising call lands between their kernels in different orders on different
+        ranks; all buffers the step needs are sized before its first collective either way, see _sharded_step).
         chunk_compute: True — every chunk runs its own forward / backward (the exchanges of one chunk travel under the
         whole compute of its neighbours; the MLP's GEMMs shrink to a chunk's examples); False — only the exchanges and
         the embedding-side kernels are chunked, the MLP runs once on the whole batch (the row exchange travels under the
@@ -45,6 +51,7 @@ class RowShard:
         self.rank, self.world, self.group = int(rank), int(world), group
         self.chunks = chunks
         self.chunk_compute = (self.world < 8) if chunk_compute is None else bool(chunk_compute)
+        self.route_ahead = True if route_ahead is None else bool(route_ahead)
         self.comm = None
 
     def local_rows(self, R):
@@ -54,7 +61,7 @@ class RowShard:
 class Comm:
     """Thin wrapper over torch.distributed for the three collectives the step needs."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, second=True):
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
@@ -63,8 +70,11 @@ class Comm:
         # collectives in issue order on one stream, and that exchange waits for the next batch's sorts — on this step's
         # communicator it would hold up this step's row exchanges behind them.  (Created by every rank, here, in the
         # same order.)
+        # (RowShard(route_ahead=False): no second communicator exists at all)
         ranks = dist.get_process_group_ranks(group if group is not None else dist.group.WORLD)
-        self.ahead_group = dist.new_group(ranks=ranks)
+        self.ahead_group = dist.new_group(ranks=ranks) if second else None
+        self._pinned = {}                # (C, parity) -> pinned host buffer of the count tables, allocated once
+        self._pin_turn = 0
         # send order of the owners (mi_shard_keys, self_rank): the other ranks in rank order, this rank LAST
         self.pos_of_rank = [j if j < self.rank else (self.world - 1 if j == self.rank else j - 1) for j in range(self.world)]
         self._pos_dev = {}
@@ -88,11 +98,17 @@ class Comm:
         if not self.direct:
             send = send.cpu()
         recv = torch.empty_like(send)
-        dist.all_to_all_single(recv, send, group=self.ahead_group if ahead else self.group)
+        dist.all_to_all_single(recv, send, group=self.ahead_group if (ahead and self.ahead_group is not None) else self.group)
         both = torch.stack([send, recv])
         if both.device.type != "cuda":
             return {"host": both, "event": None, "C": C}
-        host = torch.empty(both.shape, dtype=both.dtype, pin_memory=True)
+        # pinned host memory is allocated ONCE per table shape (two buffers in turn: a plan made ahead is still pending
+        # while this step's is read) — a hipHostMalloc between two ranks' collectives is a device-wide synchronisation
+        key = (tuple(both.shape), self._pin_turn & 1)
+        self._pin_turn += 1
+        host = self._pinned.get(key)
+        if host is None:
+            host = self._pinned[key] = torch.empty(both.shape, dtype=both.dtype, pin_memory=True)
         host.copy_(both, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
@@ -114,7 +130,7 @@ class Comm:
         there is nothing to exchange at all."""
         if self.world == 1:
             return None
-        group = self.ahead_group if ahead else self.group      # (ahead: the next batch's id exchange, see _own_ahead)
+        group = self.ahead_group if (ahead and self.ahead_group is not None) else self.group      # (ahead: the next batch's id exchange, see _own_ahead)
         if self.direct:
             return dist.all_to_all_single(out, inp, list(out_counts), list(in_counts), group=group,
                                           async_op=async_op) if async_op else \
@@ -143,7 +159,7 @@ class Comm:
 
 def _comm(m):
     if m.shard.comm is None:
-        m.shard.comm = Comm(m.shard.group)
+        m.shard.comm = Comm(m.shard.group, second=m.shard.route_ahead)
         if m.shard.comm.world != m.shard.world or m.shard.comm.rank != m.shard.rank:
             raise ValueError("RowShard(rank=%d, world=%d) does not match the process group (%d of %d)" %
                              (m.shard.rank, m.shard.world, m.shard.comm.rank, m.shard.comm.world))
@@ -252,7 +268,7 @@ def _owners_side(m, plan, train, ahead=False):
     tag, C = plan["tag"], plan["C"]
     uoff, roff, umid, rmid = plan["uoff"], plan["roff"], plan["umid"], plan["rmid"]
     nr = roff[-1]
-    recv_ids = m._buf("recv_ids" + tag, (max(nr, 1),), torch.int32)[:nr]
+    recv_ids = m._buf("recv_ids" + tag, (max(2 * plan["slot"].numel(), nr, 1),), torch.int32)[:nr]      # (capacity: see _sharded_step)
     send_rows = plan["send_rows"]
     for c in range(C):
         comm.all_to_all(recv_ids[roff[c]:rmid[c]], send_rows[uoff[c]:umid[c]], plan["rc0"][c], plan["sc0"][c], ahead=ahead)
@@ -261,7 +277,8 @@ def _owners_side(m, plan, train, ahead=False):
     plan["recv_ids"] = recv_ids
     plan["book"] = None
     if train and nr > 0:        # (sorted_entry, uniq, seg, num_uniq)
-        plan["book"] = m._sort_unique(recv_ids, nr, m.R_local, "own" + tag, ws_name="sort_ws_ahead" if ahead else "sort_ws")
+        plan["book"] = m._sort_unique(recv_ids, nr, m.R_local, "own" + tag, ws_name="sort_ws_ahead" if ahead else "sort_ws",
+                                      cap=2 * plan["slot"].numel())
     return plan
 
 
@@ -345,7 +362,7 @@ def _sharded_step(m, ids, labels, x_num, train, next_ids=None):
         m._split_weights_ahead()            # the MLP's weight planes, on a side stream beside the routing
     # (an evaluation between two train steps plans into the first buffer set: a plan made ahead is dropped first)
     plan = _finish_plan(m, _take_route(m, ids, C if train else -1))
-    if train and next_ids is not None and next_ids.shape == ids.shape and not getattr(m, "_capturing", False):
+    if train and next_ids is not None and next_ids.shape == ids.shape and not getattr(m, "_capturing", False) and m.shard.route_ahead:
         _route_ahead(m, next_ids, C)
     slot, sorted_entry, seg = plan["slot"], plan["sorted_entry"], plan["seg"]
     uoff, roff, umid, rmid, sc0, rc0 = plan["uoff"], plan["roff"], plan["umid"], plan["rmid"], plan["sc0"], plan["rc0"]
@@ -359,10 +376,16 @@ def _sharded_step(m, ids, labels, x_num, train, next_ids=None):
     if book is not None and m.adam_rows and m.step > 0:
         m._catchup(book[1], book[3], nr, defer=True)
 
-    own_rows = m._buf("own_rows", (max(nr, 1), E))[:nr] if m.use_emb else None
-    own_lin = m._buf("own_lin", (max(nr, 1),))[:nr] if m.use_linear else None
-    got_rows = m._buf("got_rows", (max(U, 1), E)) if m.use_emb else None
-    got_lin = m._buf("got_lin", (max(U, 1),)) if m.use_linear else None
+    # Buffers whose size follows the batch's content (U distinct requests <= n entries; nr requests received: ~n for ids
+    # spread over the ranks) are allocated at their CAPACITY the first time — n rows, and 2 n on the owner's side — so that
+    # no later step allocates between two collectives (an allocation that misses torch's cache is a hipMalloc: a
+    # device-wide synchronisation between kernels other ranks are waiting on).  Only a batch more than twice as
+    # concentrated on this owner as a uniform one grows them again.
+    cap_u, cap_r = max(n, 1), max(2 * n, nr, 1)
+    own_rows = m._buf("own_rows", (cap_r, E))[:nr] if m.use_emb else None
+    own_lin = m._buf("own_lin", (cap_r,))[:nr] if m.use_linear else None
+    got_rows = m._buf("got_rows", (cap_u, E))[:max(U, 1)] if m.use_emb else None
+    got_lin = m._buf("got_lin", (cap_u,))[:max(U, 1)] if m.use_linear else None
 
     def gather(ids_, n_, rows_out, lin_out):
         if n_ > 0:
@@ -383,10 +406,10 @@ def _sharded_step(m, ids, labels, x_num, train, next_ids=None):
         gather(recv_ids[mid:hi], hi - mid, got_rows[um:uhi] if m.use_emb else None, got_lin[um:uhi] if m.use_linear else None)
         return hs
 
-    d_rows = m._buf("d_rows", (max(U, 1), E)) if (train and m.use_emb) else None      # one row per distinct request, send order
-    d_lin = m._buf("d_lin", (max(U, 1),)) if (train and m.use_linear) else None
-    r_rows = m._buf("recv_d_rows", (max(nr, 1), E))[:nr] if (train and m.use_emb) else None
-    r_lin = m._buf("recv_d_lin", (max(nr, 1),))[:nr] if (train and m.use_linear) else None
+    d_rows = m._buf("d_rows", (cap_u, E))[:max(U, 1)] if (train and m.use_emb) else None      # one row per distinct request, send order
+    d_lin = m._buf("d_lin", (cap_u,))[:max(U, 1)] if (train and m.use_linear) else None
+    r_rows = m._buf("recv_d_rows", (cap_r, E))[:nr] if (train and m.use_emb) else None
+    r_lin = m._buf("recv_d_lin", (cap_r,))[:nr] if (train and m.use_linear) else None
     logits_all = m._buf("logits_all", (B,)) if C > 1 else None
     loss_all = m._buf("loss_all", (1,)) if C > 1 else None
     acc = m._buf("d_grad_acc", (m.P,)) if (train and C > 1) else None

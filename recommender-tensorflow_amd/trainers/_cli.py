@@ -22,7 +22,12 @@ _COMMON = [
     ("--world-size", dict(type=int, default=None, help="number of MI355X (one process each): launch with `python -m "
                                                        "torch.distributed.run --nproc-per-node N -m trainers.<model> ...`; the flag "
                                                        "only checks the launch (default: WORLD_SIZE of the launcher, else 1)")),
-    ("--hip-graph", dict(action="store_true", help="replay the train step as one hipGraph launch (launch-bound small batches)")),
+    ("--single-communicator", dict(action="store_true", help="N > 1 GPUs: run every collective of a step on ONE RCCL communicator (no "
+                                                             "routing of the next batch ahead on a second one)")),
+    ("--collective-timeout", dict(type=float, default=600.0, help="N > 1 GPUs: seconds after which a stuck collective aborts the process")),
+    ("--hip-graph", dict(nargs="?", const="on", default="auto", choices=["auto", "on", "off"],
+                         help="replay the train step as one hipGraph launch (bit for bit the eager step): auto = for batches of at most "
+                              "1,024 examples on one GPU, where a step is launch-bound (default: %(default)s)")),
     ("--catchup", dict(choices=["exact", "bounded"], default="exact",
                        help="Adam only: how the steps a table row sat out are replayed when it is next read — exact: TensorFlow's fp32 "
                             "sequence bit for bit; bounded: every variable within 3 ulp + 2e-6 of the movement the replay covers (98.7 %% of "
@@ -67,15 +72,19 @@ def init_distributed(args):
     import torch
     import torch.distributed as dist
     from mi355x_rec.parallel import RowShard
+    import datetime
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    # a stuck collective ends the process non-zero (the watchdog names the rank and the collective) instead of hanging the node
+    os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
+    tmo = datetime.timedelta(seconds=float(getattr(args, "collective_timeout", None) or 600.0))
     if device.startswith("cuda"):
         device = "cuda:%d" % local
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device(device))
+        dist.init_process_group("nccl", device_id=torch.device(device), timeout=tmo)
     else:
-        dist.init_process_group("gloo")
-    return rank, world, device, RowShard(rank, world)
+        dist.init_process_group("gloo", timeout=tmo)
+    return rank, world, device, RowShard(rank, world, route_ahead=not getattr(args, "single_communicator", False))
 
 
 def run(args, make_estimator):
@@ -98,7 +107,7 @@ def run(args, make_estimator):
     estimator = make_estimator(columns, config)
     estimator.warm_start_from = getattr(args, "warm_start_from", None)
     estimator.params["_shard"] = shard
-    estimator.params["hip_graph"] = bool(getattr(args, "hip_graph", False))
+    estimator.params["hip_graph"] = getattr(args, "hip_graph", "auto")
     estimator.params["catchup"] = getattr(args, "catchup", "exact")
     train_spec = get_train_spec(get_input_fn(args.train_csv, batch_size=args.batch_size, seed=rank if world > 1 else None),
                                 args.train_steps)

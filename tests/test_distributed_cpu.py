@@ -53,7 +53,8 @@ def _worker(rank, world, port, cfg, out_q, device="cpu", backend="gloo"):
         p, ids, x, y = _problem(cfg, world)
         lin_opt = OptimizerSpec(*extra["lin_opt"]) if "lin_opt" in extra else None
         m = DeepFM(vocab, n_numeric=nn, embedding_size=E, hidden_units=hidden, use_linear=flags[0], use_mf=flags[1],
-                   use_dnn=flags[2], optimizer=OptimizerSpec(opt_name, lr), device=device, shard=RowShard(rank, world, chunks=chunks, chunk_compute=extra.get("chunk_compute")),
+                   use_dnn=flags[2], optimizer=OptimizerSpec(opt_name, lr), device=device, shard=RowShard(rank, world, chunks=chunks, chunk_compute=extra.get("chunk_compute"),
+                                                                                     route_ahead=extra.get("route_ahead")),
                    numeric=extra.get("numeric", "embed"), linear_optimizer=lin_opt, reduction=extra.get("reduction", "mean"),
                    _kernels=kernels)
         m.load_oracle_params(p)
@@ -79,6 +80,7 @@ def _worker(rank, world, port, cfg, out_q, device="cpu", backend="gloo"):
         exported = m.export_numpy()
         exported["exchange"] = dict(m.last_exchange)            # of the eval step: one chunk
         exported["route_ahead_hits"] = getattr(m, "route_ahead_hits", 0)
+        exported["second_communicator"] = m.shard.comm.ahead_group is not None
         out_q.put((rank, "ok", losses, exported, ev_logits.cpu().numpy().copy()))
         dist.barrier()
         dist.destroy_process_group()
@@ -185,6 +187,20 @@ def test_eight_rank_default_step_equals_big_batch(cfg):
     check_against_big_batch(cfg, res, 8)
     assert all(res[r][1]["route_ahead_hits"] == 2 for r in range(8))
     assert all(res[r][1]["exchange"]["requests_to_self"] <= res[r][1]["exchange"]["requests_sent"] for r in range(8))
+
+
+@pytest.mark.parametrize("cfg,world", [
+    (([9, 13, 5, 6], 8, [16, 8], 32, 0, "Adam", 0.001, 4, (True, True, True), 2, dict(announce=True, route_ahead=False)), 2),
+    (([9, 13, 5, 6], 8, [16, 8], 16, 0, "Adam", 0.001, 3, (True, True, True), 2, dict(chunk_compute=False, announce=True, route_ahead=False)), 4),
+    (([19, 23, 17, 29], 8, [16, 8], 16, 3, "Adagrad", 0.05, 3, (True, False, True), 2,
+      dict(numeric="raw", lin_opt=("Ftrl", 0.2), reduction="sum", announce=True, route_ahead=False)), 8)])
+def test_single_communicator_step_equals_big_batch(cfg, world):
+    """RowShard(route_ahead=False): the whole step on ONE communicator — no second process group is created, an announced
+    next batch is ignored (its routing runs at the head of its own step) — same results; world 2, 4 (chunked exchanges,
+    one MLP pass) and 8 (config 4's model with the 8-rank defaults)."""
+    res = _run(cfg, world)
+    check_against_big_batch(cfg, res, world)
+    assert all(res[r][1]["route_ahead_hits"] == 0 and not res[r][1]["second_communicator"] for r in range(world))
 
 
 def test_four_rank_pipelined_step_equals_big_batch():

@@ -25,13 +25,18 @@ pytestmark = pytest.mark.gpu
                                  # config 4's model with the numeric columns written into the planes by the gather (E = 32),
                                  # the embedding-side kernels in two pieces
                                  ([50, 30, 20, 40], 32, [64, 32], 128, 3, "Adagrad", 0.05, 2, (True, False, True), 2,
-                                  dict(numeric="raw", lin_opt=("Ftrl", 0.2), reduction="sum", chunk_compute=False))])
+                                  dict(numeric="raw", lin_opt=("Ftrl", 0.2), reduction="sum", chunk_compute=False)),
+                                 # the whole step on ONE communicator (RowShard(route_ahead=False)): announced batches are ignored
+                                 ([50, 30, 20, 40], 64, [64, 32], 256, 0, "Adam", 0.001, 3, (True, True, True), 2,
+                                  dict(chunk_compute=False, announce=True, route_ahead=False))])
 def test_two_ranks_one_gpu_gloo(cfg):
     check_against_big_batch(cfg, _run(cfg, 2, device="cuda", backend="gloo"), 2, tol=3.0)
 
 
-@pytest.mark.parametrize("chunks,chunk_compute", [(1, True), (3, True), (3, False)])
-def test_single_rank_rccl_path(chunks, chunk_compute):
-    """chunks = 3: the asynchronous all_to_all handles of the pipelined step on RCCL's own stream"""
-    cfg = ([50, 30, 20, 40], 16, [32, 16], 96, 0, "Adam", 0.001, 3, (True, True, True), chunks, dict(chunk_compute=chunk_compute))
+@pytest.mark.parametrize("chunks,chunk_compute,route_ahead", [(1, True, True), (3, True, True), (3, False, True), (3, False, False)])
+def test_single_rank_rccl_path(chunks, chunk_compute, route_ahead):
+    """chunks = 3: the asynchronous all_to_all handles of the pipelined step on RCCL's own stream; both route modes (a
+    second RCCL communicator for the batch routed ahead / one communicator for the whole step)"""
+    cfg = ([50, 30, 20, 40], 16, [32, 16], 96, 0, "Adam", 0.001, 3, (True, True, True), chunks,
+           dict(chunk_compute=chunk_compute, announce=True, route_ahead=route_ahead))
     check_against_big_batch(cfg, _run(cfg, 1, device="cuda", backend="nccl"), 1, tol=3.0)

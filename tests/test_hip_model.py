@@ -450,6 +450,37 @@ def test_graph_train_step_replays_the_eager_step_bitwise(vocab, E, hidden, B):
         assert torch.equal(getattr(eager, k), getattr(graph, k)), k
 
 
+@pytest.mark.parametrize("kind", ["deepfm-numeric-embeddings", "wide-and-deep-raw-numeric"])
+def test_graph_train_step_with_numeric_columns_replays_the_eager_step_bitwise(kind):
+    """Round 4: numeric columns inside the captured step (a third input copy) — DeepFM's numeric embeddings
+    (deep_fm.py:62-73) with one Adam, and the canned Wide&Deep of config 4 (raw numeric columns, Ftrl + Adagrad, SUM loss:
+    no Adam schedule at all) at the CLI's small-batch shape: bit for bit the eager sequence."""
+    from mi355x_rec.engine import OptimizerSpec
+    vocab, E, hidden, B, nn = ML100K_VOCAB, 4, [16, 16], 32, 3
+    raw = kind.startswith("wide")
+    kw = dict(numeric="raw", use_mf=False, reduction="sum", optimizer=OptimizerSpec("Adagrad", 0.05),
+              linear_optimizer=OptimizerSpec("Ftrl", 0.18)) if raw else dict(optimizer=OptimizerSpec("Adam", 0.001))
+    ms = []
+    for _ in range(2):
+        m = _engine(vocab, E, hidden, nn, dropout=0.25, seed=5, **kw)
+        g = torch.Generator(device="cuda"); g.manual_seed(3)
+        m.init_variables(g, lin_scale=1e-2)
+        ms.append(m)
+    eager, graph = ms
+    assert graph.graph_ok()
+    rng = np.random.default_rng(2)
+    for step in range(8):
+        ids_s = dev(np.stack([rng.integers(0, v, B) for v in vocab], 1).astype(np.int32))
+        xs = dev(rng.standard_normal((B, nn)).astype(np.float32))
+        ys = dev((rng.random(B) < 0.3).astype(np.uint8))
+        le, ge = eager.train_step(ids_s, ys, xs)
+        lg, gg = graph.graph_train_step(ids_s, ys, xs)
+        assert torch.equal(le, lg) and torch.equal(ge, gg), step
+    assert graph._graph is not None and graph._graph["x"] is not None and graph.step == eager.step == 8
+    for k in ("table", "t_s0", "lin_state", "dense", "d_s0"):
+        assert torch.equal(getattr(eager, k), getattr(graph, k)), k
+
+
 def test_captured_step_has_no_memset_nodes():
     """Round 2's GPU fault: a captured LINEAR step whose sorts zeroed their counters with hipMemsetAsync
     faulted at replay ("write access to a read-only page") although — tools/graph_memset_nodes.py, round 3 — both memset
