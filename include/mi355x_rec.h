@@ -52,7 +52,7 @@ enum mi_status {
 };
 
 /* ---- library ---------------------------------------------------------------------------- */
-int32_t mi_abi_version(void);       /* bumps when a signature changes (currently 18) */
+int32_t mi_abi_version(void);       /* bumps when a signature changes (currently 19) */
 const char* mi_last_error(void);    /* thread-local, never NULL */
 const char* mi_build_info(void);    /* "gfx950 hipcc <ver>" */
 
@@ -505,28 +505,34 @@ int32_t mi_merge_rows(const mi_planes_t* in, int64_t rows, int32_t K, float* X, 
 /* Y[M][N] = act(X[M][K] * W[K][N] + bias) with X as planes and Wt = planes of W TRANSPOSED (rows = N);
  * epilogue as mi_dense_fwd.  Y (fp32) and / or Yp (planes, N <= 512; a positive value keeps a positive high
  * part, so "hi > 0" is the relu/dropout mask of the data gradient) receive the result; amax_out (may be
- * NULL) its abs-max. */
+ * NULL) its abs-max.
+ * mask_bits_out (may be NULL; round 4): the same mask as ONE BIT per output — [M][mask_ld] 32-bit words, mask_ld >=
+ * ceil(N / 32), bit (n & 31) of word (n >> 5) of row m = "Y[m][n] > 0" (active and kept).  The data gradients below take
+ * it instead of the stored activation: 1/32 of the bytes (2 MB instead of the 134 MB high-plane read at 65536 x 512). */
 int32_t mi_dense_fwd_planes(const mi_planes_t* X, const mi_planes_t* Wt, const float* bias, float* Y, int64_t ldy,
                             const mi_planes_t* Yp, int64_t M, int32_t N, int32_t K, int32_t relu, float keep_prob,
-                            uint64_t seed, float* amax_out, mi_stream_t stream);
+                            uint64_t seed, float* amax_out, uint32_t* mask_bits_out, int64_t mask_ld, mi_stream_t stream);
 
 /* dX[M][K] = (dY[M][N] * W[K][N]^T) .* mask with dY as planes and W = planes of W as stored (rows = K);
  * mask from Xact (planes of the previous layer's stored output: hi > 0 <=> active and kept; NULL: none),
  * survivors divided by keep_prob.  dX (fp32) and / or dXp (planes, K <= 512). * fold_sumv != NULL (layer 1 only: dX is d_concat, fp32, no mask): dX[m][k] += fold_dlogit[m] * fold_sumv[m][k % fold_E]
  * — the FM term's share of the input_layer gradient (deep_fm.py:81-87 backward) added once per example here;
- * mi_sparse_apply_fused is then called with sumv == NULL and subtracts d_logit_fm * row only. */
+ * mi_sparse_apply_fused is then called with sumv == NULL and subtracts d_logit_fm * row only.
+ * mask_bits / mask_ld (may be NULL): the mask as mi_dense_fwd_planes' mask_bits_out wrote it ([M][mask_ld] words, one bit per
+ * element of dX's K columns); taken instead of Xact when both are given — the same decisions, hence the same bits. */
 int32_t mi_dense_bwd_data_planes(const mi_planes_t* dY, const mi_planes_t* W, const mi_planes_t* Xact, float* dX,
                                  int64_t lddx, const mi_planes_t* dXp, int64_t M, int32_t N, int32_t K, float keep_prob,
                                  float* amax_out, const float* fold_sumv, const float* fold_dlogit, int32_t fold_E,
-                                 mi_stream_t stream);
+                                 const uint32_t* mask_bits, int64_t mask_ld, mi_stream_t stream);
 
 /* The data gradient of the N = 1 logits layer (deep_fm.py:108 backward) with the result as planes:
  * dX[m][k] = dY[m] * W[k], kept where Xact[m][k] > 0 and divided by keep_prob (Xact == NULL: no mask) — the
  * arithmetic of mi_dense_bwd_data's N = 1 form with ReLU, bit for bit — into dXp (required) and, if not NULL, dX.
- * amax_out as everywhere.  K a multiple of 16. */
+ * amax_out as everywhere.  K a multiple of 16.  mask_bits / mask_ld: the one-bit mask (see mi_dense_fwd_planes), taken
+ * instead of Xact when given. */
 int32_t mi_dense_bwd_data_vec_planes(const float* dY, int64_t lddy, const float* W, const float* Xact, int64_t ldxa,
                                      float keep_prob, float* dX, int64_t lddx, const mi_planes_t* dXp, int64_t M, int32_t K,
-                                     float* amax_out, mi_stream_t stream);
+                                     float* amax_out, const uint32_t* mask_bits, int64_t mask_ld, mi_stream_t stream);
 
 /* dW[K][N] = X[M][K]^T * dY[M][N] and db[N] = column sums of dY (NULL: skipped), both operands as planes
  * (replaces the same gradients as mi_dense_bwd_weight: model_utils.py:69-72 through tf.layers.dense,

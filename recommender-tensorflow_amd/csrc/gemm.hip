@@ -444,27 +444,63 @@ __global__ __launch_bounds__(kThreads) void absmax_k(const float* __restrict__ x
   mi_amax_publish(out, mx);
 }
 
-// out[i] = sum_s slab[s][i] in a fixed order (bitwise reproducible split-K).  64 outputs per block;
-// the 4 waves take every 4th slab each, then fold through LDS as (w0+w1)+(w2+w3).
-// A second vector (the bias gradient's partials) rides in the same launch: blocks past ceil(n / 64) reduce it.
+// out[i] = sum_s slab[s][i] in a fixed order (bitwise reproducible split-K): the 4 waves of a block take every 4th slab
+// each (wave g: s = g, g + 4, ...), then fold through LDS as (w0 + w1) + (w2 + w3).  A lane owns VEC consecutive outputs
+// (a block 64 VEC of them): VEC = 4 — 16-byte loads, eight in flight per lane — where that still leaves >= 512 blocks
+// (the layer-1 fold: 65 MB of slabs), VEC = 1 for the small matrices, whose parallelism is the slabs.
+// A second vector (the bias gradient's partials) rides in the same launch: blocks past the first vector's reduce it (VEC = 1).
+template <int VEC>
+__device__ __forceinline__ void slab_reduce_body(const float* __restrict__ slab, int nsplit, int64_t n, float* __restrict__ out,
+                                                 int64_t blk, float (*red)[64 * 4]) {
+  const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int64_t i = (blk * 64 + c) * VEC;
+  float acc[VEC];
+#pragma unroll
+  for (int q = 0; q < VEC; ++q) acc[q] = 0.f;
+  if (i < n) {
+    const float* p = slab + i;
+    int s = g;
+    if constexpr (VEC == 4) {
+      for (; s + 28 < nsplit; s += 32) {               // eight slabs of this wave at once
+        float4 v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = *reinterpret_cast<const float4*>(p + static_cast<int64_t>(s + 4 * q) * n);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { acc[0] += v[q].x; acc[1] += v[q].y; acc[2] += v[q].z; acc[3] += v[q].w; }
+      }
+      for (; s < nsplit; s += 4) {
+        const float4 v = *reinterpret_cast<const float4*>(p + static_cast<int64_t>(s) * n);
+        acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;
+      }
+    } else {
+#pragma unroll 8
+      for (; s < nsplit; s += 4) acc[0] += p[static_cast<int64_t>(s) * n];
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < VEC; ++q) red[g][c * VEC + q] = acc[q];
+  __syncthreads();
+  if (g == 0 && i < n) {
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) out[i + q] = (red[0][c * VEC + q] + red[1][c * VEC + q]) + (red[2][c * VEC + q] + red[3][c * VEC + q]);
+  }
+}
+template <int VEC>
 __global__ __launch_bounds__(kThreads) void slab_reduce_k(const float* __restrict__ slab, int nsplit,
                                                           int64_t n, float* __restrict__ out,
                                                           const float* __restrict__ slab2 = nullptr, int64_t n2 = 0,
                                                           float* __restrict__ out2 = nullptr) {
-  __shared__ float red[4][64];
-  const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
-  int64_t blk = blockIdx.x;
-  const int64_t nb1 = (n + 63) >> 6;
-  if (blk >= nb1) { blk -= nb1; slab = slab2; n = n2; out = out2; }      // (block-uniform)
-  const int64_t i = blk * 64 + c;
-  float acc = 0.f;
-  if (i < n) {
-#pragma unroll 4
-    for (int s = g; s < nsplit; s += 4) acc += slab[static_cast<int64_t>(s) * n + i];
-  }
-  red[g][c] = acc;
-  __syncthreads();
-  if (g == 0 && i < n) out[i] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+  __shared__ float red[4][64 * 4];
+  const int64_t nb1 = (n + 64 * VEC - 1) / (64 * VEC);
+  const int64_t blk = blockIdx.x;
+  if (blk >= nb1) slab_reduce_body<1>(slab2, nsplit, n2, out2, blk - nb1, red);        // (block-uniform)
+  else slab_reduce_body<VEC>(slab, nsplit, n, out, blk, red);
+}
+inline void slab_reduce(const float* slab, int nsplit, int64_t n, float* out, const float* slab2, int64_t n2, float* out2, hipStream_t st) {
+  const bool vec = (n & 3) == 0 && n >= 4 * 64 * 512 && (reinterpret_cast<uintptr_t>(slab) & 15u) == 0 && (reinterpret_cast<uintptr_t>(out) & 15u) == 0;
+  const int64_t nb2 = n2 > 0 ? mi::ceil_div(n2, 64) : 0;
+  if (vec) slab_reduce_k<4><<<dim3((unsigned)(mi::ceil_div(n, 256) + nb2)), dim3(kThreads), 0, st>>>(slab, nsplit, n, out, slab2, n2, out2);
+  else slab_reduce_k<1><<<dim3((unsigned)(mi::ceil_div(n, 64) + nb2)), dim3(kThreads), 0, st>>>(slab, nsplit, n, out, slab2, n2, out2);
 }
 
 // column sums, stage 1: block = 64 columns x a slab of rows; thread (c, g) strides rows by 4.
@@ -871,7 +907,7 @@ static int32_t bwd_weight_impl(const float* X, int64_t ldx, const float* dY, int
         X, ldx, dY, lddy, M, K, rows, one ? dW : slab, db ? (one ? db : cpart) : nullptr);
     MI_CHECK_LAUNCH("dense_bwd_weight(N = 1)");
     if (one) return MI_OK;
-    slab_reduce_k<<<dim3((unsigned)(mi::ceil_div(n, 64) + (db ? 1 : 0))), dim3(kThreads), 0, st>>>(slab, splits, n, dW, cpart, 1, db);
+    slab_reduce(slab, splits, n, dW, cpart, db ? 1 : 0, db, st);
     MI_CHECK_LAUNCH("dense_bwd_weight(reduce)");
     return MI_OK;
   }
@@ -890,8 +926,7 @@ static int32_t bwd_weight_impl(const float* X, int64_t ldx, const float* dY, int
     if (int32_t rc = launch<MC, MC, true, true>(a, splits, st, "dense_bwd_weight_gathered(split-K)")) return rc;
   } else if (int32_t rc = launch<MC, MC, true>(a, splits, st, "dense_bwd_weight(split-K)")) return rc;
   if (direct) return MI_OK;
-  slab_reduce_k<<<dim3((unsigned)(mi::ceil_div(n, 64) + (db ? mi::ceil_div(N, 64) : 0))), dim3(kThreads), 0, st>>>(
-      slab, splits, n, dW, cpart, N, db);
+  slab_reduce(slab, splits, n, dW, cpart, db ? N : 0, db, st);
   MI_CHECK_LAUNCH("dense_bwd_weight(reduce)");
   return MI_OK;
 }
@@ -973,8 +1008,7 @@ int32_t mi_dense_bwd_weight_planes(const mi_planes_t* X, const mi_planes_t* dY, 
     MI_CHECK_LAUNCH("dense_bwd_weight_planes(split-K)");
   }
   if (direct) return MI_OK;
-  slab_reduce_k<<<dim3((unsigned)(mi::ceil_div(n, 64) + (db ? mi::ceil_div(N, 64) : 0))), dim3(kThreads), 0, st>>>(
-      slab, splits, n, dW, cpart, N, db);
+  slab_reduce(slab, splits, n, dW, cpart, db ? N : 0, db, st);
   MI_CHECK_LAUNCH("dense_bwd_weight_planes(reduce)");
   return MI_OK;
 }

@@ -60,6 +60,10 @@ struct PlArgs {
   char* Cp; int64_t bsc; int32_t* c_exp;                // planes of the result or NULL (one column tile only)
   const float* bias; int relu; float keep_prob, keep_div, keep_rcp; uint64_t seed;   // keep_rcp = RN(1 / keep_div), from the host
   const char* mask; int64_t bsm;                        // dgrad: planes of the stored activation (hi > 0 <=> active & kept)
+  // The relu/dropout mask as ONE BIT per element, [M][mbld] 32-bit words, bit c & 31 of word c >> 5 of a row = "output c is
+  // active and kept" (value > 0): written by the forward epilogue (FWD: an output), read by the data gradient instead of the
+  // stored activation's high plane (DGRAD: an input; 2 MB instead of 134 MB at 65536 x 512) and by the logits layer's.
+  uint32_t* mbits; int64_t mbld;
   float* amax_c;                                        // abs-max vector of the result (the weight gradient's matrix-wide scales) or NULL
   // dgrad into the input_layer: the FM term's share of the concat gradient, added once here instead of once
   // per entry in the sparse apply: C[m][n] += fold_g[m] * fold_s[m][n % fold_E]   (NULL: nothing added)
@@ -277,8 +281,10 @@ __global__ __launch_bounds__(PL_THREADS, 2) void gemm_pl_k(const PlArgs a) {
   // one private LDS region per wave for the result's way out (row-contiguous stores, below)
   constexpr int FS = TN * 128 + 16;                 // bytes per fp32 row of the wave's 32 x 32 TN sub-tile (+ pad: banks)
   constexpr int WREG = 32 * FS > TN * 4096 ? 32 * FS : TN * 4096;
-  static_assert(8192 + 8 * WREG <= PL_NBUF * STAGE, "epilogue LDS");
+  constexpr int WPR = BNt / 32;                      // mask words per tile row
+  static_assert(8192 + 8 * WREG + BMt * WPR * 4 <= PL_NBUF * STAGE, "epilogue LDS");
   char* wreg = smem + 8192 + wv * WREG;
+  uint32_t* e_bits = reinterpret_cast<uint32_t*>(smem + 8192 + 8 * WREG);     // [BMt][WPR] the tile's mask words (FWD, mask bits asked for)
   for (int n = t; n < BNt; n += PL_THREADS) {
     const int gn = n0 + n;
     const bool ok = gn < a.N;
@@ -300,8 +306,9 @@ __global__ __launch_bounds__(PL_THREADS, 2) void gemm_pl_k(const PlArgs a) {
   const int nw = wn * 32 * TN;                      // this wave's first column inside the tile
   // (the hash of a column pair: (col >> 1) * MUL = pair_base + a compile-time multiple of MUL)
   const uint32_t pair_base = static_cast<uint32_t>((n0 + nw + 4 * h) >> 1) * MI_DROP_PAIR_MUL;
-  const bool masked = EPI == PL_DGRAD && a.mask != nullptr;
-  const bool divide = drop || masked;
+  const bool bitmask = EPI == PL_DGRAD && a.mbits != nullptr;
+  const bool masked = EPI == PL_DGRAD && a.mask != nullptr && !bitmask;
+  const bool divide = drop || masked || bitmask;
   const float kd = divide ? a.keep_div : 1.f, kr = divide ? a.keep_rcp : 1.f;
   const float relu_floor = a.relu ? 0.f : -__builtin_inff();
   float rmx[TM];
@@ -336,6 +343,17 @@ __global__ __launch_bounds__(PL_THREADS, 2) void gemm_pl_k(const PlArgs a) {
 #pragma unroll
       for (int q = 0; q < MK_AHEAD; ++q) mkq[q] = (masked && q < TN * 4) ? mask_word(q) : make_uint2(0x00010001u, 0x00010001u);
     }
+    // mask bits of this lane's example: the TN words of the wave's 32 TN columns (DGRAD: loaded here, one 4 TN-byte read;
+    // FWD: collected below).  No bit mask: all ones.
+    uint32_t mw[TN];
+#pragma unroll
+    for (int x = 0; x < TN; ++x) {
+      mw[x] = EPI == PL_DGRAD ? 0xffffffffu : 0u;
+      if constexpr (EPI == PL_DGRAD) {
+        const int wi = ((n0 + nw) >> 5) + x;
+        if (bitmask) mw[x] = wi < a.mbld ? a.mbits[static_cast<int64_t>(mc) * a.mbld + wi] : 0u;
+      }
+    }
 #pragma unroll
     for (int gi = 0; gi < TN * 4; ++gi) {
       const int x = gi >> 2, g = gi & 3;
@@ -349,7 +367,11 @@ __global__ __launch_bounds__(PL_THREADS, 2) void gemm_pl_k(const PlArgs a) {
       // DGRAD: the group's mask word (positive <=> active and kept; no mask: all positive)
       uint32_t w2[2] = {0u, 0u};
       if constexpr (EPI == PL_DGRAD) {
-        w2[0] = mkq[gi % MK_AHEAD].x; w2[1] = mkq[gi % MK_AHEAD].y;
+        // the group's four mask bits (columns 8 g + 4 h + j of tile x) as four "positive fp16" halves, ANDed into the
+        // planes mask's word (no planes mask: all positive; no bit mask: all ones)
+        const uint32_t nib = mw[x] >> (8 * g + 4 * h);
+        const uint32_t b0 = (nib & 1u) | ((nib & 2u) << 15), b1 = ((nib >> 2) & 1u) | ((nib & 8u) << 13);
+        w2[0] = bitmask ? b0 : mkq[gi % MK_AHEAD].x; w2[1] = bitmask ? b1 : mkq[gi % MK_AHEAD].y;
         if (masked && gi + MK_AHEAD < TN * 4) mkq[gi % MK_AHEAD] = mask_word(gi + MK_AHEAD);
       } else if (drop) {
         const uint32_t pt = pair_base + static_cast<uint32_t>((x * 32 + 8 * g) >> 1) * MI_DROP_PAIR_MUL;
@@ -403,6 +425,30 @@ __global__ __launch_bounds__(PL_THREADS, 2) void gemm_pl_k(const PlArgs a) {
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
+    if constexpr (EPI == PL_FWD) {
+      if (a.mbits) {
+        // one bit per output, from the finished values (+2.5 us on the 512 -> 256 forward, +1 us on 256 -> 128; the data
+        // gradients that read the bits instead of the activation's planes gain 25-30 and 2 us: tools/mlp_tail_bench.py)
+#pragma unroll
+        for (int x = 0; x < TN; ++x) {
+          uint32_t lo8 = 0u, hi8 = 0u;
+#pragma unroll
+          for (int r = 0; r < 8; ++r) {
+            lo8 |= (acc[x][y][r] > 0.f ? 1u : 0u) << (8 * (r >> 2) + (r & 3));
+            hi8 |= (acc[x][y][8 + r] > 0.f ? 1u : 0u) << (8 * (r >> 2) + (r & 3));
+          }
+          mw[x] = lo8 | (hi8 << 16);
+        }
+        // lane h holds the bits of columns 8 g + 4 h + j at positions 8 g + j: shifted by 4 h and ORed over the lane pair they
+        // are the tile's 32-bit word.  Into LDS as [row][word]; the workgroup stores the tile's words as whole lines below.
+#pragma unroll
+        for (int x = 0; x < TN; ++x) {
+          uint32_t wbits = mw[x] << (4 * h);
+          wbits |= static_cast<uint32_t>(__shfl_xor(static_cast<int>(wbits), 32));
+          if (h == 0) e_bits[(wm * 32 * TM + y * 32 + i) * WPR + wn * TN + x] = wbits;
+        }
+      }
+    }
     mx = fmaxf(mx, __shfl_xor(mx, 32));               // the lane pair that shares this example
     rmx[y] = mx;
     if (h == 0) e_rmax[wn * BMt + wm * 32 * TM + y * 32 + i] = mx;
@@ -416,6 +462,14 @@ __global__ __launch_bounds__(PL_THREADS, 2) void gemm_pl_k(const PlArgs a) {
     if (lane == 0) e_wmax[wv] = wmx;
   }
   __syncthreads();
+  if constexpr (EPI == PL_FWD) {
+    if (a.mbits) {
+      for (int idx = t; idx < BMt * WPR; idx += PL_THREADS) {
+        const int row = idx / WPR, wi = (n0 >> 5) + idx % WPR;
+        if (m0 + row < a.M && wi < a.mbld) a.mbits[static_cast<int64_t>(m0 + row) * a.mbld + wi] = e_bits[idx];
+      }
+    }
+  }
   if (a.amax_c && t == 0) {
     float mx = 0.f;
 #pragma unroll
@@ -630,7 +684,8 @@ __global__ __launch_bounds__(256) void vec_dgrad_planes_k(const float* __restric
                                                           const float* __restrict__ Xact, int64_t ldxa, float keep_div, float keep_rcp,
                                                           int64_t rows, int K, int rows_per_block, float* __restrict__ dX,
                                                           int64_t lddx, char* __restrict__ out, int64_t ldo_b,
-                                                          int32_t* __restrict__ row_exp, float* __restrict__ amax_out) {
+                                                          int32_t* __restrict__ row_exp, float* __restrict__ amax_out,
+                                                          const uint32_t* __restrict__ mbits, int64_t mbld) {
   // LPR lanes share a row; a lane owns the float4 groups l, l + LPR, ... (adjacent lanes read adjacent 16 bytes).
   // The plane pieces of the block's rows go through LDS as [16-k block][row][64 B] and leave as ONE contiguous run
   // per 16-k block (consecutive lanes, 16 bytes each): written piece by piece from the lanes that computed them,
@@ -648,7 +703,11 @@ __global__ __launch_bounds__(256) void vec_dgrad_planes_k(const float* __restric
     auto value4 = [&](int k) {
       const float4 w = *reinterpret_cast<const float4*>(W + k);
       float4 v = make_float4(g * w.x, g * w.y, g * w.z, g * w.w);
-      if (Xact) {
+      if (mbits) {          // the forward pass's one-bit mask instead of the stored activation (1/32 of the bytes): same decisions
+        const uint32_t nib = mbits[r * mbld + (k >> 5)] >> (k & 31);
+        v.x = (nib & 1u) ? mi_div_const(v.x, keep_div, keep_rcp) : 0.f; v.y = (nib & 2u) ? mi_div_const(v.y, keep_div, keep_rcp) : 0.f;
+        v.z = (nib & 4u) ? mi_div_const(v.z, keep_div, keep_rcp) : 0.f; v.w = (nib & 8u) ? mi_div_const(v.w, keep_div, keep_rcp) : 0.f;
+      } else if (Xact) {
         const float4 x = *reinterpret_cast<const float4*>(Xact + r * ldxa + k);
         // (mi_div_const: the bits of '/', 3 instructions; the same masked division as gemm.hip's gemv_dgrad_k)
         v.x = x.x > 0.f ? mi_div_const(v.x, keep_div, keep_rcp) : 0.f; v.y = x.y > 0.f ? mi_div_const(v.y, keep_div, keep_rcp) : 0.f;
@@ -1005,8 +1064,9 @@ int32_t mi_merge_rows(const mi_planes_t* in, int64_t rows, int32_t K, float* X, 
 
 int32_t mi_dense_fwd_planes(const mi_planes_t* X, const mi_planes_t* Wt, const float* bias, float* Y, int64_t ldy,
                             const mi_planes_t* Yp, int64_t M, int32_t N, int32_t K, int32_t relu, float keep_prob,
-                            uint64_t seed, float* amax_out, mi_stream_t stream) {
+                            uint64_t seed, float* amax_out, uint32_t* mask_bits_out, int64_t mask_ld, mi_stream_t stream) {
   MI_REQUIRE(M >= 0 && M <= INT32_MAX && N > 0 && K > 0, "dense_fwd_planes: M=%lld N=%d K=%d", (long long)M, N, K);
+  MI_REQUIRE(!mask_bits_out || mask_ld >= (N + 31) / 32, "dense_fwd_planes: mask_ld=%lld < ceil(N / 32)", (long long)mask_ld);
   if (M == 0) return MI_OK;
   MI_REQUIRE((K & 15) == 0 && (N & 15) == 0, "dense_fwd_planes: N=%d and K=%d must be multiples of 16 (use mi_dense_fwd)", N, K);
   MI_REQUIRE(planes_ok(X, M, K) && planes_ok(Wt, N, K), "dense_fwd_planes: operand planes");
@@ -1022,19 +1082,21 @@ int32_t mi_dense_fwd_planes(const mi_planes_t* X, const mi_planes_t* Wt, const f
   if (Yp) { a.Cp = static_cast<char*>(Yp->data); a.bsc = Yp->blk_stride; a.c_exp = Yp->row_exp; }
   a.bias = bias; a.relu = relu; a.keep_prob = keep_prob; a.keep_div = keep_prob; a.keep_rcp = 1.0f / keep_prob; a.seed = seed; a.st = mi::step_state();
   a.amax_c = amax_out;
+  a.mbits = mask_bits_out; a.mbld = mask_ld;
   return launch_pl<PL_FWD>(a, mi::as_stream(stream), "dense_fwd_planes");
 }
 
 int32_t mi_dense_bwd_data_planes(const mi_planes_t* dY, const mi_planes_t* W, const mi_planes_t* Xact, float* dX,
                                  int64_t lddx, const mi_planes_t* dXp, int64_t M, int32_t N, int32_t K, float keep_prob,
                                  float* amax_out, const float* fold_sumv, const float* fold_dlogit, int32_t fold_E,
-                                 mi_stream_t stream) {
+                                 const uint32_t* mask_bits, int64_t mask_ld, mi_stream_t stream) {
   // dX[M][K] = dY[M][N] * W[K][N]^T : output width K, reduction over N
   MI_REQUIRE(M >= 0 && M <= INT32_MAX && N > 0 && K > 0, "dense_bwd_data_planes: M=%lld N=%d K=%d", (long long)M, N, K);
   if (M == 0) return MI_OK;
   MI_REQUIRE((K & 15) == 0 && (N & 15) == 0, "dense_bwd_data_planes: N=%d and K=%d must be multiples of 16", N, K);
   MI_REQUIRE(planes_ok(dY, M, N) && planes_ok(W, K, N), "dense_bwd_data_planes: operand planes");
   MI_REQUIRE(!Xact || planes_ok(Xact, M, K), "dense_bwd_data_planes: activation planes");
+  MI_REQUIRE(!mask_bits || mask_ld >= (K + 31) / 32, "dense_bwd_data_planes: mask_ld=%lld < ceil(K / 32)", (long long)mask_ld);
   MI_REQUIRE(dX || dXp, "dense_bwd_data_planes: no output");
   MI_REQUIRE(!dX || (lddx >= K && (lddx & 3) == 0 && mi::aligned16(dX)), "dense_bwd_data_planes: dX leading dimension / alignment");
   MI_REQUIRE(!dXp || planes_ok(dXp, M, K), "dense_bwd_data_planes: output planes");
@@ -1045,11 +1107,12 @@ int32_t mi_dense_bwd_data_planes(const mi_planes_t* dY, const mi_planes_t* W, co
   a.M = (int)M; a.N = K; a.K = N;
   a.C = dX; a.ldc = lddx;
   if (dXp) { a.Cp = static_cast<char*>(dXp->data); a.bsc = dXp->blk_stride; a.c_exp = dXp->row_exp; }
-  a.keep_prob = keep_prob; a.keep_div = Xact ? keep_prob : 1.f; a.keep_rcp = 1.0f / a.keep_div;
+  a.keep_prob = keep_prob; a.keep_div = (Xact || mask_bits) ? keep_prob : 1.f; a.keep_rcp = 1.0f / a.keep_div;
   if (Xact) { a.mask = static_cast<const char*>(Xact->data); a.bsm = Xact->blk_stride; }
+  a.mbits = const_cast<uint32_t*>(mask_bits); a.mbld = mask_ld;          // (read only in the DGRAD epilogue; preferred over Xact)
   a.amax_c = amax_out;
   if (fold_sumv) {
-    MI_REQUIRE(fold_dlogit && fold_E >= 4 && (fold_E & 3) == 0 && K % fold_E == 0 && mi::aligned16(fold_sumv) && !Xact && !dXp && dX,
+    MI_REQUIRE(fold_dlogit && fold_E >= 4 && (fold_E & 3) == 0 && K % fold_E == 0 && mi::aligned16(fold_sumv) && !Xact && !mask_bits && !dXp && dX,
                "dense_bwd_data_planes: the FM fold needs d_logit, E a multiple of 4 that divides K, an fp32 result and no mask");
     a.fold_s = fold_sumv; a.fold_g = fold_dlogit; a.fold_E = fold_E;
   }
@@ -1059,8 +1122,9 @@ int32_t mi_dense_bwd_data_planes(const mi_planes_t* dY, const mi_planes_t* W, co
 
 int32_t mi_dense_bwd_data_vec_planes(const float* dY, int64_t lddy, const float* W, const float* Xact, int64_t ldxa,
                                      float keep_prob, float* dX, int64_t lddx, const mi_planes_t* dXp, int64_t M, int32_t K,
-                                     float* amax_out, mi_stream_t stream) {
+                                     float* amax_out, const uint32_t* mask_bits, int64_t mask_ld, mi_stream_t stream) {
   MI_REQUIRE(M >= 0 && K > 0 && (K & 15) == 0, "dense_bwd_data_vec_planes: M=%lld K=%d (K a multiple of 16)", (long long)M, K);
+  MI_REQUIRE(!mask_bits || mask_ld >= (K + 31) / 32, "dense_bwd_data_vec_planes: mask_ld=%lld < ceil(K / 32)", (long long)mask_ld);
   if (M == 0) return MI_OK;
   MI_REQUIRE(dY && W && lddy >= 1 && mi::aligned16(W), "dense_bwd_data_vec_planes: dY / W");
   MI_REQUIRE(!Xact || (mi::aligned16(Xact) && ldxa >= K && (ldxa & 3) == 0), "dense_bwd_data_vec_planes: Xact leading dimension / alignment");
@@ -1079,7 +1143,8 @@ int32_t mi_dense_bwd_data_vec_planes(const float* dY, int64_t lddy, const float*
   const int64_t nb = mi::ceil_div(M, rpb);
   MI_REQUIRE(nb <= INT32_MAX, "dense_bwd_data_vec_planes: grid too large");
 #define MI_VEC_DGRAD(L) vec_dgrad_planes_k<L><<<dim3((unsigned)nb), dim3(256), lds, mi::as_stream(stream)>>>( \
-      dY, lddy, W, Xact, ldxa, Xact ? keep_prob : 1.f, Xact ? 1.0f / keep_prob : 1.f, M, K, rpb, dX, lddx, static_cast<char*>(dXp->data), dXp->blk_stride, dXp->row_exp, amax_out)
+      dY, lddy, W, Xact, ldxa, (Xact || mask_bits) ? keep_prob : 1.f, (Xact || mask_bits) ? 1.0f / keep_prob : 1.f, M, K, rpb, dX, lddx, \
+      static_cast<char*>(dXp->data), dXp->blk_stride, dXp->row_exp, amax_out, mask_bits, mask_ld)
   switch (lpr) {
     case 4: MI_VEC_DGRAD(4); break;
     case 8: MI_VEC_DGRAD(8); break;

@@ -11,6 +11,7 @@ struct WgradPlPlan {
   int tiles_k;         // ceil(K / (64 tm))
   int splits;          // slabs over the examples
   int k_per_split;     // examples per slab (a multiple of 16)
+  int nbuf;            // LDS stage buffers of the kernel (3 or 6 for the 128-column tile, 4 otherwise)
 };
 
 // false: shape not covered (N must be 128, 256 or 512, K a multiple of 128, M a multiple of 16)

@@ -81,12 +81,12 @@ __device__ __forceinline__ void wg_static_for(F&& f) {
   }
 }
 
-template <int TN, int TM>
+template <int TN, int TM, int NBUF_ = (TN == 1 ? 3 : 4)>
 __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_pl_k(const WgArgs a, const uint4* __restrict__ sx_all,
                                                             const uint4* __restrict__ sy_all,
                                                             const uint4* __restrict__ sc_all,
                                                             const int32_t* __restrict__ kflag_all) {
-  constexpr int NBUF = TN == 1 ? 3 : 4;
+  constexpr int NBUF = NBUF_;
   constexpr int NBLK = 8 * TN + 4 * TM;                  // 1-KiB blocks (16 features x 16 examples) per stage
   constexpr int STAGE = NBLK * 1024;
   constexpr int LPS = NBLK / 8;                          // LDS-DMA instructions per thread and stage
@@ -308,7 +308,8 @@ bool wgrad_pl_plan(int64_t M, int N, int K, WgradPlPlan* p) {
   if (M <= 0 || M % 16 != 0 || (N != 128 && N != 256 && N != 512) || K <= 0 || K % 16 != 0) return false;
   p->tn = N / 128;
   p->tiles_n = 1;
-  p->tm = p->tn == 2 ? 4 : 2;
+  p->tm = p->tn == 2 ? env_int("MI_WGRAD_TM_N256", 2) : 2;      // (N = 256: 256 x 128 tiles — half the slab bytes of 256 x 256: 103 -> 90 us at 65536 x 512 x 256)
+  p->nbuf = p->tn == 1 ? env_int("MI_WGRAD_NBUF_N128", 3) : 4;
   // N = 512: one 512-column tile x 128 features.  MI_WGRAD_TILE=256 (A/B runs): two 256-column tiles x 256 features
   // (32 KB of operands per k-step instead of 40 KB for the same MFMAs, a half-empty last feature tile at K = 1664) —
   // measured slower, 469 vs 451 us on the layer-1 shape: the loop is not bound by operand bytes.
@@ -320,7 +321,8 @@ bool wgrad_pl_plan(int64_t M, int N, int K, WgradPlPlan* p) {
   // one round of resident workgroups (one per CU; the 128-column tile fits two), at least 32 k-steps per split
   // (a split pays a pipeline fill and a slab of the whole tile)
   int64_t target = (p->tn == 1 ? 512 : 256) / (p->tiles_k * p->tiles_n);
-  const int64_t max_s = M / (16 * 32) > 0 ? M / (16 * 32) : 1;
+  const int min_ksteps = env_int("MI_WGRAD_MIN_KSTEPS", 32);
+  const int64_t max_s = M / (16 * min_ksteps) > 0 ? M / (16 * min_ksteps) : 1;
   if (target > max_s) target = max_s;
   if (target < 1) target = 1;
   p->k_per_split = static_cast<int>(ceil_div(ceil_div(M, target), 16) * 16);
@@ -346,6 +348,7 @@ int32_t wgrad_pl_launch(const WgradPlPlan& p, const mi_planes_t* X, const mi_pla
   else if (p.tn == 2 && p.tm == 4) wgrad_pl_k<2, 4><<<g, b, 0, st>>>(a, sx4, sy4, sc4, kflag);
   else if (p.tn == 2 && p.tm == 2) wgrad_pl_k<2, 2><<<g, b, 0, st>>>(a, sx4, sy4, sc4, kflag);
   else if (p.tn == 1 && p.tm == 4) wgrad_pl_k<1, 4><<<g, b, 0, st>>>(a, sx4, sy4, sc4, kflag);
+  else if (p.tn == 1 && p.tm == 2 && p.nbuf == 6) wgrad_pl_k<1, 2, 6><<<g, b, 0, st>>>(a, sx4, sy4, sc4, kflag);
   else if (p.tn == 1 && p.tm == 2) wgrad_pl_k<1, 2><<<g, b, 0, st>>>(a, sx4, sy4, sc4, kflag);
   else {
     set_error("wgrad_pl_launch: no kernel for tile %d x %d", p.tn, p.tm);

@@ -16,7 +16,7 @@ import torch  # noqa: F401  (loads the HIP runtime this library must share)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmi355x_rec.so")
 
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 
 class MiError(RuntimeError):
@@ -106,7 +106,7 @@ SIGNATURES = {
     "mi_dense_fwd": (_i32, [_p, _i64, _p, _p, _p, _i64, _i64, _i32, _i32, _i32, _f32, _u64, _amax, _p]),
     "mi_dense_bwd_data": (_i32, [_p, _i64, _p, _p, _i64, _p, _i64, _i64, _i32, _i32, _f32, _i32, _amax, _p]),
     "mi_dense_bwd_weight_workspace_bytes": (_sz, [_i64, _i32, _i32]),
-    "mi_dense_bwd_data_vec_planes": (_i32, [_p, _i64, _p, _p, _i64, _f32, _p, _i64, _pl, _i64, _i32, _p, _p]),
+    "mi_dense_bwd_data_vec_planes": (_i32, [_p, _i64, _p, _p, _i64, _f32, _p, _i64, _pl, _i64, _i32, _p, _p, _i64, _p]),
     "mi_dense_bwd_weight_planes_workspace_bytes": (_sz, [_i64, _i32, _i32]),
     "mi_dense_bwd_weight_planes": (_i32, [_p, _p, _p, _p, _i64, _i32, _i32, _p, _sz, _p, _p]),
     "mi_dense_bwd_weight": (_i32, [_p, _i64, _p, _i64, _p, _p, _i64, _i32, _i32, _p, _sz, _amax, _p]),
@@ -114,8 +114,8 @@ SIGNATURES = {
     "mi_split_rows": (_i32, [_p, _i64, _i64, _i32, _i32, _pl, _p, _p]),
     "mi_split_weights": (_i32, [_p, _p, _i32, _p, _p]),
     "mi_merge_rows": (_i32, [_pl, _i64, _i32, _p, _i64, _p]),
-    "mi_dense_fwd_planes": (_i32, [_pl, _pl, _p, _p, _i64, _pl, _i64, _i32, _i32, _i32, _f32, _u64, _p, _p]),
-    "mi_dense_bwd_data_planes": (_i32, [_pl, _pl, _pl, _p, _i64, _pl, _i64, _i32, _i32, _f32, _p, _p, _p, _i32, _p]),
+    "mi_dense_fwd_planes": (_i32, [_pl, _pl, _p, _p, _i64, _pl, _i64, _i32, _i32, _i32, _f32, _u64, _p, _p, _i64, _p]),
+    "mi_dense_bwd_data_planes": (_i32, [_pl, _pl, _pl, _p, _i64, _pl, _i64, _i32, _i32, _f32, _p, _p, _p, _i32, _p, _i64, _p]),
     "mi_embed_fm_planes_fwd": (_i32, [_p, _p, _p, _i64, _i32, _i32, _p, _p, _pl, _p, _p, _i32, _i32, _p]),
     "mi_head_workspace_bytes": (_sz, [_i64]),
     "mi_sigmoid_ce_head": (_i32, [_p, _p, _p, _p, _p, _i64, _f32, _p, _p, _p, _p, _p, _sz, _p]),

@@ -827,10 +827,13 @@ class DeepFM:
                     # (no fp32 copy when its only reader, the next layer's weight gradient, takes the planes)
                     planes_only = train and direct and self._wgrad_planes_ok(B, i + 1)
                     (self._acts_in_planes.add if planes_only else self._acts_in_planes.discard)(i)
+                    # (training: the relu/dropout mask as one bit per output, for the data gradients — 1/32 of the bytes of
+                    # the stored activation they would otherwise read it from)
+                    mb = self._buf("mbits%d" % i, (B, (h + 31) // 32), torch.int32) if train else None
                     k.mi_dense_fwd_planes(self._planes(xp, B, fan), self._pl["wt%d" % i].struct, self.bias(i),
                                           None if planes_only else y, h,
                                           yp if direct else None, B, h, fan, 1, keep, self._layer_seed(i),
-                                          self._av("x%d" % (i + 1)))
+                                          self._av("x%d" % (i + 1)), mb, 0 if mb is None else mb.shape[1])
                     if need_p and not direct:
                         k.mi_split_rows(y, h, B, h, 0, yp, None)
                     xp = "x%dp" % (i + 1)
@@ -1202,8 +1205,11 @@ class DeepFM:
                     need_p = i > 0
                     dxp = self._planes("dy%dp" % (i - 1), B, fan) if need_p else None
                     direct = need_p and fan <= 512
-                    xa = self._pl["x%dp" % i].struct if (i > 0 and ("x%dp" % i) in self._pl and i < nh) else None
-                    if i > 0 and xa is None:      # (the last hidden layer's output has no planes: make them)
+                    # the mask of the layer below's output: its bits (written by the planes forward), else its planes
+                    mb = self._ws.get("mbits%d" % (i - 1)) if i > 0 else None
+                    mb = mb[:B * ((fan + 31) // 32)].view(B, (fan + 31) // 32) if mb is not None else None
+                    xa = self._pl["x%dp" % i].struct if (i > 0 and mb is None and ("x%dp" % i) in self._pl and i < nh) else None
+                    if i > 0 and xa is None and mb is None:      # (the last hidden layer's output has no planes: make them)
                         xa = self._planes("x%dp" % i, B, fan)
                         k.mi_split_rows(x, ldx, B, fan, 0, xa, None)
                     # (the fp32 copy only where something reads it: d_concat, or a weight gradient on fp32 operands)
@@ -1215,15 +1221,19 @@ class DeepFM:
                                                dx if need_f else None, fan,
                                                dxp if direct else None, B, h, fan, keep if i else 1.0,
                                                self._av("dy%d" % (i - 1)) if i else None,
-                                               c["sumv"] if fold else None, dlogit if fold else None, self.E if fold else 0)
+                                               c["sumv"] if fold else None, dlogit if fold else None, self.E if fold else 0,
+                                               mb, 0 if mb is None else mb.shape[1])
                     if need_p and not direct:
                         k.mi_split_rows(dx, fan, B, fan, 0, dxp, None)
                 elif self.planes and i == nh and i > 0 and h == 1 and fan % 16 == 0:
                     # the logits layer's matrix-vector data gradient, written straight as the planes the layer below
                     # reads (and in fp32 only if that layer's weight gradient still runs on fp32 operands)
+                    mb = self._ws.get("mbits%d" % (i - 1))
+                    mb = mb[:B * ((fan + 31) // 32)].view(B, (fan + 31) // 32) if mb is not None else None
                     k.mi_dense_bwd_data_vec_planes(dy, lddy, self.kernel(i), x, ldx, keep,
                                                    None if self._wgrad_planes_ok(B, i - 1) else dx, fan,
-                                                   self._planes("dy%dp" % (i - 1), B, fan), B, fan, self._av("dy%d" % (i - 1)))
+                                                   self._planes("dy%dp" % (i - 1), B, fan), B, fan, self._av("dy%d" % (i - 1)),
+                                                   mb, 0 if mb is None else mb.shape[1])
                 else:
                     k.mi_dense_bwd_data(dy, lddy, self.kernel(i), x if i else None, ldx, dx, fan, B, h, fan,
                                         keep if i else 1.0, self.act, None if self.planes else ga_d)

@@ -141,7 +141,7 @@ def test_dense_fwd_planes_exact_on_integers(lib, M, N, K):
     Y = torch.full((M, N + 4), -7.0, device="cuda")
     yp = PB(lib, M, N) if N <= 512 else None
     _chk(lib.mi_dense_fwd_planes(xp.ref, wt.ref, dev(b).data_ptr(), Y.data_ptr(), N + 4, yp.ref if yp else None, M, N, K, 0, 1.0,
-                                 0, None, _st()))
+                                 0, None, None, 0, _st()))
     ref = X.astype(np.float64) @ W.astype(np.float64) + b
     got = Y.cpu().numpy()
     assert np.array_equal(got[:, :N], ref.astype(np.float32))
@@ -164,7 +164,7 @@ def test_dense_fwd_planes_row_relative_error(lib, M, N, K):
     yp = PB(lib, M, N) if N <= 512 else None
     amax = torch.zeros(64, device="cuda")
     _chk(lib.mi_dense_fwd_planes(xp.ref, wt.ref, dev(b).data_ptr(), Y.data_ptr(), N, yp.ref if yp else None, M, N, K, 0, 1.0, 0,
-                                 amax.data_ptr(), _st()))
+                                 amax.data_ptr(), None, 0, _st()))
     ref = X.astype(np.float64) @ W.astype(np.float64)
     got = Y.cpu().numpy()
     assert row_rel_err(got, ref) < 1e-5
@@ -186,8 +186,10 @@ def test_dense_fwd_planes_bias_relu_dropout(lib):
     Y0 = torch.empty(M, N, device="cuda"); Y1 = torch.empty(M, N, device="cuda")
     yp = PB(lib, M, N)
     seed, keep = 0x1234567, 0.9
-    _chk(lib.mi_dense_fwd_planes(xp.ref, wt.ref, dev(b).data_ptr(), Y0.data_ptr(), N, None, M, N, K, 1, 1.0, seed, None, _st()))
-    _chk(lib.mi_dense_fwd_planes(xp.ref, wt.ref, dev(b).data_ptr(), Y1.data_ptr(), N, yp.ref, M, N, K, 1, keep, seed, None, _st()))
+    _chk(lib.mi_dense_fwd_planes(xp.ref, wt.ref, dev(b).data_ptr(), Y0.data_ptr(), N, None, M, N, K, 1, 1.0, seed, None, None, 0, _st()))
+    mb = torch.full((M, N // 32 + 1), -1, dtype=torch.int32, device="cuda")          # (one word of slack: mask_ld > N / 32)
+    _chk(lib.mi_dense_fwd_planes(xp.ref, wt.ref, dev(b).data_ptr(), Y1.data_ptr(), N, yp.ref, M, N, K, 1, keep, seed, None,
+                                 mb.data_ptr(), mb.shape[1], _st()))
     ref = np.maximum(X.astype(np.float64) @ W.astype(np.float64) + b, 0)
     y0 = Y0.cpu().numpy()
     assert np.max(np.abs(y0 - ref)) / np.sqrt(np.mean(ref * ref)) < 1e-5
@@ -196,6 +198,10 @@ def test_dense_fwd_planes_bias_relu_dropout(lib):
     assert np.array_equal(Y1.cpu().numpy(), (y0 / np.float32(keep)) * mask)      # tf.nn.dropout: div(x, keep) * mask
     hi = yp.data.cpu().numpy()[:, :M, :16].transpose(1, 0, 2).reshape(M, N).view(np.float16)
     assert np.array_equal(hi > 0, Y1.cpu().numpy() > 0)                          # "hi > 0" is the backward's mask
+    # ... and so is the one-bit form: bit n & 31 of word n >> 5 of a row
+    words = mb.cpu().numpy().view(np.uint32)
+    bits = ((words[:, :N // 32, None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(M, N).astype(bool)
+    assert np.array_equal(bits, Y1.cpu().numpy() > 0) and np.all(words[:, N // 32] == 0xffffffff)      # (the slack word is not touched)
 
 
 @pytest.mark.parametrize("M,N,K", [(256, 128, 256), (300, 256, 512), (257, 512, 1664), (130, 64, 48)])
@@ -211,7 +217,7 @@ def test_dense_bwd_data_planes(lib, M, N, K):
     dX = torch.empty(M, K, device="cuda")
     dxp = PB(lib, M, K) if K <= 512 else None
     _chk(lib.mi_dense_bwd_data_planes(dyp.ref, wp.ref, xap.ref, dX.data_ptr(), K, dxp.ref if dxp else None, M, N, K, keep, None, None, None, 0,
-                                      _st()))
+                                      None, 0, _st()))
     ref = (dY.astype(np.float64) @ W.astype(np.float64).T) * (Xact > 0) / np.float64(np.float32(keep))
     got = dX.cpu().numpy()
     assert row_rel_err(got, ref) < 1e-5
@@ -220,8 +226,21 @@ def test_dense_bwd_data_planes(lib, M, N, K):
         hb, he = host_planes(got)
         assert np.array_equal(dxp.exp.cpu().numpy(), he)
         assert np.array_equal(dxp.bits(), hb)
+    # the one-bit mask instead of the activation's planes: the same decisions, the same bits (fp32 and planes)
+    pos = Xact > 0
+    Kw = (K + 31) // 32
+    padded = np.zeros((M, Kw * 32), bool); padded[:, :K] = pos
+    words = (padded.reshape(M, Kw, 32).astype(np.uint64) << np.arange(32, dtype=np.uint64)).sum(2).astype(np.uint32)
+    dX2 = torch.empty(M, K, device="cuda")
+    dxp2 = PB(lib, M, K) if K <= 512 else None
+    mbt = dev(words.view(np.int32))
+    _chk(lib.mi_dense_bwd_data_planes(dyp.ref, wp.ref, None, dX2.data_ptr(), K, dxp2.ref if dxp2 else None, M, N, K, keep, None, None, None, 0,
+                                      mbt.data_ptr(), Kw, _st()))
+    assert np.array_equal(dX2.cpu().numpy().view(np.uint32), got.view(np.uint32))
+    if dxp is not None:
+        assert np.array_equal(dxp2.bits(), dxp.bits()) and np.array_equal(dxp2.exp.cpu().numpy(), dxp.exp.cpu().numpy())
     # without a mask (the layer-1 data gradient: the concat has no activation)
-    _chk(lib.mi_dense_bwd_data_planes(dyp.ref, wp.ref, None, dX.data_ptr(), K, None, M, N, K, 1.0, None, None, None, 0, _st()))
+    _chk(lib.mi_dense_bwd_data_planes(dyp.ref, wp.ref, None, dX.data_ptr(), K, None, M, N, K, 1.0, None, None, None, 0, None, 0, _st()))
     assert row_rel_err(dX.cpu().numpy(), dY.astype(np.float64) @ W.astype(np.float64).T) < 1e-5
 
 
@@ -238,15 +257,15 @@ def test_dense_bwd_data_planes_folds_the_fm_term(lib):
     dX = torch.empty(M, K, device="cuda")
     sv, g = dev(sumv), dev(dl)
     _chk(lib.mi_dense_bwd_data_planes(dyp.ref, wp.ref, None, dX.data_ptr(), K, None, M, N, K, 1.0, None, sv.data_ptr(),
-                                      g.data_ptr(), E, _st()))
+                                      g.data_ptr(), E, None, 0, _st()))
     ref = dY.astype(np.float64) @ W.astype(np.float64).T + dl.astype(np.float64)[:, None] * np.tile(sumv.astype(np.float64), (1, F))
     assert row_rel_err(dX.cpu().numpy(), ref) < 1e-5
     # refused where the result is not the concat gradient (mask / planes output) or E does not divide K
     xap = split(lib, np.abs(ref).astype(np.float32))
     assert lib.mi_dense_bwd_data_planes(dyp.ref, wp.ref, xap.ref, dX.data_ptr(), K, None, M, N, K, 1.0, None, sv.data_ptr(),
-                                        g.data_ptr(), E, _st()) != 0
+                                        g.data_ptr(), E, None, 0, _st()) != 0
     assert lib.mi_dense_bwd_data_planes(dyp.ref, wp.ref, None, dX.data_ptr(), K, None, M, N, K, 1.0, None, sv.data_ptr(),
-                                        g.data_ptr(), 48, _st()) != 0
+                                        g.data_ptr(), 48, None, 0, _st()) != 0
 
 
 def test_planes_entries_refuse_bad_shapes(lib):
@@ -256,12 +275,12 @@ def test_planes_entries_refuse_bad_shapes(lib):
     wt = split(lib, np.ones((24, 16), np.float32), transpose=True)
     Y = torch.empty(64, 16, device="cuda")
     with pytest.raises(MiError, match="multiples of 16"):
-        _chk(lib.mi_dense_fwd_planes(xp.ref, wt.ref, None, Y.data_ptr(), 16, None, 64, 16, 24, 0, 1.0, 0, None, _st()))
+        _chk(lib.mi_dense_fwd_planes(xp.ref, wt.ref, None, Y.data_ptr(), 16, None, 64, 16, 24, 0, 1.0, 0, None, None, 0, _st()))
     xp2 = split(lib, np.ones((64, 32), np.float32))
     w2 = split(lib, np.ones((32, 1024), np.float32), transpose=True)
     yp = PB(lib, 64, 1024)
     with pytest.raises(MiError, match="N <= 512"):
-        _chk(lib.mi_dense_fwd_planes(xp2.ref, w2.ref, None, None, 0, yp.ref, 64, 1024, 32, 0, 1.0, 0, None, _st()))
+        _chk(lib.mi_dense_fwd_planes(xp2.ref, w2.ref, None, None, 0, yp.ref, 64, 1024, 32, 0, 1.0, 0, None, None, 0, _st()))
 
 
 @pytest.mark.parametrize("E,F,B,nd,tail", [(64, 26, 300, 0, 0), (128, 40, 65, 0, 0), (32, 5, 129, 0, 0), (48, 3, 17, 0, 0),
@@ -430,12 +449,23 @@ def test_logits_layer_data_gradient_as_planes_matches_gemv_then_split_bitwise(li
     from mi355x_rec import _lib as L
     am = torch.zeros(L.AMAX_SLOTS, device="cuda")
     _chk(lib.mi_dense_bwd_data_vec_planes(dy.data_ptr(), 1, w.data_ptr(), xa.data_ptr() if mask else None, K, keep, got.data_ptr(), K,
-                                          gotp.ref, M, K, am.data_ptr(), _st()))
+                                          gotp.ref, M, K, am.data_ptr(), None, 0, _st()))
     assert np.array_equal(got.cpu().numpy().view(np.uint32), ref.cpu().numpy().view(np.uint32))
     assert np.array_equal(gotp.bits(), refp.bits()) and np.array_equal(gotp.exp.cpu().numpy(), refp.exp.cpu().numpy())
     assert float(am.max()) == float(ref.abs().max())
     # planes only
     gotp2 = PB(lib, M, K)
     _chk(lib.mi_dense_bwd_data_vec_planes(dy.data_ptr(), 1, w.data_ptr(), xa.data_ptr() if mask else None, K, keep, None, 0,
-                                          gotp2.ref, M, K, None, _st()))
+                                          gotp2.ref, M, K, None, None, 0, _st()))
     assert np.array_equal(gotp2.bits(), refp.bits())
+    if mask:          # the one-bit mask instead of the fp32 activation: same bits
+        Kw = (K + 31) // 32
+        padded = np.zeros((M, Kw * 32), bool); padded[:, :K] = Xact > 0
+        words = (padded.reshape(M, Kw, 32).astype(np.uint64) << np.arange(32, dtype=np.uint64)).sum(2).astype(np.uint32)
+        mbt = dev(words.view(np.int32))
+        gotp3 = PB(lib, M, K)
+        got3 = torch.full((M, K), float("nan"), device="cuda")
+        _chk(lib.mi_dense_bwd_data_vec_planes(dy.data_ptr(), 1, w.data_ptr(), None, K, keep, got3.data_ptr(), K, gotp3.ref, M, K, None,
+                                              mbt.data_ptr(), Kw, _st()))
+        assert np.array_equal(got3.cpu().numpy().view(np.uint32), ref.cpu().numpy().view(np.uint32))
+        assert np.array_equal(gotp3.bits(), refp.bits())

@@ -59,14 +59,14 @@ def main():
             for tile in ("1", "2", "4"):
                 os.environ["MI_PL_TILE"] = tile
                 t = timeit(lambda: _lib.check(lib.mi_dense_fwd_planes(xp.ref, wt.ref, b.data_ptr(), Y.data_ptr(), N, None, M, N, K, 1, 0.9,
-                                                                      7, None, st()), "fwd"))
+                                                                      7, None, None, 0, st()), "fwd"))
                 print("%-22s N=%4d K=%4d column tile %4d  %7.1f us  %6.1f TF/s fp32-equiv" % (name, N, K, 128 * int(tile), t * 1e3, flops / t / 1e9))
             os.environ.pop("MI_PL_TILE")
         for label, y, ypl in (("fp32+planes", Y, yp), ("fp32 only", Y, None), ("planes only", None, yp)):
             if (y is None and ypl is None) or (label != "fp32 only" and ypl is None):
                 continue
             t = timeit(lambda: _lib.check(lib.mi_dense_fwd_planes(xp.ref, wt.ref, b.data_ptr(), None if y is None else y.data_ptr(), N,
-                                                                  None if ypl is None else ypl.ref, M, N, K, 1, 0.9, 7, None, st()), "fwd"))
+                                                                  None if ypl is None else ypl.ref, M, N, K, 1, 0.9, 7, None, None, 0, st()), "fwd"))
             print("%-22s N=%4d K=%4d %-12s %7.1f us  %6.1f TF/s fp32-equiv" % (name, N, K, label, t * 1e3, flops / t / 1e9))
         del X, W, xp, wt, Y, yp
     # weight gradients from planes

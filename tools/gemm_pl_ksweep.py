@@ -29,10 +29,10 @@ def main():
                     res.append(float("nan")); continue
                 if epi == 0:
                     fn = lambda: _lib.check(lib.mi_dense_fwd_planes(xp.ref, wt.ref, b.data_ptr(), None if y is None else y.data_ptr(), N,
-                                                                    None if ypl is None else ypl.ref, M, N, K, 1, 0.9, 7, None, st()), "fwd")
+                                                                    None if ypl is None else ypl.ref, M, N, K, 1, 0.9, 7, None, None, 0, st()), "fwd")
                 else:
                     fn = lambda: _lib.check(lib.mi_dense_fwd_planes(xp.ref, wt.ref, b.data_ptr(), None if y is None else y.data_ptr(), N,
-                                                                    None if ypl is None else ypl.ref, M, N, K, 0, 1.0, 0, None, st()), "fwd")
+                                                                    None if ypl is None else ypl.ref, M, N, K, 0, 1.0, 0, None, None, 0, st()), "fwd")
                 res.append(timeit(fn) * 1e3)
             print("N=%4d act=%d K=%4d  fp32+planes %7.1f  fp32 only %7.1f  planes only %7.1f us" % (N, 1 - epi, K, *res), flush=True)
             del X, W, xp, wt, Y, yp

@@ -32,7 +32,7 @@ b = torch.zeros(N, device="cuda")
 xp, wt, yp = split(X), split(W, transpose=True), PB(M, N)
 for _ in range(3):
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-    e0.record(); assert L.mi_dense_fwd_planes(xp.ref, wt.ref, b.data_ptr(), None, N, yp.ref, M, N, K, 1, 0.9, 7, None, st()) == 0; e1.record()
+    e0.record(); assert L.mi_dense_fwd_planes(xp.ref, wt.ref, b.data_ptr(), None, N, yp.ref, M, N, K, 1, 0.9, 7, None, None, 0, st()) == 0; e1.record()
     torch.cuda.synchronize()
 buf = np.zeros(32 * 2 * 128 * 8, dtype=np.int64)
 assert L.mi_pl_stamps_read(buf.ctypes.data, buf.nbytes) == 0
