@@ -122,11 +122,17 @@ int32_t mi_bucketize_f32(const float* values, int64_t n, const float* boundaries
  * mi_sparse_catchup / mi_catchup_gap_keys — 1: lin_w, l_slot0, l_slot1 and last_step are four separate arrays;
  * 4: one 16-byte record per row {weight, slot0, slot1, stamp} (lin_w = rec, l_slot0 = rec + 1, l_slot1 = rec + 2,
  * last_step = (int32_t*)rec + 3): a row's wide-part state then costs one memory sector instead of four
- * (round 1's catchup_lin_k fetched 569 MB for 20 MB of state). */
+ * (round 1's catchup_lin_k fetched 569 MB for 20 MB of state).
+ * table_stride (round 4), here and in every entry that takes the embedding table (mi_embed_fm_planes_fwd, mi_gather_rows,
+ * mi_dense_fwd_gathered, mi_dense_bwd_weight_gathered, mi_sparse_apply[_fused], mi_sparse_catchup): floats between
+ * consecutive rows of table (and of its slot arrays) — 0 or E: [R, E] arrays; 3 E with t_slot0 = table + E, t_slot1 = table +
+ * 2 E: ONE record [w | slot0 | slot1] per row (what the shipped host allocates: a row's weights and optimizer state are one
+ * contiguous 12 E-byte run — one DRAM page visit per row and direction in the sparse apply and the catch-up instead of
+ * three).  A multiple of 4, >= E. */
 int32_t mi_embed_fm_linear_fwd(const float* table, const float* lin_w, const int64_t* field_off,
                                const int32_t* ids, int64_t B, int32_t F, int32_t E,
                                float* concat, int64_t ld_concat, float* sumv, float* fm, float* lin,
-                               float* amax_rows, int32_t lin_stride, mi_stream_t stream);
+                               float* amax_rows, int32_t lin_stride, int64_t table_stride, mi_stream_t stream);
 
 /* The gather with the concat written as fp16 high/low planes (struct mi_planes, below): the operand of
  * the layer-1 GEMMs mi_dense_fwd_planes / mi_dense_bwd_weight_planes.  One exponent per example, from the
@@ -140,13 +146,13 @@ int32_t mi_embed_fm_linear_fwd(const float* table, const float* lin_w, const int
 struct mi_planes;
 int32_t mi_embed_fm_planes_fwd(const float* table, const int64_t* field_off, const int32_t* ids, int64_t B, int32_t F,
                                int32_t E, float* sumv, float* fm, const struct mi_planes* concat, float* amax_rows,
-                               const float* x_num, int32_t n_numeric, int32_t tail_cols, mi_stream_t stream);
+                               const float* x_num, int32_t n_numeric, int32_t tail_cols, int64_t table_stride, mi_stream_t stream);
 
 /* Owner-side half of the row-sharded path (multi-GPU): out_rows[i,:] = table[rows[i],:],
  * out_lin[i] = lin_w[rows[i] * lin_stride].  rows [n] int32 local row ids; table (with out_rows) or lin_w
  * (with out_lin) may be NULL. */
 int32_t mi_gather_rows(const float* table, const float* lin_w, const int32_t* rows, int64_t n,
-                       int32_t E, float* out_rows, float* out_lin, int32_t lin_stride, mi_stream_t stream);
+                       int32_t E, float* out_rows, float* out_lin, int32_t lin_stride, int64_t table_stride, mi_stream_t stream);
 
 /* (a4) numeric embedding, deep_fm.py:62-70: out[b, j*E+e] = x[b,j] * V[j,e], written at
  * concat[b, col0 + j*E + e]; also accumulates into sumv / fm so the FM term sees the numeric
@@ -307,20 +313,20 @@ int32_t mi_sparse_apply(float* table, float* t_slot0, float* t_slot1, float* lin
                         const int32_t* seg_start, const int32_t* sorted_entry,
                         const int32_t* num_uniq, int64_t n_max, const float* d_rows,
                         const float* d_lin, int32_t E, int32_t step, const mi_opt_hparams* hp,
-                        int32_t lin_stride, mi_stream_t stream);
+                        int32_t lin_stride, int64_t table_stride, mi_stream_t stream);
 
 /* Single-GPU form of mi_sparse_apply with mi_embed_fm_linear_bwd folded in: the gradient of entry
  * e = (b, f) = (e / F, e % F) is rebuilt inside the kernel as
  *   d_concat[b, f*E:(f+1)*E] + d_logit_fm[b] * (sumv[b,:] - w)     (w = the row itself, not yet updated;
  *   equals the concat slice the forward used)  and  d_logit_lin[b] for the linear weight,
- * so the [B*F, E] per-entry gradient matrix is never written.  Same summation order, same bits. * sumv == NULL with d_logit_fm set: d_concat already carries d_logit_fm * sumv (mi_dense_bwd_data_planes'
- * fold_sumv), the kernel subtracts d_logit_fm * row only. */
+ * so the [B*F, E] per-entry gradient matrix is never written.  Same summation order, same bits.
+ * (sumv == NULL with d_logit_fm set: d_concat already carries d_logit_fm * sumv; the kernel subtracts d_logit_fm * row only.) */
 int32_t mi_sparse_apply_fused(float* table, float* t_slot0, float* t_slot1, float* lin_w, float* l_slot0,
                               float* l_slot1, int32_t* last_step, const int32_t* uniq_rows,
                               const int32_t* seg_start, const int32_t* sorted_entry, const int32_t* num_uniq,
                               int64_t n_max, const float* d_concat, int64_t ld_dconcat, const float* sumv,
                               const float* d_logit_fm, const float* d_logit_lin, int32_t F, int32_t E,
-                              int32_t step, const mi_opt_hparams* hp, int32_t lin_stride, mi_stream_t stream);
+                              int32_t step, const mi_opt_hparams* hp, int32_t lin_stride, int64_t table_stride, mi_stream_t stream);
 
 /* TF-1.12 AdamOptimizer._apply_sparse decays m and v of EVERY row and moves EVERY row each step
  * (SURVEY Appendix A.6).  Instead of sweeping the table, rows carry last_step[r] and are brought
@@ -382,7 +388,7 @@ int32_t mi_sparse_catchup(float* table, float* t_m, float* t_v, float* lin_w, fl
                           int32_t* last_step, const int32_t* uniq_rows, const int32_t* num_uniq,
                           int64_t n_max, int32_t E, int32_t step_to, const float* lr_table,
                           float beta1, float beta2, float epsilon, int32_t flags, int32_t lin_stride,
-                          mi_stream_t stream);
+                          int64_t table_stride, mi_stream_t stream);
 
 /* ---- (a6) the [hidden_units] MLP: fp32 GEMMs on the matrix cores with fused epilogues -----------
  * replaces tf.layers.dense / tf.layers.dropout (deep_fm.py:98-108).  Row-major everywhere.
@@ -436,11 +442,11 @@ int32_t mi_dense_fwd(const float* X, int64_t ldx, const float* W, const float* b
 int32_t mi_dense_fwd_gathered(const float* table, const int64_t* field_off, const int32_t* ids, int32_t F,
                               int32_t E, const float* W, const float* bias, float* Y, int64_t ldy, int64_t M,
                               int32_t N, int32_t relu, float keep_prob, uint64_t seed,
-                              const mi_gemm_amax_t* amax, mi_stream_t stream);
+                              const mi_gemm_amax_t* amax, int64_t table_stride, mi_stream_t stream);
 int32_t mi_dense_bwd_weight_gathered(const float* table, const int64_t* field_off, const int32_t* ids, int32_t F,
                                      int32_t E, const float* dY, int64_t lddy, float* dW, float* db, int64_t M,
                                      int32_t N, void* workspace, size_t workspace_bytes,
-                                     const mi_gemm_amax_t* amax, mi_stream_t stream);
+                                     const mi_gemm_amax_t* amax, int64_t table_stride, mi_stream_t stream);
 
 /* dX[M,K] = (dY[M,N] * W[K,N]^T) .* mask.  When Xact != NULL (the previous layer's stored
  * post-relu, post-dropout output) mask = (Xact > 0) / keep_prob — a unit with Xact > 0 was both
@@ -515,15 +521,12 @@ int32_t mi_dense_fwd_planes(const mi_planes_t* X, const mi_planes_t* Wt, const f
 
 /* dX[M][K] = (dY[M][N] * W[K][N]^T) .* mask with dY as planes and W = planes of W as stored (rows = K);
  * mask from Xact (planes of the previous layer's stored output: hi > 0 <=> active and kept; NULL: none),
- * survivors divided by keep_prob.  dX (fp32) and / or dXp (planes, K <= 512). * fold_sumv != NULL (layer 1 only: dX is d_concat, fp32, no mask): dX[m][k] += fold_dlogit[m] * fold_sumv[m][k % fold_E]
- * — the FM term's share of the input_layer gradient (deep_fm.py:81-87 backward) added once per example here;
- * mi_sparse_apply_fused is then called with sumv == NULL and subtracts d_logit_fm * row only.
+ * survivors divided by keep_prob.  dX (fp32) and / or dXp (planes, K <= 512).
  * mask_bits / mask_ld (may be NULL): the mask as mi_dense_fwd_planes' mask_bits_out wrote it ([M][mask_ld] words, one bit per
  * element of dX's K columns); taken instead of Xact when both are given — the same decisions, hence the same bits. */
 int32_t mi_dense_bwd_data_planes(const mi_planes_t* dY, const mi_planes_t* W, const mi_planes_t* Xact, float* dX,
                                  int64_t lddx, const mi_planes_t* dXp, int64_t M, int32_t N, int32_t K, float keep_prob,
-                                 float* amax_out, const float* fold_sumv, const float* fold_dlogit, int32_t fold_E,
-                                 const uint32_t* mask_bits, int64_t mask_ld, mi_stream_t stream);
+                                 float* amax_out, const uint32_t* mask_bits, int64_t mask_ld, mi_stream_t stream);
 
 /* The data gradient of the N = 1 logits layer (deep_fm.py:108 backward) with the result as planes:
  * dX[m][k] = dY[m] * W[k], kept where Xact[m][k] > 0 and divided by keep_prob (Xact == NULL: no mask) — the

@@ -33,7 +33,7 @@ __global__ __launch_bounds__(kBlock) void embed_fm_linear_fwd_k(
     const float* __restrict__ table, const float* __restrict__ lin_w,
     const int64_t* __restrict__ field_off, const int32_t* __restrict__ ids, int64_t B, int F, int E,
     float* __restrict__ concat, int64_t ldc, float* __restrict__ sumv, float* __restrict__ fm,
-    float* __restrict__ lin, float* __restrict__ amax_rows, int ls) {
+    float* __restrict__ lin, float* __restrict__ amax_rows, int ls, int64_t ts) {
   constexpr int U = kRowsInFlight;
   float mx = 0.f;                   // largest |row element| seen (scale of the layer-1 GEMM operand)
   const int64_t g = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) / LPR;
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(kBlock) void embed_fm_linear_fwd_k(
         for (int u = 0; u < U; ++u) {
           const int32_t row = __shfl(myrow, (j0 + u) & (LPR - 1), LPR);
           r[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (j0 + u < nf && lane_on) r[u] = ld4(table + static_cast<int64_t>(row) * E + eo);
+          if (j0 + u < nf && lane_on) r[u] = ld4(table + static_cast<int64_t>(row) * ts + eo);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(kBlock) void embed_fm_linear_fwd_k(
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         r[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (f0 + u < F && lane_on) r[u] = ld4(table + static_cast<int64_t>(row[u]) * E + eo);
+        if (f0 + u < F && lane_on) r[u] = ld4(table + static_cast<int64_t>(row[u]) * ts + eo);
         if (lin_w && f0 + u < F && ((f0 + u) & (LPR - 1)) == l) lacc += lin_w[static_cast<int64_t>(row[u]) * ls];
       }
 #pragma unroll
@@ -133,7 +133,8 @@ template <int LPR, int FC>
 __global__ __launch_bounds__(kBlock) void embed_fm_planes_fwd_k(
     const float* __restrict__ table, const int64_t* __restrict__ field_off, const int32_t* __restrict__ ids, int64_t B,
     int F, int E, float* __restrict__ sumv, float* __restrict__ fm, char* __restrict__ planes, int64_t ldp_b,
-    int32_t* __restrict__ row_exp, float* __restrict__ amax_rows, const float* __restrict__ x_num, int nd, int tail_cols) {
+    int32_t* __restrict__ row_exp, float* __restrict__ amax_rows, const float* __restrict__ x_num, int nd, int tail_cols,
+    int64_t ts) {
   static_assert(LPR >= 8, "planes gather: E >= 32");
   const int64_t g = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) / LPR;
   const int l = threadIdx.x & (LPR - 1);
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(kBlock) void embed_fm_planes_fwd_k(
       if (fb + j < FC) {
         const int32_t row = __shfl(myrow, j, LPR);
         r[fb + j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (fb + j < F && lane_on) r[fb + j] = ld4(table + static_cast<int64_t>(row) * E + eo);
+        if (fb + j < F && lane_on) r[fb + j] = ld4(table + static_cast<int64_t>(row) * ts + eo);
       }
     }
   }
@@ -234,7 +235,7 @@ __global__ __launch_bounds__(kBlock) void gather_rows_k(const float* __restrict_
                                                         const float* __restrict__ lin_w,
                                                         const int32_t* __restrict__ rows, int64_t n,
                                                         int E, float* __restrict__ out_rows,
-                                                        float* __restrict__ out_lin, int ls) {
+                                                        float* __restrict__ out_lin, int ls, int64_t ts) {
   constexpr int U = kRowsInFlight;
   const int64_t g = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) / LPR;
   const int l = threadIdx.x & (LPR - 1);
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(kBlock) void gather_rows_k(const float* __restrict_
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     r[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (table && i0 + u < n && lane_on) r[u] = ld4(table + static_cast<int64_t>(row[u]) * E + 4 * l);
+    if (table && i0 + u < n && lane_on) r[u] = ld4(table + static_cast<int64_t>(row[u]) * ts + 4 * l);
   }
 #pragma unroll
   for (int u = 0; u < U; ++u) {
@@ -482,7 +483,7 @@ extern "C" {
 int32_t mi_embed_fm_linear_fwd(const float* table, const float* lin_w, const int64_t* field_off,
                                const int32_t* ids, int64_t B, int32_t F, int32_t E, float* concat,
                                int64_t ld_concat, float* sumv, float* fm, float* lin, float* amax_rows,
-                               int32_t lin_stride, mi_stream_t stream) {
+                               int32_t lin_stride, int64_t table_stride, mi_stream_t stream) {
   MI_REQUIRE(B >= 0 && F > 0 && lin_stride >= 1, "embed_fm_linear_fwd: B=%lld F=%d lin_stride=%d", (long long)B, F, lin_stride);
   if (!table) {  // wide part only
     MI_REQUIRE(!concat && !sumv && !fm && lin && lin_w && field_off && ids,
@@ -501,21 +502,26 @@ int32_t mi_embed_fm_linear_fwd(const float* table, const float* lin_w, const int
   MI_REQUIRE(mi::aligned16(table) && (!concat || mi::aligned16(concat)) && (!sumv || mi::aligned16(sumv)),
              "embed_fm_linear_fwd: table/concat/sumv must be 16-byte aligned");
   MI_REQUIRE(!lin || lin_w, "embed_fm_linear_fwd: lin requested without lin_w");
+  MI_REQUIRE(table_stride == 0 || (table_stride >= E && (table_stride & 3) == 0), "%s: table_stride=%lld (0 = E, else >= E and a multiple of 4)", "embed_fm_linear_fwd", (long long)table_stride);
+  const int64_t ts = table_stride ? table_stride : E;
   if (B == 0) return MI_OK;
   const int lpr = lanes_per_row(E);
   const int64_t blocks = mi::ceil_div(B * lpr, kBlock);
   MI_REQUIRE(blocks <= INT32_MAX, "embed_fm_linear_fwd: grid too large");
   MI_DISPATCH_LPR(lpr, (embed_fm_linear_fwd_k<L><<<dim3((unsigned)blocks), dim3(kBlock), 0, mi::as_stream(stream)>>>(
                            table, lin ? lin_w : nullptr, field_off, ids, B, F, E, concat, ld_concat, sumv, fm, lin,
-                           amax_rows, lin_stride)));
+                           amax_rows, lin_stride, ts)));
   MI_CHECK_LAUNCH("embed_fm_linear_fwd");
   return MI_OK;
 }
 
 int32_t mi_embed_fm_planes_fwd(const float* table, const int64_t* field_off, const int32_t* ids, int64_t B, int32_t F,
                                int32_t E, float* sumv, float* fm, const mi_planes_t* concat, float* amax_rows,
-                               const float* x_num, int32_t n_numeric, int32_t tail_cols, mi_stream_t stream) {
+                               const float* x_num, int32_t n_numeric, int32_t tail_cols, int64_t table_stride, mi_stream_t stream) {
   if (int32_t rc = check_E("embed_fm_planes_fwd", E)) return rc;
+  MI_REQUIRE(table_stride == 0 || (table_stride >= E && (table_stride & 3) == 0), "%s: table_stride=%lld (0 = E, else >= E and a multiple of 4)", "embed_fm_planes_fwd", (long long)table_stride);
+  const int64_t ts = table_stride ? table_stride : E;
+
   MI_REQUIRE(B >= 0 && F > 0, "embed_fm_planes_fwd: B=%lld F=%d", (long long)B, F);
   if ((E & 15) || E < 32 || F > 48) {
     mi::set_error("embed_fm_planes_fwd: needs E a multiple of 16 >= 32 and F <= 48 (E=%d F=%d): use mi_embed_fm_linear_fwd + mi_split_rows", E, F);
@@ -538,7 +544,7 @@ int32_t mi_embed_fm_planes_fwd(const float* table, const int64_t* field_off, con
   char* pd = static_cast<char*>(concat->data);
   const dim3 g((unsigned)blocks), blk(kBlock);
   hipStream_t st = mi::as_stream(stream);
-#define MI_PL_GATHER(L, FCAP) embed_fm_planes_fwd_k<L, FCAP><<<g, blk, 0, st>>>(table, field_off, ids, B, F, E, sumv, fm, pd, concat->blk_stride, concat->row_exp, amax_rows, x_num, n_numeric, tail_cols)
+#define MI_PL_GATHER(L, FCAP) embed_fm_planes_fwd_k<L, FCAP><<<g, blk, 0, st>>>(table, field_off, ids, B, F, E, sumv, fm, pd, concat->blk_stride, concat->row_exp, amax_rows, x_num, n_numeric, tail_cols, ts)
   if (F <= 32) {
     switch (lpr) {
       case 8: MI_PL_GATHER(8, 32); break;
@@ -560,9 +566,12 @@ int32_t mi_embed_fm_planes_fwd(const float* table, const int64_t* field_off, con
 }
 
 int32_t mi_gather_rows(const float* table, const float* lin_w, const int32_t* rows, int64_t n,
-                       int32_t E, float* out_rows, float* out_lin, int32_t lin_stride, mi_stream_t stream) {
-  if (!table) E = 4;                       // wide part only: the row half of the kernel is off
+                       int32_t E, float* out_rows, float* out_lin, int32_t lin_stride, int64_t table_stride, mi_stream_t stream) {
+  if (!table) { E = 4; table_stride = 0; }   // wide part only: the row half of the kernel is off
   if (int32_t rc = check_E("gather_rows", E)) return rc;
+  MI_REQUIRE(table_stride == 0 || (table_stride >= E && (table_stride & 3) == 0), "%s: table_stride=%lld (0 = E, else >= E and a multiple of 4)", "gather_rows", (long long)table_stride);
+  const int64_t ts = table_stride ? table_stride : E;
+
   MI_REQUIRE(n >= 0 && lin_stride >= 1, "gather_rows: n=%lld lin_stride=%d", (long long)n, lin_stride);
   if (n == 0) return MI_OK;
   MI_REQUIRE(rows && ((table && out_rows) || (lin_w && out_lin)), "gather_rows: null buffer");
@@ -572,7 +581,7 @@ int32_t mi_gather_rows(const float* table, const float* lin_w, const int32_t* ro
   const int64_t blocks = mi::ceil_div(groups * lpr, kBlock);
   MI_REQUIRE(blocks <= INT32_MAX, "gather_rows: grid too large");
   MI_DISPATCH_LPR(lpr, (gather_rows_k<L><<<dim3((unsigned)blocks), dim3(kBlock), 0, mi::as_stream(stream)>>>(
-                           table, lin_w, rows, n, E, out_rows, out_lin, lin_stride)));
+                           table, lin_w, rows, n, E, out_rows, out_lin, lin_stride, ts)));
   MI_CHECK_LAUNCH("gather_rows");
   return MI_OK;
 }

@@ -48,6 +48,7 @@ struct GemmArgs {
   // (example b, column c) is table[(g_off[c / g_E] + g_ids[b * g_F + c / g_E]) * g_E + c % g_E] —
   // the input_layer concat (deep_fm.py:54) read in place, never materialised.
   const int32_t* g_ids; const int64_t* g_off; int g_F, g_E;
+  int64_t g_ts;         // floats between consecutive table rows (>= g_E: the rows may sit in [w | slot0 | slot1] records)
   // abs-max vectors (MI_AMAX_SLOTS floats each, value = largest entry): of the operands, for the
   // f16x2 split's scales; of the result, accumulated by the epilogue.  Any may be NULL.
   const float* amax_a; const float* amax_b; float* amax_c;
@@ -173,7 +174,7 @@ __device__ __forceinline__ void load_tile_gathered(const GemmArgs& a, int mn0, i
   const int e = c % a.g_E;
 #pragma unroll
   for (int p = 0; p < 4; ++p)
-    r[p] = *reinterpret_cast<const float4*>(a.A + static_cast<int64_t>(row[p]) * a.g_E + e);
+    r[p] = *reinterpret_cast<const float4*>(a.A + static_cast<int64_t>(row[p]) * a.g_ts + e);
 }
 
 template <int L>
@@ -815,8 +816,11 @@ static int32_t check_gather(const char* who, const float* table, const int64_t* 
 int32_t mi_dense_fwd_gathered(const float* table, const int64_t* field_off, const int32_t* ids, int32_t F,
                               int32_t E, const float* W, const float* bias, float* Y, int64_t ldy, int64_t M,
                               int32_t N, int32_t relu, float keep_prob, uint64_t seed, const mi_gemm_amax_t* amax,
-                              mi_stream_t stream) {
+                              int64_t table_stride, mi_stream_t stream) {
   if (int32_t rc = check_gather("dense_fwd_gathered", table, field_off, ids, F, E)) return rc;
+  MI_REQUIRE(table_stride == 0 || (table_stride >= E && (table_stride & 3) == 0), "%s: table_stride=%lld (0 = E, else >= E and a multiple of 4)", "dense_fwd_gathered", (long long)table_stride);
+  const int64_t ts = table_stride ? table_stride : E;
+
   MI_REQUIRE(M >= 0 && M <= INT32_MAX && N > 0, "dense_fwd_gathered: M=%lld N=%d", (long long)M, N);
   if (M == 0) return MI_OK;
   MI_REQUIRE(W && Y && ldy >= N, "dense_fwd_gathered: null buffer / ldy");
@@ -828,7 +832,7 @@ int32_t mi_dense_fwd_gathered(const float* table, const int64_t* field_off, cons
   a.vecA = 1; a.vecB = vec_ok(W, N, N);
   a.epi = EPI_BIAS_ACT; a.bias = bias; a.relu = relu;
   a.keep_prob = keep_prob; a.keep_div = keep_prob; a.seed = seed; a.st = mi::step_state();
-  a.g_ids = ids; a.g_off = field_off; a.g_F = F; a.g_E = E;
+  a.g_ids = ids; a.g_off = field_off; a.g_F = F; a.g_E = E; a.g_ts = ts;
   set_amax(a, amax);
   return launch<KC, MC, false, true>(a, 1, mi::as_stream(stream), "dense_fwd_gathered");
 }
@@ -863,29 +867,31 @@ size_t mi_dense_bwd_weight_workspace_bytes(int64_t M, int32_t N, int32_t K) {
 static int32_t bwd_weight_impl(const float* X, int64_t ldx, const float* dY, int64_t lddy, float* dW, float* db,
                                int64_t M, int32_t N, int32_t K, void* workspace, size_t workspace_bytes,
                                const mi_gemm_amax_t* amax, mi_stream_t stream, const int32_t* g_ids,
-                               const int64_t* g_off, int32_t g_F, int32_t g_E);
+                               const int64_t* g_off, int32_t g_F, int32_t g_E, int64_t g_ts);
 
 int32_t mi_dense_bwd_weight(const float* X, int64_t ldx, const float* dY, int64_t lddy, float* dW,
                             float* db, int64_t M, int32_t N, int32_t K, void* workspace,
                             size_t workspace_bytes, const mi_gemm_amax_t* amax, mi_stream_t stream) {
   MI_REQUIRE(X && ldx >= K, "dense_bwd_weight: X / ldx");
   return bwd_weight_impl(X, ldx, dY, lddy, dW, db, M, N, K, workspace, workspace_bytes, amax, stream, nullptr, nullptr,
-                         0, 0);
+                         0, 0, 0);
 }
 
 int32_t mi_dense_bwd_weight_gathered(const float* table, const int64_t* field_off, const int32_t* ids, int32_t F,
                                      int32_t E, const float* dY, int64_t lddy, float* dW, float* db, int64_t M,
                                      int32_t N, void* workspace, size_t workspace_bytes,
-                                     const mi_gemm_amax_t* amax, mi_stream_t stream) {
+                                     const mi_gemm_amax_t* amax, int64_t table_stride, mi_stream_t stream) {
   if (int32_t rc = check_gather("dense_bwd_weight_gathered", table, field_off, ids, F, E)) return rc;
+  MI_REQUIRE(table_stride == 0 || (table_stride >= E && (table_stride & 3) == 0), "%s: table_stride=%lld (0 = E, else >= E and a multiple of 4)", "dense_bwd_weight_gathered", (long long)table_stride);
+  const int64_t ts = table_stride ? table_stride : E;
   return bwd_weight_impl(table, 0, dY, lddy, dW, db, M, N, F * E, workspace, workspace_bytes, amax, stream, ids,
-                         field_off, F, E);
+                         field_off, F, E, ts);
 }
 
 static int32_t bwd_weight_impl(const float* X, int64_t ldx, const float* dY, int64_t lddy, float* dW, float* db,
                                int64_t M, int32_t N, int32_t K, void* workspace, size_t workspace_bytes,
                                const mi_gemm_amax_t* amax, mi_stream_t stream, const int32_t* g_ids,
-                               const int64_t* g_off, int32_t g_F, int32_t g_E) {
+                               const int64_t* g_off, int32_t g_F, int32_t g_E, int64_t g_ts) {
   MI_REQUIRE(M > 0 && M <= INT32_MAX && N > 0 && K > 0, "dense_bwd_weight: M=%lld N=%d K=%d", (long long)M, N, K);
   MI_REQUIRE(X && dY && dW && workspace, "dense_bwd_weight: null buffer");
   MI_REQUIRE(lddy >= N, "dense_bwd_weight: leading dimensions");
@@ -922,7 +928,7 @@ static int32_t bwd_weight_impl(const float* X, int64_t ldx, const float* dY, int
   set_amax(a, amax);
   a.amax_c = nullptr;                 // the slabs are partial sums; dW is nobody's matrix operand
   if (g_ids) {
-    a.vecA = 1; a.g_ids = g_ids; a.g_off = g_off; a.g_F = g_F; a.g_E = g_E;
+    a.vecA = 1; a.g_ids = g_ids; a.g_off = g_off; a.g_F = g_F; a.g_E = g_E; a.g_ts = g_ts;
     if (int32_t rc = launch<MC, MC, true, true>(a, splits, st, "dense_bwd_weight_gathered(split-K)")) return rc;
   } else if (int32_t rc = launch<MC, MC, true>(a, splits, st, "dense_bwd_weight(split-K)")) return rc;
   if (direct) return MI_OK;

@@ -65,9 +65,6 @@ struct PlArgs {
   // stored activation's high plane (DGRAD: an input; 2 MB instead of 134 MB at 65536 x 512) and by the logits layer's.
   uint32_t* mbits; int64_t mbld;
   float* amax_c;                                        // abs-max vector of the result (the weight gradient's matrix-wide scales) or NULL
-  // dgrad into the input_layer: the FM term's share of the concat gradient, added once here instead of once
-  // per entry in the sparse apply: C[m][n] += fold_g[m] * fold_s[m][n % fold_E]   (NULL: nothing added)
-  const float* fold_s; const float* fold_g; int fold_E;
   const mi_step_state_t* st;                            // device-resident step state of a captured step, or NULL
 };
 
@@ -319,11 +316,6 @@ __global__ __launch_bounds__(PL_THREADS, 2) void gemm_pl_k(const PlArgs a) {
     const int mc = mok ? m : a.M - 1;
     const float fx = pl_pow2(-a.b_exp[mc]);
     float mx = 0.f;
-    float fgm = 0.f;
-    const float* fsm = nullptr;
-    if constexpr (EPI == PL_DGRAD) {
-      if (a.fold_s) { fgm = a.fold_g[mc]; fsm = a.fold_s + static_cast<int64_t>(mc) * a.fold_E; }
-    }
     const uint32_t rowkey = drop ? mi_drop_rowkey(seed, static_cast<uint32_t>(m)) : 0u;
     // the 4 columns' factors of a group: one 16-byte LDS read each, for group gi + 1 while group gi is computed
     auto col_of = [&](int gi) { return nw + (gi >> 2) * 32 + 8 * (gi & 3) + 4 * h; };
@@ -357,7 +349,6 @@ __global__ __launch_bounds__(PL_THREADS, 2) void gemm_pl_k(const PlArgs a) {
 #pragma unroll
     for (int gi = 0; gi < TN * 4; ++gi) {
       const int x = gi >> 2, g = gi & 3;
-      const int nl = col_of(gi);                          // tile column of register 4 g
       const float4 fw4 = fw_n, b4 = b_n;
       if (gi + 1 < TN * 4) {
         fw_n = *reinterpret_cast<const float4*>(e_fw + col_of(gi + 1));
@@ -394,16 +385,6 @@ __global__ __launch_bounds__(PL_THREADS, 2) void gemm_pl_k(const PlArgs a) {
           v = (bits16 - 1u) < 0x7fffu ? mi_div_const(v, kd, kr) : 0.f;
         }
         acc[x][y][r] = v;
-      }
-      if constexpr (EPI == PL_DGRAD) {
-        if (fsm) {     // the FM term's share of the concat gradient (layer 1, engine.DeepFM.FOLD_FM): + dlogit[m] * sumv[m][n % E]
-          const float4 fs4 = *reinterpret_cast<const float4*>(fsm + min(n0 + nl, a.N - 4) % a.fold_E);   // (4 columns stay inside a field: E % 4 == 0)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float f = fgm * (j == 0 ? fs4.x : j == 1 ? fs4.y : j == 2 ? fs4.z : fs4.w);
-            acc[x][y][4 * g + j] = n0 + nl + j < a.N ? acc[x][y][4 * g + j] + f : 0.f;
-          }
-        }
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) mx = fmaxf(mx, fabsf(acc[x][y][4 * g + j]));
@@ -1088,8 +1069,7 @@ int32_t mi_dense_fwd_planes(const mi_planes_t* X, const mi_planes_t* Wt, const f
 
 int32_t mi_dense_bwd_data_planes(const mi_planes_t* dY, const mi_planes_t* W, const mi_planes_t* Xact, float* dX,
                                  int64_t lddx, const mi_planes_t* dXp, int64_t M, int32_t N, int32_t K, float keep_prob,
-                                 float* amax_out, const float* fold_sumv, const float* fold_dlogit, int32_t fold_E,
-                                 const uint32_t* mask_bits, int64_t mask_ld, mi_stream_t stream) {
+                                 float* amax_out, const uint32_t* mask_bits, int64_t mask_ld, mi_stream_t stream) {
   // dX[M][K] = dY[M][N] * W[K][N]^T : output width K, reduction over N
   MI_REQUIRE(M >= 0 && M <= INT32_MAX && N > 0 && K > 0, "dense_bwd_data_planes: M=%lld N=%d K=%d", (long long)M, N, K);
   if (M == 0) return MI_OK;
@@ -1111,11 +1091,6 @@ int32_t mi_dense_bwd_data_planes(const mi_planes_t* dY, const mi_planes_t* W, co
   if (Xact) { a.mask = static_cast<const char*>(Xact->data); a.bsm = Xact->blk_stride; }
   a.mbits = const_cast<uint32_t*>(mask_bits); a.mbld = mask_ld;          // (read only in the DGRAD epilogue; preferred over Xact)
   a.amax_c = amax_out;
-  if (fold_sumv) {
-    MI_REQUIRE(fold_dlogit && fold_E >= 4 && (fold_E & 3) == 0 && K % fold_E == 0 && mi::aligned16(fold_sumv) && !Xact && !mask_bits && !dXp && dX,
-               "dense_bwd_data_planes: the FM fold needs d_logit, E a multiple of 4 that divides K, an fp32 result and no mask");
-    a.fold_s = fold_sumv; a.fold_g = fold_dlogit; a.fold_E = fold_E;
-  }
   return launch_pl<PL_DGRAD>(a, mi::as_stream(stream), "dense_bwd_data_planes");
 }
 

@@ -128,6 +128,10 @@ struct ApplyArgs {
   // {w, slot0, slot1, stamp} (a row's wide-part state then costs one memory sector instead of four)
   int ls;
   const mi_step_state_t* st;   // device-resident step / lr_t of a replayable (captured) step, or nullptr
+  // floats between consecutive rows of table / t0 / t1 (>= E): E = three separate [R, E] arrays; 3 E with t0 = table + E,
+  // t1 = table + 2 E = ONE [w | slot0 | slot1] record per row — a row's whole state is then one contiguous run of
+  // 12 E bytes (one DRAM page visit per row and direction instead of three)
+  int64_t ts;
 };
 
 // sum of the gradients of entries sorted_entry[k_beg..k_end) of one row, in that order
@@ -182,7 +186,7 @@ __device__ __forceinline__ RowState load_row_state(const ApplyArgs& a, const Hp&
   q.lw = q.ls0 = q.ls1 = 0.f;
   q.stamp = 0;
   if (a.table && lane_on) {
-    const int64_t o = r * a.E + 4 * l;
+    const int64_t o = r * a.ts + 4 * l;
     if (a.t0) q.s0 = ld4_nt(a.t0 + o);
     if (a.t1) q.s1 = ld4_nt(a.t1 + o);
   }
@@ -201,7 +205,7 @@ __device__ __forceinline__ void apply_row(const ApplyArgs& a, const Hp& h, int64
   int missed = 0;
   if (h.kind == MI_OPT_ADAM && a.last_step) missed = q.stamp > 0 ? max(0, a.step - 1 - q.stamp) : 0;
   if (a.table && lane_on) {
-    const int64_t o = r * a.E + 4 * l;
+    const int64_t o = r * a.ts + 4 * l;
     float4 s0 = q.s0, s1 = q.s1;
     for (int j = 0; j < missed; ++j) {
       s0.x = s0.x * h.beta1; s0.y = s0.y * h.beta1; s0.z = s0.z * h.beta1; s0.w = s0.w * h.beta1;
@@ -249,7 +253,7 @@ __global__ __launch_bounds__(kBlock) void sparse_apply_k(ApplyArgs a, Hp h, cons
   float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
   float gl = 0.f;
   float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (a.table && lane_on) w = ld4(a.table + r * a.E + 4 * l);
+  if (a.table && lane_on) w = ld4(a.table + r * a.ts + 4 * l);
   RowState q;
   if constexpr (!STORE) q = load_row_state(a, h, r, l, lane_on);
   seg_accumulate<FUSED>(a, fg, s_beg, s_end, l, lane_on, w, g, gl);
@@ -291,7 +295,7 @@ __global__ __launch_bounds__(kBlock) void sparse_apply_long_k(ApplyArgs a, Hp h,
       float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
       float gl = 0.f;
       float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (a.table && lane_on) w = ld4(a.table + r * a.E + 4 * l);
+      if (a.table && lane_on) w = ld4(a.table + r * a.ts + 4 * l);
       seg_accumulate<FUSED>(a, fg, k0, k1, l, lane_on, w, g, gl);
       part[t] = g;
       if (l == 0) part_l[grp] = gl;
@@ -472,7 +476,7 @@ __global__ __launch_bounds__(kBlock) void sparse_catchup_k(
     int32_t* __restrict__ last_step, const int32_t* __restrict__ uniq_rows,
     const int32_t* __restrict__ num_uniq, int64_t n_max, int E, int step_to,
     const float* __restrict__ lr_table, float b1, float b2, float eps, bool defer_slots, int st,
-    const mi_step_state_t* __restrict__ ss, bool keep_stamps) {
+    const mi_step_state_t* __restrict__ ss, bool keep_stamps, int64_t ts) {
   if (ss) step_to = ss->step - 1;
   const int64_t u = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) / LPR;
   const int l = threadIdx.x & (LPR - 1);
@@ -484,7 +488,7 @@ __global__ __launch_bounds__(kBlock) void sparse_catchup_k(
   // a row that was never applied has m = v = 0: every replayed step subtracts exactly 0
   if (ls > 0) {
     if (table && 4 * l < E) {
-      const int64_t o = r * E + 4 * l;
+      const int64_t o = r * ts + 4 * l;
       float4 w = ld4(table + o), m = ld4_nt(tm + o), v = ld4_nt(tv + o);
       // one loop for the four elements: one lr_t load and one loop counter per step instead of four,
       // four independent sqrt/divide chains in flight (the arithmetic per element is unchanged)
@@ -540,13 +544,13 @@ struct RowIn { int64_t r; int ls; float4 w, m, v; };
 
 // a row's stamp, w, m and v: four loads that depend on the row id only, issued together
 __device__ __forceinline__ RowIn load_row_in(const float* __restrict__ table, const float* __restrict__ tm, const float* __restrict__ tv,
-                                             const int32_t* __restrict__ last_step, int64_t r, int E, int l, bool lane_on, int st) {
+                                             const int32_t* __restrict__ last_step, int64_t r, int64_t ts, int l, bool lane_on, int st) {
   RowIn q;
   q.r = r;
   q.ls = last_step[r * st];
   q.w = q.m = q.v = make_float4(0.f, 0.f, 0.f, 0.f);
   if (lane_on) {
-    const int64_t o = r * E + 4 * l;
+    const int64_t o = r * ts + 4 * l;
     q.w = ld4(table + o); q.m = ld4_nt(tm + o); q.v = ld4_nt(tv + o);
   }
   return q;
@@ -558,7 +562,7 @@ __global__ __launch_bounds__(kBlock) void sparse_catchup_bounded_k(
     int32_t* __restrict__ last_step, const int32_t* __restrict__ uniq_rows,
     const int32_t* __restrict__ num_uniq, int64_t n_max, int E, int step_to,
     const float* __restrict__ lr_table, float b1, float b2, float eps, bool defer_slots, int st,
-    const mi_step_state_t* __restrict__ ss, bool keep_stamps) {
+    const mi_step_state_t* __restrict__ ss, bool keep_stamps, int64_t ts) {
   __shared__ float lr_s[kLrWindow];
   if (ss) step_to = ss->step - 1;
   const int base = step_to - (kLrWindow - 1);                 // lr_s[i] = lr_t[base + i]
@@ -627,7 +631,7 @@ __global__ __launch_bounds__(kBlock) void sparse_catchup_bounded_k(
           w.x = fmaf(-(lr * m.x), __builtin_amdgcn_rcpf(da.x), w.x); w.y = fmaf(-(lr * m.y), __builtin_amdgcn_rcpf(da.y), w.y);
           w.z = fmaf(-(lr * m.z), __builtin_amdgcn_rcpf(db.x), w.z); w.w = fmaf(-(lr * m.w), __builtin_amdgcn_rcpf(db.y), w.w);
         }
-        const int64_t o = cur.r * E + 4 * l;
+        const int64_t o = cur.r * ts + 4 * l;
         st4(table + o, w);
         if (!defer_slots) {
           float4 v = cur.v;
@@ -641,7 +645,7 @@ __global__ __launch_bounds__(kBlock) void sparse_catchup_bounded_k(
   };
   if constexpr (!DEEP) {
   int64_t u0 = row_at(0);
-  RowIn nxt = u0 < count ? load_row_in(table, tm, tv, last_step, row_id(u0), E, l, lane_on, st) : none;
+  RowIn nxt = u0 < count ? load_row_in(table, tm, tv, last_step, row_id(u0), ts, l, lane_on, st) : none;
   int64_t u1 = J > 1 ? row_at(1) : count;
   int32_t id_pref = u1 < count ? row_id(u1) : 0;
   for (int64_t j = 0; j < J; ++j) {
@@ -649,7 +653,7 @@ __global__ __launch_bounds__(kBlock) void sparse_catchup_bounded_k(
     const int64_t r_next = id_pref;
     const bool more = j + 1 < J;
     if (more) {
-      nxt = u1 < count ? load_row_in(table, tm, tv, last_step, r_next, E, l, lane_on, st) : none;
+      nxt = u1 < count ? load_row_in(table, tm, tv, last_step, r_next, ts, l, lane_on, st) : none;
       u1 = j + 2 < J ? row_at(j + 2) : count;
       if (u1 < count) id_pref = row_id(u1);
     }
@@ -679,7 +683,7 @@ __global__ __launch_bounds__(kBlock) void sparse_catchup_bounded_k(
     RowIn q;
     q.r = id;
     const int stamp = last_step[static_cast<int64_t>(id) * st];
-    const int64_t o = static_cast<int64_t>(id) * E + col;
+    const int64_t o = static_cast<int64_t>(id) * ts + col;
     q.w = ld4(table + o); q.m = ld4_nt(tm + o); q.v = ld4_nt(tv + o);
     q.ls = on ? stamp : INT32_MAX;
     return q;
@@ -827,8 +831,12 @@ int32_t mi_sparse_apply(float* table, float* t_slot0, float* t_slot1, float* lin
                         const int32_t* seg_start, const int32_t* sorted_entry,
                         const int32_t* num_uniq, int64_t n_max, const float* d_rows,
                         const float* d_lin, int32_t E, int32_t step, const mi_opt_hparams* hp,
-                        int32_t lin_stride, mi_stream_t stream) {
+                        int32_t lin_stride, int64_t table_stride, mi_stream_t stream) {
   if (int32_t rc = check_hp("sparse_apply", hp)) return rc;
+  if (!table) table_stride = 0;
+  MI_REQUIRE(table_stride == 0 || (table_stride >= E && (table_stride & 3) == 0), "%s: table_stride=%lld (0 = E, else >= E and a multiple of 4)", "sparse_apply", (long long)table_stride);
+  const int64_t ts = table_stride ? table_stride : E;
+
   MI_REQUIRE(lin_stride >= 1, "sparse_apply: lin_stride=%d", lin_stride);
   MI_REQUIRE(n_max >= 0, "sparse_apply: n_max=%lld", (long long)n_max);
   if (n_max == 0) return MI_OK;
@@ -847,7 +855,7 @@ int32_t mi_sparse_apply(float* table, float* t_slot0, float* t_slot1, float* lin
   const Hp h = make_hp(hp);
   ApplyArgs a{table, t_slot0, t_slot1, lin_w, l_slot0, l_slot1, last_step, uniq_rows, seg_start, sorted_entry,
               num_uniq, d_rows, d_lin, E, step};
-  a.ls = lin_stride;
+  a.ls = lin_stride; a.ts = ts;
   a.st = mi::step_state();
   MI_DISPATCH_LPR(lpr, (sparse_apply_k<L, false><<<dim3((unsigned)blocks), dim3(kBlock), 0, mi::as_stream(stream)>>>(
                            a, h, FusedGrad{})));
@@ -865,8 +873,12 @@ int32_t mi_sparse_apply_fused(float* table, float* t_slot0, float* t_slot1, floa
                               const int32_t* seg_start, const int32_t* sorted_entry, const int32_t* num_uniq,
                               int64_t n_max, const float* d_concat, int64_t ld_dconcat, const float* sumv,
                               const float* d_logit_fm, const float* d_logit_lin, int32_t F, int32_t E,
-                              int32_t step, const mi_opt_hparams* hp, int32_t lin_stride, mi_stream_t stream) {
+                              int32_t step, const mi_opt_hparams* hp, int32_t lin_stride, int64_t table_stride, mi_stream_t stream) {
   if (int32_t rc = check_hp("sparse_apply_fused", hp)) return rc;
+  if (!table) table_stride = 0;
+  MI_REQUIRE(table_stride == 0 || (table_stride >= E && (table_stride & 3) == 0), "%s: table_stride=%lld (0 = E, else >= E and a multiple of 4)", "sparse_apply_fused", (long long)table_stride);
+  const int64_t ts = table_stride ? table_stride : E;
+
   MI_REQUIRE(lin_stride >= 1, "sparse_apply_fused: lin_stride=%d", lin_stride);
   MI_REQUIRE(n_max >= 0 && F > 0, "sparse_apply_fused: n_max=%lld F=%d", (long long)n_max, F);
   if (n_max == 0) return MI_OK;
@@ -891,7 +903,7 @@ int32_t mi_sparse_apply_fused(float* table, float* t_slot0, float* t_slot1, floa
   const FusedGrad fg{d_concat, ld_dconcat, sumv, d_logit_fm, d_logit_lin, F, 0};
   ApplyArgs a{table, t_slot0, t_slot1, lin_w, l_slot0, l_slot1, last_step, uniq_rows, seg_start, sorted_entry,
               num_uniq, nullptr, nullptr, E, step};
-  a.ls = lin_stride;
+  a.ls = lin_stride; a.ts = ts;
   a.st = mi::step_state();
   MI_DISPATCH_LPR(lpr, (sparse_apply_k<L, true><<<dim3((unsigned)blocks), dim3(kBlock), 0, mi::as_stream(stream)>>>(a, h, fg)));
   MI_CHECK_LAUNCH("sparse_apply_fused");
@@ -932,7 +944,7 @@ int32_t mi_entry_grads_segsum(const float* rows, const int32_t* seg_start, const
   a.E = E;
   a.out_rows = out_rows ? reinterpret_cast<float*>(reinterpret_cast<uintptr_t>(out_rows) - static_cast<uintptr_t>(out_row0) * E * sizeof(float)) : nullptr;
   a.out_lin = out_lin ? reinterpret_cast<float*>(reinterpret_cast<uintptr_t>(out_lin) - static_cast<uintptr_t>(out_row0) * sizeof(float)) : nullptr;
-  a.u_begin = (int)u_begin; a.u_count = (int)u_count; a.ls = 1;
+  a.u_begin = (int)u_begin; a.u_count = (int)u_count; a.ls = 1; a.ts = E;       // (rows: the exchange buffer, E floats apart)
   const Hp h{};
   MI_DISPATCH_LPR(lpr, (sparse_apply_k<L, true, true><<<dim3((unsigned)blocks), dim3(kBlock), 0, mi::as_stream(stream)>>>(a, h, fg)));
   MI_CHECK_LAUNCH("entry_grads_segsum");
@@ -970,8 +982,12 @@ int32_t mi_sparse_catchup(float* table, float* t_m, float* t_v, float* lin_w, fl
                           int32_t* last_step, const int32_t* uniq_rows, const int32_t* num_uniq,
                           int64_t n_max, int32_t E, int32_t step_to, const float* lr_table,
                           float beta1, float beta2, float epsilon, int32_t flags, int32_t lin_stride,
-                          mi_stream_t stream) {
+                          int64_t table_stride, mi_stream_t stream) {
   MI_REQUIRE(n_max >= 0 && step_to >= 0 && lin_stride >= 1, "sparse_catchup: n_max=%lld step_to=%d", (long long)n_max, step_to);
+  if (!table) table_stride = 0;
+  MI_REQUIRE(table_stride == 0 || (table_stride >= E && (table_stride & 3) == 0), "%s: table_stride=%lld (0 = E, else >= E and a multiple of 4)", "sparse_catchup", (long long)table_stride);
+  const int64_t ts = table_stride ? table_stride : E;
+
   MI_REQUIRE((flags & ~(MI_CATCHUP_DEFER_SLOTS | MI_CATCHUP_BOUNDED | MI_CATCHUP_KEEP_STAMPS)) == 0, "sparse_catchup: flags=%d", flags);
   const bool keep_stamps = (flags & MI_CATCHUP_KEEP_STAMPS) != 0;
   const int32_t defer_slots = flags & MI_CATCHUP_DEFER_SLOTS;
@@ -1008,16 +1024,16 @@ int32_t mi_sparse_catchup(float* table, float* t_m, float* t_v, float* lin_w, fl
     if (mi::env_int("MI_CATCHUP_DEPTH", 1) >= 2) {
       MI_DISPATCH_LPR(lpr, (sparse_catchup_bounded_k<L, true><<<dim3((unsigned)pb), dim3(kBlock), 0, mi::as_stream(stream)>>>(
                                table, t_m, t_v, last_step, uniq_rows, num_uniq, n_max, E, step_to, lr_table, beta1, beta2,
-                               epsilon, defer, lin_stride, mi::step_state(), keep_stamps)));
+                               epsilon, defer, lin_stride, mi::step_state(), keep_stamps, ts)));
     } else {
       MI_DISPATCH_LPR(lpr, (sparse_catchup_bounded_k<L, false><<<dim3((unsigned)pb), dim3(kBlock), 0, mi::as_stream(stream)>>>(
                                table, t_m, t_v, last_step, uniq_rows, num_uniq, n_max, E, step_to, lr_table, beta1, beta2,
-                               epsilon, defer, lin_stride, mi::step_state(), keep_stamps)));
+                               epsilon, defer, lin_stride, mi::step_state(), keep_stamps, ts)));
     }
   } else {
     MI_DISPATCH_LPR(lpr, (sparse_catchup_k<L><<<dim3((unsigned)blocks), dim3(kBlock), 0, mi::as_stream(stream)>>>(
                              table, t_m, t_v, last_step, uniq_rows, num_uniq, n_max, E, step_to, lr_table, beta1, beta2,
-                             epsilon, defer, lin_stride, mi::step_state(), keep_stamps)));
+                             epsilon, defer, lin_stride, mi::step_state(), keep_stamps, ts)));
   }
   MI_CHECK_LAUNCH("sparse_catchup");
   return MI_OK;

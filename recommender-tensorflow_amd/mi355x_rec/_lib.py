@@ -66,8 +66,8 @@ SIGNATURES = {
     "mi_hash_bucket_i64": (_i32, [_p, _i64, _i64, _p]),
     "mi_hash_bucket_bytes": (_i32, [_p, _p, _i64, _i64, _p]),
     "mi_bucketize_f32": (_i32, [_p, _i64, _p, _i32, _p]),
-    "mi_embed_fm_linear_fwd": (_i32, [_p, _p, _p, _p, _i64, _i32, _i32, _p, _i64, _p, _p, _p, _p, _i32, _p]),
-    "mi_gather_rows": (_i32, [_p, _p, _p, _i64, _i32, _p, _p, _i32, _p]),
+    "mi_embed_fm_linear_fwd": (_i32, [_p, _p, _p, _p, _i64, _i32, _i32, _p, _i64, _p, _p, _p, _p, _i32, _i64, _p]),
+    "mi_gather_rows": (_i32, [_p, _p, _p, _i64, _i32, _p, _p, _i32, _i64, _p]),
     "mi_numeric_embed_fwd": (_i32, [_p, _p, _p, _i64, _i32, _i32, _p, _i64, _i64, _p, _p, _p, _p]),
     "mi_numeric_raw_fwd": (_i32, [_p, _p, _i64, _i32, _p, _i64, _i64, _i32, _p, _p]),
     "mi_numeric_raw_bwd_workspace_bytes": (_sz, [_i64, _i32]),
@@ -89,17 +89,17 @@ SIGNATURES = {
     "mi_gather_u32": (_i32, [_p, _p, _i64, _p, _p]),
     "mi_dense_apply": (_i32, [_p, _p, _p, _p, _i64, C.POINTER(OptHparams), _p]),
     "mi_sparse_apply": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _p, _i32, _i32,
-                               C.POINTER(OptHparams), _i32, _p]),
+                               C.POINTER(OptHparams), _i32, _i64, _p]),
     "mi_sparse_apply_fused": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _i64, _p, _p, _p, _i32,
-                                     _i32, _i32, C.POINTER(OptHparams), _i32, _p]),
-    "mi_dense_fwd_gathered": (_i32, [_p, _p, _p, _i32, _i32, _p, _p, _p, _i64, _i64, _i32, _i32, _f32, _u64, _amax, _p]),
-    "mi_dense_bwd_weight_gathered": (_i32, [_p, _p, _p, _i32, _i32, _p, _i64, _p, _p, _i64, _i32, _p, _sz, _amax, _p]),
+                                     _i32, _i32, C.POINTER(OptHparams), _i32, _i64, _p]),
+    "mi_dense_fwd_gathered": (_i32, [_p, _p, _p, _i32, _i32, _p, _p, _p, _i64, _i64, _i32, _i32, _f32, _u64, _amax, _i64, _p]),
+    "mi_dense_bwd_weight_gathered": (_i32, [_p, _p, _p, _i32, _i32, _p, _i64, _p, _p, _i64, _i32, _p, _sz, _amax, _i64, _p]),
     "mi_selftest_sqrt": (_i32, [_u32, _i64, _p, _p]),
     "mi_selftest_div": (_i32, [_f32, _u32, _i64, _p, _p]),
     "mi_catchup_gap_keys": (_i32, [_p, _p, _p, _i64, _i32, _p, _i32, _p]),
     "mi_catchup_rows_by_gap": (_i32, [_p, _p, _p, _i64, _i32, _i32, _p, _p, _sz, _p]),
     "mi_sparse_catchup": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p, _f32, _f32,
-                                 _f32, _i32, _i32, _p]),
+                                 _f32, _i32, _i32, _i64, _p]),
     "mi_set_gemm_mode": (_i32, [_i32]),
     "mi_absmax": (_i32, [_p, _i64, _p, _p]),
     "mi_get_gemm_mode": (_i32, []),
@@ -115,8 +115,8 @@ SIGNATURES = {
     "mi_split_weights": (_i32, [_p, _p, _i32, _p, _p]),
     "mi_merge_rows": (_i32, [_pl, _i64, _i32, _p, _i64, _p]),
     "mi_dense_fwd_planes": (_i32, [_pl, _pl, _p, _p, _i64, _pl, _i64, _i32, _i32, _i32, _f32, _u64, _p, _p, _i64, _p]),
-    "mi_dense_bwd_data_planes": (_i32, [_pl, _pl, _pl, _p, _i64, _pl, _i64, _i32, _i32, _f32, _p, _p, _p, _i32, _p, _i64, _p]),
-    "mi_embed_fm_planes_fwd": (_i32, [_p, _p, _p, _i64, _i32, _i32, _p, _p, _pl, _p, _p, _i32, _i32, _p]),
+    "mi_dense_bwd_data_planes": (_i32, [_pl, _pl, _pl, _p, _i64, _pl, _i64, _i32, _i32, _f32, _p, _p, _i64, _p]),
+    "mi_embed_fm_planes_fwd": (_i32, [_p, _p, _p, _i64, _i32, _i32, _p, _p, _pl, _p, _p, _i32, _i32, _i64, _p]),
     "mi_head_workspace_bytes": (_sz, [_i64]),
     "mi_sigmoid_ce_head": (_i32, [_p, _p, _p, _p, _p, _i64, _f32, _p, _p, _p, _p, _p, _sz, _p]),
     "mi_colsum_workspace_bytes": (_sz, [_i64, _i32]),

@@ -8,12 +8,13 @@ optimizer apply.  No autograd, no torch math on the data path: torch allocates b
 (for N > 1 GPUs, ``parallel.py``) runs the RCCL collectives.
 
 Variable layout in HBM
-  table   [R, E] f32   all embedding tables stacked row-major; field f owns rows
-                       [field_off[f], field_off[f+1])  (fields in sorted column-name order,
-                       SURVEY A.2) -- one coalesced 4E-byte read per (example, field)
+  t_rec   [R, 3E] f32  one record [w | slot0 | slot1] per embedding row (fewer slots: narrower), all tables stacked;
+                       field f owns rows [field_off[f], field_off[f+1])  (fields in sorted column-name order,
+                       SURVEY A.2).  table, t_s0, t_s1 are strided [R, E] views; kernels take the record stride ts
+  table   [R, E] view  the weights: one coalesced 4E-byte read per (example, field)
   lin_state [R, 4] f32 the wide part's per-row record {weight, slot0, slot1, Adam stamp}: lin_w, l_s0, l_s1 and
                        last_step are strided views of it (one memory sector per row)
-  t_s0/t_s1            optimizer slots shaped like table
+  t_s0/t_s1            optimizer slots: views of t_rec shaped like table
   last_step [R]  i32   Adam only: step at which a row was last brought up to date (a view of lin_state, or a
                        plain array when there is no wide part)
   dense   [P]    f32   every dense variable back to back (16-float aligned segments): first TF's
@@ -292,9 +293,29 @@ class DeepFM:
             self.wide_max_vocab = max([self.vocab_sizes[f] for f in wi] or [1])
 
         f32 = dict(dtype=torch.float32, device=dev)
-        self.table = torch.zeros(self.R_local, self.E, **f32) if (self.use_emb and self.F) else None
+        # A table row and its optimizer slots are ONE record [w | slot0 | slot1] of (1 + slots) * E floats: table, t_s0 and
+        # t_s1 are strided views of it and every kernel that walks rows takes the record stride self.ts (include/
+        # mi355x_rec.h: table_stride).  The sparse apply and the catch-up, which read and write a row's whole state, then
+        # visit one contiguous 12 E-byte run per row and direction instead of three 4 E-byte runs in three arrays.
         sparse_lin_opt = self.lin_opt or self.opt
-        self.t_s0, self.t_s1 = self._slots(self.table, self.opt)
+        self.table = self.t_s0 = self.t_s1 = self.t_rec = None
+        self.ts = self.E
+        if self.use_emb and self.F:
+            a, b = self.opt.slot_init
+            nsl = (a is not None) + (b is not None)
+            if self.ROW_RECORDS:
+                self.ts = (1 + nsl) * self.E
+                self.t_rec = torch.zeros(self.R_local, self.ts, **f32)
+                self.table = self.t_rec[:, :self.E]
+                if a is not None:
+                    self.t_s0 = self.t_rec[:, self.E:2 * self.E]
+                    self.t_s0.fill_(a)
+                if b is not None:
+                    self.t_s1 = self.t_rec[:, 2 * self.E:3 * self.E]
+                    self.t_s1.fill_(b)
+            else:                                            # (A/B runs: three [R, E] arrays, the layout of rounds 1-3)
+                self.table = torch.zeros(self.R_local, self.E, **f32)
+                self.t_s0, self.t_s1 = self._slots(self.table, self.opt)
         t_adam = self.opt.name == "Adam" and self.table is not None
         l_adam = sparse_lin_opt.name == "Adam" and self.use_linear and self.F > 0
         self.adam_rows = t_adam or l_adam
@@ -703,6 +724,7 @@ class DeepFM:
         c = {"B": B}
         table, lin_w, field_off, rid = src if src is not None else (self.table, self.lin_w, self.field_off, ids)
         ls = self.ls if src is None else 1              # (rows received from their owners: plain arrays)
+        tst = self.ts if src is None else self.E         # ... E floats apart; the model's own rows: one record apart
         # the wide part's view of the batch: all columns, or (wide_fields) the wide columns' ids and field offsets
         w_off, w_ids, Fw = field_off, rid, self.F
         if self.wide_idx is not None:
@@ -742,15 +764,15 @@ class DeepFM:
                     t.zero_()
         elif side_lin:
             if pl_gather:
-                k.mi_embed_fm_planes_fwd(table, field_off, rid, B, F, self.E, sumv, fm, self._planes("x0p", B, ld), rows_amax, *tail)
+                k.mi_embed_fm_planes_fwd(table, field_off, rid, B, F, self.E, sumv, fm, self._planes("x0p", B, ld), rows_amax, *tail, tst)
             elif concat is not None or sumv is not None or rows_amax is not None:
                 k.mi_embed_fm_linear_fwd(table, None, field_off, rid, B, F, self.E, concat, ld, sumv, fm, None,
-                                         rows_amax, 1)
+                                         rows_amax, 1, tst)
             side = self._side_stream()
             side.wait_stream(torch.cuda.current_stream())        # (w_ids; the wide part's own catch-up is on this stream already)
             with torch.cuda.stream(side):
                 k.tagged("mi_embed_fm_linear_fwd", "/wide")(None, lin_w, w_off, w_ids, B, Fw, self.E, None, 0, None,
-                                                            None, lin, None, ls)
+                                                            None, lin, None, ls, 0)
             c["lin_join"] = side
         elif pl_gather:
             x0p = self._planes("x0p", B, ld)
@@ -762,10 +784,10 @@ class DeepFM:
                 xp_ = x0p if (b0 == 0 and b1 == B) else _lib.Planes(x0p.data + 64 * b0, x0p.row_exp + 4 * b0, x0p.blk_stride)
                 k.mi_embed_fm_planes_fwd(table, field_off, rid[sl], b1 - b0, F, self.E, None if sumv is None else sumv[sl],
                                          None if fm is None else fm[sl], xp_, rows_amax,
-                                         None if tail[0] is None else tail[0][sl], tail[1], tail[2])
+                                         None if tail[0] is None else tail[0][sl], tail[1], tail[2], tst)
                 if lin is not None:
                     k.tagged("mi_embed_fm_linear_fwd", "/wide")(None, lin_w, w_off, w_ids[sl], b1 - b0, Fw, self.E, None, 0, None, None,
-                                                                lin[sl], None, ls)
+                                                                lin[sl], None, ls, 0)
         elif concat is not None or sumv is not None or lin is not None or rows_amax is not None:
             emb_on = self.use_emb
             one_call = self.wide_idx is None                         # (a wide part on other columns: a call of its own)
@@ -777,10 +799,10 @@ class DeepFM:
                 if emb_on or one_call:
                     k.mi_embed_fm_linear_fwd(table if emb_on else None, lin_w if (self.use_linear and one_call) else None, field_off,
                                              rid[sl], b1 - b0, F, self.E, v(concat) if emb_on else None, ld, v(sumv), v(fm),
-                                             v(lin) if one_call else None, rows_amax, ls)
+                                             v(lin) if one_call else None, rows_amax, ls, tst if emb_on else 0)
                 if not one_call and lin is not None:
                     if Fw:
-                        k.mi_embed_fm_linear_fwd(None, lin_w, w_off, w_ids[sl], b1 - b0, Fw, self.E, None, 0, None, None, lin[sl], None, ls)
+                        k.mi_embed_fm_linear_fwd(None, lin_w, w_off, w_ids[sl], b1 - b0, Fw, self.E, None, 0, None, None, lin[sl], None, ls, 0)
                     else:
                         lin[sl].zero_()
         elif pieces:
@@ -840,7 +862,7 @@ class DeepFM:
                 elif i == 0 and gathered:
                     k.mi_dense_fwd_gathered(table, field_off, rid, F, self.E, self.kernel(0), self.bias(0), y, h,
                                             B, h, 0 if last else self.act, 1.0 if last else keep, self._layer_seed(0),
-                                            self._ga("x0", "w", "x1"))
+                                            self._ga("x0", "w", "x1"), tst)
                 else:
                     k.mi_dense_fwd(x, ldx, self.kernel(i), self.bias(i), y, h, B, h, fan, 0 if last else self.act,
                                    1.0 if last else keep, self._layer_seed(i),
@@ -850,7 +872,7 @@ class DeepFM:
             dnn = acts[-1].view(B)
             c["keep"] = keep
         c.update(concat=concat, sumv=sumv, fm=fm, lin=lin, dnn=dnn, acts=acts, x_num=x_num, ids=rid,
-                 gathered=gathered, g_table=table, g_off=field_off)
+                 gathered=gathered, g_table=table, g_off=field_off, g_ts=tst)
         return c
 
     def _head(self, c, labels, want_grad, global_batch=None):
@@ -912,12 +934,11 @@ class DeepFM:
 
     GAP_SORT_MIN = 16384      # entries from which sorting the touched rows by staleness pays for itself
     # Scheduling choices of the single-GPU step, as class attributes (no environment switches in the product; bench.py
-    # --engine-opt NAME=0/1 flips one for an A/B run; every combination gives the same bits but FOLD_FM, which moves one
-    # addition — tests/test_hip_model.py runs both):
+    # --engine-opt NAME=0/1 flips one for an A/B run; every combination gives the same bits):
     WSPLIT_AHEAD = True       # weight planes of the step made on a side stream at its head (_split_weights_ahead)
     LIN_SIDE = True           # the wide part's catch-up on the wide part's stream, beside the row kernel (_catchup)
     BYGAP_AHEAD = True        # the next batch's staleness order made a step ahead (_by_gap_ahead)
-    FOLD_FM = False           # layer-1 data gradient adds dlogit * sumv to d_concat once per example (_backward_dense)
+    ROW_RECORDS = True        # a table row and its optimizer slots as one [w | slot0 | slot1] record (__init__)
 
     def _catchup(self, uniq, num_uniq, n_max, defer=False, by_gap=None):
         """defer: the rows are about to be applied in this same step by ONE mi_sparse_apply call, which
@@ -960,7 +981,7 @@ class DeepFM:
                 self.t_s1 if ts is not None else None, self.lin_w if lsch is not None else None,
                 self.l_s0 if lsch is not None else None, self.l_s1 if lsch is not None else None,
                 self.last_step, uniq, num_uniq, n_max, self.E, self.step, (ts or lsch).table, s.beta1, s.beta2,
-                s.epsilon, flags | extra, self.ls)
+                s.epsilon, flags | extra, self.ls, self.ts)
             if side is not None and i == 0:
                 with torch.cuda.stream(side):
                     call()
@@ -1121,12 +1142,10 @@ class DeepFM:
         logits, loss, dlogit = self._head(c, labels, True)
         self._by_gap_ahead()
         # (4) backward through the MLP (+ numeric embeddings)
-        d_concat = self._backward_dense(c, dlogit, fold_fm=True)
+        d_concat = self._backward_dense(c, dlogit)
         # (5) sparse apply on the unique rows; the per-entry row gradients (deep_fm.py:54,81-87,39
-        #     backward) are rebuilt inside the kernel from d_concat / sumv / dlogit (sumv = None: the data
-        #     gradient's epilogue already added dlogit * sumv to d_concat)
-        self._apply(uniq, seg, sorted_entry, num_uniq, n, None, None,
-                    fused=(d_concat, None if c.get("fm_folded") else c["sumv"], dlogit))
+        #     backward) are rebuilt inside the kernel from d_concat / sumv / dlogit
+        self._apply(uniq, seg, sorted_entry, num_uniq, n, None, None, fused=(d_concat, c["sumv"], dlogit))
         return loss, logits
 
     def _entry_grads(self, c, d_concat, dlogit, pos, d_rows=None, d_lin=None):
@@ -1152,15 +1171,11 @@ class DeepFM:
         _, _, fan, h = self.layers[i]
         return B % 32 == 0 and fan % 128 == 0 and h % 128 == 0 and hasattr(self.k, "mi_dense_bwd_weight_planes")
 
-    def _backward_dense(self, c, dlogit, fold_fm=False, on_d_concat=None):
+    def _backward_dense(self, c, dlogit, on_d_concat=None):
         """Fills self.d_grad (dense gradients) and returns d_concat [B, D] (or None).
         on_d_concat (the row-sharded step): called with d_concat as soon as the input layer's DATA gradient is enqueued —
         which then runs BEFORE that layer's weight gradient (both need only dY of layer 1): the requester-side segment sums
-        and the gradient exchange start there and travel under the largest weight-gradient GEMM and the dense all-reduce.
-        fold_fm: the layer-1 data gradient may add the FM term's dlogit * sumv to d_concat (once per example
-        instead of once per entry in the fused sparse apply); c["fm_folded"] tells whether it did.  Taken only
-        with DeepFM.FOLD_FM: it removes the apply's per-entry sumv reads (0.44 GB of 3.7 GB at config 3) but those
-        come from L2 / Infinity Cache, and the data gradient's epilogue pays as much as the apply saves (DESIGN)."""
+        and the gradient exchange start there and travel under the largest weight-gradient GEMM and the dense all-reduce."""
         k = self.k
         B = c["B"]
         d_concat = None
@@ -1188,7 +1203,7 @@ class DeepFM:
                     elif i == 0 and c["gathered"]:
                         k.mi_dense_bwd_weight_gathered(c["g_table"], c["g_off"], c["ids"], self.F, self.E, dy, lddy,
                                                        self.kernel(0, self.d_grad), self.bias(0, self.d_grad), B, h, ws,
-                                                       ws.numel(), ga_w)
+                                                       ws.numel(), ga_w, c["g_ts"])
                     else:
                         if x is None:     # (pl_numeric, a batch the planes weight gradient does not take: the concat back in fp32)
                             x = self._buf("concat", (B, ldx))
@@ -1214,14 +1229,10 @@ class DeepFM:
                         k.mi_split_rows(x, ldx, B, fan, 0, xa, None)
                     # (the fp32 copy only where something reads it: d_concat, or a weight gradient on fp32 operands)
                     need_f = i == 0 or not (direct and self._wgrad_planes_ok(B, i - 1))
-                    fold = (fold_fm and i == 0 and self.use_mf and self.n_numeric == 0 and fan == self.F * self.E
-                            and c["sumv"] is not None and self.FOLD_FM)
-                    c["fm_folded"] = c.get("fm_folded", False) or fold
                     k.mi_dense_bwd_data_planes(self._planes("dy%dp" % i, B, h), self._pl["w%d" % i].struct, xa,
                                                dx if need_f else None, fan,
                                                dxp if direct else None, B, h, fan, keep if i else 1.0,
                                                self._av("dy%d" % (i - 1)) if i else None,
-                                               c["sumv"] if fold else None, dlogit if fold else None, self.E if fold else 0,
                                                mb, 0 if mb is None else mb.shape[1])
                     if need_p and not direct:
                         k.mi_split_rows(dx, fan, B, fan, 0, dxp, None)
@@ -1293,11 +1304,11 @@ class DeepFM:
                                             d_concat if tb is not None else None, self.D,
                                             sumv if (tb is not None and self.use_mf) else None,
                                             dlogit if (tb is not None and self.use_mf) else None,
-                                            dlogit if lw is not None else None, self.F, self.E, step, h, self.ls)
+                                            dlogit if lw is not None else None, self.F, self.E, step, h, self.ls, self.ts)
                 else:
                     k.mi_sparse_apply(*slots, self.last_step, uniq, seg, sorted_entry, num_uniq, n_max,
                                       d_rows if tb is not None else None, d_lin if lw is not None else None, self.E,
-                                      step, h, self.ls)
+                                      step, h, self.ls, self.ts)
         self.step = step
 
     # ------------------------------------------------------------------ replayable step (hipGraph)

@@ -390,7 +390,7 @@ def _sharded_step(m, ids, labels, x_num, train, next_ids=None):
     def gather(ids_, n_, rows_out, lin_out):
         if n_ > 0:
             k.mi_gather_rows(m.table if m.use_emb else None, m.lin_w if m.use_linear else None, ids_, n_, E,
-                             rows_out if m.use_emb else None, lin_out if m.use_linear else None, m.ls)
+                             rows_out if m.use_emb else None, lin_out if m.use_linear else None, m.ls, m.ts)
 
     def serve(c):
         """owners gather chunk c's rows and send them back (their own requests: straight into the receive buffer);

@@ -99,7 +99,7 @@ class NumpyKernels:
         _np(num_uniq)[0] = U
 
     # ---- embedding side ------------------------------------------------------------------
-    def mi_embed_fm_linear_fwd(self, table, lin_w, field_off, ids, B, F, E, concat, ld, sumv, fm, lin, amax=None, ls=1):
+    def mi_embed_fm_linear_fwd(self, table, lin_w, field_off, ids, B, F, E, concat, ld, sumv, fm, lin, amax=None, ls=1, ts=0):
         rows = _np(ids).astype(np.int64) + _np(field_off)[None, :]
         if table is not None:
             v = _np(table)[rows]                               # [B,F,E]
@@ -113,7 +113,7 @@ class NumpyKernels:
         if lin is not None:
             _np(lin)[:] = _np(lin_w)[rows].sum(1)
 
-    def mi_gather_rows(self, table, lin_w, rows, n, E, out_rows, out_lin, ls=1):
+    def mi_gather_rows(self, table, lin_w, rows, n, E, out_rows, out_lin, ls=1, ts=0):
         r = _np(rows)[:n]
         if table is not None:
             _np(out_rows)[:n] = _np(table)[r]
@@ -244,7 +244,7 @@ class NumpyKernels:
         _np(rows_out)[:n_max] = _np(uniq)[:n_max][np.argsort(_np(keys), kind="stable")]
 
     def mi_sparse_catchup(self, table, tm, tv, lin_w, lm, lv, last_step, uniq, num_uniq, n_max, E, step_to, lr_table,
-                          b1, b2, eps, flags=0, ls=1):
+                          b1, b2, eps, flags=0, ls=1, ts=0):
         defer = bool(flags & 1) and uniq is not None          # (flag 2, the bounded-error replay: the exact sweep stands in)
         rows = np.arange(n_max) if uniq is None else _np(uniq)[:int(_np(num_uniq)[0])]
         ls = _np(last_step)
@@ -269,7 +269,7 @@ class NumpyKernels:
                 ls[r] = step_to
 
     def mi_sparse_apply(self, table, t0, t1, lin_w, l0, l1, last_step, uniq, seg, sorted_entry, num_uniq, n_max,
-                        d_rows, d_lin, E, step, hp, ls=1):
+                        d_rows, d_lin, E, step, hp, ls=1, ts=0):
         h = _hyper(hp)
         U = int(_np(num_uniq)[0])
         rows = _np(uniq)[:U].astype(np.int64)
@@ -314,16 +314,16 @@ class NumpyKernels:
         rows = _np(ids).astype(np.int64) + _np(field_off)[None, :]
         return _np(table)[rows].reshape(len(rows), F * E)
 
-    def mi_dense_fwd_gathered(self, table, field_off, ids, F, E, W, bias, Y, ldy, M, N, relu, keep, seed, amax=None):
+    def mi_dense_fwd_gathered(self, table, field_off, ids, F, E, W, bias, Y, ldy, M, N, relu, keep, seed, amax=None, ts=0):
         X = torch.from_numpy(self._concat(table, field_off, ids, F, E))
         self.mi_dense_fwd(X, F * E, W, bias, Y, ldy, M, N, F * E, relu, keep, seed)
 
-    def mi_dense_bwd_weight_gathered(self, table, field_off, ids, F, E, dY, lddy, dW, db, M, N, ws, wsb, amax=None):
+    def mi_dense_bwd_weight_gathered(self, table, field_off, ids, F, E, dY, lddy, dW, db, M, N, ws, wsb, amax=None, ts=0):
         X = torch.from_numpy(self._concat(table, field_off, ids, F, E))
         self.mi_dense_bwd_weight(X, F * E, dY, lddy, dW, db, M, N, F * E, ws, wsb)
 
     def mi_sparse_apply_fused(self, table, t0, t1, lin_w, l0, l1, last_step, uniq, seg, sorted_entry, num_uniq,
-                              n_max, d_concat, ldd, sumv, dlf, dll, F, E, step, hp, ls=1):
+                              n_max, d_concat, ldd, sumv, dlf, dll, F, E, step, hp, ls=1, ts=0):
         n = int(_np(seg)[int(_np(num_uniq)[0])])
         e = np.arange(n)
         b, f = e // F, e % F

@@ -59,7 +59,7 @@ def test_embed_fm_linear_fwd(lib, E, B, F):
     fm = torch.empty(B, device="cuda")
     lin = torch.empty(B, device="cuda")
     _chk(lib.mi_embed_fm_linear_fwd(_p(t), _p(lw), _p(fo), _p(di), B, F, E, _p(concat), ld, _p(sumv), _p(fm),
-                                    _p(lin), None, 1, _st()))
+                                    _p(lin), None, 1, 0, _st()))
     rows = off[:-1][None, :] + ids
     ref = table[rows]                                  # [B,F,E]
     got = concat.cpu().numpy()
@@ -86,7 +86,7 @@ def test_embed_fwd_linear_only_and_gather_rows(lib):
     ids = np.stack([rng.integers(0, v, B) for v in vocab], 1).astype(np.int32)
     lw, fo, di = dev(lin_w), dev(off[:-1].copy()), dev(ids)
     lin = torch.empty(B, device="cuda")
-    _chk(lib.mi_embed_fm_linear_fwd(None, _p(lw), _p(fo), _p(di), B, F, E, None, 0, None, None, _p(lin), None, 1, _st()))
+    _chk(lib.mi_embed_fm_linear_fwd(None, _p(lw), _p(fo), _p(di), B, F, E, None, 0, None, None, _p(lin), None, 1, 0, _st()))
     rows = (off[:-1][None, :] + ids)
     ref = np.zeros(B, np.float32)
     for f in range(F):
@@ -99,7 +99,7 @@ def test_embed_fwd_linear_only_and_gather_rows(lib):
     out = torch.empty(B * F, E, device="cuda")
     olin = torch.empty(B * F, device="cuda")
     t = dev(table)
-    _chk(lib.mi_gather_rows(_p(t), _p(lw), _p(grow), B * F, E, _p(out), _p(olin), 1, _st()))
+    _chk(lib.mi_gather_rows(_p(t), _p(lw), _p(grow), B * F, E, _p(out), _p(olin), 1, 0, _st()))
     assert np.array_equal(out.cpu().numpy(), table[rows.reshape(-1)])
     assert np.array_equal(olin.cpu().numpy(), lin_w[rows.reshape(-1)])
 
@@ -218,17 +218,17 @@ def test_gathered_layer1_matches_materialised_bitwise(lib, B, F, E, N):
     dY = rng.standard_normal((B, N)).astype(np.float32)
     t, fo, di, w, bb, dy = dev(table), dev(off[:-1].copy()), dev(ids), dev(W), dev(b), dev(dY)
     concat = torch.empty(B, K, device="cuda")
-    _chk(lib.mi_embed_fm_linear_fwd(_p(t), None, _p(fo), _p(di), B, F, E, _p(concat), K, None, None, None, None, 1, _st()))
+    _chk(lib.mi_embed_fm_linear_fwd(_p(t), None, _p(fo), _p(di), B, F, E, _p(concat), K, None, None, None, None, 1, 0, _st()))
     Y0 = torch.empty(B, N, device="cuda"); Y1 = torch.empty(B, N, device="cuda")
     _chk(lib.mi_dense_fwd(_p(concat), K, _p(w), _p(bb), _p(Y0), N, B, N, K, 1, 0.9, 77, None, _st()))
-    _chk(lib.mi_dense_fwd_gathered(_p(t), _p(fo), _p(di), F, E, _p(w), _p(bb), _p(Y1), N, B, N, 1, 0.9, 77, None, _st()))
+    _chk(lib.mi_dense_fwd_gathered(_p(t), _p(fo), _p(di), F, E, _p(w), _p(bb), _p(Y1), N, B, N, 1, 0.9, 77, None, 0, _st()))
     assert torch.equal(Y0, Y1)
     ws = torch.empty(lib.mi_dense_bwd_weight_workspace_bytes(B, N, K) + 256, dtype=torch.uint8, device="cuda")
     dW0 = torch.empty(K, N, device="cuda"); dW1 = torch.empty(K, N, device="cuda")
     db0 = torch.empty(N, device="cuda"); db1 = torch.empty(N, device="cuda")
     _chk(lib.mi_dense_bwd_weight(_p(concat), K, _p(dy), N, _p(dW0), _p(db0), B, N, K, _p(ws), ws.numel(), None, _st()))
     _chk(lib.mi_dense_bwd_weight_gathered(_p(t), _p(fo), _p(di), F, E, _p(dy), N, _p(dW1), _p(db1), B, N, _p(ws),
-                                          ws.numel(), None, _st()))
+                                          ws.numel(), None, 0, _st()))
     assert torch.equal(dW0, dW1) and torch.equal(db0, db1)
     ref = table[off[:-1][None, :] + ids].reshape(B, K).astype(np.float64).T @ dY.astype(np.float64)
     assert np.max(np.abs(dW1.cpu().numpy() - ref)) / (np.sqrt(np.mean(ref * ref)) + 1e-30) < TOL
@@ -376,13 +376,13 @@ def test_f16x2_gathered_layer1_matches_materialised_bitwise(lib, B, F, E, N):
     from mi355x_rec import _lib as L
     concat = torch.empty(B, K, device="cuda")
     arows = torch.zeros(L.AMAX_SLOTS, device="cuda")
-    _chk(lib.mi_embed_fm_linear_fwd(_p(t), None, _p(fo), _p(di), B, F, E, _p(concat), K, None, None, None, _p(arows), 1, _st()))
+    _chk(lib.mi_embed_fm_linear_fwd(_p(t), None, _p(fo), _p(di), B, F, E, _p(concat), K, None, None, None, _p(arows), 1, 0, _st()))
     assert float(arows.max()) == float(concat.abs().max())
     aw, ady = _amax_vec(lib, w), _amax_vec(lib, dy)
     Y0 = torch.empty(B, N, device="cuda"); Y1 = torch.empty(B, N, device="cuda")
     _chk(lib.mi_dense_fwd(_p(concat), K, _p(w), _p(bb), _p(Y0), N, B, N, K, 1, 0.9, 77, _ga(arows, aw), _st()))
     _chk(lib.mi_dense_fwd_gathered(_p(t), _p(fo), _p(di), F, E, _p(w), _p(bb), _p(Y1), N, B, N, 1, 0.9, 77,
-                                   _ga(arows, aw), _st()))
+                                   _ga(arows, aw), 0, _st()))
     assert torch.equal(Y0, Y1)
     pre = concat.cpu().numpy().astype(np.float64) @ W.astype(np.float64) + b
     ref = np.maximum(pre, 0) / np.float64(np.float32(0.9)) * dropout_mask(77, B, N, 0.9)
@@ -393,7 +393,7 @@ def test_f16x2_gathered_layer1_matches_materialised_bitwise(lib, B, F, E, N):
     _chk(lib.mi_dense_bwd_weight(_p(concat), K, _p(dy), N, _p(dW0), _p(db0), B, N, K, _p(ws), ws.numel(),
                                  _ga(arows, ady), _st()))
     _chk(lib.mi_dense_bwd_weight_gathered(_p(t), _p(fo), _p(di), F, E, _p(dy), N, _p(dW1), _p(db1), B, N, _p(ws),
-                                          ws.numel(), _ga(arows, ady), _st()))
+                                          ws.numel(), _ga(arows, ady), 0, _st()))
     assert torch.equal(dW0, dW1) and torch.equal(db0, db1)
     ref = concat.cpu().numpy().astype(np.float64).T @ dY.astype(np.float64)
     assert np.max(np.abs(dW1.cpu().numpy() - ref)) / (np.sqrt(np.mean(ref * ref)) + 1e-30) < TOL
@@ -434,13 +434,13 @@ def test_sparse_apply_fused_equals_bwd_then_apply_bitwise(lib, name):
         if fused:
             _chk(lib.mi_sparse_apply_fused(_p(T), _p(t0), _p(t1), _p(L), _p(l0), _p(l1), None, _p(uq), _p(sg), _p(se),
                                            _p(nu), n, _p(d_dc), F * E, _p(d_sv), _p(d_dl), _p(d_dl), F, E, 1,
-                                           C.byref(h), 1, _st()))
+                                           C.byref(h), 1, 0, _st()))
         else:
             d_rows = torch.empty(n, E, device="cuda"); d_lin = torch.empty(n, device="cuda")
             _chk(lib.mi_embed_fm_linear_bwd(_p(d_dc), F * E, _p(d_cc), F * E, None, _p(d_sv), _p(d_dl), _p(d_dl), None, B, F,
                                             E, _p(d_rows), _p(d_lin), _st()))
             _chk(lib.mi_sparse_apply(_p(T), _p(t0), _p(t1), _p(L), _p(l0), _p(l1), None, _p(uq), _p(sg), _p(se),
-                                     _p(nu), n, _p(d_rows), _p(d_lin), E, 1, C.byref(h), 1, _st()))
+                                     _p(nu), n, _p(d_rows), _p(d_lin), E, 1, C.byref(h), 1, 0, _st()))
         torch.cuda.synchronize()
         res.append((T.cpu(), L.cpu(), t0.cpu(), t1.cpu()))
     for x, y in zip(*res):
@@ -475,7 +475,7 @@ def test_sparse_apply_long_segments(lib, E):
     for _ in range(2):
         T, L = dev(table), dev(lin_w)
         _chk(lib.mi_sparse_apply(_p(T), None, None, _p(L), None, None, None, _p(uq), _p(sg), _p(se), _p(nu), n, _p(dr),
-                                 _p(dli), E, 1, C.byref(h), 1, _st()))
+                                 _p(dli), E, 1, C.byref(h), 1, 0, _st()))
         torch.cuda.synchronize()
         outs.append((T.cpu().numpy(), L.cpu().numpy()))
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
@@ -576,7 +576,7 @@ def test_catchup_exact_at_range_edges(lib):
                 elw[r] = elw[r] - (lr[s] * elm[r]) / (np.sqrt(elv[r]) + eps)
     dW, dM, dV, dL, dLm, dLv, dlast, dlr = dev(w), dev(m), dev(v), dev(lw), dev(lmm), dev(lvv), dev(last), dev(lr)
     _chk(lib.mi_sparse_catchup(_p(dW), _p(dM), _p(dV), _p(dL), _p(dLm), _p(dLv), _p(dlast), None, None, R, E, step_to,
-                               _p(dlr), float(b1), float(b2), float(eps), 0, 1, _st()))
+                               _p(dlr), float(b1), float(b2), float(eps), 0, 1, 0, _st()))
     torch.cuda.synchronize()
     for got, exp in ((dW, ew), (dM, em), (dV, ev), (dL, elw), (dLm, elm), (dLv, elv)):
         assert np.array_equal(got.cpu().numpy().view(np.uint32), exp.view(np.uint32))
@@ -639,7 +639,7 @@ def test_bounded_catchup_stays_within_its_bound_of_the_sweep(lib):
     # (a) all rows, slots written (the form that runs before an evaluation / a checkpoint)
     dW, dM, dV, dL, dLm, dLv, dlast, dlr = dev(w), dev(m), dev(v), dev(lw), dev(lmm), dev(lvv), dev(last), dev(lr)
     _chk(lib.mi_sparse_catchup(_p(dW), _p(dM), _p(dV), _p(dL), _p(dLm), _p(dLv), _p(dlast), None, None, R, E, step_to,
-                               _p(dlr), float(b1), float(b2), float(eps), 2, 1, _st()))
+                               _p(dlr), float(b1), float(b2), float(eps), 2, 1, 0, _st()))
     torch.cuda.synchronize()
     check_w(dW.cpu().numpy(), ew, moved, "rows")
     check_w(dL.cpu().numpy(), elw, lmoved, "wide part")
@@ -651,7 +651,7 @@ def test_bounded_catchup_stays_within_its_bound_of_the_sweep(lib):
     dW, dM, dV, dL, dLm, dLv, dlast = dev(w), dev(m), dev(v), dev(lw), dev(lmm), dev(lvv), dev(last)
     duq, dnu = dev(np.concatenate([uq, np.zeros(96, np.int32)])), dev(np.array([3000], np.int32))
     _chk(lib.mi_sparse_catchup(_p(dW), _p(dM), _p(dV), _p(dL), _p(dLm), _p(dLv), _p(dlast), _p(duq), _p(dnu), 3096, E, step_to,
-                               _p(dlr), float(b1), float(b2), float(eps), 3, 1, _st()))
+                               _p(dlr), float(b1), float(b2), float(eps), 3, 1, 0, _st()))
     torch.cuda.synchronize()
     sel = np.zeros(R, bool); sel[uq] = True
     gw, gl = dW.cpu().numpy(), dL.cpu().numpy()
@@ -663,7 +663,7 @@ def test_bounded_catchup_stays_within_its_bound_of_the_sweep(lib):
     # (c) the flag is ignored where the bounded form has no meaning (eps too small to keep sqrt(v) + eps normal): the
     # exact form runs, and an unknown flag is refused
     assert lib.mi_sparse_catchup(_p(dW), _p(dM), _p(dV), None, None, None, _p(dlast), None, None, R, E, step_to, _p(dlr),
-                                 float(b1), float(b2), float(eps), 8, 1, _st()) != 0
+                                 float(b1), float(b2), float(eps), 8, 1, 0, _st()) != 0
 
 
 @pytest.mark.parametrize("B", [1, 37, 5000])
@@ -915,12 +915,15 @@ def test_dense_apply_bit_exact(lib, name):
         assert np.array_equal(d0.cpu().numpy(), s0)
 
 
+@pytest.mark.parametrize("layout", ["arrays", "records"])
 @pytest.mark.parametrize("name", OO.NAMES)
 @pytest.mark.parametrize("E", [4, 64])
-def test_sparse_apply_and_catchup_bit_exact(lib, name, E):
+def test_sparse_apply_and_catchup_bit_exact(lib, name, E, layout):
     """Sparse apply (+ for Adam the lazy catch-up) against the oracle's TF rule — for Adam that is
     the literal whole-table sweep of adam.py _apply_sparse_shared, so equality here shows that
-    lazy catch-up == sweep, bit for bit, including rows that sit out several steps."""
+    lazy catch-up == sweep, bit for bit, including rows that sit out several steps.
+    layout "records" (round 4, what the engine allocates): one [w | slot0 | slot1] record per row, the three pointers E
+    floats apart and table_stride = 3 E; "arrays": three [R, E] arrays (table_stride 0)."""
     from mi355x_rec.engine import OptimizerSpec, AdamSchedule
     rng = np.random.default_rng(E)
     R, steps = 50, 7
@@ -932,6 +935,11 @@ def test_sparse_apply_and_catchup_bit_exact(lib, name, E):
     ls0, ls1 = [a.copy() for a in OO.slot_init(hp, L)]
     dW, dL = dev(W), dev(L[:, 0].copy())
     d_ws0, d_ws1, d_ls0, d_ls1 = dev(ws0), dev(ws1), dev(ls0[:, 0].copy()), dev(ls1[:, 0].copy())
+    tst = 0
+    if layout == "records":
+        rec = torch.full((R, 3 * E), float("nan"), device="cuda")
+        rec[:, :E] = dW; rec[:, E:2 * E] = d_ws0; rec[:, 2 * E:] = d_ws1
+        dW, d_ws0, d_ws1, tst = rec[:, :E], rec[:, E:2 * E], rec[:, 2 * E:], 3 * E
     last = torch.zeros(R, dtype=torch.int32, device="cuda")
     powers = OO.AdamPowers(hp, np.float32) if name == "Adam" else None
     sched = AdamSchedule(spec, "cuda", 64) if name == "Adam" else None
@@ -955,17 +963,17 @@ def test_sparse_apply_and_catchup_bit_exact(lib, name, E):
         if name == "Adam" and step > 1:
             assert abs(sched.lr_t(step) - float(lr_t)) == 0.0
             _chk(lib.mi_sparse_catchup(_p(dW), _p(d_ws0), _p(d_ws1), _p(dL), _p(d_ls0), _p(d_ls1), _p(last), _p(uq),
-                                       _p(nu), n, E, step - 1, _p(sched.table), hp.beta1, hp.beta2, hp.epsilon, 0, 1, _st()))
+                                       _p(nu), n, E, step - 1, _p(sched.table), hp.beta1, hp.beta2, hp.epsilon, 0, 1, tst, _st()))
         h = spec.hparams(float(lr_t))
         dg, dgl = dev(g), dev(gl[:, 0].copy())      # keep references: launches are asynchronous
         _chk(lib.mi_sparse_apply(_p(dW), _p(d_ws0) if need0 else None, _p(d_ws1) if need1 else None, _p(dL),
                                  _p(d_ls0) if need0 else None, _p(d_ls1) if need1 else None,
                                  _p(last) if name == "Adam" else None, _p(uq), _p(sg), _p(se), _p(nu), n,
-                                 _p(dg), _p(dgl), E, step, C.byref(h), 1, _st()))
+                                 _p(dg), _p(dgl), E, step, C.byref(h), 1, tst, _st()))
         torch.cuda.synchronize()
     if name == "Adam":   # bring the rows that sat out the last steps up to date: all-rows catch-up
         _chk(lib.mi_sparse_catchup(_p(dW), _p(d_ws0), _p(d_ws1), _p(dL), _p(d_ls0), _p(d_ls1), _p(last), None, None,
-                                   R, E, steps, _p(sched.table), hp.beta1, hp.beta2, hp.epsilon, 0, 1, _st()))
+                                   R, E, steps, _p(sched.table), hp.beta1, hp.beta2, hp.epsilon, 0, 1, tst, _st()))
         assert np.all(last.cpu().numpy() == steps)
     assert np.array_equal(dW.cpu().numpy(), W)
     assert np.array_equal(dL.cpu().numpy(), L[:, 0])

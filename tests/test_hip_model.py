@@ -111,15 +111,12 @@ def _device_relu_masks(m, B):
 # 2).  The device's relu decisions are read back after each step and handed to the oracle (oracle.forward(relu_masks));
 # they may differ from the oracle's own sign test ONLY on units whose pre-activation is within 1e-6 of 0 — asserted —
 # and with both sides on the same branch every case is held to the standard bars over all five steps.
-@pytest.mark.parametrize("gemm", ["f16x2", "fp32", "f16x2+fm-fold", "f16x2+bounded"])
+@pytest.mark.parametrize("gemm", ["f16x2", "fp32", "f16x2+bounded"])
 @pytest.mark.parametrize("vocab,E,hidden,B,nn", CONFIGS)
-def test_adam_training_matches_oracle(vocab, E, hidden, B, nn, gemm, monkeypatch):
+def test_adam_training_matches_oracle(vocab, E, hidden, B, nn, gemm):
     """5 train steps with fresh batches (rows sit out steps, duplicates inside a batch): the lazy
-    catch-up path must reproduce TF Adam's dense-equivalent sparse update.  "+fm-fold": the layer-1 data
-    gradient adds dlogit * sumv to d_concat once per example (DeepFM.FOLD_FM) instead of the apply per entry;
-    "+bounded": the bounded-error replay (MI_CATCHUP_BOUNDED) — same bars."""
-    from mi355x_rec.engine import DeepFM
-    monkeypatch.setattr(DeepFM, "FOLD_FM", gemm.endswith("fm-fold"))
+    catch-up path must reproduce TF Adam's dense-equivalent sparse update.  "+bounded": the bounded-error replay
+    (MI_CATCHUP_BOUNDED) — same bars."""
     catchup = "bounded" if gemm.endswith("bounded") else "exact"
     gemm = gemm.split("+")[0]
     # Two bars on the logits.  Step 0 — identical weights on both sides, which is what north_star's "logits within 1e-5 on
@@ -276,7 +273,7 @@ def test_full_size_properties():
     assert float(err.max()) < 1e-5, float(err.max())
     # the materialising form of the gather kernel is an exact copy of the addressed rows
     concat = torch.empty(B, F * E, device="cuda")
-    m.k.mi_embed_fm_linear_fwd(m.table, None, m.field_off, ids, B, F, E, concat, F * E, None, None, None, None, 1)
+    m.k.mi_embed_fm_linear_fwd(m.table, None, m.field_off, ids, B, F, E, concat, F * E, None, None, None, None, 1, m.ts)
     concat = concat.view(B, F, E)
     assert torch.equal(concat[sel], m.table[rows[sel]])
     assert "concat" not in m._ws          # the training path never materialises it (gathered layer-1 operand)
@@ -397,7 +394,7 @@ def test_config5_one_rank_share_properties():
     rows = ids.long() + m.field_off[None, :]
     assert int(rows.max()) * E * 4 > 2 ** 34
     concat = torch.empty(B, F * E, device="cuda")
-    m.k.mi_embed_fm_linear_fwd(m.table, None, m.field_off, ids, B, F, E, concat, F * E, None, None, None, None, 1)
+    m.k.mi_embed_fm_linear_fwd(m.table, None, m.field_off, ids, B, F, E, concat, F * E, None, None, None, None, 1, m.ts)
     sel = torch.arange(0, B, 331, device="cuda")
     assert torch.equal(concat[sel].view(-1, F, E), m.table[rows[sel]])
     del concat

@@ -216,7 +216,7 @@ def test_dense_bwd_data_planes(lib, M, N, K):
     dyp, wp, xap = split(lib, dY), split(lib, W), split(lib, Xact)
     dX = torch.empty(M, K, device="cuda")
     dxp = PB(lib, M, K) if K <= 512 else None
-    _chk(lib.mi_dense_bwd_data_planes(dyp.ref, wp.ref, xap.ref, dX.data_ptr(), K, dxp.ref if dxp else None, M, N, K, keep, None, None, None, 0,
+    _chk(lib.mi_dense_bwd_data_planes(dyp.ref, wp.ref, xap.ref, dX.data_ptr(), K, dxp.ref if dxp else None, M, N, K, keep, None,
                                       None, 0, _st()))
     ref = (dY.astype(np.float64) @ W.astype(np.float64).T) * (Xact > 0) / np.float64(np.float32(keep))
     got = dX.cpu().numpy()
@@ -234,38 +234,14 @@ def test_dense_bwd_data_planes(lib, M, N, K):
     dX2 = torch.empty(M, K, device="cuda")
     dxp2 = PB(lib, M, K) if K <= 512 else None
     mbt = dev(words.view(np.int32))
-    _chk(lib.mi_dense_bwd_data_planes(dyp.ref, wp.ref, None, dX2.data_ptr(), K, dxp2.ref if dxp2 else None, M, N, K, keep, None, None, None, 0,
+    _chk(lib.mi_dense_bwd_data_planes(dyp.ref, wp.ref, None, dX2.data_ptr(), K, dxp2.ref if dxp2 else None, M, N, K, keep, None,
                                       mbt.data_ptr(), Kw, _st()))
     assert np.array_equal(dX2.cpu().numpy().view(np.uint32), got.view(np.uint32))
     if dxp is not None:
         assert np.array_equal(dxp2.bits(), dxp.bits()) and np.array_equal(dxp2.exp.cpu().numpy(), dxp.exp.cpu().numpy())
     # without a mask (the layer-1 data gradient: the concat has no activation)
-    _chk(lib.mi_dense_bwd_data_planes(dyp.ref, wp.ref, None, dX.data_ptr(), K, None, M, N, K, 1.0, None, None, None, 0, None, 0, _st()))
+    _chk(lib.mi_dense_bwd_data_planes(dyp.ref, wp.ref, None, dX.data_ptr(), K, None, M, N, K, 1.0, None, None, 0, _st()))
     assert row_rel_err(dX.cpu().numpy(), dY.astype(np.float64) @ W.astype(np.float64).T) < 1e-5
-
-
-def test_dense_bwd_data_planes_folds_the_fm_term(lib):
-    """layer-1 form: d_concat += dlogit[m] * sumv[m][k % E], added once per example in the epilogue"""
-    M, N, F, E = 300, 512, 26, 64
-    K = F * E
-    rng = np.random.default_rng(5)
-    dY = rows_spread(rng, M, N, -8)
-    W = (rng.standard_normal((K, N)) / np.sqrt(N)).astype(np.float32)
-    sumv = rng.standard_normal((M, E)).astype(np.float32)
-    dl = (rng.standard_normal(M) * 1e-3).astype(np.float32)
-    dyp, wp = split(lib, dY), split(lib, W)
-    dX = torch.empty(M, K, device="cuda")
-    sv, g = dev(sumv), dev(dl)
-    _chk(lib.mi_dense_bwd_data_planes(dyp.ref, wp.ref, None, dX.data_ptr(), K, None, M, N, K, 1.0, None, sv.data_ptr(),
-                                      g.data_ptr(), E, None, 0, _st()))
-    ref = dY.astype(np.float64) @ W.astype(np.float64).T + dl.astype(np.float64)[:, None] * np.tile(sumv.astype(np.float64), (1, F))
-    assert row_rel_err(dX.cpu().numpy(), ref) < 1e-5
-    # refused where the result is not the concat gradient (mask / planes output) or E does not divide K
-    xap = split(lib, np.abs(ref).astype(np.float32))
-    assert lib.mi_dense_bwd_data_planes(dyp.ref, wp.ref, xap.ref, dX.data_ptr(), K, None, M, N, K, 1.0, None, sv.data_ptr(),
-                                        g.data_ptr(), E, None, 0, _st()) != 0
-    assert lib.mi_dense_bwd_data_planes(dyp.ref, wp.ref, None, dX.data_ptr(), K, None, M, N, K, 1.0, None, sv.data_ptr(),
-                                        g.data_ptr(), 48, None, 0, _st()) != 0
 
 
 def test_planes_entries_refuse_bad_shapes(lib):
@@ -307,10 +283,10 @@ def test_embed_fm_planes_fwd(lib, E, F, B, nd, tail):
     cp = PB(lib, B, F * E + tail, pad=1)
     sumv = torch.empty(B, E, device="cuda"); fm = torch.empty(B, device="cuda"); amax = torch.zeros(64, device="cuda")
     _chk(lib.mi_embed_fm_planes_fwd(t.data_ptr(), fo.data_ptr(), di.data_ptr(), B, F, E, sumv.data_ptr(), fm.data_ptr(), cp.ref,
-                                    amax.data_ptr(), dx.data_ptr() if nd else None, nd, tail, _st()))
+                                    amax.data_ptr(), dx.data_ptr() if nd else None, nd, tail, 0, _st()))
     concat = torch.empty(B, F * E, device="cuda"); sumv2 = torch.empty(B, E, device="cuda"); fm2 = torch.empty(B, device="cuda")
     _chk(lib.mi_embed_fm_linear_fwd(t.data_ptr(), None, fo.data_ptr(), di.data_ptr(), B, F, E, concat.data_ptr(), F * E,
-                                    sumv2.data_ptr(), fm2.data_ptr(), None, None, 1, _st()))
+                                    sumv2.data_ptr(), fm2.data_ptr(), None, None, 1, 0, _st()))
     rows = ids.astype(np.int64) + off[:-1][None, :]
     assert np.array_equal(concat.cpu().numpy(), table[rows].reshape(B, F * E))
     full = concat.cpu().numpy()
@@ -322,9 +298,9 @@ def test_embed_fm_planes_fwd(lib, E, F, B, nd, tail):
     assert torch.equal(sumv, sumv2) and torch.equal(fm, fm2)
     assert float(amax.max()) == float(np.abs(full).max())
     if tail:      # refused: a tail that is no whole number of k-blocks, more numeric columns than the tail holds, a tail wider than 4 E
-        assert lib.mi_embed_fm_planes_fwd(t.data_ptr(), fo.data_ptr(), di.data_ptr(), B, F, E, None, None, cp.ref, None, dx.data_ptr(), nd, tail + 8, _st()) != 0
-        assert lib.mi_embed_fm_planes_fwd(t.data_ptr(), fo.data_ptr(), di.data_ptr(), B, F, E, None, None, cp.ref, None, dx.data_ptr(), tail + 1, tail, _st()) != 0
-        assert lib.mi_embed_fm_planes_fwd(t.data_ptr(), fo.data_ptr(), di.data_ptr(), B, F, E, None, None, cp.ref, None, dx.data_ptr(), nd, 4 * E + 16, _st()) != 0
+        assert lib.mi_embed_fm_planes_fwd(t.data_ptr(), fo.data_ptr(), di.data_ptr(), B, F, E, None, None, cp.ref, None, dx.data_ptr(), nd, tail + 8, 0, _st()) != 0
+        assert lib.mi_embed_fm_planes_fwd(t.data_ptr(), fo.data_ptr(), di.data_ptr(), B, F, E, None, None, cp.ref, None, dx.data_ptr(), tail + 1, tail, 0, _st()) != 0
+        assert lib.mi_embed_fm_planes_fwd(t.data_ptr(), fo.data_ptr(), di.data_ptr(), B, F, E, None, None, cp.ref, None, dx.data_ptr(), nd, 4 * E + 16, 0, _st()) != 0
 
 
 def test_split_weights_one_launch(lib):

@@ -46,7 +46,7 @@ def main():
             torch.cuda.synchronize()
             a.record()
             _lib.check(lib.mi_sparse_catchup(w.data_ptr(), m.data_ptr(), v.data_ptr(), None, None, None, last.data_ptr(),
-                                             by_gap.data_ptr(), nu.data_ptr(), U, E, step_to, lr.data_ptr(), 0.9, 0.999, 1e-8, flags, 4, st()), "catchup")
+                                             by_gap.data_ptr(), nu.data_ptr(), U, E, step_to, lr.data_ptr(), 0.9, 0.999, 1e-8, flags, 4, 0, st()), "catchup")
             b.record(); torch.cuda.synchronize()
             ts.append(a.elapsed_time(b))
         return min(ts), float(np.median(ts))

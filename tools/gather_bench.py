@@ -27,7 +27,7 @@ def run(V, want_lin=True, want_sumv=True, want_concat=False, sorted_ids=False, w
     concat = torch.empty(B, F * E, device="cuda") if want_concat else None
     amax = torch.zeros(64, device="cuda") if want_amax else None
     fn = lambda: L.mi_embed_fm_linear_fwd(p(table), p(lin_w) if want_lin else None, p(off), p(ids), B, F, E, p(concat),
-                                          F * E, p(sumv), p(fm), p(lin), p(amax), 1, st())
+                                          F * E, p(sumv), p(fm), p(lin), p(amax), 1, 0, st())
     assert fn() == 0, L.mi_last_error()
     torch.cuda.synchronize()
     ts = []

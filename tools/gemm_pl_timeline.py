@@ -43,10 +43,10 @@ def run(which):
         nk = h // 16
         if layer == 1:
             dX = torch.empty(M, fan, device="cuda")
-            fn = lambda: L.mi_dense_bwd_data_planes(dyp.ref, wp.ref, None, dX.data_ptr(), fan, None, M, h, fan, 1.0, None, None, None, 0, None, 0, st())
+            fn = lambda: L.mi_dense_bwd_data_planes(dyp.ref, wp.ref, None, dX.data_ptr(), fan, None, M, h, fan, 1.0, None, None, 0, st())
         else:
             Xa = torch.randn(M, fan, device="cuda", generator=g).relu_(); xa = split(Xa); dxp = PB(M, fan)
-            fn = lambda: L.mi_dense_bwd_data_planes(dyp.ref, wp.ref, xa.ref, None, fan, dxp.ref, M, h, fan, 0.9, None, None, None, 0, None, 0, st())
+            fn = lambda: L.mi_dense_bwd_data_planes(dyp.ref, wp.ref, xa.ref, None, fan, dxp.ref, M, h, fan, 0.9, None, None, 0, st())
     for _ in range(4):
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
         e0.record(); assert fn() == 0; e1.record(); torch.cuda.synchronize()

@@ -106,7 +106,7 @@ def main():
         dxp = PB(M, K)
         for label, xa, mb in (("mask from planes", actp[i], None), ("mask bits", None, bits[i])):
             t = timeit(lambda: chk(lib.mi_dense_bwd_data_planes(dyp.ref, wp.ref, None if xa is None else xa.ref, None, K, dxp.ref, M, N, K, keep,
-                                                                amax.data_ptr(), None, None, 0, None if mb is None else mb.data_ptr(), K // 32, st()), "dg"))
+                                                                amax.data_ptr(), None if mb is None else mb.data_ptr(), K // 32, st()), "dg"))
             rows.append(("data gradient %d <- %d, %s" % (K, N, label), t))
         ax = torch.zeros(_lib.AMAX_SLOTS, device="cuda"); ay = torch.zeros(_lib.AMAX_SLOTS, device="cuda")
         lib.mi_absmax(acts[i].data_ptr(), acts[i].numel(), ax.data_ptr(), st()); lib.mi_absmax(dY.data_ptr(), dY.numel(), ay.data_ptr(), st())

@@ -27,7 +27,7 @@ def patched(*a, **kw):
         last2.fill_(m.step - 14)                                  # every shadow row is 14 steps stale
         s = m.sched.spec
         def launch():
-            m.k.mi_sparse_catchup(t2, m2, v2, None, None, None, last2, uniq[:n], nu, n, E, m.step, m.sched.table, s.beta1, s.beta2, s.epsilon, 1, 1)
+            m.k.mi_sparse_catchup(t2, m2, v2, None, None, None, last2, uniq[:n], nu, n, E, m.step, m.sched.table, s.beta1, s.beta2, s.epsilon, 1, 1, 0)
         if mode["v"] == "serial":
             launch()
         else:

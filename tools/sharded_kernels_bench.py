@@ -97,7 +97,7 @@ def main():
     lin_state = torch.zeros(Rl, 4, device=dev)
     own_rows, own_lin = torch.empty(nr, E, device=dev), torch.empty(nr, device=dev)
     line("mi_gather_rows", timed(lambda: ck(lib.mi_gather_rows(table.data_ptr(), lin_state.data_ptr(), recv_ids.data_ptr(), nr, E, own_rows.data_ptr(),
-                                                               own_lin.data_ptr(), 4, st()))), nr * (8 * E + 4 + 16 + 4),
+                                                               own_lin.data_ptr(), 4, 0, st()))), nr * (8 * E + 4 + 16 + 4),
          "rows read + written, the 16-byte wide record read")
 
     # requester side: per-request gradient sums from d_concat (the chunk's entries)
