@@ -128,7 +128,12 @@ int32_t mi_bucketize_f32(const float* values, int64_t n, const float* boundaries
  * consecutive rows of table (and of its slot arrays) — 0 or E: [R, E] arrays; 3 E with t_slot0 = table + E, t_slot1 = table +
  * 2 E: ONE record [w | slot0 | slot1] per row (what the shipped host allocates: a row's weights and optimizer state are one
  * contiguous 12 E-byte run — one DRAM page visit per row and direction in the sparse apply and the catch-up instead of
- * three).  A multiple of 4, >= E. */
+ * three).  A multiple of 4, >= E.
+ * The PACKED EXCHANGE of the row-sharded step (round 4): a request's row and wide weight travel as ONE record of E + 4 floats
+ * [row | weight | pad x 3] (and its gradients likewise), so a chunk costs one collective per direction instead of two —
+ * mi_gather_rows(out_stride = E + 4, out_lin = out_rows + E) writes such records, the forward entries read them with
+ * table_stride = lin_stride = E + 4, mi_entry_grads_segsum(rows_stride, out_stride) reads and writes them,
+ * mi_sparse_apply(grad_stride = E + 4, d_lin = d_rows + E) applies them.  0 everywhere = separate arrays, as before. */
 int32_t mi_embed_fm_linear_fwd(const float* table, const float* lin_w, const int64_t* field_off,
                                const int32_t* ids, int64_t B, int32_t F, int32_t E,
                                float* concat, int64_t ld_concat, float* sumv, float* fm, float* lin,
@@ -152,7 +157,7 @@ int32_t mi_embed_fm_planes_fwd(const float* table, const int64_t* field_off, con
  * out_lin[i] = lin_w[rows[i] * lin_stride].  rows [n] int32 local row ids; table (with out_rows) or lin_w
  * (with out_lin) may be NULL. */
 int32_t mi_gather_rows(const float* table, const float* lin_w, const int32_t* rows, int64_t n,
-                       int32_t E, float* out_rows, float* out_lin, int32_t lin_stride, int64_t table_stride, mi_stream_t stream);
+                       int32_t E, float* out_rows, float* out_lin, int32_t lin_stride, int64_t table_stride, int64_t out_stride, mi_stream_t stream);
 
 /* (a4) numeric embedding, deep_fm.py:62-70: out[b, j*E+e] = x[b,j] * V[j,e], written at
  * concat[b, col0 + j*E + e]; also accumulates into sumv / fm so the FM term sees the numeric
@@ -201,7 +206,7 @@ int32_t mi_embed_fm_linear_bwd(const float* d_concat, int64_t ld_dconcat, const 
 int32_t mi_entry_grads_segsum(const float* rows, const int32_t* seg_start, const int32_t* sorted_entry, int64_t u_begin,
                               int64_t u_count, const float* d_concat, int64_t ld_dconcat, const float* sumv,
                               const float* d_logit_fm, const float* d_logit_lin, int64_t b0, int32_t F, int32_t E,
-                              float* out_rows, float* out_lin, int64_t out_row0, mi_stream_t stream);
+                              float* out_rows, float* out_lin, int64_t out_row0, int64_t rows_stride, int64_t out_stride, mi_stream_t stream);
 
 /* (a4) backward of the numeric embedding: dV[j,e] = sum_b x[b,j]*g[b,j,e] with
  * g = d_concat + d_logit_fm*(sumv - concat);  dw_num[j] = sum_b d_logit_lin[b]*x[b,j].
@@ -313,7 +318,7 @@ int32_t mi_sparse_apply(float* table, float* t_slot0, float* t_slot1, float* lin
                         const int32_t* seg_start, const int32_t* sorted_entry,
                         const int32_t* num_uniq, int64_t n_max, const float* d_rows,
                         const float* d_lin, int32_t E, int32_t step, const mi_opt_hparams* hp,
-                        int32_t lin_stride, int64_t table_stride, mi_stream_t stream);
+                        int32_t lin_stride, int64_t table_stride, int64_t grad_stride, mi_stream_t stream);
 
 /* Single-GPU form of mi_sparse_apply with mi_embed_fm_linear_bwd folded in: the gradient of entry
  * e = (b, f) = (e / F, e % F) is rebuilt inside the kernel as

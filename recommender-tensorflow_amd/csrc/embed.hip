@@ -235,7 +235,8 @@ __global__ __launch_bounds__(kBlock) void gather_rows_k(const float* __restrict_
                                                         const float* __restrict__ lin_w,
                                                         const int32_t* __restrict__ rows, int64_t n,
                                                         int E, float* __restrict__ out_rows,
-                                                        float* __restrict__ out_lin, int ls, int64_t ts) {
+                                                        float* __restrict__ out_lin, int ls, int64_t ts,
+                                                        int64_t os, int64_t ols) {
   constexpr int U = kRowsInFlight;
   const int64_t g = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) / LPR;
   const int l = threadIdx.x & (LPR - 1);
@@ -253,8 +254,8 @@ __global__ __launch_bounds__(kBlock) void gather_rows_k(const float* __restrict_
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     if (i0 + u < n) {
-      if (table && lane_on) st4(out_rows + (i0 + u) * E + 4 * l, r[u]);
-      if (lin_w && out_lin && (u & (LPR - 1)) == l) out_lin[i0 + u] = lin_w[static_cast<int64_t>(row[u]) * ls];
+      if (table && lane_on) st4(out_rows + (i0 + u) * os + 4 * l, r[u]);
+      if (lin_w && out_lin && (u & (LPR - 1)) == l) out_lin[(i0 + u) * ols] = lin_w[static_cast<int64_t>(row[u]) * ls];
     }
   }
 }
@@ -566,7 +567,11 @@ int32_t mi_embed_fm_planes_fwd(const float* table, const int64_t* field_off, con
 }
 
 int32_t mi_gather_rows(const float* table, const float* lin_w, const int32_t* rows, int64_t n,
-                       int32_t E, float* out_rows, float* out_lin, int32_t lin_stride, int64_t table_stride, mi_stream_t stream) {
+                       int32_t E, float* out_rows, float* out_lin, int32_t lin_stride, int64_t table_stride, int64_t out_stride,
+                       mi_stream_t stream) {
+  MI_REQUIRE(out_stride == 0 || (out_stride >= (table ? E : 1) && (!table || (out_stride & 3) == 0)),
+             "gather_rows: out_stride=%lld (0 = rows E apart and weights 1 apart, else one record of out_stride floats per request)", (long long)out_stride);
+  const int64_t os = out_stride ? out_stride : E, ols = out_stride ? out_stride : 1;
   if (!table) { E = 4; table_stride = 0; }   // wide part only: the row half of the kernel is off
   if (int32_t rc = check_E("gather_rows", E)) return rc;
   MI_REQUIRE(table_stride == 0 || (table_stride >= E && (table_stride & 3) == 0), "%s: table_stride=%lld (0 = E, else >= E and a multiple of 4)", "gather_rows", (long long)table_stride);
@@ -581,7 +586,7 @@ int32_t mi_gather_rows(const float* table, const float* lin_w, const int32_t* ro
   const int64_t blocks = mi::ceil_div(groups * lpr, kBlock);
   MI_REQUIRE(blocks <= INT32_MAX, "gather_rows: grid too large");
   MI_DISPATCH_LPR(lpr, (gather_rows_k<L><<<dim3((unsigned)blocks), dim3(kBlock), 0, mi::as_stream(stream)>>>(
-                           table, lin_w, rows, n, E, out_rows, out_lin, lin_stride, ts)));
+                           table, lin_w, rows, n, E, out_rows, out_lin, lin_stride, ts, os, ols)));
   MI_CHECK_LAUNCH("gather_rows");
   return MI_OK;
 }

@@ -132,6 +132,10 @@ struct ApplyArgs {
   // t1 = table + 2 E = ONE [w | slot0 | slot1] record per row — a row's whole state is then one contiguous run of
   // 12 E bytes (one DRAM page visit per row and direction instead of three)
   int64_t ts;
+  // floats between consecutive entries of d_rows / of d_lin (E and 1: two arrays; one value for both: the gradients arrive
+  // as ONE record [row gradient | weight gradient | pad] per request, d_lin = d_rows + E — the packed exchange of the
+  // row-sharded step), and the same for out_rows / out_lin of the STORE form
+  int64_t gs, gls, os, ols;
 };
 
 // sum of the gradients of entries sorted_entry[k_beg..k_end) of one row, in that order
@@ -163,10 +167,10 @@ __device__ __forceinline__ void seg_accumulate(const ApplyArgs& a, const FusedGr
       if (a.lin_w && l == 0) gl += fg.dll[b];
     } else {
       if (a.table && lane_on) {
-        const float4 v = ld4(a.d_rows + e * E + 4 * l);
+        const float4 v = ld4(a.d_rows + e * a.gs + 4 * l);
         g.x += v.x; g.y += v.y; g.z += v.z; g.w += v.w;
       }
-      if (a.lin_w && l == 0) gl += a.d_lin[e];
+      if (a.lin_w && l == 0) gl += a.d_lin[e * a.gls];
     }
   }
 }
@@ -235,8 +239,8 @@ __device__ __forceinline__ void apply_row(const ApplyArgs& a, const Hp& h, int64
 
 // one lane group per unique row: duplicates summed in ascending entry order (TF's CPU order)
 __device__ __forceinline__ void store_row(const ApplyArgs& a, int64_t u, int l, bool lane_on, const float4& g, float gl) {
-  if (a.out_rows && lane_on) st4(a.out_rows + u * a.E + 4 * l, g);
-  if (a.out_lin && l == 0) a.out_lin[u] = gl;
+  if (a.out_rows && lane_on) st4(a.out_rows + u * a.os + 4 * l, g);
+  if (a.out_lin && l == 0) a.out_lin[u * a.ols] = gl;
 }
 
 template <int LPR, bool FUSED, bool STORE = false>
@@ -831,8 +835,10 @@ int32_t mi_sparse_apply(float* table, float* t_slot0, float* t_slot1, float* lin
                         const int32_t* seg_start, const int32_t* sorted_entry,
                         const int32_t* num_uniq, int64_t n_max, const float* d_rows,
                         const float* d_lin, int32_t E, int32_t step, const mi_opt_hparams* hp,
-                        int32_t lin_stride, int64_t table_stride, mi_stream_t stream) {
+                        int32_t lin_stride, int64_t table_stride, int64_t grad_stride, mi_stream_t stream) {
   if (int32_t rc = check_hp("sparse_apply", hp)) return rc;
+  MI_REQUIRE(grad_stride == 0 || (grad_stride >= (table ? E : 1) && (!table || (grad_stride & 3) == 0)),
+             "sparse_apply: grad_stride=%lld (0 = d_rows E apart and d_lin 1 apart, else one record per entry)", (long long)grad_stride);
   if (!table) table_stride = 0;
   MI_REQUIRE(table_stride == 0 || (table_stride >= E && (table_stride & 3) == 0), "%s: table_stride=%lld (0 = E, else >= E and a multiple of 4)", "sparse_apply", (long long)table_stride);
   const int64_t ts = table_stride ? table_stride : E;
@@ -856,6 +862,7 @@ int32_t mi_sparse_apply(float* table, float* t_slot0, float* t_slot1, float* lin
   ApplyArgs a{table, t_slot0, t_slot1, lin_w, l_slot0, l_slot1, last_step, uniq_rows, seg_start, sorted_entry,
               num_uniq, d_rows, d_lin, E, step};
   a.ls = lin_stride; a.ts = ts;
+  a.gs = grad_stride ? grad_stride : E; a.gls = grad_stride ? grad_stride : 1;
   a.st = mi::step_state();
   MI_DISPATCH_LPR(lpr, (sparse_apply_k<L, false><<<dim3((unsigned)blocks), dim3(kBlock), 0, mi::as_stream(stream)>>>(
                            a, h, FusedGrad{})));
@@ -917,7 +924,11 @@ int32_t mi_sparse_apply_fused(float* table, float* t_slot0, float* t_slot1, floa
 int32_t mi_entry_grads_segsum(const float* rows, const int32_t* seg_start, const int32_t* sorted_entry, int64_t u_begin,
                               int64_t u_count, const float* d_concat, int64_t ld_dconcat, const float* sumv,
                               const float* d_logit_fm, const float* d_logit_lin, int64_t b0, int32_t F, int32_t E,
-                              float* out_rows, float* out_lin, int64_t out_row0, mi_stream_t stream) {
+                              float* out_rows, float* out_lin, int64_t out_row0, int64_t rows_stride, int64_t out_stride,
+                              mi_stream_t stream) {
+  MI_REQUIRE(rows_stride == 0 || (rows_stride >= E && (rows_stride & 3) == 0), "entry_grads_segsum: rows_stride=%lld", (long long)rows_stride);
+  MI_REQUIRE(out_stride == 0 || (out_stride >= (out_rows ? E : 1) && (!out_rows || (out_stride & 3) == 0)),
+             "entry_grads_segsum: out_stride=%lld (0 = out_rows E apart and out_lin 1 apart, else one record per request)", (long long)out_stride);
   MI_REQUIRE(u_begin >= 0 && u_count >= 0 && u_begin + u_count <= INT32_MAX && F > 0 && b0 >= 0, "entry_grads_segsum: u_begin=%lld u_count=%lld",
              (long long)u_begin, (long long)u_count);
   MI_REQUIRE(out_row0 >= 0 && out_row0 <= u_begin, "entry_grads_segsum: out_row0=%lld must lie in [0, u_begin=%lld]", (long long)out_row0,
@@ -942,9 +953,11 @@ int32_t mi_entry_grads_segsum(const float* rows, const int32_t* seg_start, const
   // request u is written at row u - out_row0 of the out buffers (the kernels index by u: the bases are moved back; only
   // u >= u_begin >= out_row0 is ever touched)
   a.E = E;
-  a.out_rows = out_rows ? reinterpret_cast<float*>(reinterpret_cast<uintptr_t>(out_rows) - static_cast<uintptr_t>(out_row0) * E * sizeof(float)) : nullptr;
-  a.out_lin = out_lin ? reinterpret_cast<float*>(reinterpret_cast<uintptr_t>(out_lin) - static_cast<uintptr_t>(out_row0) * sizeof(float)) : nullptr;
-  a.u_begin = (int)u_begin; a.u_count = (int)u_count; a.ls = 1; a.ts = E;       // (rows: the exchange buffer, E floats apart)
+  a.os = out_stride ? out_stride : E; a.ols = out_stride ? out_stride : 1;
+  a.out_rows = out_rows ? reinterpret_cast<float*>(reinterpret_cast<uintptr_t>(out_rows) - static_cast<uintptr_t>(out_row0) * a.os * sizeof(float)) : nullptr;
+  a.out_lin = out_lin ? reinterpret_cast<float*>(reinterpret_cast<uintptr_t>(out_lin) - static_cast<uintptr_t>(out_row0) * a.ols * sizeof(float)) : nullptr;
+  a.u_begin = (int)u_begin; a.u_count = (int)u_count; a.ls = 1;
+  a.ts = rows_stride ? rows_stride : E;                          // (rows: the exchange's receive buffer)
   const Hp h{};
   MI_DISPATCH_LPR(lpr, (sparse_apply_k<L, true, true><<<dim3((unsigned)blocks), dim3(kBlock), 0, mi::as_stream(stream)>>>(a, h, fg)));
   MI_CHECK_LAUNCH("entry_grads_segsum");

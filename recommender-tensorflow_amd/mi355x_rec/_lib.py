@@ -67,13 +67,13 @@ SIGNATURES = {
     "mi_hash_bucket_bytes": (_i32, [_p, _p, _i64, _i64, _p]),
     "mi_bucketize_f32": (_i32, [_p, _i64, _p, _i32, _p]),
     "mi_embed_fm_linear_fwd": (_i32, [_p, _p, _p, _p, _i64, _i32, _i32, _p, _i64, _p, _p, _p, _p, _i32, _i64, _p]),
-    "mi_gather_rows": (_i32, [_p, _p, _p, _i64, _i32, _p, _p, _i32, _i64, _p]),
+    "mi_gather_rows": (_i32, [_p, _p, _p, _i64, _i32, _p, _p, _i32, _i64, _i64, _p]),
     "mi_numeric_embed_fwd": (_i32, [_p, _p, _p, _i64, _i32, _i32, _p, _i64, _i64, _p, _p, _p, _p]),
     "mi_numeric_raw_fwd": (_i32, [_p, _p, _i64, _i32, _p, _i64, _i64, _i32, _p, _p]),
     "mi_numeric_raw_bwd_workspace_bytes": (_sz, [_i64, _i32]),
     "mi_numeric_raw_bwd": (_i32, [_p, _p, _i64, _i32, _p, _p, _sz, _p]),
     "mi_embed_fm_linear_bwd": (_i32, [_p, _i64, _p, _i64, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p, _p, _p]),
-    "mi_entry_grads_segsum": (_i32, [_p, _p, _p, _i64, _i64, _p, _i64, _p, _p, _p, _i64, _i32, _i32, _p, _p, _i64, _p]),
+    "mi_entry_grads_segsum": (_i32, [_p, _p, _p, _i64, _i64, _p, _i64, _p, _p, _p, _i64, _i32, _i32, _p, _p, _i64, _i64, _i64, _p]),
     "mi_numeric_embed_bwd_workspace_bytes": (_sz, [_i64, _i32, _i32]),
     "mi_numeric_embed_bwd": (_i32, [_p, _p, _i64, _p, _i64, _i64, _p, _p, _p, _i64, _i32, _i32, _p,
                                     _p, _p, _sz, _p]),
@@ -89,7 +89,7 @@ SIGNATURES = {
     "mi_gather_u32": (_i32, [_p, _p, _i64, _p, _p]),
     "mi_dense_apply": (_i32, [_p, _p, _p, _p, _i64, C.POINTER(OptHparams), _p]),
     "mi_sparse_apply": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _p, _i32, _i32,
-                               C.POINTER(OptHparams), _i32, _i64, _p]),
+                               C.POINTER(OptHparams), _i32, _i64, _i64, _p]),
     "mi_sparse_apply_fused": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _i64, _p, _p, _p, _i32,
                                      _i32, _i32, C.POINTER(OptHparams), _i32, _i64, _p]),
     "mi_dense_fwd_gathered": (_i32, [_p, _p, _p, _i32, _i32, _p, _p, _p, _i64, _i64, _i32, _i32, _f32, _u64, _amax, _i64, _p]),

@@ -722,9 +722,9 @@ class DeepFM:
         B = ids.shape[0]
         self._last_B = B
         c = {"B": B}
-        table, lin_w, field_off, rid = src if src is not None else (self.table, self.lin_w, self.field_off, ids)
-        ls = self.ls if src is None else 1              # (rows received from their owners: plain arrays)
-        tst = self.ts if src is None else self.E         # ... E floats apart; the model's own rows: one record apart
+        # (rows received from their owners: src also carries the receive buffer's row / weight strides — E and 1 for plain
+        # arrays, E + 4 for the packed exchange's records; the model's own rows: one [w | slots] record apart)
+        table, lin_w, field_off, rid, tst, ls = src if src is not None else (self.table, self.lin_w, self.field_off, ids, self.ts, self.ls)
         # the wide part's view of the batch: all columns, or (wide_fields) the wide columns' ids and field offsets
         w_off, w_ids, Fw = field_off, rid, self.F
         if self.wide_idx is not None:
@@ -1049,7 +1049,7 @@ class DeepFM:
         The result is used by the next train_step if it is given that very tensor, unmodified; otherwise it is dropped."""
         side = self._ws.get("presort_stream")
         if side is None:
-            side = self._ws["presort_stream"] = torch.cuda.Stream(device=self.device)
+            side = self._ws["presort_stream"] = torch.cuda.Stream(device=self.device)      # (a high-priority stream: no effect, same-box A/B, profiles/r04_ab_layout_and_fold.md)
         main = torch.cuda.current_stream()
         side.wait_stream(main)                       # next_ids exists, this step's own sort has left the shared workspace
         with torch.cuda.stream(side):
@@ -1268,9 +1268,10 @@ class DeepFM:
                                    self.d_grad[self.lin_num_off:] if self.use_linear else None, ws, ws.numel())
         return d_concat
 
-    def _apply(self, uniq, seg, sorted_entry, num_uniq, n_max, d_rows, d_lin, fused=None):
+    def _apply(self, uniq, seg, sorted_entry, num_uniq, n_max, d_rows, d_lin, fused=None, d_stride=0):
         """apply_gradients: dense Apply*, sparse apply on the unique rows, step += 1.
-        fused = (d_concat, sumv, dlogit): single-GPU form, entry gradients rebuilt in the kernel."""
+        fused = (d_concat, sumv, dlogit): single-GPU form, entry gradients rebuilt in the kernel.
+        d_stride: d_rows / d_lin are views of ONE record buffer, d_stride floats per entry (the packed exchange); 0: two arrays."""
         k = self.k
         step = self.step + 1
         lr_t = self.sched.lr_t(step) if self.sched else 0.0
@@ -1308,7 +1309,7 @@ class DeepFM:
                 else:
                     k.mi_sparse_apply(*slots, self.last_step, uniq, seg, sorted_entry, num_uniq, n_max,
                                       d_rows if tb is not None else None, d_lin if lw is not None else None, self.E,
-                                      step, h, self.ls, self.ts)
+                                      step, h, self.ls, self.ts, d_stride)
         self.step = step
 
     # ------------------------------------------------------------------ replayable step (hipGraph)

@@ -32,7 +32,7 @@ import torch.distributed as dist
 
 
 class RowShard:
-    def __init__(self, rank, world, group=None, chunks=None, chunk_compute=None, route_ahead=None):
+    def __init__(self, rank, world, group=None, chunks=None, chunk_compute=None, route_ahead=None, packed=True):
         """chunks: pipeline depth of a train step (None: chosen from the batch and world size, see _n_chunks).
         route_ahead: True (default) — an announced next batch is routed during this step, on a side stream and a SECOND
         RCCL communicator (see Comm / _route_ahead); False — the whole step runs on ONE communicator and one stream
@@ -52,6 +52,9 @@ class RowShard:
         self.chunks = chunks
         self.chunk_compute = (self.world < 8) if chunk_compute is None else bool(chunk_compute)
         self.route_ahead = True if route_ahead is None else bool(route_ahead)
+        # packed: rows and wide weights (and their gradients) travel as one record per request — one collective per chunk
+        # and direction instead of two (_sharded_step); False keeps them in separate buffers (A/B, tests)
+        self.packed = bool(packed)
         self.comm = None
 
     def local_rows(self, R):
@@ -382,15 +385,29 @@ def _sharded_step(m, ids, labels, x_num, train, next_ids=None):
     # device-wide synchronisation between kernels other ranks are waiting on).  Only a batch more than twice as
     # concentrated on this owner as a uniform one grows them again.
     cap_u, cap_r = max(n, 1), max(2 * n, nr, 1)
-    own_rows = m._buf("own_rows", (cap_r, E))[:nr] if m.use_emb else None
-    own_lin = m._buf("own_lin", (cap_r,))[:nr] if m.use_linear else None
-    got_rows = m._buf("got_rows", (cap_u, E))[:max(U, 1)] if m.use_emb else None
-    got_lin = m._buf("got_lin", (cap_u,))[:max(U, 1)] if m.use_linear else None
+    # PACKED exchange (a model with both an embedding and a wide part): a request's row and its wide weight travel as ONE
+    # record of E + 4 floats [row | weight | pad x 3] — and their gradients likewise — so a chunk costs one collective
+    # per direction instead of two (xGMI collectives are latency-bound at these sizes: 4 -> 2 launches per chunk).  The
+    # kernels take the record stride (include/mi355x_rec.h: out_stride / table_stride / rows_stride / grad_stride); the
+    # *_rows / *_lin names below are then strided views of the record buffers.
+    packed = bool(m.use_emb and m.use_linear and m.shard.packed)
+    EP = E + 4
+    xs = EP if packed else 0                                     # the exchange buffers' record stride as the entries take it
+
+    def rec(name, cap, cnt, need_rows, need_lin):
+        """(record buffer or None, rows view, weight view) of `cnt` requests"""
+        if packed:
+            r = m._buf(name + "_rec", (cap, EP))[:cnt]
+            return r, r[:, :E], r[:, E]
+        return (None, m._buf(name + "_rows", (cap, E))[:cnt] if need_rows else None,
+                m._buf(name + "_lin", (cap,))[:cnt] if need_lin else None)
+    own_rec, own_rows, own_lin = rec("own", cap_r, nr, m.use_emb, m.use_linear)
+    got_rec, got_rows, got_lin = rec("got", cap_u, max(U, 1), m.use_emb, m.use_linear)
 
     def gather(ids_, n_, rows_out, lin_out):
         if n_ > 0:
             k.mi_gather_rows(m.table if m.use_emb else None, m.lin_w if m.use_linear else None, ids_, n_, E,
-                             rows_out if m.use_emb else None, lin_out if m.use_linear else None, m.ls, m.ts)
+                             rows_out if m.use_emb else None, lin_out if m.use_linear else None, m.ls, m.ts, xs)
 
     def serve(c):
         """owners gather chunk c's rows and send them back (their own requests: straight into the receive buffer);
@@ -399,17 +416,19 @@ def _sharded_step(m, ids, labels, x_num, train, next_ids=None):
         ulo, um, uhi = uoff[c], umid[c], uoff[c + 1]
         hs = []
         gather(recv_ids[lo:mid], mid - lo, own_rows[lo:mid] if m.use_emb else None, own_lin[lo:mid] if m.use_linear else None)
-        if m.use_emb:
-            hs.append(comm.all_to_all(got_rows[ulo:um], own_rows[lo:mid], sc0[c], rc0[c], True))
-        if m.use_linear:
-            hs.append(comm.all_to_all(got_lin[ulo:um], own_lin[lo:mid], sc0[c], rc0[c], True))
+        if packed:
+            hs.append(comm.all_to_all(got_rec[ulo:um], own_rec[lo:mid], sc0[c], rc0[c], True))
+        else:
+            if m.use_emb:
+                hs.append(comm.all_to_all(got_rows[ulo:um], own_rows[lo:mid], sc0[c], rc0[c], True))
+            if m.use_linear:
+                hs.append(comm.all_to_all(got_lin[ulo:um], own_lin[lo:mid], sc0[c], rc0[c], True))
         gather(recv_ids[mid:hi], hi - mid, got_rows[um:uhi] if m.use_emb else None, got_lin[um:uhi] if m.use_linear else None)
         return hs
 
-    d_rows = m._buf("d_rows", (cap_u, E))[:max(U, 1)] if (train and m.use_emb) else None      # one row per distinct request, send order
-    d_lin = m._buf("d_lin", (cap_u,))[:max(U, 1)] if (train and m.use_linear) else None
-    r_rows = m._buf("recv_d_rows", (cap_r, E))[:nr] if (train and m.use_emb) else None
-    r_lin = m._buf("recv_d_lin", (cap_r,))[:nr] if (train and m.use_linear) else None
+    # gradients: one row (record) per distinct request, in send order; the owner's side receives them in request order
+    d_rec, d_rows, d_lin = rec("d", cap_u, max(U, 1), m.use_emb, m.use_linear) if train else (None, None, None)
+    r_rec, r_rows, r_lin = rec("recv_d", cap_r, nr, m.use_emb, m.use_linear) if train else (None, None, None)
     logits_all = m._buf("logits_all", (B,)) if C > 1 else None
     loss_all = m._buf("loss_all", (1,)) if C > 1 else None
     acc = m._buf("d_grad_acc", (m.P,)) if (train and C > 1) else None
@@ -431,11 +450,14 @@ def _sharded_step(m, ids, labels, x_num, train, next_ids=None):
                 k.mi_entry_grads_segsum(got_rows if m.use_mf else None, seg, sorted_entry, u0, cnt,
                                         d_concat if m.use_emb else None, m.D, cc["sumv"] if m.use_mf else None,
                                         dlogit if m.use_mf else None, dlogit if m.use_linear else None, b0, F, E,
-                                        o_rows, o_lin, row0)
-        if m.use_emb:
-            grad_h.append(comm.all_to_all(r_rows[lo:mid], d_rows[ulo:um], rc0[c], sc0[c], True))
-        if m.use_linear:
-            grad_h.append(comm.all_to_all(r_lin[lo:mid], d_lin[ulo:um], rc0[c], sc0[c], True))
+                                        o_rows, o_lin, row0, xs, xs)
+        if packed:
+            grad_h.append(comm.all_to_all(r_rec[lo:mid], d_rec[ulo:um], rc0[c], sc0[c], True))
+        else:
+            if m.use_emb:
+                grad_h.append(comm.all_to_all(r_rows[lo:mid], d_rows[ulo:um], rc0[c], sc0[c], True))
+            if m.use_linear:
+                grad_h.append(comm.all_to_all(r_lin[lo:mid], d_lin[ulo:um], rc0[c], sc0[c], True))
 
     def backward(cc, dlogit, chunks, b0):
         """MLP backward of the examples b0..; the gradients of `chunks` leave as soon as the input layer's data gradient
@@ -458,7 +480,7 @@ def _sharded_step(m, ids, labels, x_num, train, next_ids=None):
         handles = [serve(c) for c in range(C)]
         pieces = [(c * Bc, (c + 1) * Bc, (lambda c=c: _wait(handles[c]))) for c in range(C)]
         m._chunk = 0
-        cc = m._forward(ids, x_num, train, (got_rows, got_lin, zero_off, slot2), pieces=pieces)
+        cc = m._forward(ids, x_num, train, (got_rows, got_lin, zero_off, slot2, xs or E, xs or 1), pieces=pieces)
         logits, loss, dlogit = m._head(cc, labels, train, global_batch=B * m.shard.world)
         if train:
             backward(cc, dlogit, range(C), 0)
@@ -472,7 +494,7 @@ def _sharded_step(m, ids, labels, x_num, train, next_ids=None):
             rows_h = nxt
             sl = slice(c * Bc, (c + 1) * Bc)
             m._chunk = c
-            cc = m._forward(ids[sl], None if x_num is None else x_num[sl], train, (got_rows, got_lin, zero_off, slot2[sl]))
+            cc = m._forward(ids[sl], None if x_num is None else x_num[sl], train, (got_rows, got_lin, zero_off, slot2[sl], xs or E, xs or 1))
             logits, loss, dlogit = m._head(cc, None if labels is None else labels[sl], train, global_batch=B * m.shard.world)
             if C > 1:
                 logits_all[sl].copy_(logits)
@@ -504,7 +526,7 @@ def _sharded_step(m, ids, labels, x_num, train, next_ids=None):
         r["gate"].record()                                      # (the next batch's owner-side work starts here: _own_ahead)
     if book is not None:
         bs_entry, buniq, bseg, bnum = book
-        m._apply(buniq, bseg, bs_entry, bnum, nr, r_rows, r_lin)
+        m._apply(buniq, bseg, bs_entry, bnum, nr, r_rows, r_lin, d_stride=xs)
     else:
         m._apply(None, None, None, None, 0, None, None)
     _own_ahead(m)

@@ -57,7 +57,7 @@ class NumpyKernels:
             _np(slot)[se[sg[u]:sg[u + 1]]] = u
 
     def mi_entry_grads_segsum(self, rows, seg, sorted_entry, u_begin, u_count, d_concat, ldd, sumv, dlf, dll, b0, F, E,
-                              out_rows, out_lin, out_row0=0):
+                              out_rows, out_lin, out_row0=0, rows_stride=0, out_stride=0):
         sg, se = _np(seg), _np(sorted_entry)
         for u in range(u_begin, u_begin + u_count):
             g = np.zeros(E, np.float32)
@@ -113,7 +113,7 @@ class NumpyKernels:
         if lin is not None:
             _np(lin)[:] = _np(lin_w)[rows].sum(1)
 
-    def mi_gather_rows(self, table, lin_w, rows, n, E, out_rows, out_lin, ls=1, ts=0):
+    def mi_gather_rows(self, table, lin_w, rows, n, E, out_rows, out_lin, ls=1, ts=0, out_stride=0):
         r = _np(rows)[:n]
         if table is not None:
             _np(out_rows)[:n] = _np(table)[r]
@@ -269,7 +269,7 @@ class NumpyKernels:
                 ls[r] = step_to
 
     def mi_sparse_apply(self, table, t0, t1, lin_w, l0, l1, last_step, uniq, seg, sorted_entry, num_uniq, n_max,
-                        d_rows, d_lin, E, step, hp, ls=1, ts=0):
+                        d_rows, d_lin, E, step, hp, ls=1, ts=0, grad_stride=0):
         h = _hyper(hp)
         U = int(_np(num_uniq)[0])
         rows = _np(uniq)[:U].astype(np.int64)

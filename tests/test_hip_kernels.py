@@ -99,9 +99,13 @@ def test_embed_fwd_linear_only_and_gather_rows(lib):
     out = torch.empty(B * F, E, device="cuda")
     olin = torch.empty(B * F, device="cuda")
     t = dev(table)
-    _chk(lib.mi_gather_rows(_p(t), _p(lw), _p(grow), B * F, E, _p(out), _p(olin), 1, 0, _st()))
+    _chk(lib.mi_gather_rows(_p(t), _p(lw), _p(grow), B * F, E, _p(out), _p(olin), 1, 0, 0, _st()))
     assert np.array_equal(out.cpu().numpy(), table[rows.reshape(-1)])
     assert np.array_equal(olin.cpu().numpy(), lin_w[rows.reshape(-1)])
+    # the packed exchange's form (round 4): one record [row | weight | pad x 3] of E + 4 floats per request
+    rec = torch.full((B * F, E + 4), 7.0, device="cuda")
+    _chk(lib.mi_gather_rows(_p(t), _p(lw), _p(grow), B * F, E, _p(rec), rec.data_ptr() + 4 * E, 1, 0, E + 4, _st()))
+    assert torch.equal(rec[:, :E], out) and torch.equal(rec[:, E], olin) and float(rec[:, E + 1:].min()) == 7.0
 
 
 @pytest.mark.parametrize("E,F,B", [(4, 26, 33), (64, 26, 129), (16, 3, 50)])
@@ -440,7 +444,7 @@ def test_sparse_apply_fused_equals_bwd_then_apply_bitwise(lib, name):
             _chk(lib.mi_embed_fm_linear_bwd(_p(d_dc), F * E, _p(d_cc), F * E, None, _p(d_sv), _p(d_dl), _p(d_dl), None, B, F,
                                             E, _p(d_rows), _p(d_lin), _st()))
             _chk(lib.mi_sparse_apply(_p(T), _p(t0), _p(t1), _p(L), _p(l0), _p(l1), None, _p(uq), _p(sg), _p(se),
-                                     _p(nu), n, _p(d_rows), _p(d_lin), E, 1, C.byref(h), 1, 0, _st()))
+                                     _p(nu), n, _p(d_rows), _p(d_lin), E, 1, C.byref(h), 1, 0, 0, _st()))
         torch.cuda.synchronize()
         res.append((T.cpu(), L.cpu(), t0.cpu(), t1.cpu()))
     for x, y in zip(*res):
@@ -475,7 +479,7 @@ def test_sparse_apply_long_segments(lib, E):
     for _ in range(2):
         T, L = dev(table), dev(lin_w)
         _chk(lib.mi_sparse_apply(_p(T), None, None, _p(L), None, None, None, _p(uq), _p(sg), _p(se), _p(nu), n, _p(dr),
-                                 _p(dli), E, 1, C.byref(h), 1, 0, _st()))
+                                 _p(dli), E, 1, C.byref(h), 1, 0, 0, _st()))
         torch.cuda.synchronize()
         outs.append((T.cpu().numpy(), L.cpu().numpy()))
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
@@ -752,14 +756,47 @@ def test_entry_grads_segsum_writes_a_range_at_its_own_base(lib):
     d_concat = dev(rng.standard_normal((B, F * E)).astype(np.float32))
     dl = dev(rng.standard_normal(B).astype(np.float32))
     full_r = torch.full((U, E), 7.0, device="cuda"); full_l = torch.full((U,), 7.0, device="cuda")
-    _chk(lib.mi_entry_grads_segsum(None, _p(sg), _p(se), 0, U, _p(d_concat), F * E, None, None, _p(dl), 0, F, E, _p(full_r), _p(full_l), 0, _st()))
+    _chk(lib.mi_entry_grads_segsum(None, _p(sg), _p(se), 0, U, _p(d_concat), F * E, None, None, _p(dl), 0, F, E, _p(full_r), _p(full_l), 0, 0, 0, _st()))
     u0, cnt = U // 3, U // 2
     part_r = torch.full((cnt + 2, E), 7.0, device="cuda"); part_l = torch.full((cnt + 2,), 7.0, device="cuda")
-    _chk(lib.mi_entry_grads_segsum(None, _p(sg), _p(se), u0, cnt, _p(d_concat), F * E, None, None, _p(dl), 0, F, E, _p(part_r), _p(part_l), u0, _st()))
+    _chk(lib.mi_entry_grads_segsum(None, _p(sg), _p(se), u0, cnt, _p(d_concat), F * E, None, None, _p(dl), 0, F, E, _p(part_r), _p(part_l), u0, 0, 0, _st()))
     assert torch.equal(part_r[:cnt], full_r[u0:u0 + cnt]) and torch.equal(part_l[:cnt], full_l[u0:u0 + cnt])
     assert float(part_r[cnt:].min()) == 7.0 and float(part_l[cnt:].min()) == 7.0
     assert lib.mi_entry_grads_segsum(None, _p(sg), _p(se), u0, cnt, _p(d_concat), F * E, None, None, _p(dl), 0, F, E, _p(part_r), _p(part_l),
-                                     u0 + 1, _st()) != 0
+                                     u0 + 1, 0, 0, _st()) != 0
+    # the packed exchange's form (round 4): the rows the FM term reads and the sums it writes are records of E + 4 floats
+    # [row | weight | pad]; the same bits as with separate arrays, pads untouched
+    got = dev(rng.standard_normal((U, E)).astype(np.float32))
+    sumv = dev(rng.standard_normal((B, E)).astype(np.float32))
+    ref_r = torch.empty(U, E, device="cuda"); ref_l = torch.empty(U, device="cuda")
+    _chk(lib.mi_entry_grads_segsum(_p(got), _p(sg), _p(se), 0, U, _p(d_concat), F * E, _p(sumv), _p(dl), _p(dl), 0, F, E, _p(ref_r), _p(ref_l), 0, 0, 0, _st()))
+    got_rec = torch.full((U, E + 4), 3.0, device="cuda"); got_rec[:, :E] = got
+    out_rec = torch.full((cnt + 1, E + 4), 7.0, device="cuda")
+    _chk(lib.mi_entry_grads_segsum(_p(got_rec), _p(sg), _p(se), u0, cnt, _p(d_concat), F * E, _p(sumv), _p(dl), _p(dl), 0, F, E,
+                                   _p(out_rec), out_rec.data_ptr() + 4 * E, u0, E + 4, E + 4, _st()))
+    assert torch.equal(out_rec[:cnt, :E], ref_r[u0:u0 + cnt]) and torch.equal(out_rec[:cnt, E], ref_l[u0:u0 + cnt])
+    assert float(out_rec[:, E + 1:].min()) == 7.0 and float(out_rec[cnt:].min()) == 7.0
+    # ... and mi_sparse_apply takes gradients in that form (grad_stride): same bits as from two arrays
+    from mi355x_rec.engine import OptimizerSpec
+    h = OptimizerSpec("Adagrad", 0.05).hparams(0.0)
+    R = 300
+    outs = []
+    for packed in (False, True):
+        W = dev(np.linspace(-1, 1, R * E, dtype=np.float32).reshape(R, E)); A = torch.full((R, E), 0.1, device="cuda")
+        L = dev(np.linspace(-1, 1, R, dtype=np.float32)); LA = torch.full((R,), 0.1, device="cuda")
+        gr = dev(rng.standard_normal((n, E)).astype(np.float32)) if not packed else None
+        if packed:
+            grec = torch.full((n, E + 4), 9.0, device="cuda"); grec[:, :E] = g_keep; grec[:, E] = gl_keep
+            pr, pl, st_ = grec.data_ptr(), grec.data_ptr() + 4 * E, E + 4
+        else:
+            g_keep, gl_keep = gr, dev(rng.standard_normal(n).astype(np.float32))
+            pr, pl, st_ = g_keep.data_ptr(), gl_keep.data_ptr(), 0
+        _chk(lib.mi_sparse_apply(_p(W), _p(A), None, _p(L), _p(LA), None, None, _p(uq), _p(sg), _p(se), _p(nu), n, pr, pl, E, 1,
+                                 C.byref(h), 1, 0, st_, _st()))
+        torch.cuda.synchronize()
+        outs.append((W, A, L, LA))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
 
 
 def test_binary_predictions_match_oracle(lib):
@@ -969,7 +1006,7 @@ def test_sparse_apply_and_catchup_bit_exact(lib, name, E, layout):
         _chk(lib.mi_sparse_apply(_p(dW), _p(d_ws0) if need0 else None, _p(d_ws1) if need1 else None, _p(dL),
                                  _p(d_ls0) if need0 else None, _p(d_ls1) if need1 else None,
                                  _p(last) if name == "Adam" else None, _p(uq), _p(sg), _p(se), _p(nu), n,
-                                 _p(dg), _p(dgl), E, step, C.byref(h), 1, tst, _st()))
+                                 _p(dg), _p(dgl), E, step, C.byref(h), 1, tst, 0, _st()))
         torch.cuda.synchronize()
     if name == "Adam":   # bring the rows that sat out the last steps up to date: all-rows catch-up
         _chk(lib.mi_sparse_catchup(_p(dW), _p(d_ws0), _p(d_ws1), _p(dL), _p(d_ls0), _p(d_ls1), _p(last), None, None,

@@ -97,7 +97,7 @@ def main():
     lin_state = torch.zeros(Rl, 4, device=dev)
     own_rows, own_lin = torch.empty(nr, E, device=dev), torch.empty(nr, device=dev)
     line("mi_gather_rows", timed(lambda: ck(lib.mi_gather_rows(table.data_ptr(), lin_state.data_ptr(), recv_ids.data_ptr(), nr, E, own_rows.data_ptr(),
-                                                               own_lin.data_ptr(), 4, 0, st()))), nr * (8 * E + 4 + 16 + 4),
+                                                               own_lin.data_ptr(), 4, 0, 0, st()))), nr * (8 * E + 4 + 16 + 4),
          "rows read + written, the 16-byte wide record read")
 
     # requester side: per-request gradient sums from d_concat (the chunk's entries)
@@ -110,7 +110,7 @@ def main():
     for fm in (True, False):
         f = lambda: ck(lib.mi_entry_grads_segsum(own_rows.data_ptr() if fm else None, sg.data_ptr(), se.data_ptr(), 0, u0,
                                                  d_concat.data_ptr(), F * E, sumv.data_ptr() if fm else None, dlogit.data_ptr() if fm else None,
-                                                 dlogit.data_ptr(), 0, F, E, d_rows.data_ptr(), d_lin.data_ptr(), 0, st()))
+                                                 dlogit.data_ptr(), 0, F, E, d_rows.data_ptr(), d_lin.data_ptr(), 0, 0, 0, st()))
         ne = Bc * F
         line("mi_entry_grads_segsum (%s)" % ("DeepFM" if fm else "no FM term"), timed(f),
              ne * (4 * E + 4 + 4) + u0 * (4 * E + 4 + (4 * E if fm else 0)) + (ne * 4 * E if fm else 0),
