@@ -96,6 +96,9 @@ def parse():
     ap.add_argument("--route-ahead", type=int, choices=[0, 1], default=None,
                     help="row-sharded step: 0 = the whole step on ONE RCCL communicator (no routing of the next batch ahead on a "
                          "second one); default: parallel.RowShard's (1)")
+    ap.add_argument("--packed-exchange", type=int, choices=[0, 1], default=None,
+                    help="row-sharded step: 1 = rows + wide weights (and their gradients) travel as one record of E + 4 floats per "
+                         "request: one collective per chunk and direction instead of two (default: parallel.RowShard's, 0)")
     ap.add_argument("--collective-timeout", type=float, default=300.0,
                     help="seconds after which a stuck collective aborts the process (non-zero exit, rank and collective named by "
                          "torch.distributed's watchdog)")
@@ -347,7 +350,8 @@ def main():
         from mi355x_rec.parallel import RowShard
         shard = RowShard(rank, world, chunks=args.chunks,
                          chunk_compute=None if args.chunk_compute is None else bool(args.chunk_compute),
-                         route_ahead=None if args.route_ahead is None else bool(args.route_ahead))
+                         route_ahead=None if args.route_ahead is None else bool(args.route_ahead),
+                         **({} if args.packed_exchange is None else {"packed": bool(args.packed_exchange)}))
     m = DeepFM([V] * F, embedding_size=E, hidden_units=HIDDEN, dropout=DROPOUT,
                optimizer=OptimizerSpec("Adam", 0.001), device=device, seed=SEED, shard=shard, gemm=args.gemm,
                catchup=args.catchup)

@@ -32,7 +32,7 @@ import torch.distributed as dist
 
 
 class RowShard:
-    def __init__(self, rank, world, group=None, chunks=None, chunk_compute=None, route_ahead=None, packed=True):
+    def __init__(self, rank, world, group=None, chunks=None, chunk_compute=None, route_ahead=None, packed=False):
         """chunks: pipeline depth of a train step (None: chosen from the batch and world size, see _n_chunks).
         route_ahead: True (default) — an announced next batch is routed during this step, on a side stream and a SECOND
         RCCL communicator (see Comm / _route_ahead); False — the whole step runs on ONE communicator and one stream
@@ -52,8 +52,11 @@ class RowShard:
         self.chunks = chunks
         self.chunk_compute = (self.world < 8) if chunk_compute is None else bool(chunk_compute)
         self.route_ahead = True if route_ahead is None else bool(route_ahead)
-        # packed: rows and wide weights (and their gradients) travel as one record per request — one collective per chunk
-        # and direction instead of two (_sharded_step); False keeps them in separate buffers (A/B, tests)
+        # packed: rows and wide weights (and their gradients) travel as one record of E + 4 floats per request — one
+        # collective per chunk and direction instead of two (_sharded_step).  OFF by default: measured with one rank
+        # (bench.py --force-shard, profiles/r04_sharded_one_rank.md) the 272-byte records cost every kernel that walks them
+        # a third cache line per row — gather_rows +0.04, the planes gather +0.05, the segment sum +0.05, the sparse apply
+        # +0.13 ms per step — more than two small RCCL launches per chunk can give back.
         self.packed = bool(packed)
         self.comm = None
 

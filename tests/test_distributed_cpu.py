@@ -54,7 +54,7 @@ def _worker(rank, world, port, cfg, out_q, device="cpu", backend="gloo"):
         lin_opt = OptimizerSpec(*extra["lin_opt"]) if "lin_opt" in extra else None
         m = DeepFM(vocab, n_numeric=nn, embedding_size=E, hidden_units=hidden, use_linear=flags[0], use_mf=flags[1],
                    use_dnn=flags[2], optimizer=OptimizerSpec(opt_name, lr), device=device, shard=RowShard(rank, world, chunks=chunks, chunk_compute=extra.get("chunk_compute"),
-                                                                                     route_ahead=extra.get("route_ahead"), packed=extra.get("packed", True)),
+                                                                                     route_ahead=extra.get("route_ahead"), packed=extra.get("packed", False)),
                    numeric=extra.get("numeric", "embed"), linear_optimizer=lin_opt, reduction=extra.get("reduction", "mean"),
                    _kernels=kernels)
         m.load_oracle_params(p)
@@ -203,14 +203,16 @@ def test_single_communicator_step_equals_big_batch(cfg, world):
     assert all(res[r][1]["route_ahead_hits"] == 0 and not res[r][1]["second_communicator"] for r in range(world))
 
 
-@pytest.mark.parametrize("cfg", [
-    ([9, 13, 5, 6], 8, [16, 8], 32, 0, "Adam", 0.001, 3, (True, True, True), 2, dict(packed=False)),
-    ([9, 13, 5, 6], 8, [16, 8], 16, 3, "Adagrad", 0.05, 2, (True, False, True), 2,
-     dict(numeric="raw", lin_opt=("Ftrl", 0.2), reduction="sum", chunk_compute=False, packed=False))])
-def test_unpacked_exchange_equals_big_batch(cfg):
-    """RowShard(packed=False): rows and wide weights (and their gradients) in separate buffers, two collectives per chunk and
-    direction — the form of rounds 1-3; the default since round 4 packs them into one record per request."""
-    check_against_big_batch(cfg, _run(cfg, 2), 2)
+@pytest.mark.parametrize("cfg,world", [
+    (([9, 13, 5, 6], 8, [16, 8], 32, 0, "Adam", 0.001, 3, (True, True, True), 2, dict(packed=True, announce=True)), 2),
+    (([9, 13, 5, 6], 8, [16, 8], 16, 3, "Adagrad", 0.05, 2, (True, False, True), 2,
+      dict(numeric="raw", lin_opt=("Ftrl", 0.2), reduction="sum", chunk_compute=False, packed=True)), 2),
+    (([9, 13, 5, 6], 8, [16, 8], 16, 0, "Adam", 0.001, 3, (True, True, True), 2, dict(chunk_compute=False, packed=True)), 4)])
+def test_packed_exchange_equals_big_batch(cfg, world):
+    """RowShard(packed=True): a request's row and wide weight (and their gradients) travel as ONE record of E + 4 floats —
+    one collective per chunk and direction instead of two.  Same results; off by default (the one-rank
+    measurement: profiles/r04_sharded_one_rank.md)."""
+    check_against_big_batch(cfg, _run(cfg, world), world)
 
 
 def test_four_rank_pipelined_step_equals_big_batch():

@@ -28,7 +28,12 @@ pytestmark = pytest.mark.gpu
                                   dict(numeric="raw", lin_opt=("Ftrl", 0.2), reduction="sum", chunk_compute=False)),
                                  # the whole step on ONE communicator (RowShard(route_ahead=False)): announced batches are ignored
                                  ([50, 30, 20, 40], 64, [64, 32], 256, 0, "Adam", 0.001, 3, (True, True, True), 2,
-                                  dict(chunk_compute=False, announce=True, route_ahead=False))])
+                                  dict(chunk_compute=False, announce=True, route_ahead=False)),
+                                 # the packed exchange: rows + wide weights (and their gradients) as records of E + 4 floats
+                                 ([50, 30, 20, 40], 64, [64, 32], 256, 0, "Adam", 0.001, 3, (True, True, True), 2,
+                                  dict(chunk_compute=False, announce=True, packed=True)),
+                                 ([50, 30, 20, 40], 32, [64, 32], 128, 3, "Adagrad", 0.05, 2, (True, False, True), 2,
+                                  dict(numeric="raw", lin_opt=("Ftrl", 0.2), reduction="sum", packed=True))])
 def test_two_ranks_one_gpu_gloo(cfg):
     check_against_big_batch(cfg, _run(cfg, 2, device="cuda", backend="gloo"), 2, tol=3.0)
 
