@@ -533,6 +533,23 @@ int32_t mi_dense_bwd_data_planes(const mi_planes_t* dY, const mi_planes_t* W, co
                                  int64_t lddx, const mi_planes_t* dXp, int64_t M, int32_t N, int32_t K, float keep_prob,
                                  float* amax_out, const uint32_t* mask_bits, int64_t mask_ld, mi_stream_t stream);
 
+/* The logits layer AND the head of a TRAIN step in one pass over the last hidden layer's output X [M][K] (round 4): replaces
+ * deep_fm.py:108 (tf.layers.dense(net, 1)), :111 (logits += dnn_logits), :118-125 (the sigmoid cross-entropy head) and
+ * their gradients — five launches of the entries above and below (mi_dense_fwd's N = 1 form, mi_sigmoid_ce_head,
+ * mi_dense_bwd_weight's N = 1 form, mi_dense_bwd_data_vec_planes) — with two:
+ *   dnn[m] = X[m,:] . w + b;  logits[m] = lin[m] + lin_bias + fm[m] + dnn[m]  (lin / fm may be NULL);  loss_out = sum of the
+ *   per-example sigmoid cross-entropy * loss_scale;  d_logit[m] = (sigmoid(logits) - label) * loss_scale;  d_logit_sum (may be
+ *   NULL) and db = sum d_logit;  dW[k] = sum_m X[m][k] d_logit[m];  dXp (planes, + dX in fp32 if not NULL) = d_logit[m] w[k],
+ *   kept where mask_bits says so and divided by keep_prob (mask_bits NULL: no mask) — per example the bits of the unfused
+ *   sequence; the sums over examples associate differently (fixed order, reproducible).  K in {64, 128, 256}; X 16-byte
+ *   aligned, ldx a multiple of 4. */
+size_t mi_logits_head_fused_workspace_bytes(int64_t M, int32_t K);
+int32_t mi_logits_head_fused(const float* X, int64_t ldx, const float* w, const float* b, const float* lin, const float* lin_bias,
+                             const float* fm, const uint8_t* labels, int64_t M, int32_t K, float loss_scale,
+                             const uint32_t* mask_bits, int64_t mask_ld, float keep_prob, float* dnn, float* logits,
+                             float* loss_out, float* d_logit, float* d_logit_sum, float* dW, float* db, const mi_planes_t* dXp,
+                             float* dX, int64_t lddx, float* amax_out, void* workspace, size_t workspace_bytes, mi_stream_t stream);
+
 /* The data gradient of the N = 1 logits layer (deep_fm.py:108 backward) with the result as planes:
  * dX[m][k] = dY[m] * W[k], kept where Xact[m][k] > 0 and divided by keep_prob (Xact == NULL: no mask) — the
  * arithmetic of mi_dense_bwd_data's N = 1 form with ReLU, bit for bit — into dXp (required) and, if not NULL, dX.

@@ -117,6 +117,9 @@ SIGNATURES = {
     "mi_dense_fwd_planes": (_i32, [_pl, _pl, _p, _p, _i64, _pl, _i64, _i32, _i32, _i32, _f32, _u64, _p, _p, _i64, _p]),
     "mi_dense_bwd_data_planes": (_i32, [_pl, _pl, _pl, _p, _i64, _pl, _i64, _i32, _i32, _f32, _p, _p, _i64, _p]),
     "mi_embed_fm_planes_fwd": (_i32, [_p, _p, _p, _i64, _i32, _i32, _p, _p, _pl, _p, _p, _i32, _i32, _i64, _p]),
+    "mi_logits_head_fused_workspace_bytes": (_sz, [_i64, _i32]),
+    "mi_logits_head_fused": (_i32, [_p, _i64, _p, _p, _p, _p, _p, _p, _i64, _i32, _f32, _p, _i64, _f32, _p, _p, _p, _p, _p, _p, _p, _pl,
+                                    _p, _i64, _p, _p, _sz, _p]),
     "mi_head_workspace_bytes": (_sz, [_i64]),
     "mi_sigmoid_ce_head": (_i32, [_p, _p, _p, _p, _p, _i64, _f32, _p, _p, _p, _p, _p, _sz, _p]),
     "mi_colsum_workspace_bytes": (_sz, [_i64, _i32]),

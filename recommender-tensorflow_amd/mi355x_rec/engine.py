@@ -837,9 +837,14 @@ class DeepFM:
                     k.mi_split_rows(concat, ld, B, ld, 0, self._planes("x0p", B, ld), None)
                 self._split_weights(train)
             xp = "x0p"
+            # TRAIN on the planes path: the logits layer (N = 1) runs inside the fused logits + head launch (_head)
+            c["tail_fused"] = bool(train and self._tail_fusable())
             for i, (_, _, fan, h) in enumerate(self.layers):
                 last = i == nh
                 y = self._buf("act%d" % i, (B, h))
+                if last and c["tail_fused"]:
+                    acts.append(y)
+                    break
                 if self.planes and not last:
                     # the next layer's operand as planes straight from the epilogue when a workgroup owns
                     # whole rows (h <= 512); the fp32 copy feeds the logits layer / a weight gradient on fp32 operands
@@ -875,6 +880,14 @@ class DeepFM:
                  gathered=gathered, g_table=table, g_off=field_off, g_ts=tst)
         return c
 
+    def _tail_fusable(self):
+        """the logits layer + head of a train step as ONE launch (mi_logits_head_fused): planes path, a hidden layer of 64 /
+        128 / 256 units below a one-unit logits layer"""
+        if not self.TAIL_FUSED or not self.planes or len(self.layers) < 2 or not hasattr(self.k, "mi_logits_head_fused"):
+            return False
+        _, _, fan, h = self.layers[-1]
+        return h == 1 and fan in (64, 128, 256)
+
     def _head(self, c, labels, want_grad, global_batch=None):
         k = self.k
         B = c["B"]
@@ -889,6 +902,28 @@ class DeepFM:
         lb = self.dense[self.lin_bias_off:] if self.use_linear else None
         # d loss / d linear bias = sum_b dlogit lands straight in the dense gradient buffer
         dsum = self.d_grad[self.lin_bias_off:] if (want_grad and self.use_linear) else None
+        if c.get("tail_fused"):
+            nh = len(self.layers) - 1
+            _, _, fan, _ = self.layers[nh]
+            x = c["acts"][nh - 1]
+            if want_grad and labels is not None:
+                # forward AND backward of the logits layer with the head between them: dnn, logits, loss, dlogit, the bias
+                # gradient(s), the layer's weight gradient and its data gradient as planes (+ fp32 where the layer below's
+                # weight gradient still reads fp32) — one pass over the last hidden layer's output
+                mb = self._ws.get("mbits%d" % (nh - 1))
+                mb = mb[:B * ((fan + 31) // 32)].view(B, (fan + 31) // 32) if mb is not None else None
+                dx = None if self._wgrad_planes_ok(B, nh - 1) else self._buf("dact%d" % nh, (B, fan))
+                tws = self._bytes("tail_ws", k.query("mi_logits_head_fused_workspace_bytes", B, fan))
+                k.mi_logits_head_fused(x, fan, self.kernel(nh), self.bias(nh), c["lin"], lb, c["fm"], labels, B, fan, float(scale),
+                                       mb, 0 if mb is None else mb.shape[1], c["keep"], c["acts"][nh], logits, loss, dlogit, dsum,
+                                       self.kernel(nh, self.d_grad), self.bias(nh, self.d_grad), self._planes("dy%dp" % (nh - 1), B, fan),
+                                       dx, fan, self._av("dy%d" % (nh - 1)), tws, tws.numel())
+                c["dnn"] = c["acts"][nh].view(B)
+                c["tail_done"] = True
+                return logits, loss, dlogit
+            # (a forward made for training but no gradient asked for: the logits layer as its own launch after all)
+            k.mi_dense_fwd(x, fan, self.kernel(nh), self.bias(nh), c["acts"][nh], 1, B, 1, fan, 0, 1.0, self._layer_seed(nh), None)
+            c["dnn"] = c["acts"][nh].view(B)
         k.mi_sigmoid_ce_head(c["lin"], lb, c["fm"], c["dnn"], labels, B, float(scale), logits, loss, dlogit, dsum,
                              ws, ws.numel())
         return logits, loss, dlogit
@@ -939,6 +974,7 @@ class DeepFM:
     LIN_SIDE = True           # the wide part's catch-up on the wide part's stream, beside the row kernel (_catchup)
     BYGAP_AHEAD = True        # the next batch's staleness order made a step ahead (_by_gap_ahead)
     ROW_RECORDS = True        # a table row and its optimizer slots as one [w | slot0 | slot1] record (__init__)
+    TAIL_FUSED = True         # logits layer + head + the layer's backward as one launch (_head: mi_logits_head_fused)
 
     def _catchup(self, uniq, num_uniq, n_max, defer=False, by_gap=None):
         """defer: the rows are about to be applied in this same step by ONE mi_sparse_apply call, which
@@ -1188,6 +1224,10 @@ class DeepFM:
             ws = self._bytes("wgrad_ws", wsz)
             for i in range(nh, -1, -1):
                 _, _, fan, h = self.layers[i]
+                if i == nh and c.get("tail_done"):        # (the fused logits + head launch made dW, db and the planes of dX)
+                    dy, lddy = self._ws.get("dact%d" % nh), fan
+                    dy = dy[:B * fan].view(B, fan) if dy is not None else None
+                    continue
                 x = c["acts"][i - 1] if i else c["concat"]
                 ldx = self.layers[i - 1][3] if i else self.D
                 # abs-max of dY: known for every layer but the last (dlogit feeds the N = 1 layer,

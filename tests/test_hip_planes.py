@@ -445,3 +445,69 @@ def test_logits_layer_data_gradient_as_planes_matches_gemv_then_split_bitwise(li
                                               mbt.data_ptr(), Kw, _st()))
         assert np.array_equal(got3.cpu().numpy().view(np.uint32), ref.cpu().numpy().view(np.uint32))
         assert np.array_equal(gotp3.bits(), refp.bits())
+
+
+@pytest.mark.parametrize("M,K,keep,parts", [(300, 128, 0.9, (True, True)), (4099, 64, 1.0, (True, False)), (1000, 256, 0.75, (False, True)),
+                                            (65, 128, 0.9, (False, False))])
+def test_logits_head_fused_equals_the_unfused_sequence(lib, M, K, keep, parts):
+    """mi_logits_head_fused (round 4: the logits layer's forward, the head, and the layer's backward in one pass over the last
+    hidden layer's output) against the five launches it replaces — mi_dense_fwd (N = 1), mi_sigmoid_ce_head, mi_dense_bwd_weight
+    (N = 1), mi_dense_bwd_data_vec_planes: the logits layer's dot product to 2e-6 of sum |x w|; from there on everything per
+    example (logits, d_logit, the planes and the fp32 copy of the data gradient, its abs-max) bit for bit, the sums over examples
+    (loss, d_logit_sum = db, dW) to 1e-6 of their size (another association), twice the same bits."""
+    from mi355x_rec import _lib as L
+    has_lin, has_fm = parts
+    rng = np.random.default_rng(M + K)
+    X = (np.maximum(rng.standard_normal((M, K)), 0) * (rng.random((M, K)) < keep) / keep).astype(np.float32)     # a relu + dropout layer's output
+    w = (rng.standard_normal(K) / np.sqrt(K)).astype(np.float32)
+    b = np.float32(0.03)
+    lin = rng.standard_normal(M).astype(np.float32) * 0.1; fm = rng.standard_normal(M).astype(np.float32) * 0.1
+    y = (rng.random(M) < 0.3).astype(np.uint8)
+    scale = np.float32(1.0 / M)
+    Kw = (K + 31) // 32
+    padded = np.zeros((M, Kw * 32), bool); padded[:, :K] = X > 0
+    words = (padded.reshape(M, Kw, 32).astype(np.uint64) << np.arange(32, dtype=np.uint64)).sum(2).astype(np.uint32)
+    dX_, dw, db_, dlin, dfm, dy_, dbits = dev(X), dev(w), dev(np.array([b], np.float32)), dev(lin), dev(fm), dev(y), dev(words.view(np.int32))
+    lb = dev(np.array([0.07], np.float32))
+    pl = dlin.data_ptr() if has_lin else None
+    pf = dfm.data_ptr() if has_fm else None
+    # ---- fused, twice
+    outs = []
+    for _ in range(2):
+        dnn1 = torch.full((M,), float("nan"), device="cuda"); logits1 = torch.empty(M, device="cuda"); loss1 = torch.empty(1, device="cuda")
+        dl1 = torch.empty(M, device="cuda"); ds1 = torch.empty(1, device="cuda"); dW1 = torch.empty(K, device="cuda"); dB1 = torch.empty(1, device="cuda")
+        p1 = PB(lib, M, K); g1 = torch.full((M, K), float("nan"), device="cuda"); am1 = torch.zeros(L.AMAX_SLOTS, device="cuda")
+        tws = torch.empty(int(lib.mi_logits_head_fused_workspace_bytes(M, K)) + 256, dtype=torch.uint8, device="cuda")
+        _chk(lib.mi_logits_head_fused(dX_.data_ptr(), K, dw.data_ptr(), db_.data_ptr(), pl, lb.data_ptr(), pf, dy_.data_ptr(), M, K, float(scale),
+                                      dbits.data_ptr(), Kw, keep, dnn1.data_ptr(), logits1.data_ptr(), loss1.data_ptr(), dl1.data_ptr(), ds1.data_ptr(),
+                                      dW1.data_ptr(), dB1.data_ptr(), p1.ref, g1.data_ptr(), K, am1.data_ptr(), tws.data_ptr(), tws.numel(), _st()))
+        torch.cuda.synchronize()
+        outs.append((dnn1, logits1, loss1, dl1, ds1, dW1, dB1, p1.bits(), p1.exp.cpu().numpy(), g1, am1))
+    # ---- the unfused sequence (the head and the backward on the fused kernel's dnn)
+    dnn0 = torch.empty(M, device="cuda"); logits0 = torch.empty(M, device="cuda"); loss0 = torch.empty(1, device="cuda")
+    dl0 = torch.empty(M, device="cuda"); ds0 = torch.empty(1, device="cuda")
+    _chk(lib.mi_dense_fwd(dX_.data_ptr(), K, dw.data_ptr(), db_.data_ptr(), dnn0.data_ptr(), 1, M, 1, K, 0, 1.0, 0, None, _st()))
+    # the dot product: gemv_fwd_k's association, but hipcc contracts the two kernels' multiply-adds differently — to 2e-6 of
+    # sum |x w|; everything after it is compared on the fused kernel's own dnn
+    dnn1 = outs[0][0]
+    assert float(((dnn1 - dnn0).abs() / ((dX_.abs() * dw.abs()[None, :]).sum(1) + 1e-6)).max()) < 2e-6
+    dnn0 = dnn1.clone()
+    hws = torch.empty(int(lib.mi_head_workspace_bytes(M)) + 256, dtype=torch.uint8, device="cuda")
+    _chk(lib.mi_sigmoid_ce_head(pl, lb.data_ptr(), pf, dnn0.data_ptr(), dy_.data_ptr(), M, float(scale), logits0.data_ptr(), loss0.data_ptr(),
+                                dl0.data_ptr(), ds0.data_ptr(), hws.data_ptr(), hws.numel(), _st()))
+    dW0 = torch.empty(K, device="cuda"); dB0 = torch.empty(1, device="cuda")
+    wws = torch.empty(int(lib.mi_dense_bwd_weight_workspace_bytes(M, 1, K)) + 256, dtype=torch.uint8, device="cuda")
+    _chk(lib.mi_dense_bwd_weight(dX_.data_ptr(), K, dl0.data_ptr(), 1, dW0.data_ptr(), dB0.data_ptr(), M, 1, K, wws.data_ptr(), wws.numel(), None, _st()))
+    p0 = PB(lib, M, K); g0 = torch.empty(M, K, device="cuda"); am0 = torch.zeros(L.AMAX_SLOTS, device="cuda")
+    _chk(lib.mi_dense_bwd_data_vec_planes(dl0.data_ptr(), 1, dw.data_ptr(), None, K, keep, g0.data_ptr(), K, p0.ref, M, K, am0.data_ptr(),
+                                          dbits.data_ptr(), Kw, _st()))
+    dnn1, logits1, loss1, dl1, ds1, dW1, dB1, bits1, exp1, g1, am1 = outs[0]
+    bit = lambda a, b_: np.array_equal(a.cpu().numpy().view(np.uint32), b_.cpu().numpy().view(np.uint32))
+    assert bit(logits1, logits0) and bit(dl1, dl0) and bit(g1, g0)
+    assert np.array_equal(bits1, p0.bits()) and np.array_equal(exp1, p0.exp.cpu().numpy()) and float(am1.max()) == float(am0.max())
+    close = lambda a, b_, ref: float((a - b_).abs().max()) <= 1e-6 * float(ref.abs().max()) + 1e-12
+    assert close(loss1, loss0, loss0) and close(ds1, ds0, dl0.abs().sum()[None]) and close(dB1, dB0, dl0.abs().sum()[None])
+    assert close(dW1, dW0, (dX_.abs() * dl0.abs()[:, None]).sum(0))
+    assert bit(ds1, dB1)
+    for a, b_ in zip(outs[0], outs[1]):          # reproducible
+        assert np.array_equal(a, b_) if isinstance(a, np.ndarray) else torch.equal(a, b_)
