@@ -602,7 +602,10 @@ def main():
         total_bytes = gather_bytes if planes_gather else Bl * (F * (4 * E + (4 if wide_split else 8)) + 4 * E + (4 if wide_split else 8))
         achieved = gather_bytes / (g_ms * 1e-3) / 1e9
         gemm_keys = ("mi_dense_fwd", "mi_dense_fwd_gathered", "mi_dense_bwd_data", "mi_dense_bwd_weight", "mi_dense_bwd_weight_gathered",
-                     "mi_dense_fwd_planes", "mi_dense_bwd_data_planes", "mi_dense_bwd_weight_planes")
+                     "mi_dense_fwd_planes", "mi_dense_bwd_data_planes", "mi_dense_bwd_weight_planes",
+                     # (round 4: the logits layer's forward and backward run inside the fused logits + head launch — counted
+                     # here in full, the head's own ~10 us included)
+                     "mi_logits_head_fused")
         # (the planes path's own overhead launches count against it: they exist only because of it)
         gemm_overhead_keys = ("mi_dense_bwd_data_vec_planes", "mi_split_weights", "mi_absmax", "mi_split_rows")
         gemm_ms = sum(v[2] for k, v in km.items() if k in gemm_keys + gemm_overhead_keys) / args.steps

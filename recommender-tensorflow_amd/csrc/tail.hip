@@ -10,7 +10,7 @@
 //     loss      += (max(x, 0) - x y + log1p(exp(-|x|))) * scale,   d[m] = (sigmoid(x) - y) * scale
 //     dX[m][k]   = d[m] * w[k], kept where mask bit k is set, divided by keep_prob  -> planes (vec_dgrad_planes_k's arithmetic)
 //     dW[k]     += X[m][k] * d[m],  db += d[m]            (per-block partial sums, folded in block order by tail_fold_k)
-// Two launches (this kernel + a fold of 512 x (K + 2) partials).  HBM bound: 4 K + K / 8 + ~20 bytes read and 4 K + ~16
+// Two launches (this kernel + a fold of the blocks' (K + 2) partials).  HBM bound: 4 K + K / 8 + ~20 bytes read and 4 K + ~16
 // written per example.  Results are reproducible (fixed orders); the loss / dW sums associate differently from the
 // unfused sequence (tests hold them to 1e-6 of it), everything per-example is the unfused sequence's bits.
 #include "common.h"
@@ -48,141 +48,185 @@ struct TailArgs {
   int rpb;                                         // examples per block (a multiple of kGroups)
 };
 
-template <int Q>                                   // float4 pieces per lane: K = 64 Q
+// A block walks kTiles consecutive tiles of `rpb` examples (rpb = 4096 / K: a 16-KB planes image, P = rpb / 16 passes of its
+// 16 lane groups); ALL of a tile's loads — its P examples' X pieces, lin, fm, labels and mask words per lane group — are
+// issued before anything is computed (one memory latency per tile, not per pass), the dW / loss / d sums stay in registers
+// across the tiles.  (First version: one 80-example tile per block, 48 KB of LDS = 3 blocks per CU, loads pass by pass:
+// 43 us alone at config 3 against 51 for the five launches it replaces; this form: see tools/mlp_tail_bench.py.)
+constexpr int kTiles = 2;
+
+template <int Q, int P>                            // float4 pieces per lane: K = 64 Q; passes per tile: rpb = 16 P
 __global__ __launch_bounds__(kBlock) void logits_head_tail_k(const TailArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char lds[];
-  const int K = 64 * Q;
-  char* stage = lds;                                               // [K / 16][rpb][64 B] planes image of the block's rows
-  float* red = reinterpret_cast<float*>(lds + (K >> 4) * a.rpb * ROWB);   // [kGroups][K + 2]
+  constexpr int K = 64 * Q, RPB = kGroups * P;
+  // [K / 16][RPB][64 B] planes image of a tile; the 16-k blocks 32 bytes further apart than their rows need, so that the four
+  // blocks a lane group writes at once fall on different banks
+  constexpr int BLK = RPB * ROWB + 32;
+  __shared__ __attribute__((aligned(16))) char stage[(K >> 4) * BLK];
+  __shared__ float red[kGroups][K + 2];
   const int t = threadIdx.x, l = t & (kLpr - 1), grp = t / kLpr;
-  const int64_t r0 = static_cast<int64_t>(blockIdx.x) * a.rpb;
-  const int nrows = static_cast<int>(min(static_cast<int64_t>(a.rpb), a.M - r0));
   float4 w4[Q], accw[Q];
 #pragma unroll
   for (int q = 0; q < Q; ++q) { w4[q] = *reinterpret_cast<const float4*>(a.w + 4 * l + 64 * q); accw[q] = make_float4(0.f, 0.f, 0.f, 0.f); }
   const float b0 = a.b ? a.b[0] : 0.f;
   const float lb = (a.lin && a.lin_bias) ? a.lin_bias[0] : 0.f;
   float acc_l = 0.f, acc_d = 0.f, bmx = 0.f;
-  for (int rl = grp; rl < a.rpb; rl += kGroups) {                  // (uniform trip count: shuffles below)
-    const bool on = rl < nrows;
-    const int64_t r = r0 + (on ? rl : 0);
-    float4 x[Q];
-    float acc = 0.f;
+  struct TileIn { float4 x[P][Q]; uint32_t mw[P][Q]; float lin_v[P], fm_v[P], y_v[P]; };
+  // every load of a tile, issued together (rows past the end of the batch: row 0 of the tile, unused)
+  auto load_tile = [&](int tile, TileIn& in) {
+    const int64_t r0 = min((static_cast<int64_t>(blockIdx.x) * kTiles + tile) * RPB, a.M - 1);
+    const int nrows = static_cast<int>(min(static_cast<int64_t>(RPB), a.M - r0));
 #pragma unroll
-    for (int q = 0; q < Q; ++q) {
-      x[q] = *reinterpret_cast<const float4*>(a.X + r * a.ldx + 4 * l + 64 * q);
-      acc += (x[q].x * w4[q].x + x[q].y * w4[q].y) + (x[q].z * w4[q].z + x[q].w * w4[q].w);
-    }
-#pragma unroll
-    for (int o = kLpr / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, kLpr);
-    const float dnn = acc + b0;
-    float z = 0.f;
-    if (a.lin) z += a.lin[r] + lb;
-    if (a.fm) z += a.fm[r];
-    z += dnn;
-    const float y = a.labels[r] ? 1.f : 0.f;
-    const float loss = (fmaxf(z, 0.f) - z * y + log1pf(expf(-fabsf(z)))) * a.scale;
-    const float g = (t_sigmoid(z) - y) * a.scale;
-    if (on && l == 0) {
-      if (a.dnn) a.dnn[r] = dnn;
-      a.logits[r] = z;
-      a.d_logit[r] = g;
-      acc_l += loss; acc_d += g;
-    }
-    // the layer's data gradient, masked, and its abs-max over the example
-    uint32_t mw[Q];
-    float4 v[Q];
-    float mx = 0.f;
-#pragma unroll
-    for (int q = 0; q < Q; ++q) {
-      const int k = 4 * l + 64 * q;
-      v[q] = make_float4(g * w4[q].x, g * w4[q].y, g * w4[q].z, g * w4[q].w);
-      if (a.mbits) {
-        mw[q] = a.mbits[r * a.mbld + (k >> 5)] >> (k & 31);
-        v[q].x = (mw[q] & 1u) ? mi_div_const(v[q].x, a.keep_div, a.keep_rcp) : 0.f; v[q].y = (mw[q] & 2u) ? mi_div_const(v[q].y, a.keep_div, a.keep_rcp) : 0.f;
-        v[q].z = (mw[q] & 4u) ? mi_div_const(v[q].z, a.keep_div, a.keep_rcp) : 0.f; v[q].w = (mw[q] & 8u) ? mi_div_const(v[q].w, a.keep_div, a.keep_rcp) : 0.f;
-      }
-      if (on && a.dX) *reinterpret_cast<float4*>(a.dX + r * a.lddx + k) = v[q];
-      mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[q].x), fabsf(v[q].y))), fmaxf(fabsf(v[q].z), fabsf(v[q].w)));
-      if (on) { accw[q].x += x[q].x * g; accw[q].y += x[q].y * g; accw[q].z += x[q].z * g; accw[q].w += x[q].w * g; }
-    }
-#pragma unroll
-    for (int o = kLpr / 2; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, kLpr));
-    if (on) {
-      bmx = fmaxf(bmx, mx);
-      const int s = t_exp_for(mx);
-      const float sc = t_pow2(s);
-      if (l == 0) a.row_exp[r] = s;
+    for (int p = 0; p < P; ++p) {
+      const int rl = grp + kGroups * p;
+      const int64_t r = r0 + (rl < nrows ? rl : 0);
 #pragma unroll
       for (int q = 0; q < Q; ++q) {
-        const float u[4] = {v[q].x * sc, v[q].y * sc, v[q].z * sc, v[q].w * sc};
-        uint32_t ph[2], pq[2];
+        const int k = 4 * l + 64 * q;
+        in.x[p][q] = *reinterpret_cast<const float4*>(a.X + r * a.ldx + k);
+        in.mw[p][q] = a.mbits ? a.mbits[r * a.mbld + (k >> 5)] >> (k & 31) : 0xfu;
+      }
+      in.lin_v[p] = a.lin ? a.lin[r] : 0.f;
+      in.fm_v[p] = a.fm ? a.fm[r] : 0.f;
+      in.y_v[p] = a.labels[r] ? 1.f : 0.f;
+    }
+  };
+  TileIn cur, nxt;
+  load_tile(0, cur);
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          const t_f32x2 uu = {u[2 * e], u[2 * e + 1]};
-          t_h16x2 hh = __builtin_convertvector(uu, t_h16x2);
-          uint32_t hb = __builtin_bit_cast(uint32_t, hh);
-          if (uu[0] > 0.f && (hb & 0xffffu) == 0u) hb |= 1u;          // positive stays positive in the high plane
-          if (uu[1] > 0.f && (hb >> 16) == 0u) hb |= 0x10000u;
-          hh = __builtin_bit_cast(t_h16x2, hb);
-          const t_f32x2 rr2 = {uu[0] - static_cast<float>(hh[0]), uu[1] - static_cast<float>(hh[1])};
-          ph[e] = hb;
-          pq[e] = __builtin_bit_cast(uint32_t, __builtin_convertvector(rr2, t_h16x2));
+  for (int tile = 0; tile < kTiles; ++tile) {
+    const int64_t r0 = (static_cast<int64_t>(blockIdx.x) * kTiles + tile) * RPB;
+    if (r0 >= a.M) break;                                            // (block-uniform)
+    const int nrows = static_cast<int>(min(static_cast<int64_t>(RPB), a.M - r0));
+    if (tile + 1 < kTiles) load_tile(tile + 1, nxt);                 // the next tile's loads travel under this tile's arithmetic
+    const auto& x = cur.x; const auto& mw = cur.mw; const auto& lin_v = cur.lin_v; const auto& fm_v = cur.fm_v; const auto& y_v = cur.y_v;
+    if (tile > 0) __syncthreads();                                   // the previous tile's planes have left the stage
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const int rl = grp + kGroups * p;
+      const bool on = rl < nrows;
+      const int64_t r = r0 + (on ? rl : 0);
+      float acc = 0.f;
+#pragma unroll
+      for (int q = 0; q < Q; ++q) acc += (x[p][q].x * w4[q].x + x[p][q].y * w4[q].y) + (x[p][q].z * w4[q].z + x[p][q].w * w4[q].w);
+#pragma unroll
+      for (int o = kLpr / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, kLpr);
+      const float dnn = acc + b0;
+      float z = 0.f;
+      if (a.lin) z += lin_v[p] + lb;
+      if (a.fm) z += fm_v[p];
+      z += dnn;
+      const float y = y_v[p];
+      const float loss = (fmaxf(z, 0.f) - z * y + log1pf(expf(-fabsf(z)))) * a.scale;
+      const float g = (t_sigmoid(z) - y) * a.scale;
+      if (on && l == 0) {
+        if (a.dnn) a.dnn[r] = dnn;
+        a.logits[r] = z;
+        a.d_logit[r] = g;
+        acc_l += loss; acc_d += g;
+      }
+      // the layer's data gradient, masked, and its abs-max over the example
+      float4 v[Q];
+      float mx = 0.f;
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+        const int k = 4 * l + 64 * q;
+        v[q] = make_float4(g * w4[q].x, g * w4[q].y, g * w4[q].z, g * w4[q].w);
+        if (a.mbits) {
+          const uint32_t m = mw[p][q];
+          v[q].x = (m & 1u) ? mi_div_const(v[q].x, a.keep_div, a.keep_rcp) : 0.f; v[q].y = (m & 2u) ? mi_div_const(v[q].y, a.keep_div, a.keep_rcp) : 0.f;
+          v[q].z = (m & 4u) ? mi_div_const(v[q].z, a.keep_div, a.keep_rcp) : 0.f; v[q].w = (m & 8u) ? mi_div_const(v[q].w, a.keep_div, a.keep_rcp) : 0.f;
         }
-        const int qq = l + kLpr * q;                                   // float4 index inside the row: k = 4 qq
-        char* d = stage + ((qq >> 2) * a.rpb + rl) * ROWB + (qq & 3) * 8;
-        *reinterpret_cast<uint2*>(d) = make_uint2(ph[0], ph[1]);
-        *reinterpret_cast<uint2*>(d + 32) = make_uint2(pq[0], pq[1]);
+        if (on && a.dX) *reinterpret_cast<float4*>(a.dX + r * a.lddx + k) = v[q];
+        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[q].x), fabsf(v[q].y))), fmaxf(fabsf(v[q].z), fabsf(v[q].w)));
+        if (on) { accw[q].x += x[p][q].x * g; accw[q].y += x[p][q].y * g; accw[q].z += x[p][q].z * g; accw[q].w += x[p][q].w * g; }
+      }
+#pragma unroll
+      for (int o = kLpr / 2; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, kLpr));
+      if (on) {
+        bmx = fmaxf(bmx, mx);
+        const int s = t_exp_for(mx);
+        const float sc = t_pow2(s);
+        if (l == 0) a.row_exp[r] = s;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+          const float u[4] = {v[q].x * sc, v[q].y * sc, v[q].z * sc, v[q].w * sc};
+          uint32_t ph[2], pq[2];
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const t_f32x2 uu = {u[2 * e], u[2 * e + 1]};
+            t_h16x2 hh = __builtin_convertvector(uu, t_h16x2);
+            uint32_t hb = __builtin_bit_cast(uint32_t, hh);
+            if (uu[0] > 0.f && (hb & 0xffffu) == 0u) hb |= 1u;          // positive stays positive in the high plane
+            if (uu[1] > 0.f && (hb >> 16) == 0u) hb |= 0x10000u;
+            hh = __builtin_bit_cast(t_h16x2, hb);
+            const t_f32x2 rr2 = {uu[0] - static_cast<float>(hh[0]), uu[1] - static_cast<float>(hh[1])};
+            ph[e] = hb;
+            pq[e] = __builtin_bit_cast(uint32_t, __builtin_convertvector(rr2, t_h16x2));
+          }
+          const int qq = l + kLpr * q;                                   // float4 index inside the row: k = 4 qq
+          char* d = stage + (qq >> 2) * BLK + rl * ROWB + (qq & 3) * 8;
+          *reinterpret_cast<uint2*>(d) = make_uint2(ph[0], ph[1]);
+          *reinterpret_cast<uint2*>(d + 32) = make_uint2(pq[0], pq[1]);
+        }
       }
     }
+    __syncthreads();
+    // the planes of the tile's rows: one contiguous run per 16-k block
+    // (all of a thread's pieces are read from LDS first, then stored: (K / 16) * RPB * 4 / 256 independent 16-byte stores)
+    const int run16 = nrows * 4;
+    constexpr int NPC = (K >> 4) * RPB * 4 / kBlock;
+    uint4 pc[NPC];
+#pragma unroll
+    for (int j = 0; j < NPC; ++j) {
+      const int idx = j * kBlock + t, kb = idx / (RPB * 4), pp = idx % (RPB * 4);
+      pc[j] = *reinterpret_cast<const uint4*>(stage + kb * BLK + pp * 16);
+    }
+#pragma unroll
+    for (int j = 0; j < NPC; ++j) {
+      const int idx = j * kBlock + t, kb = idx / (RPB * 4), pp = idx % (RPB * 4);
+      if (pp < run16) *reinterpret_cast<uint4*>(a.out + kb * a.ldo_b + r0 * ROWB + pp * 16) = pc[j];
+    }
+    if (tile + 1 < kTiles) cur = nxt;
   }
   // the block's partial sums: dW over its examples (the 16 lane groups in group order), sum d, sum loss
 #pragma unroll
-  for (int q = 0; q < Q; ++q) *reinterpret_cast<float4*>(red + grp * (K + 2) + 4 * l + 64 * q) = accw[q];
-  if (l == 0) { red[grp * (K + 2) + K] = acc_d; red[grp * (K + 2) + K + 1] = acc_l; }
+  for (int q = 0; q < Q; ++q) *reinterpret_cast<float4*>(&red[grp][4 * l + 64 * q]) = accw[q];
+  if (l == 0) { red[grp][K] = acc_d; red[grp][K + 1] = acc_l; }
   __syncthreads();
   for (int k = t; k < K + 2; k += kBlock) {
     float s = 0.f;
 #pragma unroll
-    for (int gq = 0; gq < kGroups; ++gq) s += red[gq * (K + 2) + k];
+    for (int gq = 0; gq < kGroups; ++gq) s += red[gq][k];
     a.part[static_cast<int64_t>(blockIdx.x) * (K + 2) + k] = s;
-  }
-  // the planes of the block's rows: one contiguous run per 16-k block
-  const int run16 = nrows * 4;
-  for (int kb = 0; kb < (K >> 4); ++kb) {
-    const uint4* src = reinterpret_cast<const uint4*>(stage + kb * a.rpb * ROWB);
-    uint4* dst = reinterpret_cast<uint4*>(a.out + kb * a.ldo_b + r0 * ROWB);
-    for (int p = t; p < run16; p += kBlock) dst[p] = src[p];
   }
   if (a.amax_out) mi_amax_publish(a.amax_out, bmx);                  // (every thread of the block reaches this)
 }
 
-// out[k] = sum over the blocks' partials, in block order per wave (wave g takes blocks g, g + 4, ...), then (w0 + w1) + (w2 + w3):
-// dW [K], then the sum of d (into db and / or d_sum) and the loss
+// out[k] = the sum of the blocks' partials: 16 columns x 16 slices of the partials per workgroup (slice s: partials s, s + 16,
+// ... in order), the slices folded in order — dW [K], then the sum of d (into db and / or d_sum) and the loss
 __global__ __launch_bounds__(kBlock) void tail_fold_k(const float* __restrict__ part, int nparts, int K, float* __restrict__ dW,
                                                       float* __restrict__ db, float* __restrict__ d_sum, float* __restrict__ loss) {
-  __shared__ float red[4][64];
-  const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
-  const int k = blockIdx.x * 64 + c;
+  __shared__ float red[16][17];
+  const int c = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int k = blockIdx.x * 16 + c;
   float acc = 0.f;
   if (k < K + 2) {
 #pragma unroll 8
-    for (int s = g; s < nparts; s += 4) acc += part[static_cast<int64_t>(s) * (K + 2) + k];
+    for (int s = sl; s < nparts; s += 16) acc += part[static_cast<int64_t>(s) * (K + 2) + k];
   }
-  red[g][c] = acc;
+  red[sl][c] = acc;
   __syncthreads();
-  if (g == 0 && k < K + 2) {
-    const float v = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+  if (sl == 0 && k < K + 2) {
+    float v = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v += red[q][c];
     if (k < K) dW[k] = v;
     else if (k == K) { if (db) db[0] = v; if (d_sum) d_sum[0] = v; }
     else if (loss) loss[0] = v;
   }
 }
 
-int tail_rows_per_block(int K) {           // a 32-40 KB planes image + the [16][K + 2] partials: under 64 KB of LDS
-  int rpb = (40 * 1024 / (K * 4)) / kGroups * kGroups;
-  return std::max(kGroups, std::min(128, rpb));
-}
+int tail_rows_per_block(int K) { return kTiles * (4096 / K); }     // kTiles tiles of 4096 / K examples (a 16-KB planes image)
 
 }  // namespace
 
@@ -223,16 +267,15 @@ int32_t mi_logits_head_fused(const float* X, int64_t ldx, const float* w, const 
   a.rpb = tail_rows_per_block(K);
   const int64_t nb = mi::ceil_div(M, a.rpb);
   MI_REQUIRE(nb <= INT32_MAX, "logits_head_fused: grid too large");
-  const size_t lds = static_cast<size_t>(K >> 4) * a.rpb * ROWB + static_cast<size_t>(kGroups) * (K + 2) * sizeof(float);
   hipStream_t st = mi::as_stream(stream);
   const dim3 g(static_cast<unsigned>(nb)), blk(kBlock);
   switch (K) {
-    case 64: logits_head_tail_k<1><<<g, blk, lds, st>>>(a); break;
-    case 128: logits_head_tail_k<2><<<g, blk, lds, st>>>(a); break;
-    default: logits_head_tail_k<4><<<g, blk, lds, st>>>(a); break;
+    case 64: logits_head_tail_k<1, 4><<<g, blk, 0, st>>>(a); break;
+    case 128: logits_head_tail_k<2, 2><<<g, blk, 0, st>>>(a); break;
+    default: logits_head_tail_k<4, 1><<<g, blk, 0, st>>>(a); break;
   }
   MI_CHECK_LAUNCH("logits_head_fused");
-  tail_fold_k<<<dim3(static_cast<unsigned>(mi::ceil_div(K + 2, 64))), blk, 0, st>>>(a.part, static_cast<int>(nb), K, dW, db, d_logit_sum, loss_out);
+  tail_fold_k<<<dim3(static_cast<unsigned>(mi::ceil_div(K + 2, 16))), blk, 0, st>>>(a.part, static_cast<int>(nb), K, dW, db, d_logit_sum, loss_out);
   MI_CHECK_LAUNCH("logits_head_fused(fold)");
   return MI_OK;
 }

@@ -100,6 +100,21 @@ def main():
     ws = torch.empty(int(lib.mi_dense_bwd_weight_workspace_bytes(M, 1, 128)) + 256, dtype=torch.uint8, device="cuda")
     rows.append(("logits layer weight gradient (gemv + fold)", timeit(lambda: chk(lib.mi_dense_bwd_weight(
         acts[2].data_ptr(), 128, dl.data_ptr(), 1, dW4.data_ptr(), db4.data_ptr(), M, 1, 128, ws.data_ptr(), ws.numel(), None, st()), "wg"))))
+    # the fused form of the five launches around the head (round 4)
+    lin = torch.randn(M, device="cuda", generator=g) * 0.1; fm = torch.randn(M, device="cuda", generator=g) * 0.1
+    yl = (torch.rand(M, device="cuda", generator=g) < 0.25).to(torch.uint8)
+    lb = torch.zeros(1, device="cuda"); b4 = torch.zeros(1, device="cuda")
+    logits = torch.empty(M, device="cuda"); loss = torch.empty(1, device="cuda"); dsum = torch.empty(1, device="cuda")
+    hws = torch.empty(int(lib.mi_head_workspace_bytes(M)) + 256, dtype=torch.uint8, device="cuda")
+    rows.append(("head (logits sum, loss, d_logit)", timeit(lambda: chk(lib.mi_sigmoid_ce_head(
+        lin.data_ptr(), lb.data_ptr(), fm.data_ptr(), y1.data_ptr(), yl.data_ptr(), M, 1.0 / M, logits.data_ptr(), loss.data_ptr(), dl.data_ptr(),
+        dsum.data_ptr(), hws.data_ptr(), hws.numel(), st()), "head"))))
+    tws = torch.empty(int(lib.mi_logits_head_fused_workspace_bytes(M, 128)) + 256, dtype=torch.uint8, device="cuda")
+    rows.append(("FUSED logits layer + head + its backward (mi_logits_head_fused)", timeit(lambda: chk(lib.mi_logits_head_fused(
+        acts[2].data_ptr(), 128, w4.data_ptr(), b4.data_ptr(), lin.data_ptr(), lb.data_ptr(), fm.data_ptr(), yl.data_ptr(), M, 128, 1.0 / M,
+        bits[2].data_ptr(), 4, keep, y1.data_ptr(), logits.data_ptr(), loss.data_ptr(), dl.data_ptr(), dsum.data_ptr(), dW4.data_ptr(), db4.data_ptr(),
+        dyp2.ref, None, 128, amax.data_ptr(), tws.data_ptr(), tws.numel(), st()), "tail"))))
+    dl = torch.randn(M, device="cuda", generator=g) * 1e-5
     for i, (K, N) in ((1, (256, 128)), (0, (512, 256))):            # data gradient of layer i+2: dX [M, K] = dY [M, N] W^T, mask of the K-wide activation
         dY = torch.randn(M, N, device="cuda", generator=g) * 1e-5
         dyp, wp = split(dY), split(Ws[i])
