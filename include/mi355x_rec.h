@@ -571,6 +571,22 @@ int32_t mi_dense_bwd_weight_planes(const mi_planes_t* X, const mi_planes_t* dY, 
                                    int32_t N, int32_t K, void* workspace, size_t workspace_bytes,
                                    const mi_gemm_amax_t* amax, mi_stream_t stream);
 
+/* The weight gradients of SEVERAL layers from planes in one call (round 4): one launch makes every layer's per-example
+ * factors, one launch per layer runs its split-K GEMM, one launch folds every layer's slabs — for the three hidden layers of
+ * config 3 five launches instead of nine (the backward then runs all data gradients first: each needs only the layer
+ * above's dY, and the factors of every layer need its finished dY planes and abs-max).  Results are those of
+ * mi_dense_bwd_weight_planes per job, bit for bit.  workspace: mi_dense_bwd_weight_planes_batch_workspace_bytes, 32-byte
+ * aligned; at most MI_MAX_WEIGHT_JOBS jobs. */
+typedef struct mi_wgrad_job {
+  mi_planes_t X, dY;        /* the layer's input and the gradient of its output, [M] rows each */
+  float* dW; float* db;     /* [K][N], [N] (db may be NULL) */
+  int32_t N, K;
+  mi_gemm_amax_t amax;      /* a = abs-max vector of X, b = of dY */
+} mi_wgrad_job_t;
+size_t mi_dense_bwd_weight_planes_batch_workspace_bytes(const mi_wgrad_job_t* jobs, int32_t n_jobs, int64_t M);
+int32_t mi_dense_bwd_weight_planes_batch(const mi_wgrad_job_t* jobs, int32_t n_jobs, int64_t M, void* workspace,
+                                         size_t workspace_bytes, mi_stream_t stream);
+
 /* ---- (a7,a8) logits sum + sigmoid cross-entropy head -----------------------------------------
  * replaces `logits += ...` (deep_fm.py:36,44,90,111) and
  * tf.contrib.estimator.binary_classification_head (deep_fm.py:118-125).

@@ -497,8 +497,29 @@ __global__ __launch_bounds__(kThreads) void slab_reduce_k(const float* __restric
   if (blk >= nb1) slab_reduce_body<1>(slab2, nsplit, n2, out2, blk - nb1, red);        // (block-uniform)
   else slab_reduce_body<VEC>(slab, nsplit, n, out, blk, red);
 }
+// the folds of several layers' slabs in ONE launch (mi_dense_bwd_weight_planes_batch): blocks [block0, ...) are job j's
+struct FoldJob { const float* slab; int nsplit; int64_t n; float* out; const float* slab2; int64_t n2; float* out2; int vec; int block0; };
+struct FoldJobs { FoldJob j[MI_MAX_WEIGHT_JOBS]; int n; };
+inline bool fold_vec_ok(const float* slab, int64_t n, const float* out) {
+  return (n & 3) == 0 && n >= 4 * 64 * 512 && (reinterpret_cast<uintptr_t>(slab) & 15u) == 0 && (reinterpret_cast<uintptr_t>(out) & 15u) == 0;
+}
+inline int64_t fold_blocks(const FoldJob& f) { return mi::ceil_div(f.n, f.vec ? 256 : 64) + (f.n2 > 0 ? mi::ceil_div(f.n2, 64) : 0); }
+__global__ __launch_bounds__(kThreads) void slab_reduce_multi_k(const FoldJobs js) {
+  __shared__ float red[4][64 * 4];
+  int ji = 0;
+#pragma unroll
+  for (int q = 1; q < MI_MAX_WEIGHT_JOBS; ++q)
+    if (q < js.n && static_cast<int>(blockIdx.x) >= js.j[q].block0) ji = q;
+  const FoldJob& f = js.j[ji];
+  const int64_t blk = static_cast<int>(blockIdx.x) - f.block0;
+  const int64_t nb1 = (f.n + (f.vec ? 256 : 64) - 1) / (f.vec ? 256 : 64);
+  if (blk >= nb1) slab_reduce_body<1>(f.slab2, f.nsplit, f.n2, f.out2, blk - nb1, red);        // (block-uniform branches)
+  else if (f.vec) slab_reduce_body<4>(f.slab, f.nsplit, f.n, f.out, blk, red);
+  else slab_reduce_body<1>(f.slab, f.nsplit, f.n, f.out, blk, red);
+}
+
 inline void slab_reduce(const float* slab, int nsplit, int64_t n, float* out, const float* slab2, int64_t n2, float* out2, hipStream_t st) {
-  const bool vec = (n & 3) == 0 && n >= 4 * 64 * 512 && (reinterpret_cast<uintptr_t>(slab) & 15u) == 0 && (reinterpret_cast<uintptr_t>(out) & 15u) == 0;
+  const bool vec = fold_vec_ok(slab, n, out);
   const int64_t nb2 = n2 > 0 ? mi::ceil_div(n2, 64) : 0;
   if (vec) slab_reduce_k<4><<<dim3((unsigned)(mi::ceil_div(n, 256) + nb2)), dim3(kThreads), 0, st>>>(slab, nsplit, n, out, slab2, n2, out2);
   else slab_reduce_k<1><<<dim3((unsigned)(mi::ceil_div(n, 64) + nb2)), dim3(kThreads), 0, st>>>(slab, nsplit, n, out, slab2, n2, out2);
@@ -954,9 +975,15 @@ size_t mi_dense_bwd_weight_planes_workspace_bytes(int64_t M, int32_t N, int32_t 
   return slabs + static_cast<size_t>(M > 0 ? M : 0) * 12 + 256;   // + the per-example factors
 }
 
-int32_t mi_dense_bwd_weight_planes(const mi_planes_t* X, const mi_planes_t* dY, float* dW, float* db, int64_t M,
-                                   int32_t N, int32_t K, void* workspace, size_t workspace_bytes,
-                                   const mi_gemm_amax_t* amax, mi_stream_t stream) {
+// One layer's weight gradient from planes, in three stages that a batch of layers shares launch by launch: the per-example
+// factors (wgrad_scale_k: ONE launch for all layers), the split-K GEMM (one launch per layer), the slab folds (ONE launch).
+struct WgradJobPlan {
+  const mi_planes_t* X; const mi_planes_t* dY; float* dW; float* db; int64_t M; int N, K; const float* amax_a; const float* amax_b;
+  bool dma; mi::WgradPlPlan plan; int splits; int64_t n; bool direct;
+  char* fac; float* slab; float* cpart; float* out; float* cout;
+};
+static int32_t wgrad_job_plan(const mi_planes_t* X, const mi_planes_t* dY, float* dW, float* db, int64_t M, int32_t N, int32_t K,
+                              void* workspace, size_t workspace_bytes, const mi_gemm_amax_t* amax, WgradJobPlan* jp) {
   MI_REQUIRE(M > 0 && M <= INT32_MAX && N > 0 && K > 0, "dense_bwd_weight_planes: M=%lld N=%d K=%d", (long long)M, N, K);
   MI_REQUIRE(M % BK == 0 && N % BN == 0 && K % BM == 0,
              "dense_bwd_weight_planes: M=%lld N=%d K=%d (examples a multiple of 32, N and K multiples of 128)", (long long)M, N, K);
@@ -971,52 +998,111 @@ int32_t mi_dense_bwd_weight_planes(const mi_planes_t* X, const mi_planes_t* dY, 
                   mi_dense_bwd_weight_planes_workspace_bytes(M, N, K));
     return MI_ERR_WORKSPACE;
   }
-  hipStream_t st = mi::as_stream(stream);
-  mi::WgradPlPlan plan;
-  const bool dma = wgrad_plan(M, N, K, &plan);
-  const int splits = dma ? plan.splits : wgrad_splits(M, N, K);
-  const int64_t n = static_cast<int64_t>(K) * N;
-  char* fac = static_cast<char*>(workspace);                               // per-example factors first (alignment)
-  float* slab = reinterpret_cast<float*>(fac + ((static_cast<size_t>(M) * 12 + 255) & ~size_t(255)));
-  float* cpart = slab + static_cast<int64_t>(splits) * n;                 // [splits][N] bias-gradient partials
-  const bool direct = splits == 1;    // one split: the "slab" IS the result
-  float* out = direct ? dW : slab;
-  float* cout = db ? (direct ? db : cpart) : nullptr;
-  const dim3 sg((unsigned)mi::ceil_div(M, kThreads)), sb(kThreads);
-  if (dma) {
-    uint16_t* sx16 = reinterpret_cast<uint16_t*>(fac);
-    uint16_t* sy16 = sx16 + M;
-    uint16_t* sc16 = sy16 + M;
-    int32_t* kflag = reinterpret_cast<int32_t*>(sc16 + M);                 // [M / 16]
-    wgrad_scale_k<<<sg, sb, 0, st>>>(X->row_exp, dY->row_exp, amax->a, amax->b, M, nullptr, nullptr, nullptr, sx16, sy16, sc16, kflag);
-    MI_CHECK_LAUNCH("dense_bwd_weight_planes(scales)");
-    if (int32_t rc = mi::wgrad_pl_launch(plan, X, dY, sx16, sy16, sc16, kflag, amax->a, amax->b, out, cout, M, N, K, st)) return rc;
-  } else {
-    uint32_t* scw = reinterpret_cast<uint32_t*>(fac);
-    uint32_t* scy = scw + M;
-    float* yf = reinterpret_cast<float*>(scy + M);
-    wgrad_scale_k<<<sg, sb, 0, st>>>(X->row_exp, dY->row_exp, amax->a, amax->b, M, scw, scy, yf, nullptr, nullptr, nullptr, nullptr);
-    MI_CHECK_LAUNCH("dense_bwd_weight_planes(scales)");
-    WgPlArgs wa{};
-    wa.A = static_cast<const char*>(X->data); wa.bsa = X->blk_stride;
-    wa.B = static_cast<const char*>(dY->data); wa.bsb = dY->blk_stride;
-    wa.scw = scw; wa.scy = scy; wa.yf = yf;
-    GemmArgs& a = wa.g;                 // dW[K,N] = X[M,K]^T * dY[M,N] : gemm K x N x (reduce M)
-    a.M = K; a.N = N; a.K = (int)M; a.k_per_split = (int)wgrad_k_per_split(M, splits);
-    a.C = out; a.ldc = N; a.epi = EPI_SLAB; a.keep_prob = 1.f; a.keep_div = 1.f;
-    a.colsum_part = cout;
-    a.amax_a = amax->a; a.amax_b = amax->b; a.amax_c = nullptr;
-    a.tiles_m = K / BM; a.tiles_n = N / BN;
-    const int64_t nblocks = static_cast<int64_t>(a.tiles_m) * a.tiles_n * splits;
-    MI_REQUIRE(nblocks <= INT32_MAX, "dense_bwd_weight_planes: grid too large");
-    if (db) gemm_wgrad_pl_k<true><<<dim3((unsigned)nblocks), dim3(kThreads), 0, st>>>(wa);
-    else gemm_wgrad_pl_k<false><<<dim3((unsigned)nblocks), dim3(kThreads), 0, st>>>(wa);
-    MI_CHECK_LAUNCH("dense_bwd_weight_planes(split-K)");
-  }
-  if (direct) return MI_OK;
-  slab_reduce(slab, splits, n, dW, cpart, db ? N : 0, db, st);
-  MI_CHECK_LAUNCH("dense_bwd_weight_planes(reduce)");
+  WgradJobPlan& p = *jp;
+  p.X = X; p.dY = dY; p.dW = dW; p.db = db; p.M = M; p.N = N; p.K = K; p.amax_a = amax->a; p.amax_b = amax->b;
+  p.dma = wgrad_plan(M, N, K, &p.plan);
+  p.splits = p.dma ? p.plan.splits : wgrad_splits(M, N, K);
+  p.n = static_cast<int64_t>(K) * N;
+  p.fac = static_cast<char*>(workspace);                                   // per-example factors first (alignment)
+  p.slab = reinterpret_cast<float*>(p.fac + ((static_cast<size_t>(M) * 12 + 255) & ~size_t(255)));
+  p.cpart = p.slab + static_cast<int64_t>(p.splits) * p.n;                 // [splits][N] bias-gradient partials
+  p.direct = p.splits == 1;           // one split: the "slab" IS the result
+  p.out = p.direct ? dW : p.slab;
+  p.cout = db ? (p.direct ? db : p.cpart) : nullptr;
   return MI_OK;
+}
+static WgScaleJob wgrad_scale_job(const WgradJobPlan& p, int block0) {
+  WgScaleJob j{};
+  j.x_exp = p.X->row_exp; j.y_exp = p.dY->row_exp; j.amax_a = p.amax_a; j.amax_b = p.amax_b; j.M = p.M; j.block0 = block0;
+  if (p.dma) {
+    j.sx16 = reinterpret_cast<uint16_t*>(p.fac); j.sy16 = j.sx16 + p.M; j.sc16 = j.sy16 + p.M;
+    j.kflag = reinterpret_cast<int32_t*>(j.sc16 + p.M);                    // [M / 16]
+  } else {
+    j.scw = reinterpret_cast<uint32_t*>(p.fac); j.scy = j.scw + p.M; j.yf = reinterpret_cast<float*>(j.scy + p.M);
+  }
+  return j;
+}
+static int32_t wgrad_job_gemm(const WgradJobPlan& p, hipStream_t st) {
+  const int64_t M = p.M;
+  if (p.dma) {
+    const uint16_t* sx16 = reinterpret_cast<const uint16_t*>(p.fac);
+    const uint16_t* sy16 = sx16 + M;
+    const uint16_t* sc16 = sy16 + M;
+    const int32_t* kflag = reinterpret_cast<const int32_t*>(sc16 + M);
+    return mi::wgrad_pl_launch(p.plan, p.X, p.dY, sx16, sy16, sc16, kflag, p.amax_a, p.amax_b, p.out, p.cout, M, p.N, p.K, st);
+  }
+  WgPlArgs wa{};
+  wa.A = static_cast<const char*>(p.X->data); wa.bsa = p.X->blk_stride;
+  wa.B = static_cast<const char*>(p.dY->data); wa.bsb = p.dY->blk_stride;
+  wa.scw = reinterpret_cast<const uint32_t*>(p.fac); wa.scy = wa.scw + M; wa.yf = reinterpret_cast<const float*>(wa.scy + M);
+  GemmArgs& a = wa.g;                 // dW[K,N] = X[M,K]^T * dY[M,N] : gemm K x N x (reduce M)
+  a.M = p.K; a.N = p.N; a.K = (int)M; a.k_per_split = (int)wgrad_k_per_split(M, p.splits);
+  a.C = p.out; a.ldc = p.N; a.epi = EPI_SLAB; a.keep_prob = 1.f; a.keep_div = 1.f;
+  a.colsum_part = p.cout;
+  a.amax_a = p.amax_a; a.amax_b = p.amax_b; a.amax_c = nullptr;
+  a.tiles_m = p.K / BM; a.tiles_n = p.N / BN;
+  const int64_t nblocks = static_cast<int64_t>(a.tiles_m) * a.tiles_n * p.splits;
+  MI_REQUIRE(nblocks <= INT32_MAX, "dense_bwd_weight_planes: grid too large");
+  if (p.db) gemm_wgrad_pl_k<true><<<dim3((unsigned)nblocks), dim3(kThreads), 0, st>>>(wa);
+  else gemm_wgrad_pl_k<false><<<dim3((unsigned)nblocks), dim3(kThreads), 0, st>>>(wa);
+  MI_CHECK_LAUNCH("dense_bwd_weight_planes(split-K)");
+  return MI_OK;
+}
+
+int32_t mi_dense_bwd_weight_planes_batch(const mi_wgrad_job_t* jobs, int32_t n_jobs, int64_t M, void* workspace, size_t workspace_bytes,
+                                         mi_stream_t stream) {
+  MI_REQUIRE(jobs && n_jobs > 0 && n_jobs <= MI_MAX_WEIGHT_JOBS, "dense_bwd_weight_planes_batch: n_jobs=%d (1..%d)", n_jobs, MI_MAX_WEIGHT_JOBS);
+  hipStream_t st = mi::as_stream(stream);
+  WgradJobPlan plans[MI_MAX_WEIGHT_JOBS];
+  WgScaleJobs sj{};
+  FoldJobs fj{};
+  size_t off = 0;
+  int sblocks = 0, fblocks = 0;
+  for (int q = 0; q < n_jobs; ++q) {
+    const mi_wgrad_job_t& u = jobs[q];
+    const size_t need = mi_dense_bwd_weight_planes_workspace_bytes(M, u.N, u.K);
+    if (off + need > workspace_bytes) {
+      mi::set_error("dense_bwd_weight_planes_batch: workspace %zu too small (job %d ends at %zu)", workspace_bytes, q, off + need);
+      return MI_ERR_WORKSPACE;
+    }
+    if (int32_t rc = wgrad_job_plan(&u.X, &u.dY, u.dW, u.db, M, u.N, u.K, static_cast<char*>(workspace) + off, need, &u.amax, &plans[q])) return rc;
+    off += (need + 255) & ~size_t(255);
+    sj.j[q] = wgrad_scale_job(plans[q], sblocks);
+    sblocks += static_cast<int>(mi::ceil_div(M, kThreads));
+    if (!plans[q].direct) {
+      FoldJob& f = fj.j[fj.n];
+      f.slab = plans[q].slab; f.nsplit = plans[q].splits; f.n = plans[q].n; f.out = u.dW;
+      f.slab2 = u.db ? plans[q].cpart : nullptr; f.n2 = u.db ? u.N : 0; f.out2 = u.db;
+      f.vec = fold_vec_ok(f.slab, f.n, f.out) ? 1 : 0; f.block0 = fblocks;
+      fblocks += static_cast<int>(fold_blocks(f));
+      ++fj.n;
+    }
+  }
+  sj.n = n_jobs;
+  wgrad_scale_k<<<dim3((unsigned)sblocks), dim3(kThreads), 0, st>>>(sj);
+  MI_CHECK_LAUNCH("dense_bwd_weight_planes(scales)");
+  for (int q = 0; q < n_jobs; ++q)
+    if (int32_t rc = wgrad_job_gemm(plans[q], st)) return rc;
+  if (fj.n > 0) {
+    slab_reduce_multi_k<<<dim3((unsigned)fblocks), dim3(kThreads), 0, st>>>(fj);
+    MI_CHECK_LAUNCH("dense_bwd_weight_planes(reduce)");
+  }
+  return MI_OK;
+}
+
+size_t mi_dense_bwd_weight_planes_batch_workspace_bytes(const mi_wgrad_job_t* jobs, int32_t n_jobs, int64_t M) {
+  size_t tot = 0;
+  for (int q = 0; jobs && q < n_jobs; ++q) tot += (mi_dense_bwd_weight_planes_workspace_bytes(M, jobs[q].N, jobs[q].K) + 255) & ~size_t(255);
+  return tot + 256;
+}
+
+int32_t mi_dense_bwd_weight_planes(const mi_planes_t* X, const mi_planes_t* dY, float* dW, float* db, int64_t M,
+                                   int32_t N, int32_t K, void* workspace, size_t workspace_bytes,
+                                   const mi_gemm_amax_t* amax, mi_stream_t stream) {
+  MI_REQUIRE(X && dY && amax, "dense_bwd_weight_planes: null argument");
+  mi_wgrad_job_t job{};
+  job.X = *X; job.dY = *dY; job.dW = dW; job.db = db; job.N = N; job.K = K; job.amax = *amax;
+  return mi_dense_bwd_weight_planes_batch(&job, 1, M, workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"

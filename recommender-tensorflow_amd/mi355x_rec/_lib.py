@@ -44,6 +44,12 @@ class Planes(C.Structure):
     _fields_ = [("data", C.c_void_p), ("row_exp", C.c_void_p), ("blk_stride", C.c_int64)]
 
 
+class WgradJob(C.Structure):
+    """mi_wgrad_job_t: one layer of mi_dense_bwd_weight_planes_batch"""
+    _fields_ = [("X", Planes), ("dY", Planes), ("dW", C.c_void_p), ("db", C.c_void_p), ("N", C.c_int32), ("K", C.c_int32),
+                ("amax", GemmAmax)]
+
+
 class WeightJob(C.Structure):
     """mi_weight_job_t"""
     _fields_ = [("offset", C.c_int64), ("K", C.c_int32), ("N", C.c_int32), ("w", Planes), ("wt", Planes)]
@@ -110,6 +116,8 @@ SIGNATURES = {
     "mi_dense_bwd_weight_planes_workspace_bytes": (_sz, [_i64, _i32, _i32]),
     "mi_dense_bwd_weight_planes": (_i32, [_p, _p, _p, _p, _i64, _i32, _i32, _p, _sz, _p, _p]),
     "mi_dense_bwd_weight": (_i32, [_p, _i64, _p, _i64, _p, _p, _i64, _i32, _i32, _p, _sz, _amax, _p]),
+    "mi_dense_bwd_weight_planes_batch_workspace_bytes": (_sz, [_p, _i32, _i64]),
+    "mi_dense_bwd_weight_planes_batch": (_i32, [_p, _i32, _i64, _p, _sz, _p]),
     "mi_planes_bytes": (_sz, [_i64, _i32]),
     "mi_split_rows": (_i32, [_p, _i64, _i64, _i32, _i32, _pl, _p, _p]),
     "mi_split_weights": (_i32, [_p, _p, _i32, _p, _p]),

@@ -975,6 +975,7 @@ class DeepFM:
     BYGAP_AHEAD = True        # the next batch's staleness order made a step ahead (_by_gap_ahead)
     ROW_RECORDS = True        # a table row and its optimizer slots as one [w | slot0 | slot1] record (__init__)
     TAIL_FUSED = True         # logits layer + head + the layer's backward as one launch (_head: mi_logits_head_fused)
+    WGRAD_BATCH = True        # the planes weight gradients of a backward pass as one batch after the data gradients (_backward_dense)
 
     def _catchup(self, uniq, num_uniq, n_max, defer=False, by_gap=None):
         """defer: the rows are about to be applied in this same step by ONE mi_sparse_apply call, which
@@ -1222,6 +1223,12 @@ class DeepFM:
             wsz = max(k.query("mi_dense_bwd_weight_planes_workspace_bytes" if self._wgrad_planes_ok(B, j) else
                               "mi_dense_bwd_weight_workspace_bytes", B, h, fan) for j, (_, _, fan, h) in enumerate(self.layers))
             ws = self._bytes("wgrad_ws", wsz)
+            # Weight gradients that read planes are collected and run AFTER the last data gradient, as one batch
+            # (mi_dense_bwd_weight_planes_batch: one launch for every layer's per-example factors, one GEMM per layer, one
+            # launch for every layer's slab fold — at config 3 five launches instead of nine, ~40 us of small launches and
+            # the gaps around them off the step).  A data gradient needs only the dY of the layer above; the factors need
+            # the finished dY planes and their abs-max, which is why they could not move earlier one by one.
+            batch = [] if (self.WGRAD_BATCH and hasattr(k, "mi_dense_bwd_weight_planes_batch")) else None
             for i in range(nh, -1, -1):
                 _, _, fan, h = self.layers[i]
                 if i == nh and c.get("tail_done"):        # (the fused logits + head launch made dW, db and the planes of dX)
@@ -1236,7 +1243,9 @@ class DeepFM:
                 ga_w = self._ga("x%d" % i, dyn, None) if dyn else None
                 ga_d = self._ga(dyn, "w", "dy%d" % (i - 1) if i else None) if (dyn or i) else None
                 def weight_gradient(i=i, fan=fan, h=h, x=x, ldx=ldx, dy=dy, lddy=lddy, ga_w=ga_w):
-                    if self._wgrad_planes_ok(B, i):
+                    if self._wgrad_planes_ok(B, i) and batch is not None:
+                        batch.append((i, fan, h, ga_w))
+                    elif self._wgrad_planes_ok(B, i):
                         k.mi_dense_bwd_weight_planes(self._pl["x%dp" % i].struct, self._pl["dy%dp" % i].struct,
                                                      self.kernel(i, self.d_grad), self.bias(i, self.d_grad), B, h, fan, ws,
                                                      ws.numel(), ga_w)
@@ -1296,6 +1305,15 @@ class DeepFM:
                     weight_gradient()
                 dy, lddy = dx, fan
             d_concat = dy
+            for lo in range(0, len(batch or ()), _lib.MAX_WEIGHT_JOBS):
+                part = batch[lo:lo + _lib.MAX_WEIGHT_JOBS]
+                arr = (_lib.WgradJob * len(part))()
+                for q, (i, fan, h, ga_w) in enumerate(part):
+                    arr[q].X, arr[q].dY = self._pl["x%dp" % i].struct, self._pl["dy%dp" % i].struct
+                    arr[q].dW, arr[q].db = ptr(self.kernel(i, self.d_grad)), ptr(self.bias(i, self.d_grad))
+                    arr[q].N, arr[q].K, arr[q].amax = h, fan, ga_w
+                bws = self._bytes("wgrad_batch_ws", k.query("mi_dense_bwd_weight_planes_batch_workspace_bytes", arr, len(part), B))
+                k.mi_dense_bwd_weight_planes_batch(arr, len(part), B, bws, bws.numel())
         if self.n_numeric and self.raw_numeric:
             if self.use_linear:       # a raw numeric column owns no deep variable: only its linear_model weight
                 ws = self._bytes("num_ws", k.query("mi_numeric_raw_bwd_workspace_bytes", B, self.n_numeric))
