@@ -207,7 +207,8 @@ def host_threads():
 
 
 def log(msg):
-    print("[bench] " + msg, file=sys.stderr, flush=True)
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("[bench] " + msg, file=sys.stderr, flush=True)
 
 
 def cpu_baseline():
