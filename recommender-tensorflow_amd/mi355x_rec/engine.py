@@ -192,7 +192,7 @@ class DeepFM:
     kernel_0's rows only — tf_names maps them).
     shard: parallel.RowShard for N > 1 GPUs (row-sharded tables, data-parallel MLP).
     field_dims / wide_fields (the canned DNNLinearCombinedClassifier with dnn_feature_columns != linear_feature_columns,
-    linear_deep.py:32-39 / SURVEY A.7; single GPU): per-field embedding dimensions (<= embedding_size; 0 = the column is
+    linear_deep.py:32-39 / SURVEY A.7; one GPU or row-sharded over N): per-field embedding dimensions (<= embedding_size; 0 = the column is
     not in the deep part) and per-field flags "the column has a linear weight".  The fused [R, E] table keeps one E: a
     narrower column uses the first field_dims[f] of them and its other columns — with the matching rows of kernel_0 — are
     zero and stay zero under every optimizer here (their gradients are products with those zeros), which is the smaller
@@ -230,8 +230,6 @@ class DeepFM:
         if self.field_dims is not None and all(d == int(embedding_size) for d in self.field_dims):
             self.field_dims = None
         if self.field_dims is not None or self.wide_fields is not None:
-            if shard is not None:
-                raise NotImplementedError("per-field embedding dimensions / a wide part on a subset of the columns: single GPU only")
             if use_mf or (n_numeric and numeric == "embed"):
                 raise ValueError("field_dims / wide_fields belong to the canned estimators (no FM term, raw numeric columns)")
             for v in (self.field_dims, self.wide_fields):
@@ -242,8 +240,6 @@ class DeepFM:
         flags = lambda v: None if (v is None or all(v)) else [bool(x) for x in v]
         self.deep_numeric, self.wide_numeric = flags(deep_numeric), flags(wide_numeric)
         if self.deep_numeric is not None or self.wide_numeric is not None:
-            if shard is not None:
-                raise NotImplementedError("numeric columns that only one of the wide / deep parts reads: single GPU only")
             if numeric != "raw":
                 raise ValueError("deep_numeric / wide_numeric belong to the canned estimators (raw numeric columns)")
             for v in (self.deep_numeric, self.wide_numeric):
@@ -499,19 +495,17 @@ class DeepFM:
             s = 1.0 / math.sqrt(self.E)
             torch.nn.init.trunc_normal_(self.table, 0.0, s, -2.0 * s, 2.0 * s, generator=g)
             if self.field_dims is not None:          # a column of dimension d: N(0, 1/sqrt(d)) in its d columns, 0 in the rest
-                off = self.field_off_host
                 for f, d in enumerate(self.field_dims):
-                    blk = self.table[off[f]:off[f + 1]]
+                    blk = self.table[slice(*self._field_rows(f))]
                     if d:
                         blk[:, :d].mul_(math.sqrt(self.E / d))
                     blk[:, d:].zero_()
         if self.lin_w is not None and lin_scale:
             self.lin_w.normal_(0.0, lin_scale, generator=g)
             if self.wide_fields is not None:
-                off = self.field_off_host
                 for f, on in enumerate(self.wide_fields):
                     if not on:
-                        self.lin_w[off[f]:off[f + 1]].zero_()
+                        self.lin_w[slice(*self._field_rows(f))].zero_()
         for i, (_, _, fan, h) in enumerate(self.layers):
             fan_in = (self.D_logical if self._k0_rows is not None else self.D_in) if i == 0 else fan
             lim = math.sqrt(6.0 / (fan_in + h))
@@ -527,6 +521,14 @@ class DeepFM:
             self._seg(self.dense, self.num_emb_off, (self.n_numeric, self.E)).uniform_(-lim, lim, generator=g)
         if self._frozen is not None:
             self.dense.index_fill_(0, self._frozen, 0.0)
+
+    def _field_rows(self, f):
+        """[lo, hi): the rows of field f in this rank's tables (row r of the model lives on rank r % world at r // world)"""
+        off = self.field_off_host
+        if self.shard is None:
+            return int(off[f]), int(off[f + 1])
+        r, w = self.shard.rank, self.shard.world
+        return (int(off[f]) - r + w - 1) // w, (int(off[f + 1]) - r + w - 1) // w
 
     def _my_rows(self, a):
         """rows of a [R, ...] array that live on this rank, in local order"""
@@ -730,7 +732,8 @@ class DeepFM:
         if self.wide_idx is not None:
             w_ids = self._buf("wide_ids", (B, self.Fw), rid.dtype)
             torch.index_select(rid, 1, self.wide_idx, out=w_ids)             # (a column copy: torch as plumbing)
-            w_off, Fw = self.wide_off_t, self.Fw
+            # (rows received from their owners are addressed by slot: every field's offset is 0 there)
+            w_off, Fw = (self.wide_off_t if src is None else field_off[:self.Fw]), self.Fw
             c["wide_ids"] = w_ids
         concat = sumv = fm = None
         ld = self.D

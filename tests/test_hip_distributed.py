@@ -33,7 +33,13 @@ pytestmark = pytest.mark.gpu
                                  ([50, 30, 20, 40], 64, [64, 32], 256, 0, "Adam", 0.001, 3, (True, True, True), 2,
                                   dict(chunk_compute=False, announce=True, packed=True)),
                                  ([50, 30, 20, 40], 32, [64, 32], 128, 3, "Adagrad", 0.05, 2, (True, False, True), 2,
-                                  dict(numeric="raw", lin_opt=("Ftrl", 0.2), reduction="sum", packed=True))])
+                                  dict(numeric="raw", lin_opt=("Ftrl", 0.2), reduction="sum", packed=True)),
+                                 # wide and deep parts on different columns, per-column embedding dimensions, numeric columns
+                                 # that one part reads (linear_deep.py:32-39 with two different lists) on two ranks
+                                 ([50, 30, 20, 40, 7, 11], 32, [64, 32], 128, 3, "Adagrad", 0.05, 3, (True, False, True), 2,
+                                  dict(numeric="raw", lin_opt=("Ftrl", 0.2), reduction="sum", field_dims=[32, 16, 32, 0, 8, 32],
+                                       wide_fields=[True, False, True, True, False, True], deep_numeric=[True, False, True],
+                                       wide_numeric=[True, True, False]))])
 def test_two_ranks_one_gpu_gloo(cfg):
     check_against_big_batch(cfg, _run(cfg, 2, device="cuda", backend="gloo"), 2, tol=3.0)
 
