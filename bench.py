@@ -401,11 +401,14 @@ def main():
             out = m.train_step(ids, y, next_ids=batches[cursor[0] % len(batches)][0] if presort[0] else None)
         return out
 
+    enqueue_s = [0.0]
+
     def timed(nsteps):
         """barrier + synchronize, nsteps steps, barrier + synchronize; max over ranks"""
         sync()
         t0 = time.perf_counter()
         out = run(nsteps)
+        enqueue_s[0] = time.perf_counter() - t0          # (host time to enqueue the steps: far below dt = the host runs ahead)
         sync()
         dt = time.perf_counter() - t0
         if world > 1:
@@ -433,7 +436,7 @@ def main():
     dt, (loss, _) = timed(args.steps)
     roof_timers, m.timers, m.k.timer_only = m.timers, None, None
     final_loss = float(loss.item())
-    log("steady state: %.3f ms/step" % (dt / args.steps * 1e3))
+    log("steady state: %.3f ms/step (host enqueue %.3f ms/step)" % (dt / args.steps * 1e3, enqueue_s[0] / args.steps * 1e3))
     steps_before = cursor[0] - args.steps
     m.timers = {}
     idt, _ = timed(args.steps)

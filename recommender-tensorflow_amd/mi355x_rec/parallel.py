@@ -81,6 +81,21 @@ class Comm:
         self.ahead_group = dist.new_group(ranks=ranks) if second else None
         self._pinned = {}                # (C, parity) -> pinned host buffer of the count tables, allocated once
         self._pin_turn = 0
+        if self.direct and torch.cuda.is_available():
+            # RCCL creates a communicator — and the point-to-point channels an all_to_all uses — at the first collective
+            # that needs them, with allocations and device-wide synchronisations of its own.  Do that HERE, for both
+            # communicators, one after the other and in the same order on every rank, with the device idle: the first
+            # train step then issues collectives on communicators that already exist (the second one's first use would
+            # otherwise fall on a side stream in the middle of the first step's exchanges).
+            dev = torch.device("cuda", torch.cuda.current_device())
+            for g in ([self.group] if self.ahead_group is None else [self.group, self.ahead_group]):
+                one = torch.ones(self.world, dtype=torch.int64, device=dev)
+                got = torch.empty_like(one)
+                dist.all_reduce(one, group=g)
+                dist.all_to_all_single(got, one, group=g)
+                torch.cuda.synchronize(dev)
+                if int(got.sum().item()) != self.world * self.world:
+                    raise RuntimeError("rank %d: the warm-up all_to_all returned %s" % (self.rank, got.tolist()))
         # send order of the owners (mi_shard_keys, self_rank): the other ranks in rank order, this rank LAST
         self.pos_of_rank = [j if j < self.rank else (self.world - 1 if j == self.rank else j - 1) for j in range(self.world)]
         self._pos_dev = {}
