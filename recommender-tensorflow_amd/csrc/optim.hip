@@ -113,6 +113,7 @@ struct FusedGrad {
 // Segments longer than this are left to sparse_apply_long_k (a workgroup per row instead of a lane
 // group): with skewed ids one row can own thousands of a batch's entries.
 constexpr int kLongSeg = 48;
+constexpr int kRun = 8;            // consecutive rows a lane group of sparse_apply_long_k's scan looks at
 
 struct ApplyArgs {
   float* table; float* t0; float* t1;
@@ -265,8 +266,10 @@ __global__ __launch_bounds__(kBlock) void sparse_apply_k(ApplyArgs a, Hp h, cons
   else apply_row(a, h, r, l, lane_on, w, g, gl, q);
 }
 
-// Rows with more than kLongSeg entries: a workgroup per row.  Workgroup j looks at the rows
-// j, j + grid, j + 2 grid, ... (hot rows have neighbouring ids: the stride spreads them), collects
+// Rows with more than kLongSeg entries: a workgroup per row.  Workgroup j looks at the rows of the runs
+// j, j + grid, j + 2 grid, ... of kRun consecutive rows (hot rows have neighbouring ids: the stride spreads them; a run
+// is 32 bytes of seg_start — with single rows every lane of the scan pulled its own cache line: 14 us per step at
+// config 3 for finding nothing), collects
 // the long ones, and for each splits the segment into kBlock/LPR contiguous slices, one per lane
 // group, summed in order; the slice sums are then added in slice order.  A fixed order, so results
 // are reproducible; it differs from the one-pass order only in fp32 association.
@@ -289,7 +292,7 @@ __global__ __launch_bounds__(kBlock) void sparse_apply_long_k(ApplyArgs a, Hp h,
   {
     int any = 0;
     for (int64_t base = 0; base < U; base += per_round) {
-      const int64_t u = base + static_cast<int64_t>(t) * gridDim.x + blockIdx.x;
+      const int64_t u = base + (static_cast<int64_t>(t / kRun) * gridDim.x + blockIdx.x) * kRun + t % kRun;
       if (u < U) any |= (a.seg_start[ub + u + 1] - a.seg_start[ub + u] > kLongSeg) ? 1 : 0;
     }
     if (!__syncthreads_or(any)) return;
@@ -297,7 +300,7 @@ __global__ __launch_bounds__(kBlock) void sparse_apply_long_k(ApplyArgs a, Hp h,
   for (int64_t base = 0; base < U; base += per_round) {
     if (t == 0) n_list = 0;
     __syncthreads();
-    const int64_t u = base + static_cast<int64_t>(t) * gridDim.x + blockIdx.x;
+    const int64_t u = base + (static_cast<int64_t>(t / kRun) * gridDim.x + blockIdx.x) * kRun + t % kRun;
     if (u < U && a.seg_start[ub + u + 1] - a.seg_start[ub + u] > kLongSeg) list[atomicAdd(&n_list, 1)] = static_cast<int>(ub + u);
     __syncthreads();
     const int n = n_list;
