@@ -89,7 +89,12 @@ __device__ long long g_pl_stamps[32 * 2 * 128 * 8];
 #define PL_MARK(row) do {} while (0)
 #endif
 
-template <int TN, int TM, int EPI>
+// HOT: the call of a steady-state training step, its launch-uniform options fixed at compile time — whole tiles (M a multiple
+// of the row tile, N the column tile), no fp32 copy of the result, planes out; FWD: dropout on and the mask bits written; DGRAD:
+// the mask read as bits.  The generic kernel tests these per launch, and hipcc keeps every option's code and a scalar branch
+// or a select per group of columns for each: ~4,000-5,900 instructions per wave of epilogue, which two waves per SIMD issue
+// in 28-31 k cycles per tile (in-kernel marks, tools/gemm_pl_timeline.py: as long as 12 of the 16-32 k-steps of a small layer).
+template <int TN, int TM, int EPI, bool HOT = false>
 // (TN == 1: two workgroups share a CU — 4 waves per SIMD, at most 128 registers: said, not hoped)
 __global__ __launch_bounds__(PL_THREADS, 2) void gemm_pl_k(const PlArgs a) {
   // stage buffers: 4 where one workgroup per CU runs anyway (256 registers); 3 for the 128-column tile, whose
@@ -284,7 +289,7 @@ __global__ __launch_bounds__(PL_THREADS, 2) void gemm_pl_k(const PlArgs a) {
   uint32_t* e_bits = reinterpret_cast<uint32_t*>(smem + 8192 + 8 * WREG);     // [BMt][WPR] the tile's mask words (FWD, mask bits asked for)
   for (int n = t; n < BNt; n += PL_THREADS) {
     const int gn = n0 + n;
-    const bool ok = gn < a.N;
+    const bool ok = HOT || gn < a.N;
     e_fw[n] = ok ? pl_pow2(-a.a_exp[ok ? gn : 0]) : 0.f;
     e_bias[n] = (EPI == PL_FWD && a.bias && ok) ? a.bias[gn] : 0.f;
   }
@@ -297,14 +302,15 @@ __global__ __launch_bounds__(PL_THREADS, 2) void gemm_pl_k(const PlArgs a) {
   // the layer-2 data gradient's).  Now the options only select VALUES (no dropout: threshold 2^16 and divisor 1; no mask:
   // an all-positive mask word), the per-element code is straight-line, and the uniform branches that remain are per group
   // of four columns (hash / mask load / fp32 copy).
-  const bool drop = EPI == PL_FWD && a.keep_prob < 1.f;
+  const bool drop = EPI == PL_FWD && (HOT || a.keep_prob < 1.f);
+  float* const Cf = HOT ? nullptr : a.C;
   const uint32_t thresh16 = drop ? mi_drop_thresh16(a.keep_prob) : 0x10000u;
   const uint64_t seed = a.seed + (a.st ? a.st->seed_term : 0ull);
   const int nw = wn * 32 * TN;                      // this wave's first column inside the tile
   // (the hash of a column pair: (col >> 1) * MUL = pair_base + a compile-time multiple of MUL)
   const uint32_t pair_base = static_cast<uint32_t>((n0 + nw + 4 * h) >> 1) * MI_DROP_PAIR_MUL;
-  const bool bitmask = EPI == PL_DGRAD && a.mbits != nullptr;
-  const bool masked = EPI == PL_DGRAD && a.mask != nullptr && !bitmask;
+  const bool bitmask = EPI == PL_DGRAD && (HOT || a.mbits != nullptr);
+  const bool masked = !HOT && EPI == PL_DGRAD && a.mask != nullptr && !bitmask;
   const bool divide = drop || masked || bitmask;
   const float kd = divide ? a.keep_div : 1.f, kr = divide ? a.keep_rcp : 1.f;
   const float relu_floor = a.relu ? 0.f : -__builtin_inff();
@@ -312,7 +318,7 @@ __global__ __launch_bounds__(PL_THREADS, 2) void gemm_pl_k(const PlArgs a) {
 #pragma unroll
   for (int y = 0; y < TM; ++y) {
     const int m = m0 + wm * 32 * TM + y * 32 + i;
-    const bool mok = m < a.M;
+    const bool mok = HOT || m < a.M;
     const int mc = mok ? m : a.M - 1;
     const float fx = pl_pow2(-a.b_exp[mc]);
     float mx = 0.f;
@@ -343,7 +349,7 @@ __global__ __launch_bounds__(PL_THREADS, 2) void gemm_pl_k(const PlArgs a) {
       mw[x] = EPI == PL_DGRAD ? 0xffffffffu : 0u;
       if constexpr (EPI == PL_DGRAD) {
         const int wi = ((n0 + nw) >> 5) + x;
-        if (bitmask) mw[x] = wi < a.mbld ? a.mbits[static_cast<int64_t>(mc) * a.mbld + wi] : 0u;
+        if (bitmask) mw[x] = (HOT || wi < a.mbld) ? a.mbits[static_cast<int64_t>(mc) * a.mbld + wi] : 0u;
       }
     }
 #pragma unroll
@@ -388,11 +394,11 @@ __global__ __launch_bounds__(PL_THREADS, 2) void gemm_pl_k(const PlArgs a) {
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) mx = fmaxf(mx, fabsf(acc[x][y][4 * g + j]));
-      if (a.C)
+      if (Cf)
         *reinterpret_cast<float4*>(wreg + i * FS + (x * 32 + 8 * g + 4 * h) * 4) =
             make_float4(acc[x][y][4 * g], acc[x][y][4 * g + 1], acc[x][y][4 * g + 2], acc[x][y][4 * g + 3]);
     }
-    if (a.C) {
+    if (Cf) {
       // the wave's 32 rows x 32 TN columns went through its own LDS region: read them back row by row, so that
       // a store instruction writes whole 128 TN-byte row segments instead of 64 scattered 16-byte pieces
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -402,12 +408,12 @@ __global__ __launch_bounds__(PL_THREADS, 2) void gemm_pl_k(const PlArgs a) {
         const int row = it * RPI + lane / LPR_, c16 = lane % LPR_;
         const float4 v4 = *reinterpret_cast<const float4*>(wreg + row * FS + c16 * 16);
         const int mm = m0 + wm * 32 * TM + y * 32 + row, nn = n0 + nw + c16 * 4;
-        if (mm < a.M && nn < a.N) *reinterpret_cast<float4*>(a.C + static_cast<int64_t>(mm) * a.ldc + nn) = v4;
+        if (mm < a.M && nn < a.N) *reinterpret_cast<float4*>(Cf + static_cast<int64_t>(mm) * a.ldc + nn) = v4;
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     if constexpr (EPI == PL_FWD) {
-      if (a.mbits) {
+      if (HOT || a.mbits) {
         // one bit per output, from the finished values (+2.5 us on the 512 -> 256 forward, +1 us on 256 -> 128; the data
         // gradients that read the bits instead of the activation's planes gain 25-30 and 2 us: tools/mlp_tail_bench.py)
 #pragma unroll
@@ -442,12 +448,13 @@ __global__ __launch_bounds__(PL_THREADS, 2) void gemm_pl_k(const PlArgs a) {
     for (int o = 16; o > 0; o >>= 1) wmx = fmaxf(wmx, __shfl_xor(wmx, o));
     if (lane == 0) e_wmax[wv] = wmx;
   }
+  PL_MARK(4);                          // element loops done (this wave)
   __syncthreads();
   if constexpr (EPI == PL_FWD) {
-    if (a.mbits) {
+    if (HOT || a.mbits) {
       for (int idx = t; idx < BMt * WPR; idx += PL_THREADS) {
         const int row = idx / WPR, wi = (n0 >> 5) + idx % WPR;
-        if (m0 + row < a.M && wi < a.mbld) a.mbits[static_cast<int64_t>(m0 + row) * a.mbld + wi] = e_bits[idx];
+        if (HOT || (m0 + row < a.M && wi < a.mbld)) a.mbits[static_cast<int64_t>(m0 + row) * a.mbld + wi] = e_bits[idx];
       }
     }
   }
@@ -459,7 +466,7 @@ __global__ __launch_bounds__(PL_THREADS, 2) void gemm_pl_k(const PlArgs a) {
     const unsigned int bits = __float_as_uint(mx);
     if (bits > *reinterpret_cast<volatile unsigned int*>(slot)) atomicMax(slot, bits);
   }
-  if (!a.Cp) {
+  if (!HOT && !a.Cp) {
 #ifdef MI_PL_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
@@ -472,7 +479,7 @@ __global__ __launch_bounds__(PL_THREADS, 2) void gemm_pl_k(const PlArgs a) {
   for (int y = 0; y < TM; ++y) {
     const int ml = wm * 32 * TM + y * 32 + i;
     const int m = m0 + ml;
-    const bool mok = m < a.M;
+    const bool mok = HOT || m < a.M;
     const float mx = fmaxf(fmaxf(e_rmax[ml], e_rmax[BMt + ml]), fmaxf(e_rmax[2 * BMt + ml], e_rmax[3 * BMt + ml]));
     const int s = pl_exp_for(mx);
     const float sc = pl_pow2(s);
@@ -528,11 +535,12 @@ __global__ __launch_bounds__(PL_THREADS, 2) void gemm_pl_k(const PlArgs a) {
       const int blk = off >> 11, row = (off >> 6) & 31, slot = (off >> 4) & 3;
       const uint4 v4 = *reinterpret_cast<const uint4*>(wreg + off);
       const int mm = m0 + wm * 32 * TM + y * 32 + row, ncol = n0 + nw + blk * 16;
-      if (mm < a.M && ncol < a.N)
+      if (HOT || (mm < a.M && ncol < a.N))
         *reinterpret_cast<uint4*>(a.Cp + (ncol >> 4) * a.bsc + static_cast<int64_t>(mm) * PL_ROWB + ((slot ^ ((row >> 1) & 3)) << 4)) = v4;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
+  PL_MARK(5);                          // planes converted, stores issued
 #ifdef MI_PL_STAMPS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
@@ -950,7 +958,16 @@ int32_t launch_pl(PlArgs& a, hipStream_t st, const char* what) {
     return MI_ERR_UNSUPPORTED;
   }
   const dim3 g(static_cast<unsigned>(blocks)), b(PL_THREADS);
-  if (tn == 1 && tm == 4) gemm_pl_k<1, 4, EPI><<<g, b, 0, st>>>(a);
+  // the steady-state training call (see gemm_pl_k: HOT)
+  const bool hot = a.Cp && !a.C && a.tiles_n == 1 && a.N == bn && a.M % bm == 0 && a.amax_c &&
+                   (EPI == PL_FWD ? (a.keep_prob < 1.f && a.mbits && a.mbld * 32 == a.N && a.bias)
+                                  : (a.mbits && a.mbld * 32 == a.N));
+  if (hot && tn == 1 && tm == 4) gemm_pl_k<1, 4, EPI, true><<<g, b, 0, st>>>(a);
+  else if (hot && tn == 2 && tm == 4) gemm_pl_k<2, 4, EPI, true><<<g, b, 0, st>>>(a);
+  // (not the 512-column forward — layer 1, at the chip's power limit either way: its fixed-option epilogue needs more than
+  // 256 registers)
+  else if (hot && tn == 4 && EPI == PL_DGRAD) gemm_pl_k<4, 2, PL_DGRAD, true><<<g, b, 0, st>>>(a);
+  else if (tn == 1 && tm == 4) gemm_pl_k<1, 4, EPI><<<g, b, 0, st>>>(a);
   else if (tn == 1) gemm_pl_k<1, 2, EPI><<<g, b, 0, st>>>(a);
   else if (tn == 2 && tm == 4) gemm_pl_k<2, 4, EPI><<<g, b, 0, st>>>(a);
   else if (tn == 2) gemm_pl_k<2, 2, EPI><<<g, b, 0, st>>>(a);

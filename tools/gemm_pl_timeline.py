@@ -34,7 +34,9 @@ def run(which):
         X = torch.randn(M, fan, device="cuda", generator=g).relu_(); W = torch.randn(fan, h, device="cuda", generator=g) / fan ** 0.5
         b = torch.zeros(h, device="cuda"); xp, wt, yp = split(X), split(W, transpose=True), PB(M, h)
         nk = fan // 16
-        fn = lambda: L.mi_dense_fwd_planes(xp.ref, wt.ref, b.data_ptr(), None, h, yp.ref, M, h, fan, 1, 0.9, 7, None, None, 0, st())
+        # (as in a training step: dropout, mask bits out, abs-max out, no fp32 copy)
+        bits = torch.zeros(M, h // 32, dtype=torch.int32, device="cuda"); am = torch.zeros(64, device="cuda")
+        fn = lambda: L.mi_dense_fwd_planes(xp.ref, wt.ref, b.data_ptr(), None, h, yp.ref, M, h, fan, 1, 0.9, 7, am.data_ptr(), bits.data_ptr(), h // 32, st())
     else:
         dY = torch.randn(M, h, device="cuda", generator=g) * 1e-4
         dY[torch.rand(M, h, device="cuda", generator=g) < 0.5] = 0
@@ -45,15 +47,17 @@ def run(which):
             dX = torch.empty(M, fan, device="cuda")
             fn = lambda: L.mi_dense_bwd_data_planes(dyp.ref, wp.ref, None, dX.data_ptr(), fan, None, M, h, fan, 1.0, None, None, 0, st())
         else:
-            Xa = torch.randn(M, fan, device="cuda", generator=g).relu_(); xa = split(Xa); dxp = PB(M, fan)
-            fn = lambda: L.mi_dense_bwd_data_planes(dyp.ref, wp.ref, xa.ref, None, fan, dxp.ref, M, h, fan, 0.9, None, None, 0, st())
+            dxp = PB(M, fan)
+            bits = torch.randint(-2 ** 31, 2 ** 31 - 1, (M, fan // 32), dtype=torch.int32, device="cuda", generator=g)
+            am = torch.zeros(64, device="cuda")
+            fn = lambda: L.mi_dense_bwd_data_planes(dyp.ref, wp.ref, None, None, fan, dxp.ref, M, h, fan, 0.9, am.data_ptr(), bits.data_ptr(), fan // 32, st())
     for _ in range(4):
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
         e0.record(); assert fn() == 0; e1.record(); torch.cuda.synchronize()
     buf = np.zeros(32 * 2 * 128 * 8, dtype=np.int64)
     assert L.mi_pl_stamps_read(buf.ctypes.data, buf.nbytes) == 0
     d = buf.reshape(32, 2, 128, 8).astype(np.float64)
-    marks = d[:, :, :4, 7]                                   # [wg][grp][entry, first k-step, loop end, epilogue end]
+    marks = d[:, :, :6, 7]                                   # [wg][grp][entry, first k-step, loop end, epilogue end]
     ok = marks[:, 0, 0] > 0
     t0 = marks[ok][:, :, 0].min()
     print("%s: kernel %.1f us, nk = %d; clock64 ticks (100 MHz? no: shader clock)" % (which, e0.elapsed_time(e1) * 1e3, nk))
@@ -66,6 +70,8 @@ def run(which):
     mm = marks[ok][:, 0]
     print("  mean: prologue %.0f, k-loop %.0f (%.0f per k-step), epilogue %.0f" % ((mm[:, 1] - mm[:, 0]).mean(), (mm[:, 2] - mm[:, 1]).mean(),
                                                                                 (mm[:, 2] - mm[:, 1]).mean() / nk, (mm[:, 3] - mm[:, 2]).mean()))
+    print("  epilogue: element loops %.0f, barrier + planes conversion + store issue %.0f, store drain %.0f" %
+          ((mm[:, 4] - mm[:, 2]).mean(), (mm[:, 5] - mm[:, 4]).mean(), (mm[:, 3] - mm[:, 5]).mean()))
     lo, hi = min(2, nk - 1), min(nk, 100)
     ph = np.diff(d[ok][:, :, lo:hi, :7], axis=3)
     names = ["issue+frag reads", "wait LDS", "wait DMA", "barrier 1", "MFMAs", "barrier 2"]
