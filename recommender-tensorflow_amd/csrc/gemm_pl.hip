@@ -535,8 +535,15 @@ __global__ __launch_bounds__(PL_THREADS, 2) void gemm_pl_k(const PlArgs a) {
       const int blk = off >> 11, row = (off >> 6) & 31, slot = (off >> 4) & 3;
       const uint4 v4 = *reinterpret_cast<const uint4*>(wreg + off);
       const int mm = m0 + wm * 32 * TM + y * 32 + row, ncol = n0 + nw + blk * 16;
-      if (HOT || (mm < a.M && ncol < a.N))
+      if constexpr (HOT) {
+        // a uniform block base + ONE 32-bit lane offset + a compile-time constant (the planes of a hot launch are below 2 GB):
+        // a ds_read and a store per 1 KiB; the general form's 64-bit address of every store was ten instructions
+        const uint32_t lane_off = static_cast<uint32_t>(m0 + wm * 32 * TM + (lane >> 2)) * PL_ROWB + (((lane & 3) ^ ((lane >> 3) & 3)) << 4);
+        char* const blk_base = a.Cp + static_cast<int64_t>(((n0 + nw) >> 4) + (q >> 1)) * a.bsc;
+        *reinterpret_cast<uint4*>(blk_base + (lane_off + static_cast<uint32_t>(y * 32 + (q & 1) * 16) * PL_ROWB)) = v4;
+      } else if (mm < a.M && ncol < a.N) {
         *reinterpret_cast<uint4*>(a.Cp + (ncol >> 4) * a.bsc + static_cast<int64_t>(mm) * PL_ROWB + ((slot ^ ((row >> 1) & 3)) << 4)) = v4;
+      }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
@@ -959,7 +966,7 @@ int32_t launch_pl(PlArgs& a, hipStream_t st, const char* what) {
   }
   const dim3 g(static_cast<unsigned>(blocks)), b(PL_THREADS);
   // the steady-state training call (see gemm_pl_k: HOT)
-  const bool hot = a.Cp && !a.C && a.tiles_n == 1 && a.N == bn && a.M % bm == 0 && a.amax_c &&
+  const bool hot = a.Cp && !a.C && a.tiles_n == 1 && a.N == bn && a.M % bm == 0 && a.amax_c && a.bsc < (int64_t(1) << 31) &&
                    (EPI == PL_FWD ? (a.keep_prob < 1.f && a.mbits && a.mbld * 32 == a.N && a.bias)
                                   : (a.mbits && a.mbld * 32 == a.N));
   if (hot && tn == 1 && tm == 4) gemm_pl_k<1, 4, EPI, true><<<g, b, 0, st>>>(a);
