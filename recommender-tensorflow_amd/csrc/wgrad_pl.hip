@@ -316,6 +316,7 @@ bool wgrad_pl_plan(int64_t M, int N, int K, WgradPlPlan* p) {
   if (p->tn == 4) {
     if (env_int("MI_WGRAD_TILE", 512) == 256) { p->tn = 2; p->tm = 4; p->tiles_n = 2; }      // (the tools' build only)
   }
+  if (p->tn == 2 && env_int("MI_WGRAD_N256_AS_128", 0)) { p->tn = 1; p->tm = 2; p->tiles_n = 2; p->nbuf = env_int("MI_WGRAD_NBUF_N128", 3); }   // (the tools' build only)
   if (K % 128 != 0) return false;
   p->tiles_k = static_cast<int>(ceil_div(K, 64 * p->tm));      // (the last tile may be half empty)
   // one round of resident workgroups (one per CU; the 128-column tile fits two), at least 32 k-steps per split

@@ -244,6 +244,60 @@ def test_dense_bwd_data_planes(lib, M, N, K):
     assert row_rel_err(dX.cpu().numpy(), dY.astype(np.float64) @ W.astype(np.float64).T) < 1e-5
 
 
+# (the 256-row tiles — and with them the fixed-option kernels for 128 and 256 columns — are taken when they fill the chip:
+# 65536 rows; the 512-column data gradient has 128-row tiles at any size)
+@pytest.mark.parametrize("M,N,K", [(65536, 256, 512), (65536, 128, 256), (512, 256, 512)])
+def test_training_variant_of_the_forward_equals_the_general_kernel_bitwise(lib, M, N, K):
+    """gemm_pl_k<..., HOT>: the call of a steady-state training step (whole tiles, no fp32 copy, planes + mask bits + abs-max
+    out, dropout on) runs a kernel whose launch options are compile-time constants.  Same planes, exponents, mask bits and
+    abs-max as the general kernel — which the same call with an fp32 copy asked for runs."""
+    rng = np.random.default_rng(M + N + K)
+    X = rows_spread(rng, M, K)
+    W = (rng.standard_normal((K, N)) / np.sqrt(K)).astype(np.float32)
+    b = (rng.standard_normal(N) * 1e-3).astype(np.float32)
+    xp, wt = split(lib, X), split(lib, W, transpose=True)
+    out = []
+    for fp32_copy in (True, False):
+        Y = torch.empty(M, N, device="cuda") if fp32_copy else None
+        yp = PB(lib, M, N)
+        mb = torch.zeros(M, N // 32, dtype=torch.int32, device="cuda")
+        am = torch.zeros(64, device="cuda")
+        _chk(lib.mi_dense_fwd_planes(xp.ref, wt.ref, dev(b).data_ptr(), Y.data_ptr() if fp32_copy else None, N, yp.ref, M, N, K, 1,
+                                     0.9, 0xabcdef, am.data_ptr(), mb.data_ptr(), N // 32, _st()))
+        out.append((yp.bits(), yp.exp.cpu().numpy(), mb.cpu().numpy(), float(am.max().item()), Y))
+    (b0, e0, m0, a0, Y), (b1, e1, m1, a1, _) = out
+    assert np.array_equal(b0, b1) and np.array_equal(e0, e1) and np.array_equal(m0, m1) and a0 == a1
+    hb, he = host_planes(Y.cpu().numpy())
+    assert np.array_equal(b1, hb) and np.array_equal(e1, he) and a1 == float(Y.abs().max().item())
+
+
+@pytest.mark.parametrize("M,N,K", [(768, 256, 512), (65536, 128, 256), (65536, 64, 128), (512, 128, 256)])
+def test_training_variant_of_the_data_gradient_equals_the_general_kernel_bitwise(lib, M, N, K):
+    """... and the data gradient's (mask as bits, planes + abs-max out, no fp32 copy): dX[M][K] from dY[M][N]"""
+    rng = np.random.default_rng(M + N + K + 1)
+    dY = rows_spread(rng, M, N)
+    W = (rng.standard_normal((K, N)) / np.sqrt(N)).astype(np.float32)
+    words = rng.integers(0, 2 ** 32, (M, K // 32), dtype=np.uint64).astype(np.uint32)
+    dyp, wp, mbt = split(lib, dY), split(lib, W), dev(words.view(np.int32))
+    out = []
+    for fp32_copy in (True, False):
+        dX = torch.empty(M, K, device="cuda") if fp32_copy else None
+        dxp = PB(lib, M, K)
+        am = torch.zeros(64, device="cuda")
+        _chk(lib.mi_dense_bwd_data_planes(dyp.ref, wp.ref, None, dX.data_ptr() if fp32_copy else None, K, dxp.ref, M, N, K, 0.9,
+                                          am.data_ptr(), mbt.data_ptr(), K // 32, _st()))
+        out.append((dxp.bits(), dxp.exp.cpu().numpy(), float(am.max().item()), dX))
+    (b0, e0, a0, dX), (b1, e1, a1, _) = out
+    assert np.array_equal(b0, b1) and np.array_equal(e0, e1) and a0 == a1
+    got = dX.cpu().numpy()
+    bits = ((words[:, :, None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(M, K).astype(bool)
+    r = slice(0, 2048)                                          # (fp64 on the first rows)
+    ref = (dY[r].astype(np.float64) @ W.astype(np.float64).T) * bits[r] / np.float64(np.float32(0.9))
+    assert row_rel_err(got[r], ref) < 1e-5 and np.all(got[~bits] == 0)
+    hb, he = host_planes(got)
+    assert np.array_equal(b1, hb) and np.array_equal(e1, he)
+
+
 def test_planes_entries_refuse_bad_shapes(lib):
     from mi355x_rec._lib import MiError
     X = np.ones((64, 24), np.float32)

@@ -155,8 +155,10 @@ def main():
             del X, dY
         for env in ({}, {"MI_WGRAD_TM_N256": "2"}, {"MI_WGRAD_NBUF_N128": "6"}, {"MI_WGRAD_MIN_KSTEPS": "16"},
                     {"MI_WGRAD_NBUF_N128": "6", "MI_WGRAD_MIN_KSTEPS": "16"}, {"MI_WGRAD_TM_N256": "2", "MI_WGRAD_MIN_KSTEPS": "16"},
-                    {"MI_WGRAD_MIN_KSTEPS": "64"}, {"MI_WGRAD_TM_N256": "2", "MI_WGRAD_MIN_KSTEPS": "64"}):
-            for k_ in ("MI_WGRAD_TM_N256", "MI_WGRAD_NBUF_N128", "MI_WGRAD_MIN_KSTEPS"):
+                    {"MI_WGRAD_MIN_KSTEPS": "64"}, {"MI_WGRAD_TM_N256": "2", "MI_WGRAD_MIN_KSTEPS": "64"},
+                    {"MI_WGRAD_N256_AS_128": "1"}, {"MI_WGRAD_N256_AS_128": "1", "MI_WGRAD_MIN_KSTEPS": "64"},
+                    {"MI_WGRAD_N256_AS_128": "1", "MI_WGRAD_MIN_KSTEPS": "128"}):
+            for k_ in ("MI_WGRAD_TM_N256", "MI_WGRAD_NBUF_N128", "MI_WGRAD_MIN_KSTEPS", "MI_WGRAD_N256_AS_128"):
                 os.environ.pop(k_, None)
             os.environ.update(env)
             line = []
