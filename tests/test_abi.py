@@ -45,3 +45,10 @@ def test_only_gfx950_code_objects():
     if out.returncode == 0 and out.stdout.strip():
         targets = [t for t in out.stdout.split() if "amdgcn" in t]
         assert targets and all("gfx950" in t for t in targets), targets
+
+
+def test_shipped_library_reads_no_environment_variables():
+    """tuning switches live in the tools' build (make -C csrc tuning, -DMI_TUNING) only — the product
+    library does not even import getenv."""
+    out = subprocess.run(["nm", "-D", "--undefined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "getenv" not in out
