@@ -609,7 +609,8 @@ def main():
                      "mi_dense_fwd_planes", "mi_dense_bwd_data_planes", "mi_dense_bwd_weight_planes",
                      # (round 4: the logits layer's forward and backward run inside the fused logits + head launch — counted
                      # here in full, the head's own ~10 us included)
-                     "mi_logits_head_fused", "mi_dense_bwd_weight_planes_batch")
+                     # ... and, where the last hidden layer runs there too (mi_hidden_logits_head_fused), that launch)
+                     "mi_logits_head_fused", "mi_hidden_logits_head_fused", "mi_dense_bwd_weight_planes_batch")
         # (the planes path's own overhead launches count against it: they exist only because of it)
         gemm_overhead_keys = ("mi_dense_bwd_data_vec_planes", "mi_split_weights", "mi_absmax", "mi_split_rows")
         gemm_ms = sum(v[2] for k, v in km.items() if k in gemm_keys + gemm_overhead_keys) / args.steps

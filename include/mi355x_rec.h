@@ -52,7 +52,7 @@ enum mi_status {
 };
 
 /* ---- library ---------------------------------------------------------------------------- */
-int32_t mi_abi_version(void);       /* bumps when a signature changes (currently 19) */
+int32_t mi_abi_version(void);       /* bumps when a signature changes (currently 20) */
 const char* mi_last_error(void);    /* thread-local, never NULL */
 const char* mi_build_info(void);    /* "gfx950 hipcc <ver>" */
 
@@ -63,7 +63,7 @@ const char* mi_build_info(void);    /* "gfx950 hipcc <ver>" */
  *   mi_sparse_apply[_fused]              step <- state->step, hp->lr_t <- state->lr_t
  *   mi_dense_apply                       hp->lr_t <- state->lr_t
  *   mi_sparse_catchup, mi_catchup_gap_keys, mi_catchup_rows_by_gap   step_to <- state->step - 1
- *   mi_dense_fwd[_gathered|_planes]      seed <- seed + state->seed_term       (dropout masks differ every step)
+ *   mi_dense_fwd[_gathered|_planes], mi_hidden_logits_head_fused   seed <- seed + state->seed_term   (dropout masks differ every step)
  * mi_step_advance (the first node of the captured step): step += 1, lr_t = lr_table[step], seed_term = step * 1000003.
  * Register the state only while capturing; eager calls between replays keep using their arguments. */
 typedef struct mi_step_state {
@@ -549,6 +549,22 @@ int32_t mi_logits_head_fused(const float* X, int64_t ldx, const float* w, const 
                              const uint32_t* mask_bits, int64_t mask_ld, float keep_prob, float* dnn, float* logits,
                              float* loss_out, float* d_logit, float* d_logit_sum, float* dW, float* db, const mi_planes_t* dXp,
                              float* dX, int64_t lddx, float* amax_out, void* workspace, size_t workspace_bytes, mi_stream_t stream);
+
+/* ... and the LAST HIDDEN layer with them (round 4): Y = dropout(relu(X W + bias)) [M][N] from planes as in
+ * mi_dense_fwd_planes, then — in the GEMM's epilogue, Y never leaves the chip — everything mi_logits_head_fused does with it:
+ * dnn, logits, loss, d_logit, the bias gradient(s), the logits layer's weight gradient dW [N] and its data gradient
+ * dXp [M][N] (planes: d_logit[m] w[n], kept where Y[m][n] > 0, divided by keep_prob).  Replaces deep_fm.py:98-125 from the
+ * last hidden layer up, forward and backward, with two launches (the GEMM and a fold of its workgroups' N + 2 partial sums);
+ * saves the layer's output written and read back (2 x 4 M N bytes) and its mask bits.  N = 128 (one column tile holds the whole
+ * layer); K a multiple of 16.  Per example the arithmetic of the two entries it fuses; the sum h . w of the logits layer and the
+ * sums over examples associate in its own fixed order (tests: 2e-6 of sum |h w|, everything downstream on its own dnn). */
+size_t mi_hidden_logits_head_fused_workspace_bytes(int64_t M, int32_t N);
+int32_t mi_hidden_logits_head_fused(const mi_planes_t* X, const mi_planes_t* Wt, const float* bias, int64_t M, int32_t N, int32_t K,
+                                    int32_t relu, float keep_prob, uint64_t seed, const float* w, const float* b, const float* lin,
+                                    const float* lin_bias, const float* fm, const uint8_t* labels, float loss_scale, float* dnn,
+                                    float* logits, float* loss_out, float* d_logit, float* d_logit_sum, float* dW, float* db,
+                                    const mi_planes_t* dXp, float* amax_out, void* workspace, size_t workspace_bytes,
+                                    mi_stream_t stream);
 
 /* The data gradient of the N = 1 logits layer (deep_fm.py:108 backward) with the result as planes:
  * dX[m][k] = dY[m] * W[k], kept where Xact[m][k] > 0 and divided by keep_prob (Xact == NULL: no mask) — the

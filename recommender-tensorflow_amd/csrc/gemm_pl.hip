@@ -49,7 +49,7 @@ constexpr int PL_THREADS = 512;
 constexpr int PL_BK = 16;
 constexpr int PL_ROWB = 64;       // bytes per tile row and stage: 16 k x (hi, lo) x 2 B
 
-enum { PL_FWD = 0, PL_DGRAD = 1 };
+enum { PL_FWD = 0, PL_DGRAD = 1, PL_TOP = 2 };
 
 struct PlArgs {
   const char* A; int64_t bsa; const int32_t* a_exp;     // weight side (rows = output columns); bsa: k-block stride in bytes
@@ -66,6 +66,11 @@ struct PlArgs {
   uint32_t* mbits; int64_t mbld;
   float* amax_c;                                        // abs-max vector of the result (the weight gradient's matrix-wide scales) or NULL
   const mi_step_state_t* st;                            // device-resident step state of a captured step, or NULL
+  // PL_TOP (mi_hidden_logits_head_fused): the one-unit logits layer and the head behind this layer, in its epilogue
+  const float* top_w; const float* top_b;               // logits layer: weights [N], bias [1] (or NULL)
+  const float* top_lin; const float* top_lin_bias; const float* top_fm; const uint8_t* top_labels; float top_scale;
+  float* top_dnn; float* top_logits; float* top_dlogit; // per example (top_dnn may be NULL)
+  float* top_part;                                      // [workgroups][N + 2]: the logits layer's dW partial, sum d, sum loss
 };
 
 __device__ __forceinline__ float pl_pow2(int s) { return __uint_as_float(static_cast<uint32_t>(127 + s) << 23); }
@@ -272,6 +277,228 @@ __global__ __launch_bounds__(PL_THREADS, 2) void gemm_pl_k(const PlArgs a) {
   }
   if (!g1) __builtin_amdgcn_s_barrier();
   PL_MARK(2);
+
+  // ---------------------------------------------------------------- PL_TOP: the last hidden layer + logits layer + head
+  // (mi_hidden_logits_head_fused; TN = 1: the workgroup's 128 columns are the whole layer.)  The layer's output never leaves the
+  // chip: it stays in the accumulators through
+  //   h     = dropout(relu(acc 2^-s_x 2^-s_w + bias))                     (the FWD epilogue's arithmetic)
+  //   dnn   = h . w + b ; logits = lin + lin_bias + fm + dnn ; loss, d = (sigmoid(logits) - label) scale   (tail.hip's)
+  //   dW   += h d ; db += d                                               (per-workgroup partials, folded by tail_fold_k)
+  //   dX    = d w, kept where h > 0, divided by keep_prob  -> planes       (what the layer below's data gradient reads)
+  // A lane owns an example (i) and 16 of its 128 columns (wave column group wn, half h, registers r): sums over a row's
+  // columns go lane pair -> LDS -> the four column groups in order; sums over examples go through a 32-lane butterfly.
+  if constexpr (EPI == PL_TOP) {
+    static_assert(TN == 1, "PL_TOP: one 128-column tile");
+    pl_wait_vmcnt<0>();
+    __syncthreads();
+    float* e_fw = reinterpret_cast<float*>(smem);     // [128] 2^-s of the weight row
+    float* e_bias = e_fw + 128;                       // [128]
+    float* e_w = e_bias + 128;                        // [128] logits-layer weights
+    float* e_part = e_w + 128;                        // [4][BMt] per column group: dot-product partials, then row abs-max
+    float* e_dw = e_part + 4 * BMt;                   // [2][128] dW partial of each row half of the tile
+    float* e_sc = e_dw + 256;                         // [2][2] per row half: sum loss, sum d
+    float* e_wmax = e_sc + 4;                         // [8]
+    static_assert((128 * 3 + 4 * BMt + 256 + 4 + 8) * 4 <= 8192 && 8192 + 8 * 4096 <= PL_NBUF * STAGE, "PL_TOP LDS");
+    char* wreg = smem + 8192 + wv * 4096;
+    for (int n = t; n < 128; n += PL_THREADS) {
+      const bool ok = n < a.N;
+      e_fw[n] = ok ? pl_pow2(-a.a_exp[ok ? n : 0]) : 0.f;
+      e_bias[n] = (a.bias && ok) ? a.bias[n] : 0.f;
+      e_w[n] = ok ? a.top_w[n] : 0.f;
+    }
+    __syncthreads();
+    const bool drop = a.keep_prob < 1.f;
+    const uint32_t thresh16 = drop ? mi_drop_thresh16(a.keep_prob) : 0x10000u;
+    const uint64_t seed = a.seed + (a.st ? a.st->seed_term : 0ull);
+    const int nw = wn * 32;
+    const uint32_t pair_base = static_cast<uint32_t>((nw + 4 * h) >> 1) * MI_DROP_PAIR_MUL;
+    const float kd = a.keep_div, kr = a.keep_rcp;       // (1 and 1 without dropout)
+    const float relu_floor = a.relu ? 0.f : -__builtin_inff();
+    // this lane's 16 logits-layer weights: register r <-> column nw + 8 (r >> 2) + 4 h + (r & 3)
+    float wr[16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 w4 = *reinterpret_cast<const float4*>(e_w + nw + 8 * g + 4 * h);
+      wr[4 * g] = w4.x; wr[4 * g + 1] = w4.y; wr[4 * g + 2] = w4.z; wr[4 * g + 3] = w4.w;
+    }
+    // ---- the layer's output into the accumulators, and this lane's share of h . w
+#pragma unroll
+    for (int y = 0; y < TM; ++y) {
+      const int rl = wm * 32 * TM + y * 32 + i;
+      const int m = m0 + rl;
+      const int mc = m < a.M ? m : a.M - 1;
+      const float fx = pl_pow2(-a.b_exp[mc]);
+      const uint32_t rowkey = drop ? mi_drop_rowkey(seed, static_cast<uint32_t>(m)) : 0u;
+      float p = 0.f;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 fw4 = *reinterpret_cast<const float4*>(e_fw + nw + 8 * g + 4 * h);
+        const float4 b4 = *reinterpret_cast<const float4*>(e_bias + nw + 8 * g + 4 * h);
+        uint32_t w2[2] = {0u, 0u};
+        if (drop) {
+          const uint32_t pt = pair_base + static_cast<uint32_t>((8 * g) >> 1) * MI_DROP_PAIR_MUL;
+          w2[0] = mi_drop_pairhash(rowkey, pt);
+          w2[1] = mi_drop_pairhash(rowkey, pt + MI_DROP_PAIR_MUL);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int r = 4 * g + j;
+          const float fwj = j == 0 ? fw4.x : j == 1 ? fw4.y : j == 2 ? fw4.z : fw4.w;
+          float v = (acc[0][y][r] * fx) * fwj;
+          v += j == 0 ? b4.x : j == 1 ? b4.y : j == 2 ? b4.z : b4.w;
+          v = fmaxf(v, relu_floor);
+          const uint32_t bits16 = (j & 1) ? (w2[j >> 1] >> 16) : (w2[j >> 1] & 0xffffu);
+          v = bits16 < thresh16 ? mi_div_const(v, kd, kr) : 0.f;
+          acc[0][y][r] = v;
+          p = fmaf(v, wr[r], p);
+        }
+      }
+      p += __shfl_xor(p, 32);                          // the lane pair that shares this example
+      if (h == 0) e_part[wn * BMt + rl] = p;
+    }
+    __syncthreads();
+    // ---- the head, per example (every column group computes its rows' values; group 0 writes them)
+    const float b0 = a.top_b ? a.top_b[0] : 0.f;
+    const float lb = (a.top_lin && a.top_lin_bias) ? a.top_lin_bias[0] : 0.f;
+    float gy[TM];
+    float acc_l = 0.f, acc_d = 0.f;
+#pragma unroll
+    for (int y = 0; y < TM; ++y) {
+      const int rl = wm * 32 * TM + y * 32 + i;
+      const int m = m0 + rl;
+      const bool mok = m < a.M;
+      const int mc = mok ? m : a.M - 1;
+      const float dnn = ((e_part[rl] + e_part[BMt + rl]) + (e_part[2 * BMt + rl] + e_part[3 * BMt + rl])) + b0;
+      float z = 0.f;
+      if (a.top_lin) z += a.top_lin[mc] + lb;
+      if (a.top_fm) z += a.top_fm[mc];
+      z += dnn;
+      const float yl = a.top_labels[mc] ? 1.f : 0.f;
+      const float loss = (fmaxf(z, 0.f) - z * yl + log1pf(expf(-fabsf(z)))) * a.top_scale;
+      const float e = expf(-fabsf(z));
+      const float sg = z >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+      const float g = mok ? (sg - yl) * a.top_scale : 0.f;
+      gy[y] = g;
+      if (mok && wn == 0 && h == 0) {
+        if (a.top_dnn) a.top_dnn[m] = dnn;
+        a.top_logits[m] = z;
+        a.top_dlogit[m] = g;
+        acc_l += loss; acc_d += g;
+      }
+    }
+    __syncthreads();                                    // e_part is about to hold the row maxima
+    // ---- the logits layer's backward: dW partial sums (registers, over the tile's rows), dX into the accumulators
+    float dw[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dw[r] = 0.f;
+    float rmx[TM];
+#pragma unroll
+    for (int y = 0; y < TM; ++y) {
+      const int rl = wm * 32 * TM + y * 32 + i;
+      const float g = gy[y];
+      float mx = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float hv = acc[0][y][r];
+        dw[r] = fmaf(hv, g, dw[r]);
+        const float v = hv > 0.f ? mi_div_const(g * wr[r], kd, kr) : 0.f;
+        acc[0][y][r] = v;
+        mx = fmaxf(mx, fabsf(v));
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      rmx[y] = mx;
+      if (h == 0) e_part[wn * BMt + rl] = mx;
+    }
+    // sums over the 32 examples of this wave (both y blocks already added): a butterfly inside each half-wave
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float sv = dw[r];
+#pragma unroll
+      for (int o = 1; o < 32; o <<= 1) sv += __shfl_xor(sv, o);
+      dw[r] = sv;
+    }
+    if (i == 0) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<float4*>(e_dw + wm * 128 + nw + 8 * g + 4 * h) = make_float4(dw[4 * g], dw[4 * g + 1], dw[4 * g + 2], dw[4 * g + 3]);
+    }
+    if (wn == 0) {                                      // (lanes with h == 1 hold zeros)
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { acc_l += __shfl_xor(acc_l, o); acc_d += __shfl_xor(acc_d, o); }
+      if (lane == 0) { e_sc[wm * 2] = acc_l; e_sc[wm * 2 + 1] = acc_d; }
+    }
+    if (a.amax_c) {
+      float wmx = 0.f;
+#pragma unroll
+      for (int y = 0; y < TM; ++y) wmx = fmaxf(wmx, rmx[y]);          // (rows past M hold zeros: d = 0)
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) wmx = fmaxf(wmx, __shfl_xor(wmx, o));
+      if (lane == 0) e_wmax[wv] = wmx;
+    }
+    __syncthreads();
+    if (t < 128) a.top_part[static_cast<int64_t>(blockIdx.x) * (a.N + 2) + t] = e_dw[t] + e_dw[128 + t];
+    else if (t == 128) a.top_part[static_cast<int64_t>(blockIdx.x) * (a.N + 2) + a.N] = e_sc[1] + e_sc[3];
+    else if (t == 129) a.top_part[static_cast<int64_t>(blockIdx.x) * (a.N + 2) + a.N + 1] = e_sc[0] + e_sc[2];
+    if (a.amax_c && t == 0) {
+      float mx = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) mx = fmaxf(mx, e_wmax[w]);
+      unsigned int* slot = reinterpret_cast<unsigned int*>(a.amax_c) + (blockIdx.x & (MI_AMAX_SLOTS - 1));
+      const unsigned int bits = __float_as_uint(mx);
+      if (bits > *reinterpret_cast<volatile unsigned int*>(slot)) atomicMax(slot, bits);
+    }
+    // ---- dX as planes: row exponent from the row's abs-max over the 128 columns (tail.hip's conversion: a positive value keeps
+    // a positive high part)
+#pragma unroll
+    for (int y = 0; y < TM; ++y) {
+      const int ml = wm * 32 * TM + y * 32 + i;
+      const int m = m0 + ml;
+      const float mx = fmaxf(fmaxf(e_part[ml], e_part[BMt + ml]), fmaxf(e_part[2 * BMt + ml], e_part[3 * BMt + ml]));
+      const int sx = pl_exp_for(mx);
+      const float sc = pl_pow2(sx);
+      if (m < a.M && h == 0 && wn == 0) a.c_exp[m] = sx;
+      uint32_t ph[8], pq[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float u0 = acc[0][y][2 * q] * sc, u1 = acc[0][y][2 * q + 1] * sc;
+        const fl32x2 uu = {u0, u1};
+        h16x2 hh = __builtin_convertvector(uu, h16x2);
+        uint32_t hb = __builtin_bit_cast(uint32_t, hh);
+        if (u0 > 0.f && (hb & 0xffffu) == 0u) hb |= 1u;
+        if (u1 > 0.f && (hb >> 16) == 0u) hb |= 0x10000u;
+        hh = __builtin_bit_cast(h16x2, hb);
+        const fl32x2 rr2 = {u0 - static_cast<float>(hh[0]), u1 - static_cast<float>(hh[1])};
+        const h16x2 ll = __builtin_convertvector(rr2, h16x2);
+        ph[q] = hb;
+        pq[q] = __builtin_bit_cast(uint32_t, ll);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        auto r1 = __builtin_amdgcn_permlane32_swap(ph[q], ph[q + 4], false, false);
+        ph[q] = r1[0]; ph[q + 4] = r1[1];
+        auto r2 = __builtin_amdgcn_permlane32_swap(pq[q], pq[q + 4], false, false);
+        pq[q] = r2[0]; pq[q + 4] = r2[1];
+      }
+      char* d = wreg + (h * 32 + i) * 64;
+      const int rot = (i >> 1) & 3;
+      *reinterpret_cast<uint4*>(d + ((0 ^ rot) << 4)) = make_uint4(ph[0], ph[1], ph[4], ph[5]);
+      *reinterpret_cast<uint4*>(d + ((1 ^ rot) << 4)) = make_uint4(ph[2], ph[3], ph[6], ph[7]);
+      *reinterpret_cast<uint4*>(d + ((2 ^ rot) << 4)) = make_uint4(pq[0], pq[1], pq[4], pq[5]);
+      *reinterpret_cast<uint4*>(d + ((3 ^ rot) << 4)) = make_uint4(pq[2], pq[3], pq[6], pq[7]);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int off = q * 1024 + lane * 16;
+        const int blk = off >> 11, row = (off >> 6) & 31, slot = (off >> 4) & 3;
+        const uint4 v4 = *reinterpret_cast<const uint4*>(wreg + off);
+        const int mm = m0 + wm * 32 * TM + y * 32 + row, ncol = nw + blk * 16;
+        if (mm < a.M && ncol < a.N)
+          *reinterpret_cast<uint4*>(a.Cp + (ncol >> 4) * a.bsc + static_cast<int64_t>(mm) * PL_ROWB + ((slot ^ ((row >> 1) & 3)) << 4)) = v4;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    return;
+  }
 
   // ---------------------------------------------------------------- epilogue
   pl_wait_vmcnt<0>();                 // the tail's re-issued loads
@@ -931,6 +1158,30 @@ __global__ __launch_bounds__(256) void selftest_div_k(float d, float r, uint32_t
   }
 }
 
+// out[k] = the sum of the workgroups' partials of gemm_pl_k<.., PL_TOP> (tail.hip's tail_fold_k: 16 columns x 16 slices per
+// workgroup, the slices folded in order): the logits layer's dW [N], the sum of d (db and / or d_sum), the loss
+__global__ __launch_bounds__(256) void top_fold_k(const float* __restrict__ part, int nparts, int N, float* __restrict__ dW,
+                                                  float* __restrict__ db, float* __restrict__ d_sum, float* __restrict__ loss) {
+  __shared__ float red[16][17];
+  const int c = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int k = blockIdx.x * 16 + c;
+  float acc = 0.f;
+  if (k < N + 2) {
+#pragma unroll 8
+    for (int q = sl; q < nparts; q += 16) acc += part[static_cast<int64_t>(q) * (N + 2) + k];
+  }
+  red[sl][c] = acc;
+  __syncthreads();
+  if (sl == 0 && k < N + 2) {
+    float v = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v += red[q][c];
+    if (k < N) dW[k] = v;
+    else if (k == N) { if (db) db[0] = v; if (d_sum) d_sum[0] = v; }
+    else if (loss) loss[0] = v;
+  }
+}
+
 bool planes_ok(const mi_planes_t* p, int64_t rows, int K) {
   return p && p->data && p->row_exp && mi::aligned16(p->data) && p->blk_stride >= rows * PL_ROWB && (p->blk_stride & 63) == 0 && rows >= 0;
 }
@@ -1118,6 +1369,47 @@ int32_t mi_dense_bwd_data_planes(const mi_planes_t* dY, const mi_planes_t* W, co
   return launch_pl<PL_DGRAD>(a, mi::as_stream(stream), "dense_bwd_data_planes");
 }
 
+
+size_t mi_hidden_logits_head_fused_workspace_bytes(int64_t M, int32_t N) {
+  if (M <= 0 || N <= 0) return 256;
+  return static_cast<size_t>(mi::ceil_div(M, 128)) * (N + 2) * sizeof(float) + 256;
+}
+
+int32_t mi_hidden_logits_head_fused(const mi_planes_t* X, const mi_planes_t* Wt, const float* bias, int64_t M, int32_t N, int32_t K,
+                                    int32_t relu, float keep_prob, uint64_t seed, const float* w, const float* b, const float* lin,
+                                    const float* lin_bias, const float* fm, const uint8_t* labels, float loss_scale, float* dnn,
+                                    float* logits, float* loss_out, float* d_logit, float* d_logit_sum, float* dW, float* db,
+                                    const mi_planes_t* dXp, float* amax_out, void* workspace, size_t workspace_bytes,
+                                    mi_stream_t stream) {
+  MI_REQUIRE(M > 0 && M <= INT32_MAX && N == 128 && K > 0 && (K & 15) == 0,
+             "hidden_logits_head_fused: M=%lld N=%d (128) K=%d (a multiple of 16)", (long long)M, N, K);
+  MI_REQUIRE(planes_ok(X, M, K) && planes_ok(Wt, N, K), "hidden_logits_head_fused: operand planes");
+  MI_REQUIRE(w && labels && logits && d_logit && dW && workspace && mi::aligned16(w), "hidden_logits_head_fused: null buffer / alignment");
+  MI_REQUIRE(planes_ok(dXp, M, N), "hidden_logits_head_fused: output planes");
+  MI_REQUIRE(keep_prob > 0.f && keep_prob <= 1.f, "hidden_logits_head_fused: keep_prob=%f", keep_prob);
+  MI_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15u) == 0, "hidden_logits_head_fused: workspace alignment");
+  if (workspace_bytes < mi_hidden_logits_head_fused_workspace_bytes(M, N)) {
+    mi::set_error("hidden_logits_head_fused: workspace %zu < %zu", workspace_bytes, mi_hidden_logits_head_fused_workspace_bytes(M, N));
+    return MI_ERR_WORKSPACE;
+  }
+  PlArgs a{};
+  a.A = static_cast<const char*>(Wt->data); a.bsa = Wt->blk_stride; a.a_exp = Wt->row_exp;
+  a.B = static_cast<const char*>(X->data); a.bsb = X->blk_stride; a.b_exp = X->row_exp;
+  a.M = (int)M; a.N = N; a.K = K; a.tiles_n = 1;
+  a.Cp = static_cast<char*>(dXp->data); a.bsc = dXp->blk_stride; a.c_exp = dXp->row_exp;
+  a.bias = bias; a.relu = relu; a.keep_prob = keep_prob; a.keep_div = keep_prob; a.keep_rcp = 1.0f / keep_prob; a.seed = seed; a.st = mi::step_state();
+  a.amax_c = amax_out;
+  a.top_w = w; a.top_b = b; a.top_lin = lin; a.top_lin_bias = lin_bias; a.top_fm = fm; a.top_labels = labels; a.top_scale = loss_scale;
+  a.top_dnn = dnn; a.top_logits = logits; a.top_dlogit = d_logit; a.top_part = static_cast<float*>(workspace);
+  const int64_t blocks = mi::ceil_div(M, 128);
+  hipStream_t st = mi::as_stream(stream);
+  gemm_pl_k<1, 2, PL_TOP><<<dim3(static_cast<unsigned>(blocks)), dim3(PL_THREADS), 0, st>>>(a);
+  MI_CHECK_LAUNCH("hidden_logits_head_fused");
+  top_fold_k<<<dim3(static_cast<unsigned>(mi::ceil_div(N + 2, 16))), dim3(256), 0, st>>>(a.top_part, static_cast<int>(blocks), N, dW, db,
+                                                                                         d_logit_sum, loss_out);
+  MI_CHECK_LAUNCH("hidden_logits_head_fused(fold)");
+  return MI_OK;
+}
 
 int32_t mi_dense_bwd_data_vec_planes(const float* dY, int64_t lddy, const float* W, const float* Xact, int64_t ldxa,
                                      float keep_prob, float* dX, int64_t lddx, const mi_planes_t* dXp, int64_t M, int32_t K,

@@ -16,7 +16,7 @@ import torch  # noqa: F401  (loads the HIP runtime this library must share)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmi355x_rec.so")
 
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 
 class MiError(RuntimeError):
@@ -128,6 +128,9 @@ SIGNATURES = {
     "mi_logits_head_fused_workspace_bytes": (_sz, [_i64, _i32]),
     "mi_logits_head_fused": (_i32, [_p, _i64, _p, _p, _p, _p, _p, _p, _i64, _i32, _f32, _p, _i64, _f32, _p, _p, _p, _p, _p, _p, _p, _pl,
                                     _p, _i64, _p, _p, _sz, _p]),
+    "mi_hidden_logits_head_fused_workspace_bytes": (_sz, [_i64, _i32]),
+    "mi_hidden_logits_head_fused": (_i32, [_pl, _pl, _p, _i64, _i32, _i32, _i32, _f32, _u64, _p, _p, _p, _p, _p, _p, _f32, _p, _p, _p, _p,
+                                           _p, _p, _p, _pl, _p, _p, _sz, _p]),
     "mi_head_workspace_bytes": (_sz, [_i64]),
     "mi_sigmoid_ce_head": (_i32, [_p, _p, _p, _p, _p, _i64, _f32, _p, _p, _p, _p, _p, _sz, _p]),
     "mi_colsum_workspace_bytes": (_sz, [_i64, _i32]),

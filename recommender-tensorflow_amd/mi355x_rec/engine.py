@@ -437,6 +437,7 @@ class DeepFM:
                        all(h % 16 == 0 for h in self.hidden))
         self._pl = {}
         self._acts_in_planes = set()      # hidden layers whose last training output exists as planes only
+        self.summaries_next = False       # set before a train step whose layer_summaries() will be recorded (Estimator.train)
         # layer 1's operand: the gather kernel writes it as planes when the embedding size allows; otherwise
         # the concat is materialised in fp32 (as with numeric columns) and split
         self.pl_gather_ok = self.E % 16 == 0 and self.E >= 32 and self.F <= 48
@@ -842,6 +843,7 @@ class DeepFM:
             xp = "x0p"
             # TRAIN on the planes path: the logits layer (N = 1) runs inside the fused logits + head launch (_head)
             c["tail_fused"] = bool(train and self._tail_fusable())
+            c["top_fused"] = bool(c["tail_fused"] and self._top_fusable(B))
             for i, (_, _, fan, h) in enumerate(self.layers):
                 last = i == nh
                 y = self._buf("act%d" % i, (B, h))
@@ -849,23 +851,14 @@ class DeepFM:
                     acts.append(y)
                     break
                 if self.planes and not last:
-                    # the next layer's operand as planes straight from the epilogue when a workgroup owns
-                    # whole rows (h <= 512); the fp32 copy feeds the logits layer / a weight gradient on fp32 operands
-                    need_p = i + 1 < nh
-                    yp = self._planes("x%dp" % (i + 1), B, h) if need_p else None
-                    direct = need_p and h <= 512
-                    # (no fp32 copy when its only reader, the next layer's weight gradient, takes the planes)
-                    planes_only = train and direct and self._wgrad_planes_ok(B, i + 1)
-                    (self._acts_in_planes.add if planes_only else self._acts_in_planes.discard)(i)
-                    # (training: the relu/dropout mask as one bit per output, for the data gradients — 1/32 of the bytes of
-                    # the stored activation they would otherwise read it from)
-                    mb = self._buf("mbits%d" % i, (B, (h + 31) // 32), torch.int32) if train else None
-                    k.mi_dense_fwd_planes(self._planes(xp, B, fan), self._pl["wt%d" % i].struct, self.bias(i),
-                                          None if planes_only else y, h,
-                                          yp if direct else None, B, h, fan, 1, keep, self._layer_seed(i),
-                                          self._av("x%d" % (i + 1)), mb, 0 if mb is None else mb.shape[1])
-                    if need_p and not direct:
-                        k.mi_split_rows(y, h, B, h, 0, yp, None)
+                    if c["top_fused"] and i == nh - 1:
+                        # the last hidden layer: inside the fused logits + head launch (_head), its output stays on the chip
+                        c["top"] = (i, xp, keep, self._layer_seed(i))
+                        self._acts_in_planes.discard(i)
+                        acts.append(y)
+                        x, ldx = y, h
+                        continue
+                    self._hidden_forward_planes(c, i, xp, y, keep, self._layer_seed(i), train)
                     xp = "x%dp" % (i + 1)
                 elif i == 0 and gathered:
                     k.mi_dense_fwd_gathered(table, field_off, rid, F, self.E, self.kernel(0), self.bias(0), y, h,
@@ -891,6 +884,41 @@ class DeepFM:
         _, _, fan, h = self.layers[-1]
         return h == 1 and fan in (64, 128, 256)
 
+    def _top_fusable(self, B):
+        """the last hidden layer runs inside the fused logits + head launch too (mi_hidden_logits_head_fused): a 128-unit layer
+        below the one-unit logits layer whose weight gradient reads planes, a batch that fills the chip, and nobody about to
+        look at the layer's output (summaries_next: the Estimator says so before a step whose layer_summary it records)"""
+        if not (self.TOP_FUSED and self._tail_fusable() and hasattr(self.k, "mi_hidden_logits_head_fused")):
+            return False
+        nh = len(self.layers) - 1
+        if nh < 1 or B < self.TOP_FUSED_MIN_BATCH or getattr(self, "summaries_next", False):
+            return False
+        _, _, fan, h = self.layers[nh - 1]
+        return h == 128 and fan % 16 == 0 and self._wgrad_planes_ok(B, nh - 1)
+
+    def _hidden_forward_planes(self, c, i, xp, y, keep, seed, train):
+        """hidden layer i's forward on the planes path (see _forward): the next layer's operand as planes straight from the
+        epilogue when a workgroup owns whole rows (h <= 512), the fp32 copy where something reads it"""
+        k = self.k
+        B = c["B"]
+        nh = len(self.layers) - 1
+        _, _, fan, h = self.layers[i]
+        need_p = i + 1 < nh
+        yp = self._planes("x%dp" % (i + 1), B, h) if need_p else None
+        direct = need_p and h <= 512
+        # (no fp32 copy when its only reader, the next layer's weight gradient, takes the planes)
+        planes_only = train and direct and self._wgrad_planes_ok(B, i + 1)
+        (self._acts_in_planes.add if planes_only else self._acts_in_planes.discard)(i)
+        # (training: the relu/dropout mask as one bit per output, for the data gradients — 1/32 of the bytes of
+        # the stored activation they would otherwise read it from)
+        mb = self._buf("mbits%d" % i, (B, (h + 31) // 32), torch.int32) if train else None
+        k.mi_dense_fwd_planes(self._planes(xp, B, fan), self._pl["wt%d" % i].struct, self.bias(i),
+                              None if planes_only else y, h,
+                              yp if direct else None, B, h, fan, 1, keep, seed,
+                              self._av("x%d" % (i + 1)), mb, 0 if mb is None else mb.shape[1])
+        if need_p and not direct:
+            k.mi_split_rows(y, h, B, h, 0, yp, None)
+
     def _head(self, c, labels, want_grad, global_batch=None):
         k = self.k
         B = c["B"]
@@ -905,6 +933,23 @@ class DeepFM:
         lb = self.dense[self.lin_bias_off:] if self.use_linear else None
         # d loss / d linear bias = sum_b dlogit lands straight in the dense gradient buffer
         dsum = self.d_grad[self.lin_bias_off:] if (want_grad and self.use_linear) else None
+        if c.get("top") is not None:
+            nh = len(self.layers) - 1
+            i, xp, keep, seed = c.pop("top")
+            _, _, fan, h = self.layers[i]
+            if want_grad and labels is not None:
+                tws = self._bytes("top_ws", k.query("mi_hidden_logits_head_fused_workspace_bytes", B, h))
+                k.mi_hidden_logits_head_fused(self._planes(xp, B, fan), self._pl["wt%d" % i].struct, self.bias(i), B, h, fan, 1, keep,
+                                              seed, self.kernel(nh), self.bias(nh), c["lin"], lb, c["fm"], labels, float(scale),
+                                              c["acts"][nh], logits, loss, dlogit, dsum, self.kernel(nh, self.d_grad),
+                                              self.bias(nh, self.d_grad), self._planes("dy%dp" % (nh - 1), B, h),
+                                              self._av("dy%d" % (nh - 1)), tws, tws.numel())
+                c["dnn"] = c["acts"][nh].view(B)
+                c["tail_done"] = True
+                self._top_step = self.step
+                return logits, loss, dlogit
+            # (a forward made for training but no gradient asked for: the layer as its own launch after all)
+            self._hidden_forward_planes(c, i, xp, c["acts"][i], keep, seed, True)
         if c.get("tail_fused"):
             nh = len(self.layers) - 1
             _, _, fan, _ = self.layers[nh]
@@ -979,6 +1024,8 @@ class DeepFM:
     ROW_RECORDS = True        # a table row and its optimizer slots as one [w | slot0 | slot1] record (__init__)
     TAIL_FUSED = True         # logits layer + head + the layer's backward as one launch (_head: mi_logits_head_fused)
     WGRAD_BATCH = True        # the planes weight gradients of a backward pass as one batch after the data gradients (_backward_dense)
+    TOP_FUSED = True          # ... and the last hidden layer with them, in its GEMM's epilogue (_head: mi_hidden_logits_head_fused)
+    TOP_FUSED_MIN_BATCH = 4096
 
     def _catchup(self, uniq, num_uniq, n_max, defer=False, by_gap=None):
         """defer: the rows are about to be applied in this same step by ONE mi_sparse_apply call, which
@@ -1476,6 +1523,8 @@ class DeepFM:
         if self.use_dnn:
             for i, (_, _, _, h) in enumerate(self.layers):
                 a = self._ws.get("act%d" % i)
+                if i == len(self.layers) - 2 and getattr(self, "_top_step", None) == self.step - 1:
+                    continue      # (the last step kept this layer's output on the chip: _top_fusable — summaries_next was not set)
                 if a is not None and i in self._acts_in_planes:      # the last step wrote planes only: merge them
                     k.mi_merge_rows(self._pl["x%dp" % (i + 1)].struct, B, h, a, h)
                 if a is not None:

@@ -245,6 +245,11 @@ class Estimator:
                 break
             if steps is not None and done >= steps:
                 break
+            eng = self._engine()
+            if eng is not None and hasattr(eng, "summaries_next"):
+                # (the step whose layer_summary statistics are recorded keeps every layer's output in memory: engine._top_fusable)
+                n_sum = self.config.save_summary_steps
+                eng.summaries_next = bool(n_sum and (self.global_step + 1) % n_sum == 0)
             spec = self.model_fn(features, labels, ModeKeys.TRAIN, self.params)
             loss = spec.loss
             done += 1

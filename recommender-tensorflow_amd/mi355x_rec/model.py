@@ -88,6 +88,8 @@ def run_batch(features, labels, mode, params, make_engine):
         # (trainers.deep_fm at the reference's defaults, B = 32: 2-2.5x the eager rate), "on" / True always, "off" never
         hg = params.get("hip_graph", "auto")
         graph = hg in (True, "on") or (hg == "auto" and ids.shape[0] <= GRAPH_AUTO_MAX_BATCH)
+        if getattr(eng, "summaries_next", False) and ids.shape[0] >= getattr(eng, "TOP_FUSED_MIN_BATCH", 1 << 62):
+            graph = False         # (a captured large-batch step keeps the last hidden layer on the chip: this one is looked at)
         if graph and eng.device.type == "cuda" and hasattr(eng, "graph_ok") and eng.graph_ok():
             loss, logits = eng.graph_train_step(ids, y, x)
         else:

@@ -565,3 +565,72 @@ def test_logits_head_fused_equals_the_unfused_sequence(lib, M, K, keep, parts):
     assert bit(ds1, dB1)
     for a, b_ in zip(outs[0], outs[1]):          # reproducible
         assert np.array_equal(a, b_) if isinstance(a, np.ndarray) else torch.equal(a, b_)
+
+
+@pytest.mark.parametrize("M,K,keep,parts", [(4096, 256, 0.9, (True, True)), (300, 64, 1.0, (True, False)), (1029, 512, 0.75, (False, True)),
+                                            (128, 128, 0.9, (False, False))])
+def test_hidden_logits_head_fused_equals_the_layer_forward_then_the_fused_tail(lib, M, K, keep, parts):
+    """mi_hidden_logits_head_fused (round 4: the last hidden layer's GEMM with the logits layer, the head and the logits layer's
+    backward in its epilogue — the layer's output never reaches memory) against mi_dense_fwd_planes + the unfused tail on
+    that output: the logits layer's dot product to 2e-6 of sum |h w|; from there on, on the kernel's own dnn, everything per
+    example bit for bit (logits, d_logit, the planes of the data gradient, their exponents and abs-max), the sums over examples
+    (loss, d_logit_sum = db, dW) to 1e-6 of their size; twice the same bits."""
+    from mi355x_rec import _lib as L
+    N = 128
+    has_lin, has_fm = parts
+    rng = np.random.default_rng(M + K + 7)
+    X = rows_spread(rng, M, K, lo_exp=-8)
+    W = (rng.standard_normal((K, N)) / np.sqrt(K)).astype(np.float32)
+    bias = (rng.standard_normal(N) * 0.1).astype(np.float32)
+    w = (rng.standard_normal(N) / np.sqrt(N)).astype(np.float32)
+    b = np.float32(0.03)
+    lin = rng.standard_normal(M).astype(np.float32) * 0.1; fm = rng.standard_normal(M).astype(np.float32) * 0.1
+    y = (rng.random(M) < 0.3).astype(np.uint8)
+    scale = np.float32(1.0 / M)
+    seed = 0x5eed1234
+    xp, wt = split(lib, X), split(lib, W, transpose=True)
+    dbias, dw, db_, dlin, dfm, dy_ = dev(bias), dev(w), dev(np.array([b], np.float32)), dev(lin), dev(fm), dev(y)
+    lb = dev(np.array([0.07], np.float32))
+    pl = dlin.data_ptr() if has_lin else None
+    pf = dfm.data_ptr() if has_fm else None
+    # ---- the layer alone: its output and mask bits
+    Y = torch.empty(M, N, device="cuda")
+    mb = torch.zeros(M, N // 32, dtype=torch.int32, device="cuda")
+    _chk(lib.mi_dense_fwd_planes(xp.ref, wt.ref, dbias.data_ptr(), Y.data_ptr(), N, None, M, N, K, 1, keep, seed, None, mb.data_ptr(), N // 32, _st()))
+    # ---- fused, twice
+    outs = []
+    for _ in range(2):
+        dnn1 = torch.full((M,), float("nan"), device="cuda"); logits1 = torch.empty(M, device="cuda"); loss1 = torch.empty(1, device="cuda")
+        dl1 = torch.empty(M, device="cuda"); ds1 = torch.empty(1, device="cuda"); dW1 = torch.empty(N, device="cuda"); dB1 = torch.empty(1, device="cuda")
+        p1 = PB(lib, M, N); am1 = torch.zeros(L.AMAX_SLOTS, device="cuda")
+        tws = torch.empty(int(lib.mi_hidden_logits_head_fused_workspace_bytes(M, N)) + 256, dtype=torch.uint8, device="cuda")
+        _chk(lib.mi_hidden_logits_head_fused(xp.ref, wt.ref, dbias.data_ptr(), M, N, K, 1, keep, seed, dw.data_ptr(), db_.data_ptr(), pl,
+                                             lb.data_ptr(), pf, dy_.data_ptr(), float(scale), dnn1.data_ptr(), logits1.data_ptr(),
+                                             loss1.data_ptr(), dl1.data_ptr(), ds1.data_ptr(), dW1.data_ptr(), dB1.data_ptr(), p1.ref,
+                                             am1.data_ptr(), tws.data_ptr(), tws.numel(), _st()))
+        torch.cuda.synchronize()
+        outs.append((dnn1, logits1, loss1, dl1, ds1, dW1, dB1, p1.bits(), p1.exp.cpu().numpy(), am1))
+    dnn1, logits1, loss1, dl1, ds1, dW1, dB1, bits1, exp1, am1 = outs[0]
+    # the logits layer's dot product on the layer's output (fp64)
+    ref_dnn = (Y.double() * dw.double()[None, :]).sum(1) + float(b)
+    assert float(((dnn1.double() - ref_dnn).abs() / ((Y.abs() * dw.abs()[None, :]).sum(1).double() + 1e-6)).max()) < 2e-6
+    # ---- the unfused head and backward on the kernel's own dnn
+    logits0 = torch.empty(M, device="cuda"); loss0 = torch.empty(1, device="cuda"); dl0 = torch.empty(M, device="cuda"); ds0 = torch.empty(1, device="cuda")
+    hws = torch.empty(int(lib.mi_head_workspace_bytes(M)) + 256, dtype=torch.uint8, device="cuda")
+    _chk(lib.mi_sigmoid_ce_head(pl, lb.data_ptr(), pf, dnn1.data_ptr(), dy_.data_ptr(), M, float(scale), logits0.data_ptr(), loss0.data_ptr(),
+                                dl0.data_ptr(), ds0.data_ptr(), hws.data_ptr(), hws.numel(), _st()))
+    dW0 = torch.empty(N, device="cuda"); dB0 = torch.empty(1, device="cuda")
+    wws = torch.empty(int(lib.mi_dense_bwd_weight_workspace_bytes(M, 1, N)) + 256, dtype=torch.uint8, device="cuda")
+    _chk(lib.mi_dense_bwd_weight(Y.data_ptr(), N, dl0.data_ptr(), 1, dW0.data_ptr(), dB0.data_ptr(), M, 1, N, wws.data_ptr(), wws.numel(), None, _st()))
+    p0 = PB(lib, M, N); am0 = torch.zeros(L.AMAX_SLOTS, device="cuda")
+    _chk(lib.mi_dense_bwd_data_vec_planes(dl0.data_ptr(), 1, dw.data_ptr(), None, N, keep, None, N, p0.ref, M, N, am0.data_ptr(),
+                                          mb.data_ptr(), N // 32, _st()))
+    bit = lambda a, b_: np.array_equal(a.cpu().numpy().view(np.uint32), b_.cpu().numpy().view(np.uint32))
+    assert bit(logits1, logits0) and bit(dl1, dl0)
+    assert np.array_equal(bits1, p0.bits()) and np.array_equal(exp1, p0.exp.cpu().numpy()) and float(am1.max()) == float(am0.max())
+    close = lambda a, b_, ref: float((a - b_).abs().max()) <= 1e-6 * float(ref.abs().max()) + 1e-12
+    assert close(loss1, loss0, loss0) and close(ds1, ds0, dl0.abs().sum()[None]) and close(dB1, dB0, dl0.abs().sum()[None])
+    assert close(dW1, dW0, (Y.abs() * dl0.abs()[:, None]).sum(0))
+    assert bit(ds1, dB1)
+    for a, b_ in zip(outs[0], outs[1]):          # reproducible
+        assert np.array_equal(a, b_) if isinstance(a, np.ndarray) else torch.equal(a, b_)
