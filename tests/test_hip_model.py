@@ -636,3 +636,29 @@ def test_bench_configuration_at_full_size_is_bitwise_the_plain_sequence(catchup)
     for k in ("table", "t_s0", "t_s1", "lin_state", "dense", "d_s0", "d_s1"):
         assert torch.equal(getattr(plain, k), getattr(pre, k)), k
     assert plain.step == pre.step == n_steps
+
+
+def test_last_hidden_layer_inside_the_fused_head_launch_matches_the_oracle():
+    """Round 4: from 4,096 examples on a 128-unit last hidden layer runs inside mi_hidden_logits_head_fused (engine._top_fusable;
+    its output never reaches memory).  Three dropout steps against the oracle (masks replayed), every variable within 2e-6;
+    and the protocol with the Estimator: a step announced as summarised (summaries_next) keeps the unfused launches, so that
+    layer_summaries() sees that layer's output; after a fused step the entry is left out rather than stale."""
+    vocab, E, hidden, B = [50, 40, 30, 60, 20, 35, 45, 25], 32, [256, 128], 4096
+    p, ids, x, y = make_problem(17, vocab, E, hidden, B)
+    m = _engine(vocab, E, hidden, dropout=0.1, seed=11)
+    assert m.planes
+    m.load_oracle_params(p)
+    st = O.TrainState(p, OO.Hyper("Adam", 0.001))
+    rng = np.random.default_rng(3)
+    for step in range(3):
+        ids_s = np.stack([rng.integers(0, v, B) for v in vocab], 1).astype(np.int32)
+        masks = [dropout_mask(m._layer_seed(i), B, h, 0.9) for i, h in enumerate(hidden)]
+        loss_o, logit_o = O.train_step(p, st, ids_s, y, dropout_masks=masks, keep_prob=0.9)
+        m.summaries_next = step == 1
+        loss_g, logit_g = m.train_step(dev(ids_s), dev(y))
+        fused = getattr(m, "_top_step", None) == m.step - 1
+        assert fused == (step != 1)
+        assert ("dnn/hiddenlayer_1" in m.layer_summaries()) == (step == 1)
+        assert abs(loss_g.item() - float(loss_o)) / abs(float(loss_o)) < 2e-5, step
+        assert max_err_scaled(logit_g.cpu().numpy(), logit_o) < 5e-5, step
+    _compare_vars(m, p, 2e-6)
