@@ -113,7 +113,11 @@ struct FusedGrad {
 // Segments longer than this are left to sparse_apply_long_k (a workgroup per row instead of a lane
 // group): with skewed ids one row can own thousands of a batch's entries.
 constexpr int kLongSeg = 48;
-constexpr int kRun = 8;            // consecutive rows a lane group of sparse_apply_long_k's scan looks at
+// consecutive rows a workgroup of sparse_apply_long_k owns together.  1: a workgroup's rows are a grid apart.  (Measured with 8 —
+// 32 bytes of seg_start per lane group instead of a cache line per lane: the scan that finds nothing, uniform ids, 17 -> 8 us,
+// but Zipf(1.05) ids 2.60 -> 3.25 ms per step: a field's hot rows are its first ids, and eight of them then queue up in one
+// workgroup.  The spread is worth more than the scan.)
+constexpr int kRun = 1;
 
 struct ApplyArgs {
   float* table; float* t0; float* t1;
@@ -267,9 +271,7 @@ __global__ __launch_bounds__(kBlock) void sparse_apply_k(ApplyArgs a, Hp h, cons
 }
 
 // Rows with more than kLongSeg entries: a workgroup per row.  Workgroup j looks at the rows of the runs
-// j, j + grid, j + 2 grid, ... of kRun consecutive rows (hot rows have neighbouring ids: the stride spreads them; a run
-// is 32 bytes of seg_start — with single rows every lane of the scan pulled its own cache line: 14 us per step at
-// config 3 for finding nothing), collects
+// j, j + grid, j + 2 grid, ... of kRun consecutive rows (hot rows have neighbouring ids: the stride spreads them), collects
 // the long ones, and for each splits the segment into kBlock/LPR contiguous slices, one per lane
 // group, summed in order; the slice sums are then added in slice order.  A fixed order, so results
 // are reproducible; it differs from the one-pass order only in fp32 association.
