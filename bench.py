@@ -340,6 +340,9 @@ def main():
             dist.init_process_group("gloo", timeout=tmo)
 
     from mi355x_rec.engine import DeepFM, OptimizerSpec
+    if os.environ.get("MI_TUNING_LIB"):          # A/B runs of the tools' build (make -C csrc tuning: it reads the MI_* switches)
+        from mi355x_rec import _lib
+        _lib.LIB_PATH = os.path.join(ROOT, "tools", "probe", "libmi355x_rec_tuning.so")
     for opt in args.engine_opt:
         name, _, val = opt.partition("=")
         if not hasattr(DeepFM, name):
