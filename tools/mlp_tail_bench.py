@@ -114,6 +114,14 @@ def main():
         acts[2].data_ptr(), 128, w4.data_ptr(), b4.data_ptr(), lin.data_ptr(), lb.data_ptr(), fm.data_ptr(), yl.data_ptr(), M, 128, 1.0 / M,
         bits[2].data_ptr(), 4, keep, y1.data_ptr(), logits.data_ptr(), loss.data_ptr(), dl.data_ptr(), dsum.data_ptr(), dW4.data_ptr(), db4.data_ptr(),
         dyp2.ref, None, 128, amax.data_ptr(), tws.data_ptr(), tws.numel(), st()), "tail"))))
+    # ... and with the last hidden layer's GEMM in front of it, in one launch (+ a fold)
+    wt3 = split(Ws[1], transpose=True); b3 = torch.zeros(128, device="cuda")
+    pws = torch.empty(int(lib.mi_hidden_logits_head_fused_workspace_bytes(M, 128)) + 256, dtype=torch.uint8, device="cuda")
+    rows.append(("FUSED layer 256 -> 128 + logits layer + head + backward (mi_hidden_logits_head_fused)", timeit(lambda: chk(
+        lib.mi_hidden_logits_head_fused(actp[1].ref, wt3.ref, b3.data_ptr(), M, 128, 256, 1, keep, 7, w4.data_ptr(), b4.data_ptr(), lin.data_ptr(),
+                                        lb.data_ptr(), fm.data_ptr(), yl.data_ptr(), 1.0 / M, y1.data_ptr(), logits.data_ptr(), loss.data_ptr(),
+                                        dl.data_ptr(), dsum.data_ptr(), dW4.data_ptr(), db4.data_ptr(), dyp2.ref, amax.data_ptr(),
+                                        pws.data_ptr(), pws.numel(), st()), "top"))))
     dl = torch.randn(M, device="cuda", generator=g) * 1e-5
     for i, (K, N) in ((1, (256, 128)), (0, (512, 256))):            # data gradient of layer i+2: dX [M, K] = dY [M, N] W^T, mask of the K-wide activation
         dY = torch.randn(M, N, device="cuda", generator=g) * 1e-5
