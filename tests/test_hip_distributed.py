@@ -39,7 +39,15 @@ pytestmark = pytest.mark.gpu
                                  ([50, 30, 20, 40, 7, 11], 32, [64, 32], 128, 3, "Adagrad", 0.05, 3, (True, False, True), 2,
                                   dict(numeric="raw", lin_opt=("Ftrl", 0.2), reduction="sum", field_dims=[32, 16, 32, 0, 8, 32],
                                        wide_fields=[True, False, True, True, False, True], deep_numeric=[True, False, True],
-                                       wide_numeric=[True, True, False]))])
+                                       wide_numeric=[True, True, False])),
+                                 # 4,096 examples per rank and a 128-unit last hidden layer: it runs inside the fused logits + head
+                                 # launch (engine._top_fusable), one forward / backward (chunk_compute=False) and a chunk of 4,096 each
+                                 # (SUM loss: with the mean over 8,192+ examples many gradient elements lie below Adam's epsilon, where
+                                 # an update amplifies a 1e-10 difference of the gradient to 1e-5 of the weight)
+                                 ([50, 30, 20, 40], 32, [128, 128], 4096, 0, "Adam", 0.001, 2, (True, True, True), 2,
+                                  dict(chunk_compute=False, reduction="sum")),
+                                 ([50, 30, 20, 40], 32, [128, 128], 8192, 0, "Adam", 0.001, 2, (True, True, True), 2,
+                                  dict(chunk_compute=True, reduction="sum"))])
 def test_two_ranks_one_gpu_gloo(cfg):
     check_against_big_batch(cfg, _run(cfg, 2, device="cuda", backend="gloo"), 2, tol=3.0)
 
