@@ -92,7 +92,7 @@ def parse():
                     help="lazy Adam replay of the steps a row sat out: TF's fp32 op sequence bit for bit, or the bounded-error "
                          "form (every variable within 3 ulp + 2e-6 of the replayed movement of the sweep; include/mi355x_rec.h MI_CATCHUP_BOUNDED)")
     ap.add_argument("--engine-opt", action="append", default=[], metavar="NAME=0|1",
-                    help="A/B runs: set a scheduling attribute of engine.DeepFM (WSPLIT_AHEAD, LIN_SIDE, BYGAP_AHEAD, FOLD_FM, ...)")
+                    help="A/B runs: set a scheduling attribute of engine.DeepFM (WSPLIT_AHEAD, LIN_SIDE, BYGAP_AHEAD, WGRAD_BATCH, ...)")
     ap.add_argument("--route-ahead", type=int, choices=[0, 1], default=None,
                     help="row-sharded step: 0 = the whole step on ONE RCCL communicator (no routing of the next batch ahead on a "
                          "second one); default: parallel.RowShard's (1)")
@@ -543,7 +543,7 @@ def main():
                                        "after a pool switch: more catch-up work than `value`).  At this batch size nothing is "
                                        "launch-bound: the replay pays two input copies into the captured buffers and has no weight split "
                                        "ahead; the capture pays at small batches (configs.c2: B = 32)"}
-        m._graph = None
+        m.drop_graphs()
         if args.gemm != "fp32":
             keep = (m.gemm, m.planes, m.gather_mlp)
             m.gemm, m.planes, m.gather_mlp = "fp32", False, True
@@ -647,18 +647,30 @@ def main():
                           "traffic_note": "PMC bytes per launch (profiles/traffic.json); above the algorithmic bytes by the per-ENTRY reads of "
                                           "sumv (served by L2 / Infinity Cache, counted at the fabric) and the wide-part records"}
         if sparse_stats is not None and "mi_sparse_catchup" in km and sparse_stats["rows_with_state"]:
+            # the ROW kernel's launches only: the wide part's call (engine._catchup, LIN_SIDE: its own stream) is timed under its
+            # own key — round 4 divided the rows' bytes by the mean over BOTH kernels' launches
             c_ms = km["mi_sparse_catchup"][0]
             Us = sparse_stats["rows_with_state"]
-            c_bytes = Us * (16 * E + 32)          # w, m, v read + w written (deferred slots) + the 16-byte wide record read and written
+            wide_apart = "mi_sparse_catchup/wide" in km
+            # w, m, v read + w written (deferred slots); + the 16-byte wide record read and written when ONE call does both
+            c_bytes = Us * (16 * E + (0 if wide_apart else 32))
             cyc = 236.0 if mode_catchup == "exact" else 83.0
             issue_ms = sparse_stats["element_steps"] / 256.0 * cyc / 1024.0 / 2.1e9 * 1e3
-            roof_catchup = {"kernel": "sparse_catchup_%s (+ catchup_lin_k): lazy replay of TF Adam's dense-equivalent update on the rows "
+            roof_catchup = {"kernel": "sparse_catchup_%s: lazy replay of TF Adam's dense-equivalent update on the rows "
                                       "about to be read (w only: the apply decays m, v)" % ("bounded_k" if mode_catchup == "bounded" else "k"),
                             "mode": mode_catchup, "bound": "hbm" if mode_catchup == "bounded" else "valu issue",
                             "achieved": c_bytes / (c_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": c_bytes / (c_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_launch_ms": c_ms,
                             "algorithmic_bytes_per_launch": int(c_bytes),
-                            "algorithmic_bytes_note": "per row with state: w, m, v read (12E) + w written (4E) + the 16-byte wide record read and written = 16E + 32",
+                            "algorithmic_bytes_note": "per row with state: w, m, v read (12E) + w written (4E) = 16E" +
+                                                      (" (the wide part's records: roofline_catchup.wide)" if wide_apart else " + the 16-byte wide record read and written = 16E + 32"),
+                            "wide": None if not wide_apart else {
+                                "kernel": "catchup_lin_k: the wide part's {w, m, v, stamp} records of the same rows, on the wide part's stream beside the row kernel",
+                                "avg_launch_ms": km["mi_sparse_catchup/wide"][0], "algorithmic_bytes_per_launch": int(Us * 32),
+                                "achieved": Us * 32 / (km["mi_sparse_catchup/wide"][0] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": Us * 32 / (km["mi_sparse_catchup/wide"][0] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                "traffic": tr("catchup_lin_k"),
+                                "note": "16-byte records scattered over 128-byte lines: the traffic is 8x the algorithmic bytes by construction"},
                             "rows_with_state": Us, "mean_replayed_steps": sparse_stats["mean_replayed_steps"],
                             "element_steps_per_launch": sparse_stats["element_steps"],
                             "issue_model": {"cycles_per_wave_and_replayed_step": cyc, "simds": 1024, "clock_GHz": 2.1,

@@ -198,7 +198,9 @@ class DeepFM:
     zero and stay zero under every optimizer here (their gradients are products with those zeros), which is the smaller
     embedding exactly; the wide part runs on the wide columns' ids only.
     catchup: how the steps a row sat out under TF Adam's dense-equivalent sparse update are replayed when
-    the row is next read — "exact": TF's fp32 op sequence, the sweep's bits; "bounded": the same m chain and numerators
+    the row is next read — "bounded" (the default: what bench.py's `value` is timed in and what the trainers' CLIs run; inside
+    the north star's 1e-5 on logits / loss) or "exact" (--catchup exact: TensorFlow's bits, ~8 % slower at
+    config 3).  "exact": TF's fp32 op sequence, the sweep's bits; "bounded": the same m chain and numerators
     with sqrt(v_j) ~ sqrtf(v_0) beta2^(j/2) and a 1-ulp reciprocal: every variable within 3 ulp + 2e-6 of the movement the
     replay covers (98.7 % of them within 1e-7 relative of the sweep, 96.7 % bit-identical; include/mi355x_rec.h,
     MI_CATCHUP_BOUNDED), a third of the instructions."""
@@ -206,7 +208,7 @@ class DeepFM:
     def __init__(self, vocab_sizes, n_numeric=0, embedding_size=4, hidden_units=(16, 16),
                  use_linear=True, use_mf=True, use_dnn=True, dropout=0.0, optimizer=None,
                  linear_optimizer=None, reduction="mean", device="cuda", seed=0, shard=None,
-                 gemm="f16x2", numeric="embed", activation="relu", catchup="exact", field_dims=None, wide_fields=None,
+                 gemm="f16x2", numeric="embed", activation="relu", catchup="bounded", field_dims=None, wide_fields=None,
                  deep_numeric=None, wide_numeric=None, _kernels=None):
         if len(vocab_sizes) + n_numeric == 0:
             raise ValueError("At least 1 feature column of categorical_columns or numeric_columns "
@@ -1006,6 +1008,7 @@ class DeepFM:
             return parallel.sharded_eval_step(self, ids, labels, x_num)
         c = self._forward(ids, x_num, False)
         logits, loss, _ = self._head(c, labels, False)
+        self._top_step = None            # (every layer's output of THIS forward is in memory: layer_summaries may show them all)
         return loss, logits
 
     def finalize_rows(self):
@@ -1026,6 +1029,7 @@ class DeepFM:
     WGRAD_BATCH = True        # the planes weight gradients of a backward pass as one batch after the data gradients (_backward_dense)
     TOP_FUSED = True          # ... and the last hidden layer with them, in its GEMM's epilogue (_head: mi_hidden_logits_head_fused)
     TOP_FUSED_MIN_BATCH = 4096
+    GRAPH_SHAPES_MAX = 4      # captured steps kept at a time, one per batch shape (graph_train_step)
 
     def _catchup(self, uniq, num_uniq, n_max, defer=False, by_gap=None):
         """defer: the rows are about to be applied in this same step by ONE mi_sparse_apply call, which
@@ -1063,7 +1067,9 @@ class DeepFM:
             parts = [(t_sched, l_sched, 0)]
         for i, (ts, lsch, extra) in enumerate(parts):
             s = (ts or lsch).spec
-            call = lambda: self.k.mi_sparse_catchup(
+            # (the wide part's own call is timed under its own key: bench.py prices the row kernel and the wide kernel apart)
+            entry = self.k.tagged("mi_sparse_catchup", "/wide") if (ts is None and hasattr(self.k, "tagged")) else self.k.mi_sparse_catchup
+            call = lambda entry=entry: entry(
                 self.table if ts is not None else None, self.t_s0 if ts is not None else None,
                 self.t_s1 if ts is not None else None, self.lin_w if lsch is not None else None,
                 self.l_s0 if lsch is not None else None, self.l_s1 if lsch is not None else None,
@@ -1439,23 +1445,34 @@ class DeepFM:
         if not self.graph_ok():
             raise NotImplementedError("graph_train_step: the device-resident step state carries ONE lr_t (two different Adams)")
         self._prep(ids, labels, x_num)
-        g = getattr(self, "_graph", None)
+        # one captured graph per batch shape (an epoch's short last batch no longer evicts the full batch's graph: two
+        # captures per epoch before), a handful at most
+        graphs = self.__dict__.setdefault("_graphs", {})
+        shape = tuple(ids.shape)
+        g = self._graph = graphs.get(shape)
         if g is not None and g["gen"] != self._graph_gen():
             # A captured graph holds the raw addresses of the workspaces, the planes and the lr_t table.  Something
             # since the capture made one of them move (loss() / predict on a larger batch, a train_step of another
             # shape, layer_summaries' workspaces, a restored checkpoint far into a run): the old storage may already
-            # belong to another tensor, so the graph is dropped and the step captured again (buffers only grow: the
+            # belong to another tensor, so every graph is dropped and the step captured again (buffers only grow: the
             # new capture needs no sizing step).
+            graphs.clear()
             g = self._graph = None
-            self._graph_warm = tuple(ids.shape)
-        if g is None or g["shape"] != tuple(ids.shape):
-            if not getattr(self, "_graph_warm", None) == tuple(ids.shape):
-                self._graph_warm = tuple(ids.shape)
+            self.__dict__.setdefault("_graph_warm", set()).add(shape)
+        if g is None:
+            warm = self.__dict__.setdefault("_graph_warm", set())
+            if shape not in warm:
+                warm.add(shape)
                 return self.train_step(ids, labels, x_num)              # sizes every workspace
-            g = self._graph = self._capture(ids, labels, x_num)
+            if len(graphs) >= self.GRAPH_SHAPES_MAX:
+                graphs.pop(next(iter(graphs)))
+            self._top_step = None
+            g = self._graph = graphs[shape] = self._capture(ids, labels, x_num)
+            g["top"] = getattr(self, "_top_step", None) == self.step - 1     # (the captured step keeps the last hidden layer on the chip)
             return g["loss"], g["logits"]
         if self._gsched() is not None and self.step + 2 >= len(self._gsched().host):
-            self._graph = None                                          # the lr_t table has to grow: capture again
+            graphs.clear()                                              # the lr_t table has to grow: capture again
+            self._graph = None
             return self.graph_train_step(ids, labels, x_num)
         if g["dev_step"] != self.step:                                  # eager steps ran in between: resync
             self._write_step_state(g["state"])
@@ -1467,7 +1484,16 @@ class DeepFM:
         g["graph"].replay()
         self.step += 1
         g["dev_step"] = self.step
+        # (layer_summaries: did the step that just ran leave the last hidden layer's output in memory?  A replay runs what
+        # was captured, whatever summaries_next says now)
+        self._top_step = self.step - 1 if g.get("top") else None
+        self._acts_in_planes = set(g.get("acts_in_planes", self._acts_in_planes))
         return g["loss"], g["logits"]
+
+    def drop_graphs(self):
+        """forget every captured step (the next graph_train_step of a shape captures again, without a sizing step)"""
+        self._graph = None
+        self.__dict__.setdefault("_graphs", {}).clear()
 
     def _gsched(self):
         """the one Adam schedule a captured step reads lr_t from"""
@@ -1504,7 +1530,8 @@ class DeepFM:
             self.k.query("mi_set_step_state", None)
         graph.replay()                                                  # capture records, this executes the step
         return {"graph": graph, "state": state, "ids": g_ids, "y": g_y, "x": g_x, "loss": loss, "logits": logits,
-                "shape": tuple(ids.shape), "dev_step": self.step, "gen": self._graph_gen()}
+                "shape": tuple(ids.shape), "dev_step": self.step, "gen": self._graph_gen(),
+                "acts_in_planes": tuple(self._acts_in_planes)}
 
     def layer_summaries(self):
         """What the reference's layer_summary calls record (model_utils.py:4-6 at deep_fm.py:43,89,105,
@@ -1587,6 +1614,16 @@ class DeepFM:
             v = getattr(self, key, None)
             if v is not None:
                 sd[key] = v.detach().to("cpu", copy=True).contiguous()    # (views of one record array: independent copies)
+        if self.wide_fields is not None and "lin_w" in sd:
+            # a column outside linear_feature_columns owns no linear weight in the reference model; one apply kernel serves
+            # every row of a batch and does write those slots (never read): a checkpoint carries them at their initial values
+            a, b = (self.lin_opt or self.opt).slot_init
+            for f, on in enumerate(self.wide_fields):
+                if not on:
+                    lo, hi = self._field_rows(f)
+                    for key, fill in (("lin_w", 0.0), ("l_s0", a), ("l_s1", b)):
+                        if key in sd and fill is not None:
+                            sd[key][lo:hi] = fill
         return sd
 
     def load_state_dict(self, sd):
@@ -1617,4 +1654,4 @@ class DeepFM:
         self.step = int(sd["step"])
         self._final_step = self.step
         self._presorted = None           # (a sort of a batch announced before the restore: dropped)
-        self._graph = None               # (captured steps are re-captured against the restored state)
+        self.drop_graphs()               # (captured steps are re-captured against the restored state)

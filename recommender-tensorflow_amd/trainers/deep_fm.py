@@ -30,7 +30,7 @@ def model_fn(features, labels, mode, params):
                       hidden_units=params.get("hidden_units", [16, 16]), use_linear=flags[0], use_mf=flags[1],
                       use_dnn=flags[2], dropout=params.get("dropout", 0), optimizer=opt, reduction="mean",
                       device=device, seed=params.get("seed", 0), shard=shard, activation=activation,
-                      catchup=params.get("catchup", "exact"))
+                      catchup=params.get("catchup", "bounded"))
 
     return run_batch(features, labels, mode, params, make)
 

@@ -23,6 +23,7 @@ ML100K_VOCAB = [2, 2, 7, 2, 2, 2, 2, 2, 2, 2, 2, 3, 2, 2000, 2, 2, 50, 8, 2, 2, 
 def _engine(vocab, E, hidden, n_numeric=0, **kw):
     from mi355x_rec.engine import DeepFM, OptimizerSpec
     opt = kw.pop("optimizer", OptimizerSpec("Adam", 0.001))
+    kw.setdefault("catchup", "exact")       # (the library's default is "bounded": the tests that mean it say so)
     return DeepFM(vocab, n_numeric=n_numeric, embedding_size=E, hidden_units=hidden, optimizer=opt, **kw)
 
 
@@ -445,6 +446,68 @@ def test_graph_train_step_replays_the_eager_step_bitwise(vocab, E, hidden, B):
     assert graph._graph is not None and graph.step == eager.step == 9
     for k in ("table", "t_s0", "t_s1", "lin_state", "dense", "d_s0", "d_s1"):
         assert torch.equal(getattr(eager, k), getattr(graph, k)), k
+
+
+def test_graph_train_step_with_column_subsets_and_two_batch_shapes_replays_the_eager_step_bitwise():
+    """the captured step of the canned DNNLinearCombined model with dnn_feature_columns != linear_feature_columns
+    (per-column dimensions, wide / deep column subsets, numeric columns only one part reads: the wide_idx index_select, the
+    _frozen index_fill_, _k0_rows) — bit for bit the eager sequence; and a second batch shape (an epoch's short last batch)
+    gets a graph of its own without evicting the first (one capture per shape, not one per change of shape)."""
+    from mi355x_rec.engine import OptimizerSpec
+    vocab, E, hidden, nn = [9, 13, 5, 7], 8, [16], 3
+    kw = dict(numeric="raw", use_mf=False, reduction="sum", optimizer=OptimizerSpec("Adagrad", 0.05), linear_optimizer=OptimizerSpec("Ftrl", 0.18),
+              field_dims=[8, 3, 0, 4], wide_fields=[True, False, True, True], deep_numeric=[True, False, True], wide_numeric=[False, True, True])
+    ms = []
+    for _ in range(2):
+        m = _engine(vocab, E, hidden, nn, dropout=0.25, seed=5, **kw)
+        g = torch.Generator(device="cuda"); g.manual_seed(3)
+        m.init_variables(g, lin_scale=1e-2)
+        ms.append(m)
+    eager, graph = ms
+    assert graph.graph_ok()
+    rng = np.random.default_rng(2)
+    captures = []
+    orig = graph._capture
+    graph._capture = lambda *a, **k: (captures.append((graph.step, a[0].shape[0])), orig(*a, **k))[1]
+    for step, B in enumerate([32, 32, 32, 32, 11, 11, 11, 32, 32, 11, 32, 11]):
+        ids_s = dev(np.stack([rng.integers(0, v, B) for v in vocab], 1).astype(np.int32))
+        xs = dev(rng.standard_normal((B, nn)).astype(np.float32))
+        ys = dev((rng.random(B) < 0.3).astype(np.uint8))
+        le, ge = eager.train_step(ids_s, ys, xs)
+        lg, gg = graph.graph_train_step(ids_s, ys, xs)
+        assert torch.equal(le, lg) and torch.equal(ge, gg), step
+    # both shapes hold a graph, and once both have been seen (the second shape's sizing step may move a workspace, which
+    # costs the first its graph once) alternating between them captures nothing
+    assert len(graph._graphs) == 2 and all(st <= 7 for st, _ in captures) and len(captures) <= 3, captures
+    for k in ("table", "t_s0", "lin_state", "dense", "d_s0"):
+        assert torch.equal(getattr(eager, k), getattr(graph, k)), k
+    assert float(graph.dense.index_select(0, graph._frozen).abs().max()) == 0.0
+
+
+def test_layer_summaries_after_a_replay_know_what_the_captured_step_kept_on_the_chip():
+    """with hip_graph "on" and B >= 4096 the captured step runs the last hidden layer inside the fused top launch — its
+    output never reaches memory.  layer_summaries() after a REPLAY must leave that layer out (not report a stale buffer), and after
+    an eval forward (which writes every layer) show it again."""
+    from mi355x_rec.engine import OptimizerSpec
+    vocab, E, hidden, B = [50, 30, 20, 40], 64, [256, 128], 4096
+    m = _engine(vocab, E, hidden, dropout=0.1, seed=5, optimizer=OptimizerSpec("Adam", 0.001))
+    g = torch.Generator(device="cuda"); g.manual_seed(3)
+    m.init_variables(g, lin_scale=1e-2)
+    rng = np.random.default_rng(2)
+    batch = lambda: (dev(np.stack([rng.integers(0, v, B) for v in vocab], 1).astype(np.int32)), dev((rng.random(B) < 0.3).astype(np.uint8)))
+    for _ in range(4):                                   # eager (sizes), capture, two replays
+        m.graph_train_step(*batch())
+    assert m._graph is not None and m._graph["top"]
+    s = m.layer_summaries()
+    assert "dnn/hiddenlayer_0" in s and "dnn/hiddenlayer_1" not in s and "dnn/logits" in s
+    m.summaries_next = True                              # an eager step that is looked at keeps every layer in memory
+    m.train_step(*batch())
+    assert "dnn/hiddenlayer_1" in m.layer_summaries()
+    m.summaries_next = False
+    m.graph_train_step(*batch())
+    assert "dnn/hiddenlayer_1" not in m.layer_summaries()
+    m.loss(*batch())
+    assert "dnn/hiddenlayer_1" in m.layer_summaries()
 
 
 @pytest.mark.parametrize("kind", ["deepfm-numeric-embeddings", "wide-and-deep-raw-numeric"])
