@@ -52,7 +52,7 @@ enum mi_status {
 };
 
 /* ---- library ---------------------------------------------------------------------------- */
-int32_t mi_abi_version(void);       /* bumps when a signature changes (currently 20) */
+int32_t mi_abi_version(void);       /* bumps when a signature changes (currently 21) */
 const char* mi_last_error(void);    /* thread-local, never NULL */
 const char* mi_build_info(void);    /* "gfx950 hipcc <ver>" */
 
@@ -235,16 +235,30 @@ int32_t mi_sort_unique_rows(const int32_t* rows, int64_t n, int64_t num_rows_tot
                             int32_t* num_uniq, void* workspace, size_t workspace_bytes,
                             mi_stream_t stream);
 
+/* mi_sort_unique_rows + mi_segment_slots in one entry (round 5): additionally slot_of_entry [n] = the segment u of every entry
+ * (the row-sharded step's "slot of my row in the receive buffer"), written by the compaction as it goes — the separate
+ * binary-search entry costs 112 us at 1.7 M entries. */
+int32_t mi_sort_unique_rows_slots(const int32_t* rows, int64_t n, int64_t num_rows_total,
+                                  int32_t* sorted_entry, int32_t* uniq_rows, int32_t* seg_start,
+                                  int32_t* num_uniq, int32_t* slot_of_entry, void* workspace, size_t workspace_bytes,
+                                  mi_stream_t stream);
+
 /* mi_global_rows + mi_sort_unique_rows in one entry for the single-GPU step: ids [B][F] (local ids, field f's rows are
  * field_off[f] + id: disjoint ranges in ascending field order), max_vocab >= every field's id range.  Same outputs,
  * bit for bit (equal rows keep ascending example order): sorted_entry [B*F] (entry = b * F + f), uniq_rows (global
  * rows), seg_start, num_uniq.  Every field's ids are sorted on their own, so the radix passes cover the bits of
  * max_vocab, not of the whole table.  B a multiple of 4096, F <= 64 (anything else: the two-entry form).
- * workspace: mi_sort_unique_fields_workspace_bytes(B, F), 256-byte aligned. */
+ * workspace: mi_sort_unique_fields_workspace_bytes(B, F), 256-byte aligned.
+ * beside (round 5, ABI 21): how the work is cut into launches — same results either way.  0: the stream has the GPU to itself
+ * (a step that was not told its next batch sorts at its head): ONE launch per radix pass and one for the compaction, the
+ * tiles of a field exchanging their digit counts inside the launch (5 launches, 130 us at config 3 against 145).  1: the
+ * call runs on a side stream BESIDE the step's bandwidth-bound kernels (the next batch's sort, beside this batch's Adam
+ * catch-up): the round-1 form, 14 short launches that hold no resources while they wait — beside the catch-up the fused
+ * form's resident, waiting workgroups cost the step 0.03 ms more than they save (profiles/r05_sort_and_side_streams.md). */
 size_t mi_sort_unique_fields_workspace_bytes(int64_t B, int32_t F);
 int32_t mi_sort_unique_fields(const int32_t* ids, const int64_t* field_off, int64_t B, int32_t F, int64_t max_vocab,
                               int32_t* sorted_entry, int32_t* uniq_rows, int32_t* seg_start, int32_t* num_uniq,
-                              void* workspace, size_t workspace_bytes, mi_stream_t stream);
+                              void* workspace, size_t workspace_bytes, int32_t beside, mi_stream_t stream);
 
 /* Routing helpers of the row-sharded multi-GPU path (row r lives on rank r % world as local row
  * r / world; the reference's own multi-worker mode is TF's parameter-server placement of whole

@@ -27,6 +27,9 @@ constexpr int kTile = kBlock * kItems;     // 4096
 constexpr int kMaxBits = 9;
 constexpr int kMaxBins = 1 << kMaxBits;    // 512
 constexpr int kMaxPasses = 4;
+constexpr int kFusedMaxBits = 10;          // digit width limit of the fused per-field passes (pass_fused_k)
+constexpr int kFusedMaxBins = 1 << kFusedMaxBits;
+constexpr int kFusedMaxTps = 256;          // tiles per field up to which a field's tiles wait for each other inside one launch
 
 // (our own kernel instead of hipMemsetAsync: a plain kernel node when the step is captured into a hipGraph — a
 // LINEAR captured step with memset nodes faulted at replay on this ROCm, the same step with a forked side stream
@@ -102,6 +105,14 @@ __global__ __launch_bounds__(kBlock) void gap_hist_k(const int32_t* __restrict__
     hist[static_cast<int64_t>(threadIdx.x) * ntiles + blockIdx.x] = static_cast<int32_t>(c);
     if (c) atomicAdd(&bin_total[threadIdx.x], static_cast<int32_t>(c));
   }
+}
+
+// a wave's private LDS word, read / written where other lanes of the SAME wave write / read it in between
+__device__ __forceinline__ int32_t lds_ld(int32_t* p) {
+  return __hip_atomic_load((__attribute__((address_space(3))) int32_t*)(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
+__device__ __forceinline__ void lds_st(int32_t* p, int32_t v) {
+  __hip_atomic_store((__attribute__((address_space(3))) int32_t*)(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
 
 __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
@@ -192,7 +203,9 @@ __global__ __launch_bounds__(kBlock) void scatter_k(const int32_t* __restrict__ 
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  volatile int32_t* run = running[w];
+  // (the running slots through wavefront-scope atomics on the LDS array itself: a volatile POINTER to it loses the address
+  // space and compiles to flat loads / stores with sc0 sc1)
+  int32_t* run = running[w];
 #pragma unroll
   for (int r = 0; r < kItems; ++r) {
     const bool valid = base + r * 64 + lane < n;
@@ -205,10 +218,10 @@ __global__ __launch_bounds__(kBlock) void scatter_k(const int32_t* __restrict__ 
     }
     const int rank = __popcll(peers & lt_mask);
     int32_t dst = 0;
-    if (valid) dst = run[d] + rank;
+    if (valid) dst = lds_ld(run + d) + rank;
     __builtin_amdgcn_wave_barrier();            // every peer has read the slot before its leader moves it
     if (valid) {
-      if (rank == 0) run[d] = dst + __popcll(peers);
+      if (rank == 0) lds_st(run + d, dst + __popcll(peers));
       keys_out[dst] = key[r];
       vals_out[dst] = val[r];
     }
@@ -271,7 +284,8 @@ __global__ __launch_bounds__(kBlock) void compact_k(const int32_t* __restrict__ 
                                                     int32_t* __restrict__ uniq_rows,
                                                     int32_t* __restrict__ seg_start,
                                                     int32_t* __restrict__ num_uniq, int64_t seg_len = 0,
-                                                    const int64_t* __restrict__ field_off = nullptr) {
+                                                    const int64_t* __restrict__ field_off = nullptr,
+                                                    int32_t* __restrict__ slot_of_entry = nullptr) {
   __shared__ int32_t wc[4];
   const int t = threadIdx.x, w = t >> 6, lane = t & 63;
   const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -291,12 +305,15 @@ __global__ __launch_bounds__(kBlock) void compact_k(const int32_t* __restrict__ 
     __syncthreads();                       // previous round's wc consumed
     if (lane == 0) wc[w] = __popcll(hb);
     __syncthreads();
+    int idx = run + __popcll(hb & lt_mask);
+    for (int ww = 0; ww < w; ++ww) idx += wc[ww];
     if (head) {
-      int idx = run + __popcll(hb & lt_mask);
-      for (int ww = 0; ww < w; ++ww) idx += wc[ww];
       uniq_rows[idx] = seg_len > 0 ? static_cast<int32_t>(field_off[i / seg_len] + key) : key;   // (local id -> global row)
       seg_start[idx] = static_cast<int32_t>(i);
     }
+    // (the segment a position belongs to: the heads up to and including its own, minus one — what mi_segment_slots finds by
+    // binary search, 112 us at 1.7 M entries, for the price of one scattered 4-byte store here)
+    if (slot_of_entry && valid) slot_of_entry[vals[i]] = head ? idx : idx - 1;
     run += wc[0] + wc[1] + wc[2] + wc[3];
   }
   if (blockIdx.x == 0 && t == 0) {
@@ -321,10 +338,214 @@ __global__ __launch_bounds__(kBlock) void ids_field_major_k(const int32_t* __res
   }
 }
 
+
+// ---- One launch per radix pass, one for the compaction (mi_sort_unique_fields) --------------------------
+// hist_k + bin_scan_k + scatter_k of a pass as ONE kernel: a tile counts its digits, PUBLISHES the counts, waits until the
+// other tiles of its field have published theirs (tps <= kFusedMaxTps workgroups, consecutive block ids: dispatched together),
+// derives its own offsets from them and scatters.  14 dependent launches of ~12 us each (most of them a few workgroups or
+// ONE) become 4-5.  Cross-workgroup traffic goes through agent-scope atomics (the L2s of the 8 XCDs are not coherent for
+// plain loads inside a launch): relaxed stores of the counts, a release increment of the field's arrival counter, an
+// acquire spin on it, relaxed loads of the counts.  The spin is bounded (every wave reaches its exit: a tile that never
+// sees its field complete raises *err and goes on with what it has — garbage that tests catch — instead of hanging the GPU).
+__device__ __forceinline__ void st_agent(int32_t* p, int32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int32_t ld_agent(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+constexpr int kSpinMax = 1 << 22;          // x s_sleep 8 (~0.25 us): about a second
+
+// pass 0 reads ids [B][F] itself (key = the local id of (b, seg), value = the entry b * F + seg): no field-major copy
+template <int MAXBINS>
+__global__ __launch_bounds__(kBlock) void pass_fused_k(const int32_t* __restrict__ keys_in, const int32_t* __restrict__ vals_in,
+                                                       const int32_t* __restrict__ ids, int64_t B, int F, int shift, int nbits,
+                                                       int tps, int32_t* __restrict__ thist, int32_t* __restrict__ ready,
+                                                       int32_t* __restrict__ err, int32_t* __restrict__ keys_out,
+                                                       int32_t* __restrict__ vals_out, int nap) {
+  __shared__ int32_t running[4][MAXBINS];     // per wave: digit counts, then the next output slot of each digit
+  __shared__ int32_t offsT[MAXBINS];          // this tile's first slot per digit
+  __shared__ int32_t totS[MAXBINS];           // the field's total per digit
+  __shared__ int32_t wsum[4];
+  const int t = threadIdx.x, w = t >> 6, lane = t & 63;
+  const int nbins = 1 << nbits;
+  const int seg = blockIdx.x / tps, tis = blockIdx.x - seg * tps;
+  for (int b = t; b < 4 * MAXBINS; b += kBlock) (&running[0][0])[b] = 0;
+  __syncthreads();
+  const int64_t base = static_cast<int64_t>(blockIdx.x) * kTile + w * (64 * kItems);
+  int32_t key[kItems], val[kItems];
+#pragma unroll
+  for (int r = 0; r < kItems; ++r) {
+    const int64_t i = base + r * 64 + lane;         // (B is a multiple of kTile: every position exists)
+    if (ids) {
+      const int64_t e = (i - static_cast<int64_t>(seg) * B) * F + seg;
+      key[r] = ids[e];
+      val[r] = static_cast<int32_t>(e);
+    } else {
+      key[r] = keys_in[i];
+      val[r] = vals_in[i];
+    }
+    atomicAdd(&running[w][(static_cast<uint32_t>(key[r]) >> shift) & (nbins - 1)], 1);
+  }
+  __syncthreads();
+  for (int b = t; b < nbins; b += kBlock)
+    st_agent(thist + static_cast<int64_t>(blockIdx.x) * nbins + b, running[0][b] + running[1][b] + running[2][b] + running[3][b]);
+  // (the counts went out as write-through stores: once they are acknowledged — vmcnt 0 in every wave, then the barrier —
+  // a RELAXED increment publishes them.  A release increment would write back this XCD's whole L2, an acquire load in the
+  // spin invalidate it on every turn: 160-190 us per sort instead of 150 for the 14 launches this replaces.)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (t == 0) {
+    __hip_atomic_fetch_add(ready + seg, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int spins = 0;
+    while (ld_agent(ready + seg) < tps) {
+      if (nap >= 2) __builtin_amdgcn_s_sleep(100); else if (nap == 1) __builtin_amdgcn_s_sleep(32); else __builtin_amdgcn_s_sleep(4);
+      if (++spins > kSpinMax) { atomicExch(err, 1); break; }
+    }
+  }
+  __syncthreads();
+  // per digit: the field's total and the part of it that lies in the tiles before this one (L2-bypassing loads, kept in
+  // flight eight at a time: one after the other they cost a memory latency each)
+  for (int b = t; b < nbins; b += kBlock) {
+    const int32_t* col = thist + static_cast<int64_t>(seg) * tps * nbins + b;
+    int total = 0, before = 0;
+    for (int t0 = 0; t0 < tps; t0 += 8) {
+      int v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = (t0 + j < tps) ? ld_agent(col + static_cast<int64_t>(t0 + j) * nbins) : 0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        total += v[j];
+        before += (t0 + j < tis) ? v[j] : 0;
+      }
+    }
+    totS[b] = total;
+    offsT[b] = before;
+  }
+  __syncthreads();
+  // exclusive scan of the totals over the digits: thread t owns `per` consecutive digits
+  {
+    const int per = nbins > kBlock ? nbins / kBlock : 1;
+    int own = 0;
+    if (t * per < nbins)
+      for (int j = 0; j < per; ++j) own += totS[t * per + j];
+    const int incl = wave_incl_scan(own, lane);
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    int pre = incl - own + static_cast<int>(static_cast<int64_t>(seg) * B);
+    for (int ww = 0; ww < w; ++ww) pre += wsum[ww];
+    if (t * per < nbins)
+      for (int j = 0; j < per; ++j) {
+        const int b = t * per + j;
+        const int c = totS[b];
+        offsT[b] += pre;
+        pre += c;
+      }
+  }
+  __syncthreads();
+  int32_t first[MAXBINS / 64];
+#pragma unroll
+  for (int q = 0; q < MAXBINS / 64; ++q) {
+    const int b = q * 64 + lane;
+    int32_t f = 0;
+    if (b < nbins) {
+      f = offsT[b];
+      for (int ww = 0; ww < w; ++ww) f += running[ww][b];
+    }
+    first[q] = f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < MAXBINS / 64; ++q)
+    if (q * 64 + lane < nbins) running[w][q * 64 + lane] = first[q];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  int32_t* run = running[w];
+#pragma unroll
+  for (int r = 0; r < kItems; ++r) {
+    const unsigned int d = (static_cast<uint32_t>(key[r]) >> shift) & (nbins - 1);
+    unsigned long long peers = ~0ull;
+    for (int b = 0; b < nbits; ++b) {
+      const unsigned long long m = __ballot((d >> b) & 1u);
+      peers &= ((d >> b) & 1u) ? m : ~m;
+    }
+    const int rank = __popcll(peers & lt_mask);
+    const int32_t dst = lds_ld(run + d) + rank;
+    __builtin_amdgcn_wave_barrier();            // every peer has read the slot before its leader moves it
+    if (rank == 0) lds_st(run + d, dst + __popcll(peers));
+    keys_out[dst] = key[r];
+    vals_out[dst] = val[r];
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// head_count_k + scan_small_k + compact_k as one launch: a tile publishes its number of row heads (+ 1: 0 = not there yet)
+// and waits for the tiles BEFORE it only — lower block ids, dispatched earlier — to know where its rows start.
+__global__ __launch_bounds__(kBlock) void compact_fused_k(const int32_t* __restrict__ keys, const int32_t* __restrict__ vals, int64_t n,
+                                                          int32_t* __restrict__ hcf, int32_t* __restrict__ err,
+                                                          int32_t* __restrict__ sorted_entry, int32_t* __restrict__ uniq_rows,
+                                                          int32_t* __restrict__ seg_start, int32_t* __restrict__ num_uniq,
+                                                          int64_t seg_len, const int64_t* __restrict__ field_off) {
+  __shared__ int32_t red[4];
+  __shared__ int32_t wc[4];
+  const int t = threadIdx.x, w = t >> 6, lane = t & 63;
+  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  const int64_t base = static_cast<int64_t>(blockIdx.x) * kTile;
+  int c = 0;
+#pragma unroll
+  for (int r = 0; r < kItems; ++r) {
+    const int64_t i = base + r * kBlock + t;
+    if (i < n && is_head(keys, i, seg_len)) ++c;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+  if (lane == 0) red[w] = c;
+  __syncthreads();
+  const int mine = red[0] + red[1] + red[2] + red[3];
+  if (t == 0) st_agent(hcf + blockIdx.x, mine + 1);
+  int part = 0;
+  for (int j = t; j < static_cast<int>(blockIdx.x); j += kBlock) {
+    int v, spins = 0;
+    while ((v = ld_agent(hcf + j)) == 0) {
+      __builtin_amdgcn_s_sleep(8);
+      if (++spins > kSpinMax) { atomicExch(err, 1); v = 1; break; }
+    }
+    part += v - 1;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+  __syncthreads();                         // red[] read by everyone
+  if (lane == 0) red[w] = part;
+  __syncthreads();
+  int run = red[0] + red[1] + red[2] + red[3];
+  for (int r = 0; r < kItems; ++r) {
+    const int64_t i = base + r * kBlock + t;
+    const bool valid = i < n;
+    int32_t key = 0;
+    bool head = false;
+    if (valid) {
+      key = keys[i];
+      head = is_head(keys, i, seg_len);
+      sorted_entry[i] = vals[i];
+    }
+    const unsigned long long hb = __ballot(head);
+    __syncthreads();                       // previous round's wc consumed
+    if (lane == 0) wc[w] = __popcll(hb);
+    __syncthreads();
+    if (head) {
+      int idx = run + __popcll(hb & lt_mask);
+      for (int ww = 0; ww < w; ++ww) idx += wc[ww];
+      uniq_rows[idx] = seg_len > 0 ? static_cast<int32_t>(field_off[i / seg_len] + key) : key;   // (local id -> global row)
+      seg_start[idx] = static_cast<int32_t>(i);
+    }
+    run += wc[0] + wc[1] + wc[2] + wc[3];
+  }
+  if (blockIdx.x == gridDim.x - 1 && t == 0) {
+    num_uniq[0] = run;
+    seg_start[run] = static_cast<int32_t>(n);
+  }
+}
+
 int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
 struct Layout {
-  int64_t ntiles, keysA, keysB, valsA, valsB, hist, heads, bin_total, total, bytes;
+  int64_t ntiles, keysA, keysB, valsA, valsB, hist, heads, bin_total, total, sync, sync_words, bytes;
 };
 
 Layout layout_for(int64_t n, int nseg = 1) {
@@ -336,10 +557,14 @@ Layout layout_for(int64_t n, int nseg = 1) {
   L.keysB = o; o += nb;
   L.valsA = o; o += nb;
   L.valsB = o; o += nb;
-  L.hist = o; o += align_up(L.ntiles * kMaxBins * 4, 256);
+  L.hist = o; o += align_up(L.ntiles * (nseg > 1 ? kFusedMaxBins : kMaxBins) * 4, 256);
   L.heads = o; o += align_up(L.ntiles * 4, 256);
   L.bin_total = o; o += static_cast<int64_t>(kMaxPasses) * (nseg > 1 ? nseg : 1) * kMaxBins * 4;
   L.total = o; o += 256;
+  // the fused passes' sync words (mi_sort_unique_fields): [pass][field] arrival counters, one published head count per
+  // tile, one error word — zeroed by the entry's first launch
+  L.sync_words = static_cast<int64_t>(kMaxPasses) * (nseg > 1 ? nseg : 1) + L.ntiles + 1;
+  L.sync = o; o += align_up(L.sync_words * 4, 256);
   L.bytes = o;
   return L;
 }
@@ -352,7 +577,7 @@ namespace {
 constexpr int kSmallN = 1024;
 __global__ __launch_bounds__(kBlock) void sort_small_k(const int32_t* __restrict__ keys, int n, int32_t* __restrict__ sorted_entry,
                                                        int32_t* __restrict__ uniq_rows, int32_t* __restrict__ seg_start,
-                                                       int32_t* __restrict__ num_uniq) {
+                                                       int32_t* __restrict__ num_uniq, int32_t* __restrict__ slot_of_entry = nullptr) {
   // bitonic sort of (key << 10 | index) in LDS: the index makes equal keys keep their order (stable), padding sorts
   // last.  (The first version ranked every key against every other: 87 us of the 280-us B = 32 step.)
   __shared__ unsigned long long a[kSmallN];
@@ -393,6 +618,7 @@ __global__ __launch_bounds__(kBlock) void sort_small_k(const int32_t* __restrict
     int pre = carry;
     for (int w = 0; w < (t >> 6); ++w) pre += wsum[w];
     if (i < n) head[i] = v ? pre + incl - 1 : -1;
+    if (slot_of_entry && i < n) slot_of_entry[a[i] & 1023u] = pre + incl - 1;      // (heads up to and including i, minus one)
     carry += wsum[0] + wsum[1] + wsum[2] + wsum[3];
   }
   __syncthreads();
@@ -406,10 +632,10 @@ extern "C" {
 
 size_t mi_sort_unique_workspace_bytes(int64_t n) { return static_cast<size_t>(layout_for(n).bytes); }
 
-int32_t mi_sort_unique_rows(const int32_t* rows, int64_t n, int64_t num_rows_total,
-                            int32_t* sorted_entry, int32_t* uniq_rows, int32_t* seg_start,
-                            int32_t* num_uniq, void* workspace, size_t workspace_bytes,
-                            mi_stream_t stream) {
+static int32_t sort_unique_rows_impl(const int32_t* rows, int64_t n, int64_t num_rows_total,
+                                     int32_t* sorted_entry, int32_t* uniq_rows, int32_t* seg_start,
+                                     int32_t* num_uniq, int32_t* slot_of_entry, void* workspace, size_t workspace_bytes,
+                                     mi_stream_t stream) {
   MI_REQUIRE(n > 0 && n < (int64_t)INT32_MAX - kTile, "sort_unique_rows: n=%lld", (long long)n);
   MI_REQUIRE(num_rows_total > 0 && num_rows_total <= (int64_t)INT32_MAX, "sort_unique_rows: num_rows_total=%lld",
              (long long)num_rows_total);
@@ -424,7 +650,7 @@ int32_t mi_sort_unique_rows(const int32_t* rows, int64_t n, int64_t num_rows_tot
   }
   hipStream_t st = mi::as_stream(stream);
   if (n <= kSmallN) {
-    sort_small_k<<<dim3(1), dim3(kBlock), 0, st>>>(rows, static_cast<int>(n), sorted_entry, uniq_rows, seg_start, num_uniq);
+    sort_small_k<<<dim3(1), dim3(kBlock), 0, st>>>(rows, static_cast<int>(n), sorted_entry, uniq_rows, seg_start, num_uniq, slot_of_entry);
     MI_CHECK_LAUNCH("sort_unique_rows(small)");
     return MI_OK;
   }
@@ -465,9 +691,22 @@ int32_t mi_sort_unique_rows(const int32_t* rows, int64_t n, int64_t num_rows_tot
   MI_CHECK_LAUNCH("sort_unique_rows(heads)");
   scan_small_k<<<dim3(1), dim3(1024), 0, st>>>(heads, ntiles, total);
   MI_CHECK_LAUNCH("sort_unique_rows(scan heads)");
-  compact_k<<<dim3(ntiles), dim3(kBlock), 0, st>>>(kin, vin, n, heads, total, sorted_entry, uniq_rows, seg_start, num_uniq);
+  compact_k<<<dim3(ntiles), dim3(kBlock), 0, st>>>(kin, vin, n, heads, total, sorted_entry, uniq_rows, seg_start, num_uniq, 0, nullptr,
+                                                   slot_of_entry);
   MI_CHECK_LAUNCH("sort_unique_rows(compact)");
   return MI_OK;
+}
+
+int32_t mi_sort_unique_rows(const int32_t* rows, int64_t n, int64_t num_rows_total, int32_t* sorted_entry, int32_t* uniq_rows,
+                            int32_t* seg_start, int32_t* num_uniq, void* workspace, size_t workspace_bytes, mi_stream_t stream) {
+  return sort_unique_rows_impl(rows, n, num_rows_total, sorted_entry, uniq_rows, seg_start, num_uniq, nullptr, workspace, workspace_bytes, stream);
+}
+
+int32_t mi_sort_unique_rows_slots(const int32_t* rows, int64_t n, int64_t num_rows_total, int32_t* sorted_entry, int32_t* uniq_rows,
+                                  int32_t* seg_start, int32_t* num_uniq, int32_t* slot_of_entry, void* workspace,
+                                  size_t workspace_bytes, mi_stream_t stream) {
+  MI_REQUIRE(slot_of_entry && uniq_rows, "sort_unique_rows_slots: null buffer");
+  return sort_unique_rows_impl(rows, n, num_rows_total, sorted_entry, uniq_rows, seg_start, num_uniq, slot_of_entry, workspace, workspace_bytes, stream);
 }
 
 
@@ -510,7 +749,7 @@ size_t mi_sort_unique_fields_workspace_bytes(int64_t B, int32_t F) {
 
 int32_t mi_sort_unique_fields(const int32_t* ids, const int64_t* field_off, int64_t B, int32_t F, int64_t max_vocab,
                               int32_t* sorted_entry, int32_t* uniq_rows, int32_t* seg_start, int32_t* num_uniq,
-                              void* workspace, size_t workspace_bytes, mi_stream_t stream) {
+                              void* workspace, size_t workspace_bytes, int32_t beside, mi_stream_t stream) {
   const int64_t n = B * F;
   MI_REQUIRE(B > 0 && F > 0 && F <= kFieldsMax && B % kTile == 0 && n < (int64_t)INT32_MAX - kTile,
              "sort_unique_fields: B=%lld (a multiple of %d) F=%d (<= %d)", (long long)B, kTile, F, kFieldsMax);
@@ -538,6 +777,38 @@ int32_t mi_sort_unique_fields(const int32_t* ids, const int64_t* field_off, int6
   const int nbits = (bits + passes - 1) / passes;   // digit width, <= 9
   const int nbins = 1 << nbits;
 
+  if (tps <= kFusedMaxTps && !beside && mi::env_int("MI_SORT_FUSED", 1) != 0) {
+    // one launch per pass + one for the compaction (pass_fused_k / compact_fused_k above): 20-bit ids = 2 passes of 10 bits
+    const int fbits = mi::env_int("MI_SORT_BITS", kFusedMaxBits) < kFusedMaxBits ? mi::env_int("MI_SORT_BITS", kFusedMaxBits) : kFusedMaxBits;
+    const int fpasses = (bits + fbits - 1) / fbits;
+    const int fnb = (bits + fpasses - 1) / fpasses;
+    MI_REQUIRE(fpasses <= kMaxPasses, "sort_unique_fields: %d passes", fpasses);
+    int32_t* sync = reinterpret_cast<int32_t*>(ws + L.sync);
+    int32_t* ready = sync;                                   // [pass][field]
+    int32_t* hcf = sync + static_cast<int64_t>(kMaxPasses) * F;  // [tile]
+    int32_t* err = hcf + ntiles;
+    zero_i32(sync, L.sync_words, st);
+    MI_CHECK_LAUNCH("sort_unique_fields(zero)");
+    const int32_t* kin = nullptr;
+    const int32_t* vin = nullptr;
+    const int nap = mi::env_int("MI_SORT_NAP", 1);
+    for (int p = 0; p < fpasses; ++p) {
+      int32_t* kout = kbuf[p & 1];
+      int32_t* vout = vbuf[p & 1];
+      if (fnb > 9)
+        pass_fused_k<kFusedMaxBins><<<dim3(ntiles), dim3(kBlock), 0, st>>>(kin, vin, p == 0 ? ids : nullptr, B, F, fnb * p, fnb, tps, hist,
+                                                                          ready + static_cast<int64_t>(p) * F, err, kout, vout, nap);
+      else
+        pass_fused_k<kMaxBins><<<dim3(ntiles), dim3(kBlock), 0, st>>>(kin, vin, p == 0 ? ids : nullptr, B, F, fnb * p, fnb, tps, hist,
+                                                                      ready + static_cast<int64_t>(p) * F, err, kout, vout, nap);
+      MI_CHECK_LAUNCH("sort_unique_fields(pass)");
+      kin = kout;
+      vin = vout;
+    }
+    compact_fused_k<<<dim3(ntiles), dim3(kBlock), 0, st>>>(kin, vin, n, hcf, err, sorted_entry, uniq_rows, seg_start, num_uniq, B, field_off);
+    MI_CHECK_LAUNCH("sort_unique_fields(compact)");
+    return MI_OK;
+  }
   zero_i32(bin_total, static_cast<int64_t>(kMaxPasses) * F * kMaxBins, st);
   MI_CHECK_LAUNCH("sort_unique_fields(zero)");
   // the ids field by field (keys = local ids); pass 0 reads them from the buffer pass 1 will overwrite

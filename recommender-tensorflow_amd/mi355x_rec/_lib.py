@@ -16,7 +16,7 @@ import torch  # noqa: F401  (loads the HIP runtime this library must share)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmi355x_rec.so")
 
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 
 class MiError(RuntimeError):
@@ -85,8 +85,9 @@ SIGNATURES = {
                                     _p, _p, _sz, _p]),
     "mi_sort_unique_workspace_bytes": (_sz, [_i64]),
     "mi_sort_unique_fields_workspace_bytes": (_sz, [_i64, _i32]),
-    "mi_sort_unique_fields": (_i32, [_p, _p, _i64, _i32, _i64, _p, _p, _p, _p, _p, _sz, _p]),
+    "mi_sort_unique_fields": (_i32, [_p, _p, _i64, _i32, _i64, _p, _p, _p, _p, _p, _sz, _i32, _p]),
     "mi_sort_unique_rows": (_i32, [_p, _i64, _i64, _p, _p, _p, _p, _p, _sz, _p]),
+    "mi_sort_unique_rows_slots": (_i32, [_p, _i64, _i64, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "mi_global_rows": (_i32, [_p, _p, _i64, _i32, _p, _p]),
     "mi_shard_keys": (_i32, [_p, _i64, _i32, _i64, _i64, _i32, _p, _p]),
     "mi_route_requests": (_i32, [_p, _p, _i64, _i64, _i32, _p, _p, _p]),

@@ -1092,7 +1092,7 @@ class DeepFM:
         return (self.device.type == "cuda" and self.use_emb and self.use_linear and self.use_dnn and self.n_numeric == 0
                 and self.F > 0 and B >= 4096)
 
-    def _sort_unique(self, keys, n, key_range, tag, ws_name="sort_ws", cap=None):
+    def _sort_unique(self, keys, n, key_range, tag, ws_name="sort_ws", cap=None, slot=None):
         """mi_sort_unique_rows into persistent buffers named after `tag` (ws_name: a workspace of its own for a sort that
         runs on a side stream beside the main stream's).  cap: allocate for that many keys (a count that varies from step
         to step must not reallocate between the collectives of a multi-GPU step)."""
@@ -1103,7 +1103,10 @@ class DeepFM:
         seg = self._buf(tag + "_seg", (cap + 1,), i32)[:n + 1]
         num_uniq = self._buf(tag + "_nu", (1,), i32)
         ws = self._bytes(ws_name, self.k.query("mi_sort_unique_workspace_bytes", cap))
-        self.k.mi_sort_unique_rows(keys, n, key_range, sorted_entry, uniq, seg, num_uniq, ws, ws.numel())
+        if slot is not None:          # (+ every entry's segment, written by the compaction: parallel._route)
+            self.k.mi_sort_unique_rows_slots(keys, n, key_range, sorted_entry, uniq, seg, num_uniq, slot, ws, ws.numel())
+        else:
+            self.k.mi_sort_unique_rows(keys, n, key_range, sorted_entry, uniq, seg, num_uniq, ws, ws.numel())
         return sorted_entry, uniq, seg, num_uniq
 
     PRESORT_MIN = 16384       # entries from which sorting the next batch beside this step's catch-up pays
@@ -1121,7 +1124,8 @@ class DeepFM:
             seg, num_uniq = self._buf(tag + "_seg", (n + 1,), i32), self._buf(tag + "_nu", (1,), i32)
             ws = self._bytes("sortf_ws", k.query("mi_sort_unique_fields_workspace_bytes", B, self.F))
             sort = k.tagged("mi_sort_unique_fields", "/next batch, side stream") if (side and hasattr(k, "tagged")) else k.mi_sort_unique_fields
-            sort(ids, self.field_off, B, self.F, self.max_vocab, sorted_entry, uniq, seg, num_uniq, ws, ws.numel())
+            # (beside: on a side stream next to the catch-up the many-short-launches form, alone on the step's stream the fused one)
+            sort(ids, self.field_off, B, self.F, self.max_vocab, sorted_entry, uniq, seg, num_uniq, ws, ws.numel(), 1 if side else 0)
             return sorted_entry, uniq, seg, num_uniq
         rows = self._buf("rows", (n,), torch.int32)
         k.mi_global_rows(ids, self.field_off, B, self.F, rows)
@@ -1458,9 +1462,9 @@ class DeepFM:
             # new capture needs no sizing step).
             graphs.clear()
             g = self._graph = None
-            self.__dict__.setdefault("_graph_warm", set()).add(shape)
+            self._warm_shapes().add(shape)
         if g is None:
-            warm = self.__dict__.setdefault("_graph_warm", set())
+            warm = self._warm_shapes()
             if shape not in warm:
                 warm.add(shape)
                 return self.train_step(ids, labels, x_num)              # sizes every workspace
@@ -1489,6 +1493,12 @@ class DeepFM:
         self._top_step = self.step - 1 if g.get("top") else None
         self._acts_in_planes = set(g.get("acts_in_planes", self._acts_in_planes))
         return g["loss"], g["logits"]
+
+    def _warm_shapes(self):
+        """batch shapes whose sizing step (an eager step before the capture) has run"""
+        if not isinstance(self.__dict__.get("_graph_warm"), set):
+            self._graph_warm = set()
+        return self._graph_warm
 
     def drop_graphs(self):
         """forget every captured step (the next graph_train_step of a shape captures again, without a sizing step)"""

@@ -239,13 +239,14 @@ def _route(m, ids, C, tag="", ahead=False):
     k.mi_global_rows(ids, m.field_off, B, m.F, rows)
     key = m._buf("route_key" + tag, (n,), i32)
     k.mi_shard_keys(rows, n, sh.world, (n // C) if C > 1 else 0, Rl, sh.rank, key)
+    # (slot: the distinct request every entry belongs to = where its row lands in the receive buffer; the sort's
+    # compaction writes it as it goes)
+    slot = m._buf("route_slot" + tag, (n,), i32)
     sorted_entry, uniq, seg, num_uniq = m._sort_unique(key, n, C * sh.world * Rl, "route" + tag,
-                                                       ws_name="sort_ws_ahead" if ahead else "sort_ws")
+                                                       ws_name="sort_ws_ahead" if ahead else "sort_ws", slot=slot)
     send_rows = m._buf("send_rows" + tag, (n,), i32)
     counts = m._buf("route_counts" + tag, (C * sh.world,), i32)
     k.mi_route_requests(uniq, num_uniq, n, Rl, C * sh.world, send_rows, counts)
-    slot = m._buf("route_slot" + tag, (n,), i32)
-    k.mi_segment_slots(seg, sorted_entry, num_uniq, n, slot)
     return {"slot": slot, "send_rows": send_rows, "sorted_entry": sorted_entry, "seg": seg, "C": C, "tag": tag,
             "pending": comm.start_counts(counts, C, ahead=ahead)}
 

@@ -98,6 +98,10 @@ class NumpyKernels:
         _np(seg)[U] = n
         _np(num_uniq)[0] = U
 
+    def mi_sort_unique_rows_slots(self, rows, n, total, sorted_entry, uniq, seg, num_uniq, slot, ws, wsb):
+        self.mi_sort_unique_rows(rows, n, total, sorted_entry, uniq, seg, num_uniq, ws, wsb)
+        self.mi_segment_slots(seg, sorted_entry, num_uniq, n, slot)
+
     # ---- embedding side ------------------------------------------------------------------
     def mi_embed_fm_linear_fwd(self, table, lin_w, field_off, ids, B, F, E, concat, ld, sumv, fm, lin, amax=None, ls=1, ts=0):
         rows = _np(ids).astype(np.int64) + _np(field_off)[None, :]

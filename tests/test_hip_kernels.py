@@ -847,6 +847,29 @@ def test_sort_unique_rows(lib, n, R):
     assert np.array_equal(sg.cpu().numpy()[:U + 1], np.r_[starts, n].astype(np.int32))
 
 
+@pytest.mark.parametrize("n,R", [(1, 10), (100, 7), (1000, 3), (5000, 300), (70000, 4106), (300000, 26_000_000), (4097, 65536)])
+def test_sort_unique_rows_slots_equals_sort_then_segment_slots(lib, n, R):
+    """mi_sort_unique_rows_slots = mi_sort_unique_rows + mi_segment_slots (the entry the row-sharded step's routing used until
+    round 5), bit for bit: same sort outputs, and slot_of_entry[e] = the segment of entry e"""
+    rng = np.random.default_rng(n + R)
+    rows = rng.integers(0, R, n).astype(np.int32)
+    r = dev(rows)
+    def outs():
+        return (torch.empty(n, dtype=torch.int32, device="cuda"), torch.empty(n, dtype=torch.int32, device="cuda"),
+                torch.empty(n + 1, dtype=torch.int32, device="cuda"), torch.empty(1, dtype=torch.int32, device="cuda"),
+                torch.full((n,), -1, dtype=torch.int32, device="cuda"))
+    ws = torch.empty(lib.mi_sort_unique_workspace_bytes(n) + 256, dtype=torch.uint8, device="cuda")
+    se, uq, sg, nu, sl = outs()
+    _chk(lib.mi_sort_unique_rows_slots(_p(r), n, R, _p(se), _p(uq), _p(sg), _p(nu), _p(sl), _p(ws), ws.numel(), _st()))
+    se2, uq2, sg2, nu2, sl2 = outs()
+    _chk(lib.mi_sort_unique_rows(_p(r), n, R, _p(se2), _p(uq2), _p(sg2), _p(nu2), _p(ws), ws.numel(), _st()))
+    _chk(lib.mi_segment_slots(_p(sg2), _p(se2), _p(nu2), n, _p(sl2), _st()))
+    U = int(nu.item())
+    assert U == int(nu2.item()) and torch.equal(se, se2) and torch.equal(uq[:U], uq2[:U]) and torch.equal(sg[:U + 1], sg2[:U + 1])
+    assert torch.equal(sl, sl2)
+    assert np.array_equal(np.unique(rows)[sl.cpu().numpy()], rows)          # the slot's row is the entry's row
+
+
 @pytest.mark.parametrize("n_max,U,st", [(5000, 4100, 1), (200000, 150000, 4), (4097, 4097, 1), (70, 0, 4)])
 def test_catchup_rows_by_gap_is_the_stable_sort_of_the_gap_keys(lib, n_max, U, st):
     """mi_catchup_rows_by_gap == mi_catchup_gap_keys + stable sort + gather (the three entries it replaces)"""
@@ -870,12 +893,21 @@ def test_catchup_rows_by_gap_is_the_stable_sort_of_the_gap_keys(lib, n_max, U, s
     assert np.array_equal(out.cpu().numpy()[:U], rows[order][:U])
 
 
-@pytest.mark.parametrize("B,F,vocab", [(4096, 26, 1_000_000), (8192, 3, 50), (4096, 40, 1_250_000), (4096, 1, 7)])
-def test_sort_unique_fields_equals_global_rows_then_sort(lib, B, F, vocab):
-    """the per-field (segmented) sort gives the outputs of mi_global_rows + mi_sort_unique_rows bit for bit"""
+@pytest.mark.parametrize("beside", [0, 1])
+@pytest.mark.parametrize("B,F,vocab", [(4096, 26, 1_000_000), (8192, 3, 50), (4096, 40, 1_250_000), (4096, 1, 7), (65536, 26, 1_000_000),
+                                       (65536, 5, -1_000_000), (12288, 64, 3_000_000)])
+def test_sort_unique_fields_equals_global_rows_then_sort(lib, B, F, vocab, beside):
+    """the per-field (segmented) sort gives the outputs of mi_global_rows + mi_sort_unique_rows bit for bit — in both of its
+    forms (beside = 0: one launch per radix pass, the tiles of a field exchanging their digit counts inside it, and one for the
+    compaction; beside = 1: the 14 short launches), up to config 3's full size, with Zipf-skewed ids (vocab < 0: most of a
+    field's entries share a few rows, segments of thousands) and with more than 2^20 ids per field (3 passes)"""
     rng = np.random.default_rng(B + F)
+    zipf, vocab = vocab < 0, abs(vocab)
     vs = [max(2, vocab - 13 * f) for f in range(F)]
-    ids = np.stack([rng.integers(0, v, B) for v in vs], 1).astype(np.int32)
+    if zipf:
+        ids = np.stack([np.minimum(rng.zipf(1.05, B) - 1, v - 1) for v in vs], 1).astype(np.int32)
+    else:
+        ids = np.stack([rng.integers(0, v, B) for v in vs], 1).astype(np.int32)
     ids[B // 2] = ids[0]                                   # duplicates across examples
     if F > 1:
         ids[:, 1] = ids[0, 1] if B < 5000 else ids[:, 1]   # a field with ONE id: a segment of B duplicates
@@ -887,7 +919,7 @@ def test_sort_unique_fields_equals_global_rows_then_sort(lib, B, F, vocab):
                 torch.empty(n + 1, dtype=torch.int32, device="cuda"), torch.empty(1, dtype=torch.int32, device="cuda"))
     se, uq, sg, nu = outs()
     ws = torch.empty(lib.mi_sort_unique_fields_workspace_bytes(B, F) + 256, dtype=torch.uint8, device="cuda")
-    _chk(lib.mi_sort_unique_fields(_p(d_ids), _p(d_off), B, F, max(vs), _p(se), _p(uq), _p(sg), _p(nu), _p(ws), ws.numel(), _st()))
+    _chk(lib.mi_sort_unique_fields(_p(d_ids), _p(d_off), B, F, max(vs), _p(se), _p(uq), _p(sg), _p(nu), _p(ws), ws.numel(), beside, _st()))
     rows = torch.empty(n, dtype=torch.int32, device="cuda")
     _chk(lib.mi_global_rows(_p(d_ids), _p(d_off), B, F, _p(rows), _st()))
     se2, uq2, sg2, nu2 = outs()
@@ -897,7 +929,7 @@ def test_sort_unique_fields_equals_global_rows_then_sort(lib, B, F, vocab):
     assert int(nu.item()) == U
     assert torch.equal(se, se2)
     assert torch.equal(uq[:U], uq2[:U]) and torch.equal(sg[:U + 1], sg2[:U + 1])
-    assert lib.mi_sort_unique_fields(_p(d_ids), _p(d_off), B - 1, F, max(vs), _p(se), _p(uq), _p(sg), _p(nu), _p(ws), ws.numel(), _st()) != 0
+    assert lib.mi_sort_unique_fields(_p(d_ids), _p(d_off), B - 1, F, max(vs), _p(se), _p(uq), _p(sg), _p(nu), _p(ws), ws.numel(), beside, _st()) != 0
 
 
 def test_colsum_and_layer_stats(lib):
