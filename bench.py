@@ -95,7 +95,10 @@ def parse():
                     help="A/B runs: set a scheduling attribute of engine.DeepFM (WSPLIT_AHEAD, LIN_SIDE, BYGAP_AHEAD, WGRAD_BATCH, ...)")
     ap.add_argument("--route-ahead", type=int, choices=[0, 1], default=None,
                     help="row-sharded step: 0 = the whole step on ONE RCCL communicator (no routing of the next batch ahead on a "
-                         "second one); default: parallel.RowShard's (1)")
+                         "second one) — the default under a launcher for N > 1: two communicators have never run on more than one "
+                         "GPU; 1 = the next batch routed ahead on a second communicator (faster by ~0.25 ms with one rank; "
+                         "--force-shard's default).  `python bench.py --gpus N` without a launcher tries both, in fresh processes")
+    ap.add_argument("--cpu-baseline-json", default=None, help=argparse.SUPPRESS)     # (parent -> rank 0: the baseline it timed before starting the ranks)
     ap.add_argument("--packed-exchange", type=int, choices=[0, 1], default=None,
                     help="row-sharded step: 1 = rows + wide weights (and their gradients) travel as one record of E + 4 floats per "
                          "request: one collective per chunk and direction instead of two (default: parallel.RowShard's, 0)")
@@ -105,10 +108,9 @@ def parse():
     return ap.parse_args()
 
 
-def spawn_ranks(n):
-    """`python bench.py --gpus N` without a launcher: start N fresh rank processes through torch.distributed.run — children of
-    this process, which has not touched the GPU (nothing here initialises HIP before this point) — relay their output (rank 0
-    prints the JSON line) and exit with their status."""
+def _run_rank_set(n, extra, label, timeout_s):
+    """N fresh rank processes through torch.distributed.run — children of this process, which never touches the GPU.
+    Returns (exit status, rank 0's JSON line or None)."""
     import socket
     import subprocess
     with socket.socket() as so:
@@ -116,9 +118,68 @@ def spawn_ranks(n):
         port = so.getsockname()[1]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    log("no launcher in the environment: starting %d ranks: %s" % (n, " ".join(cmd)))
-    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+           "--master-port", str(port), os.path.abspath(__file__)] + [a for a in sys.argv[1:]] + extra
+    log("%s: starting %d ranks: %s" % (label, n, " ".join(cmd)))
+    try:
+        p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True, timeout=timeout_s)
+        rc, text = p.returncode, p.stdout
+    except subprocess.TimeoutExpired as e:
+        rc, text = -9, (e.stdout.decode() if isinstance(e.stdout, bytes) else (e.stdout or ""))
+    line = None
+    for ln in text.splitlines():
+        if ln.startswith("{"):
+            line = ln
+        elif ln.strip():
+            print(ln, file=sys.stderr)
+    return rc, line
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher.  This process has not touched the GPU and never will:
+      1. the CPU baseline, timed HERE before any rank exists (the ranks' host threads then do not compete with it), handed to
+         rank 0 as a file;
+      2. a set of fresh ranks in the conservative mode — every collective of a step on ONE communicator (--route-ahead 0): its
+         line is the record if nothing else works;
+      3. a second set of fresh ranks with the next batch routed ahead on a second communicator (--route-ahead 1).  If it
+         finishes, the faster of the two lines is printed, with both modes' numbers in config; if it dies (a collective
+         timeout ends the ranks non-zero) the first line is printed with the failure named, and the exit status is 0."""
+    import tempfile
+    n = args.gpus
+    extra = []
+    if not args.no_cpu_baseline:
+        log("cpu baseline (before the ranks start)")
+        cb = cpu_baseline()
+        f = tempfile.NamedTemporaryFile("w", suffix=".json", delete=False)
+        json.dump(cb, f)
+        f.close()
+        extra = ["--cpu-baseline-json", f.name]
+    budget = 3.0 * args.collective_timeout + 900.0
+    if args.route_ahead is not None:                       # the caller chose a mode: one set
+        rc, line = _run_rank_set(n, extra, "ranks", budget)
+        if line:
+            print(line)
+        raise SystemExit(rc if not line else 0)
+    rc1, line1 = _run_rank_set(n, extra + ["--route-ahead", "0"], "set 1 (one communicator)", budget)
+    if not line1:
+        raise SystemExit(rc1 or 1)
+    rc2, line2 = _run_rank_set(n, extra + ["--route-ahead", "1", "--no-second-dist", "--no-cpu-baseline"], "set 2 (routing ahead on a second communicator)", budget)
+    d1 = json.loads(line1)
+    modes = {"one_communicator": {"value": d1["value"], "ms_per_step": d1["ms_per_step"]}}
+    best = d1
+    if line2:
+        d2 = json.loads(line2)
+        modes["route_ahead_second_communicator"] = {"value": d2["value"], "ms_per_step": d2["ms_per_step"]}
+        if d2["value"] > d1["value"]:
+            for k_ in ("cpu_baseline", "other_distribution"):
+                if k_ in d1 and k_ not in d2:
+                    d2[k_] = d1[k_]
+            best = d2
+    else:
+        modes["route_ahead_second_communicator"] = {"failed": "exit status %d, no line (a collective timeout ends the ranks non-zero)" % rc2}
+    best["config"]["communicator_modes"] = modes
+    best["config"]["communicator_mode_of_value"] = "one_communicator" if best is d1 else "route_ahead_second_communicator"
+    print(json.dumps(best))
+    raise SystemExit(0)
 
 
 def make_batches(n, gen, device, zipf, B):
@@ -317,7 +378,7 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
-            spawn_ranks(args.gpus)                   # (never returns)
+            spawn_ranks(args)                        # (never returns)
         raise SystemExit("--gpus %d but the launcher started %d ranks" % (args.gpus, world))
     if args.same_device:
         local = 0
@@ -352,9 +413,12 @@ def main():
     shard = None
     if world > 1 or args.force_shard:
         from mi355x_rec.parallel import RowShard
+        # N > 1 under a launcher: ONE communicator unless asked otherwise (the conservative mode for hardware this path has never
+        # run on); one rank (--force-shard): parallel.RowShard's default, the routing ahead on a second communicator
+        ra = args.route_ahead if args.route_ahead is not None else (0 if world > 1 else None)
         shard = RowShard(rank, world, chunks=args.chunks,
                          chunk_compute=None if args.chunk_compute is None else bool(args.chunk_compute),
-                         route_ahead=None if args.route_ahead is None else bool(args.route_ahead),
+                         route_ahead=None if ra is None else bool(ra),
                          **({} if args.packed_exchange is None else {"packed": bool(args.packed_exchange)}))
     m = DeepFM([V] * F, embedding_size=E, hidden_units=HIDDEN, dropout=DROPOUT,
                optimizer=OptimizerSpec("Adam", 0.001), device=device, seed=SEED, shard=shard, gemm=args.gemm,
@@ -588,6 +652,11 @@ def main():
         torch.cuda.empty_cache()
         configs = other_configs(device, sync)
 
+    if world > 1:
+        # every collective of the run is done: the group goes away HERE, before rank 0 assembles the line (and times the CPU
+        # baseline for half a minute) — no rank waits inside a collective meanwhile
+        dist.barrier()
+        dist.destroy_process_group()
     if rank == 0:
         km = kernel_ms(timers)
         ms_step = dt / args.steps * 1e3
@@ -626,11 +695,13 @@ def main():
         pmc = {}
         try:
             with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-                pmc = json.load(f) if world == 1 else {}
+                pmc = json.load(f)
         except (OSError, ValueError):
             pass
         tr = lambda name: pmc.get(name, {}).get("bytes_per_launch")
         traffic = tr("embed_fm_planes_fwd_k" if planes_gather else "embed_fm_linear_fwd_k")
+        if traffic is not None and int(Bl) != B_FULL:
+            traffic = traffic * Bl / B_FULL               # (counted on the single-GPU launch of 65536 examples: scaled to this launch's)
         # the two other bandwidth / issue-bound kernels of the step (lazy sparse Adam = 28E + 8 bytes per distinct row)
         roof_apply = roof_catchup = None
         if sparse_stats is not None and "mi_sparse_apply_fused" in km:
@@ -703,6 +774,8 @@ def main():
                                 "bf16x3": "fp32 GEMMs via 3-way bf16 operand split, fp32 accumulate",
                                 "fp32": "fp32-input MFMA"}[args.gemm],
                        "parallelism": "dp%d + row-sharded embeddings (all-to-all)" % world if (world > 1 or args.force_shard) else "single GPU",
+                       "communicators": (None if shard is None else ("two: the next batch is routed ahead on a second communicator" if shard.route_ahead
+                                                                     else "one: every collective of a step in program order on one communicator")),
                        "catchup": ("bounded-error lazy Adam replay (MI_CATCHUP_BOUNDED: every variable within 3 ulp + 2e-6 of the replayed "
                                    "movement of TF's sweep, 98.7 % within 1e-7 relative; the exact mode is the extra catchup_exact)"
                                    if mode_catchup == "bounded" else "lazy Adam replay bit-exact with TF's dense-equivalent sweep"),
@@ -748,9 +821,15 @@ def main():
             out["other_distribution"] = other
         if other_scaling is not None:
             out["other_scaling"] = other_scaling
-        if world == 1 and not args.no_cpu_baseline:
+        if args.cpu_baseline_json:
+            with open(args.cpu_baseline_json) as f:
+                out["cpu_baseline"] = json.load(f)
+        elif not args.no_cpu_baseline:
+            # (N > 1 under a launcher: every collective of the run is done — the other ranks wait in the final barrier)
             log("cpu baseline")
             out["cpu_baseline"] = cpu_baseline()
+            if world > 1:
+                out["cpu_baseline"]["sample"] += "; timed on rank 0's host threads after the GPU legs, the other %d ranks idle in a barrier" % (world - 1)
         # Numbers a record that truncates long strings and keeps only the line's tail must still show: flat numeric
         # copies in `config` (the strict legs beside the headline's two disclosed modes; the other rooflines; the other
         # BASELINE configs), and the same as a compact `summary` object at the very END of the line.
@@ -782,9 +861,6 @@ def main():
         out["summary"] = dict(num, value=int(out["value"]),
                               kernel_ms_per_step={k_: round(v_[2] / args.steps, 4) for k_, v_ in sorted(top.items(), key=lambda kv: -kv[1][2])[:14]})
         print(json.dumps(out))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
