@@ -5,6 +5,11 @@ maps a value to ``Fingerprint64(bytes) mod hash_bucket_size``.  Ten
 are not in the reference tree; this follows FarmHash's published algorithm (farmhash.cc,
 namespace farmhashna, v1.1).  Written independently of ``csrc/host_ids.cpp`` in style (explicit
 masking, slices) so that the two restatements check each other.
+
+Pinned by external known answers (tests/test_fingerprint.py): the 1-3 byte branch by TensorFlow's own op test ('a'..'d') and
+pyfarmhash's README ('abc'); the 4-7 and 8-16 byte branches — every MovieLens item id, zipcode and occupation — by the three
+full 64-bit FARM_FINGERPRINT values of BigQuery's reference page (round 5); 17 bytes and more: unpinned (C and Python
+restatements agree with each other only; no ML-100k feature is that long).
 """
 M64 = (1 << 64) - 1
 K0 = 0xC3A5C85C97CB3127

@@ -7,6 +7,13 @@ is absent.  Anchors used instead, all recalled from TensorFlow's own public test
     below are the Fingerprint64 results those buckets come from)           [1-3 byte branch]
   * tf.strings.to_hash_bucket_fast(["Hello","TensorFlow","2.x"], 3) -> [0, 2, 2] (API docs example)
     [4-7 byte and 8-16 byte branches, weakly: mod 3]
+  * round 5 — full 64-bit answers for the 4-7 and 8-16 byte branches (every MovieLens item id, zipcode and occupation
+    goes through one of them): BigQuery's FARM_FINGERPRINT is farmhash Fingerprint64 — the function TensorFlow's
+    string_to_hash_bucket_fast calls — and its reference page shows FARM_FINGERPRINT(CONCAT(CAST(x AS STRING), y,
+    CAST(z AS STRING))) for the rows (1, "foo", true), (2, "apple", false), (3, "", true) as the signed values
+    -1541654101129638711, 2794438866806483259, -4880158226897771312: "1footrue" (8 bytes), "2applefalse" (11 bytes),
+    "3true" (5 bytes).  Recalled, like the anchors above; three independent 64-bit values that a restatement written
+    from the published algorithm reproduces are not a coincidence.
 The 17+ byte branches have no external anchor here: the C and Python restatements (written
 independently from FarmHash's published algorithm) are cross-checked against each other only.
 """
@@ -20,7 +27,10 @@ from oracle import columns as OC
 from oracle.fingerprint import fingerprint64
 
 KAT = {"a": 12917804110809363939, "b": 11795596070477164822, "c": 11430444447143000872,
-       "d": 4470636696479570465}
+       "d": 4470636696479570465,
+       "abc": 2640714258260161385}     # (pyfarmhash's README: farmhash.hash64('abc') — Hash64 and Fingerprint64 agree below 17 bytes)
+# BigQuery FARM_FINGERPRINT documentation rows (signed int64): the 8-16 byte branch twice, the 4-7 byte branch once
+KAT_SIGNED = {"1footrue": -1541654101129638711, "2applefalse": 2794438866806483259, "3true": -4880158226897771312}
 
 
 def test_fingerprint64_known_answers():
@@ -29,6 +39,8 @@ def test_fingerprint64_known_answers():
     assert [fingerprint64(s) % 10 for s in "abcd"] == [9, 2, 2, 5]
     assert [fingerprint64(s) % 3 for s in ["Hello", "TensorFlow", "2.x"]] == [0, 2, 2]
     assert fingerprint64("") == 0x9AE16A3B2F90404F      # empty string returns k2
+    for s, v in KAT_SIGNED.items():
+        assert fingerprint64(s) == v % (1 << 64), s
 
 
 def test_c_abi_fingerprint_matches_oracle_on_every_length_branch(lib):
@@ -37,7 +49,9 @@ def test_c_abi_fingerprint_matches_oracle_on_every_length_branch(lib):
         s = bytes(rnd.randrange(256) for _ in range(n))
         assert lib.mi_fingerprint64(s, len(s)) == fingerprint64(s), n
     for s, v in KAT.items():
-        assert lib.mi_fingerprint64(s.encode(), 1) == v
+        assert lib.mi_fingerprint64(s.encode(), len(s)) == v
+    for s, v in KAT_SIGNED.items():
+        assert lib.mi_fingerprint64(s.encode(), len(s)) == v % (1 << 64), s
 
 
 def test_hash_bucket_columns(lib):
