@@ -21,7 +21,7 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
-// Tuning switches (MI_PL_TILE, MI_WGRAD_TILE, MI_WGRAD_PL, MI_CATCHUP_BLOCKS, MI_CATCHUP_DEPTH, MI_SORT_MEMSET): read from the
+// Tuning switches (MI_PL_TILE, MI_WGRAD_TILE, MI_WGRAD_PL, MI_CATCHUP_BLOCKS, MI_CATCHUP_DEPTH, MI_SORT_MEMSET, MI_SORT_FUSED, MI_SORT_BITS, MI_SORT_NAP): read from the
 // environment ONLY in the tools' build of the library (`make tuning` -> tools/probe/libmi355x_rec_tuning.so, -DMI_TUNING; the
 // tools/*_bench.py scripts load that file).  The shipped libmi355x_rec.so has no environment switch: env_int is the
 // built-in value, and the measured-and-dropped variants behind the switches are dead code the compiler removes.
