@@ -829,7 +829,7 @@ def main():
             log("cpu baseline")
             out["cpu_baseline"] = cpu_baseline()
             if world > 1:
-                out["cpu_baseline"]["sample"] += "; timed on rank 0's host threads after the GPU legs, the other %d ranks idle in a barrier" % (world - 1)
+                out["cpu_baseline"]["sample"] += "; timed on rank 0's host threads after the GPU legs, the process group gone and the other %d ranks leaving" % (world - 1)
         # Numbers a record that truncates long strings and keeps only the line's tail must still show: flat numeric
         # copies in `config` (the strict legs beside the headline's two disclosed modes; the other rooflines; the other
         # BASELINE configs), and the same as a compact `summary` object at the very END of the line.

@@ -778,8 +778,9 @@ int32_t mi_sort_unique_fields(const int32_t* ids, const int64_t* field_off, int6
   const int nbins = 1 << nbits;
 
   if (tps <= kFusedMaxTps && !beside && mi::env_int("MI_SORT_FUSED", 1) != 0) {
-    // one launch per pass + one for the compaction (pass_fused_k / compact_fused_k above): 20-bit ids = 2 passes of 10 bits
-    const int fbits = mi::env_int("MI_SORT_BITS", kFusedMaxBits) < kFusedMaxBits ? mi::env_int("MI_SORT_BITS", kFusedMaxBits) : kFusedMaxBits;
+    // one launch per pass + one for the compaction (pass_fused_k / compact_fused_k above).  Digits of 7 bits: 20-bit ids = 3
+    // passes, 130 us at config 3 against 149 for 2 passes of 10 bits (1,024 bins per 4,096-key tile scatter 16-byte runs)
+    const int fbits = mi::env_int("MI_SORT_BITS", 7) < kFusedMaxBits ? mi::env_int("MI_SORT_BITS", 7) : kFusedMaxBits;
     const int fpasses = (bits + fbits - 1) / fbits;
     const int fnb = (bits + fpasses - 1) / fpasses;
     MI_REQUIRE(fpasses <= kMaxPasses, "sort_unique_fields: %d passes", fpasses);
