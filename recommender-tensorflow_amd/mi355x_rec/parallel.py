@@ -35,11 +35,14 @@ class RowShard:
     def __init__(self, rank, world, group=None, chunks=None, chunk_compute=None, route_ahead=None, packed=False):
         """chunks: pipeline depth of a train step (None: chosen from the batch and world size, see _n_chunks).
         route_ahead: True (default) — an announced next batch is routed during this step, on a side stream and a SECOND
-        RCCL communicator (see Comm / _route_ahead); False — the whole step runs on ONE communicator and one stream
-        order: no second communicator is created, every collective of a step is issued in program order (the
+        RCCL communicator (see Comm / _route_ahead); False — the whole step runs on ONE communicator: no second
+        communicator is created, every COLLECTIVE of a step is issued in program order on the step's stream (the
         conservative form for a first run on new hardware: two communicators progressing concurrently on two streams
         can deadlock if a device-synchronising call lands between their kernels in different orders on different
-        ranks; all buffers the step needs are sized before its first collective either way, see _sharded_step).
+        ranks; all buffers the step needs are sized before its first collective either way, see _sharded_step).  An
+        announced next batch still has the LOCAL half of its routing — the request sort, a pure function of its ids,
+        no collective — made ahead on a side stream (round 5); its count exchange, id exchange and the owners' sort
+        stay at the head of its own step.
         chunk_compute: True — every chunk runs its own forward / backward (the exchanges of one chunk travel under the
         whole compute of its neighbours; the MLP's GEMMs shrink to a chunk's examples); False — only the exchanges and
         the embedding-side kernels are chunked, the MLP runs once on the whole batch (the row exchange travels under the
@@ -220,7 +223,7 @@ def _n_chunks(m, B, train):
     return c
 
 
-def _route(m, ids, C, tag="", ahead=False):
+def _route(m, ids, C, tag="", ahead=False, exchange=True):
     """Plan the exchange for this batch, C chunks of B/C examples.  The entries are sorted by request key
     (chunk, owner, owner-local row) — owners in send order: the other ranks by rank, this rank last; the DISTINCT keys
     are the requests, in send order (a chunk's requests to the rank itself end its run and stay on the device).  Returns
@@ -228,7 +231,8 @@ def _route(m, ids, C, tag="", ahead=False):
     owner-local rows to ask for, the sort's (sorted_entry, seg_start) over the entries, and the pending count
     exchange: Comm.finish_counts gives send_counts[c][rank], recv_counts[c][rank]).
     tag / ahead: a second set of buffers and a sort workspace of its own, for the routing of the NEXT batch started on a
-    side stream while this step still uses the first set (_route_ahead)."""
+    side stream while this step still uses the first set (_route_ahead).  exchange=False: the local half only — the
+    plan carries the request counts ("counts") and no collective has been issued (_take_route starts the count exchange)."""
     k, sh = m.k, m.shard
     comm = _comm(m)
     i32 = torch.int32
@@ -247,8 +251,12 @@ def _route(m, ids, C, tag="", ahead=False):
     send_rows = m._buf("send_rows" + tag, (n,), i32)
     counts = m._buf("route_counts" + tag, (C * sh.world,), i32)
     k.mi_route_requests(uniq, num_uniq, n, Rl, C * sh.world, send_rows, counts)
-    return {"slot": slot, "send_rows": send_rows, "sorted_entry": sorted_entry, "seg": seg, "C": C, "tag": tag,
-            "pending": comm.start_counts(counts, C, ahead=ahead)}
+    plan = {"slot": slot, "send_rows": send_rows, "sorted_entry": sorted_entry, "seg": seg, "C": C, "tag": tag}
+    if exchange:
+        plan["pending"] = comm.start_counts(counts, C, ahead=ahead)
+    else:
+        plan["counts"] = counts
+    return plan
 
 
 def _finish_plan(m, plan):
@@ -262,6 +270,8 @@ def _finish_plan(m, plan):
     if "uoff" in plan:
         return plan
     me, C = m.shard.rank, plan["C"]
+    if "pending" not in plan:            # (the local half was made ahead on one communicator: the count exchange starts here, in program order)
+        plan["pending"] = _comm(m).start_counts(plan.pop("counts"), C)
     send_counts, recv_counts = _comm(m).finish_counts(plan.pop("pending"))
     uoff, roff = [0], [0]
     for c in range(C):
@@ -316,13 +326,14 @@ def _route_ahead(m, next_ids, C):
     if side is None:
         side = m._ws["route_stream"] = torch.cuda.Stream(device=m.device) if m.device.type == "cuda" else None
     tag = "_b" if getattr(m, "_route_tag", "") == "" else ""      # the buffer set this step's plan does NOT live in
+    second = bool(m.shard.route_ahead)     # a second communicator exists: the count exchange goes ahead too
     if side is None:
-        plan = _route(m, next_ids, C, tag, ahead=True)
+        plan = _route(m, next_ids, C, tag, ahead=True, exchange=second)
     else:
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            plan = _route(m, next_ids, C, tag, ahead=True)
-    m._routed = {"ids": next_ids, "version": next_ids._version, "plan": plan, "C": C, "tag": tag, "stream": side}
+            plan = _route(m, next_ids, C, tag, ahead=True, exchange=second)
+    m._routed = {"ids": next_ids, "version": next_ids._version, "plan": plan, "C": C, "tag": tag, "stream": side, "second": second}
 
 
 def _own_ahead(m):
@@ -331,7 +342,7 @@ def _own_ahead(m):
     way) and enqueues, on the side stream and the second communicator, the next batch's id exchange and the owners' sort
     of the requests they receive.  Both depend on ids only; the next step then starts with the catch-up."""
     r = getattr(m, "_routed", None)
-    if r is None:
+    if r is None or not r.get("second", True):       # (one communicator: the collectives of the next batch wait for its own step)
         return
     plan = _finish_plan(m, r["plan"])
     if r["stream"] is None:
@@ -356,7 +367,8 @@ def _take_route(m, ids, C):
             m._route_tag = r["tag"]
             m.route_ahead_hits = getattr(m, "route_ahead_hits", 0) + 1
             return r["plan"]
-        _finish_plan(m, r["plan"])                    # (an announced batch that did not come: its exchange still completes)
+        if "pending" in r["plan"]:
+            _finish_plan(m, r["plan"])                # (an announced batch that did not come: its exchange still completes)
     m._route_tag = ""
     return _route(m, ids, max(C, 1))
 
@@ -384,8 +396,8 @@ def _sharded_step(m, ids, labels, x_num, train, next_ids=None):
         m._split_weights_ahead()            # the MLP's weight planes, on a side stream beside the routing
     # (an evaluation between two train steps plans into the first buffer set: a plan made ahead is dropped first)
     plan = _finish_plan(m, _take_route(m, ids, C if train else -1))
-    if train and next_ids is not None and next_ids.shape == ids.shape and not getattr(m, "_capturing", False) and m.shard.route_ahead:
-        _route_ahead(m, next_ids, C)
+    if train and next_ids is not None and next_ids.shape == ids.shape and not getattr(m, "_capturing", False):
+        _route_ahead(m, next_ids, C)        # (RowShard(route_ahead=False): its local half only)
     slot, sorted_entry, seg = plan["slot"], plan["sorted_entry"], plan["seg"]
     uoff, roff, umid, rmid, sc0, rc0 = plan["uoff"], plan["roff"], plan["umid"], plan["rmid"], plan["sc0"], plan["rc0"]
     U, nr = uoff[-1], roff[-1]

@@ -204,12 +204,14 @@ def test_eight_rank_default_step_equals_big_batch(cfg):
     (([19, 23, 17, 29], 8, [16, 8], 16, 3, "Adagrad", 0.05, 3, (True, False, True), 2,
       dict(numeric="raw", lin_opt=("Ftrl", 0.2), reduction="sum", announce=True, route_ahead=False)), 8)])
 def test_single_communicator_step_equals_big_batch(cfg, world):
-    """RowShard(route_ahead=False): the whole step on ONE communicator — no second process group is created, an announced
-    next batch is ignored (its routing runs at the head of its own step) — same results; world 2, 4 (chunked exchanges,
-    one MLP pass) and 8 (config 4's model with the 8-rank defaults)."""
+    """RowShard(route_ahead=False): the whole step on ONE communicator — no second process group is created; of an announced
+    next batch only the LOCAL half of the routing (the request sort: no collective) is made ahead, its count exchange, id
+    exchange and owners' sort run at the head of its own step, in program order — same results; world 2, 4 (chunked
+    exchanges, one MLP pass) and 8 (config 4's model with the 8-rank defaults)."""
     res = _run(cfg, world)
     check_against_big_batch(cfg, res, world)
-    assert all(res[r][1]["route_ahead_hits"] == 0 and not res[r][1]["second_communicator"] for r in range(world))
+    steps = cfg[7]
+    assert all(res[r][1]["route_ahead_hits"] == steps - 1 and not res[r][1]["second_communicator"] for r in range(world))
 
 
 @pytest.mark.parametrize("cfg,world", [
