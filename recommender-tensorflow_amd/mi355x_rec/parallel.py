@@ -40,9 +40,10 @@ class RowShard:
         conservative form for a first run on new hardware: two communicators progressing concurrently on two streams
         can deadlock if a device-synchronising call lands between their kernels in different orders on different
         ranks; all buffers the step needs are sized before its first collective either way, see _sharded_step).  An
-        announced next batch still has the LOCAL half of its routing — the request sort, a pure function of its ids,
-        no collective — made ahead on a side stream (round 5); its count exchange, id exchange and the owners' sort
-        stay at the head of its own step.
+        announced next batch is still prepared ahead (round 5): its request sort — local work, no collective — on a
+        side stream; its count exchange and id exchange on THIS communicator and the step's stream, in program order
+        (after this step's row exchanges / before its dense all-reduce); the owners' sort behind that on the side
+        stream (_ahead_in_order).  The next step then starts with the catch-up, and no host wait drains the queue.
         chunk_compute: True — every chunk runs its own forward / backward (the exchanges of one chunk travel under the
         whole compute of its neighbours; the MLP's GEMMs shrink to a chunk's examples); False — only the exchanges and
         the embedding-side kernels are chunked, the MLP runs once on the whole batch (the row exchange travels under the
@@ -290,10 +291,11 @@ def _finish_plan(m, plan):
     return plan
 
 
-def _owners_side(m, plan, train, ahead=False):
+def _owners_side(m, plan, train, ahead=False, sort_stream=None):
     """Requests to their owners (small), then — for a train step — which rows this owner's step touches (sort + unique
     of everything it was asked for: the sparse apply's segments and the catch-up's row list).  ahead: on the second
-    communicator, into the plan's own buffer set (see _own_ahead)."""
+    communicator (if there is one), into the plan's own buffer set (see _own_ahead).  sort_stream: the id exchange on the
+    current stream, the sort — local work — behind it on that stream (_ahead_in_order)."""
     if "recv_ids" in plan:
         return plan
     comm = _comm(m)
@@ -309,8 +311,14 @@ def _owners_side(m, plan, train, ahead=False):
     plan["recv_ids"] = recv_ids
     plan["book"] = None
     if train and nr > 0:        # (sorted_entry, uniq, seg, num_uniq)
-        plan["book"] = m._sort_unique(recv_ids, nr, m.R_local, "own" + tag, ws_name="sort_ws_ahead" if ahead else "sort_ws",
+        sort = lambda: m._sort_unique(recv_ids, nr, m.R_local, "own" + tag, ws_name="sort_ws_ahead" if ahead else "sort_ws",
                                       cap=2 * plan["slot"].numel())
+        if sort_stream is None:
+            plan["book"] = sort()
+        else:
+            sort_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(sort_stream):
+                plan["book"] = sort()
     return plan
 
 
@@ -355,6 +363,28 @@ def _own_ahead(m):
             r["stream"].wait_event(r["gate"])
         with torch.cuda.stream(r["stream"]):
             _owners_side(m, plan, True, ahead=True)
+
+
+def _ahead_in_order(m, stage):
+    """RowShard(route_ahead=False) with an announced next batch: what the second communicator's mode does ahead, on ONE
+    communicator — every collective on the step's stream, at the same place of every rank's program:
+      stage "counts" (right after this step's row exchanges are enqueued): the step's stream waits for the side stream's
+        request sort (started at the head of the step: long done) and the next batch's count exchange is issued;
+      stage "owners" (right before the dense all-reduce): the host takes the split sizes — the GPU passed the count exchange
+        long ago and still has the backward queued behind it: no drained queue, which is what a host wait at the HEAD of a
+        step costs — issues the next batch's id exchange, and the owners' sort of what arrived (local work) goes to the
+        side stream, beside the weight gradients, the all-reduce and the sparse apply."""
+    r = getattr(m, "_routed", None)
+    if r is None or r.get("second", True):
+        return
+    plan = r["plan"]
+    if stage == "counts":
+        if "counts" in plan:
+            if r["stream"] is not None:
+                torch.cuda.current_stream().wait_stream(r["stream"])
+            plan["pending"] = _comm(m).start_counts(plan.pop("counts"), plan["C"])
+    elif "pending" in plan or "uoff" in plan:
+        _owners_side(m, _finish_plan(m, plan), True, ahead=True, sort_stream=r["stream"])
 
 
 def _take_route(m, ids, C):
@@ -509,6 +539,8 @@ def _sharded_step(m, ids, labels, x_num, train, next_ids=None):
         # chunked exchanges, ONE forward / backward: every chunk's rows are served at once (gather, exchange, gather, ...),
         # the embedding-side kernels of chunk c wait for its exchange only, the MLP sees the whole batch
         handles = [serve(c) for c in range(C)]
+        if train:
+            _ahead_in_order(m, "counts")
         pieces = [(c * Bc, (c + 1) * Bc, (lambda c=c: _wait(handles[c]))) for c in range(C)]
         m._chunk = 0
         cc = m._forward(ids, x_num, train, (got_rows, got_lin, zero_off, slot2, xs or E, xs or 1), pieces=pieces)
@@ -519,6 +551,8 @@ def _sharded_step(m, ids, labels, x_num, train, next_ids=None):
     else:
         C_acc = C
         rows_h = serve(0)
+        if train:
+            _ahead_in_order(m, "counts")
         for c in range(C):
             nxt = serve(c + 1) if c + 1 < C else []          # on the links while chunk c computes
             _wait(rows_h)
@@ -549,6 +583,7 @@ def _sharded_step(m, ids, labels, x_num, train, next_ids=None):
         return loss, logits
     if C_acc > 1:
         m.d_grad.copy_(acc)
+    _ahead_in_order(m, "owners")
     comm.all_reduce(m.d_grad)                                   # dense gradients: SUM over ranks
     _wait(grad_h)
     r = getattr(m, "_routed", None)

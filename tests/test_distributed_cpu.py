@@ -204,10 +204,10 @@ def test_eight_rank_default_step_equals_big_batch(cfg):
     (([19, 23, 17, 29], 8, [16, 8], 16, 3, "Adagrad", 0.05, 3, (True, False, True), 2,
       dict(numeric="raw", lin_opt=("Ftrl", 0.2), reduction="sum", announce=True, route_ahead=False)), 8)])
 def test_single_communicator_step_equals_big_batch(cfg, world):
-    """RowShard(route_ahead=False): the whole step on ONE communicator — no second process group is created; of an announced
-    next batch only the LOCAL half of the routing (the request sort: no collective) is made ahead, its count exchange, id
-    exchange and owners' sort run at the head of its own step, in program order — same results; world 2, 4 (chunked
-    exchanges, one MLP pass) and 8 (config 4's model with the 8-rank defaults)."""
+    """RowShard(route_ahead=False): the whole step on ONE communicator — no second process group is created; an announced
+    next batch is still prepared ahead, with every collective (count exchange, id exchange) on the one communicator in
+    program order and only local work (the request sort, the owners' sort) on the side stream (parallel._ahead_in_order) —
+    same results; world 2, 4 (chunked exchanges, one MLP pass) and 8 (config 4's model with the 8-rank defaults)."""
     res = _run(cfg, world)
     check_against_big_batch(cfg, res, world)
     steps = cfg[7]

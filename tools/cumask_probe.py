@@ -9,7 +9,14 @@ bounded catch-up — the bench's configuration), no kernel change: launches are 
   part 3  (ii) forward + data-gradient GEMMs on k CUs  ||  an extra catch-up of the same size on shadow tables on 256 - k
           (what a catch-up made a step AHEAD would cost the step): none / serialised on the whole chip / beside
   part 4  (i) + (ii) together: projected step = that step - the head-of-step catch-up it would replace
-Usage: python tools/cumask_probe.py [--parts 0,1,2,3,4] [--ks 128,160,176,192,208,224] [--steps 30]
+  part 5  a streaming copy and a tiny launch on c CUs (no model)
+  part 6  the WHOLE step with one masked queue as its stream (continuously busy: how every kernel scales over CU count)
+  part 7  what a hand-over between two queues costs: pooled / default / masked in every pairing (no model)
+  part 8  (iii) an extra weight-gradient batch on k CUs beside the head of the step (catch-up + gather on 256 - k)
+--dedicated 1 (default): the step's main and side streams are dedicated full-mask queues too (see part 7).
+Results: profiles/r05_cumask_probe.md.  Masked streams are destroyed after each configuration: more than ~6 alive in one
+process make every kernel of the process erratic.
+Usage: python tools/cumask_probe.py [--parts 0,...,8] [--ks 128,160,176,192,208,224] [--alone 256,192,...] [--steps 30]
 """
 import argparse, ctypes as C, glob, os, sys, threading, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
