@@ -681,7 +681,7 @@ class DeepFM:
             return
         side = self._ws.get("wsplit_stream")
         if side is None:
-            side = self._ws["wsplit_stream"] = torch.cuda.Stream(device=self.device)
+            side = self._ws["wsplit_stream"] = self._new_side_stream()
         # (the planes' and job buffers must exist before another stream writes them: sized on this stream by an earlier step)
         if "wjobs_train" not in self._ws:
             return
@@ -1030,6 +1030,12 @@ class DeepFM:
     TOP_FUSED = True          # ... and the last hidden layer with them, in its GEMM's epilogue (_head: mi_hidden_logits_head_fused)
     TOP_FUSED_MIN_BATCH = 4096
     GRAPH_SHAPES_MAX = 4      # captured steps kept at a time, one per batch shape (graph_train_step)
+    SIDE_PRIORITY = 0         # -1: side streams are created with high priority.  HIP serves every stream priority from its own pool
+                              # of hardware queues, so a high-priority stream can never share a queue with the step's (normal-priority)
+                              # stream; normal-priority streams share 4 queues by reference count and may (parallel._side_stream)
+
+    def _new_side_stream(self, priority=None):
+        return torch.cuda.Stream(device=self.device, priority=self.SIDE_PRIORITY if priority is None else priority)
 
     def _catchup(self, uniq, num_uniq, n_max, defer=False, by_gap=None):
         """defer: the rows are about to be applied in this same step by ONE mi_sparse_apply call, which
@@ -1084,7 +1090,7 @@ class DeepFM:
     def _side_stream(self):
         side = self._ws.get("side_stream")
         if side is None:
-            side = self._ws["side_stream"] = torch.cuda.Stream(device=self.device)
+            side = self._ws["side_stream"] = self._new_side_stream()
         return side
 
     def _wide_on_side_stream(self, B):
@@ -1146,7 +1152,7 @@ class DeepFM:
         The result is used by the next train_step if it is given that very tensor, unmodified; otherwise it is dropped."""
         side = self._ws.get("presort_stream")
         if side is None:
-            side = self._ws["presort_stream"] = torch.cuda.Stream(device=self.device)      # (a high-priority stream: no effect, same-box A/B, profiles/r04_ab_layout_and_fold.md)
+            side = self._ws["presort_stream"] = self._new_side_stream()      # (a high-priority stream: no effect, same-box A/B, profiles/r04_ab_layout_and_fold.md)
         main = torch.cuda.current_stream()
         side.wait_stream(main)                       # next_ids exists, this step's own sort has left the shared workspace
         with torch.cuda.stream(side):

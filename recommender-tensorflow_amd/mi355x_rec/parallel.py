@@ -332,7 +332,12 @@ def _route_ahead(m, next_ids, C):
     Every rank must announce (or not announce) its next batch alike: the count exchange is a collective."""
     side = m._ws.get("route_stream")
     if side is None:
-        side = m._ws["route_stream"] = torch.cuda.Stream(device=m.device) if m.device.type == "cuda" else None
+        # HIGH priority: HIP serves each stream priority from its own pool of hardware queues; a normal-priority stream is put
+        # on the least-referenced of 4 queues and can land on the one the step's stream uses — with one communicator it did
+        # (rocprofv3 kernel trace: the owners' sort on the step's queue, between the weight gradients and the apply: serial,
+        # +0.2 ms per step).  The kernels themselves get no scheduling advantage from it (measured: profiles/r04_ab_layout_and_fold.md).
+        side = m._ws["route_stream"] = (m._new_side_stream(priority=-1) if hasattr(m, "_new_side_stream") else
+                                        torch.cuda.Stream(device=m.device, priority=-1)) if m.device.type == "cuda" else None
     tag = "_b" if getattr(m, "_route_tag", "") == "" else ""      # the buffer set this step's plan does NOT live in
     second = bool(m.shard.route_ahead)     # a second communicator exists: the count exchange goes ahead too
     if side is None:
