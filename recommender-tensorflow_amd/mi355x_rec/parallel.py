@@ -336,8 +336,11 @@ def _route_ahead(m, next_ids, C):
         # on the least-referenced of 4 queues and can land on the one the step's stream uses — with one communicator it did
         # (rocprofv3 kernel trace: the owners' sort on the step's queue, between the weight gradients and the apply: serial,
         # +0.2 ms per step).  The kernels themselves get no scheduling advantage from it (measured: profiles/r04_ab_layout_and_fold.md).
-        side = m._ws["route_stream"] = (m._new_side_stream(priority=-1) if hasattr(m, "_new_side_stream") else
-                                        torch.cuda.Stream(device=m.device, priority=-1)) if m.device.type == "cuda" else None
+        # (with the second communicator the normal-priority stream of rounds 3-4 stays: there the high-priority one costs the
+        # one-rank step 0.1 ms — 3.74 against 3.62 ms, same box — presumably next to RCCL's own high-priority stream)
+        prio = 0 if m.shard.route_ahead else -1
+        side = m._ws["route_stream"] = (m._new_side_stream(priority=prio) if hasattr(m, "_new_side_stream") else
+                                        torch.cuda.Stream(device=m.device, priority=prio)) if m.device.type == "cuda" else None
     tag = "_b" if getattr(m, "_route_tag", "") == "" else ""      # the buffer set this step's plan does NOT live in
     second = bool(m.shard.route_ahead)     # a second communicator exists: the count exchange goes ahead too
     if side is None:
