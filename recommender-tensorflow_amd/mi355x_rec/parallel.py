@@ -322,14 +322,17 @@ def _owners_side(m, plan, train, ahead=False, sort_stream=None):
     return plan
 
 
-def _route_ahead(m, next_ids, C):
+def _route_ahead(m, next_ids, C, after=None):
     """The routing of the NEXT batch — a pure function of its ids: a radix sort's worth of small kernels, the count
     exchange (on a communicator of its own) and the copy of the split sizes to the host — started on a side stream at
     the HEAD of this step, as soon as this step's own plan is on the host.  The next sharded_train_step picks it up if it
     is given that very tensor, unmodified: its split sizes have then been on the host for a whole step — the host, which
     enqueues a step in less time than the GPU takes to run it, never waits for them (started at the END of the step
     the wait only moved: measured, no gain), and no routing sort stands at the head of the step.
-    Every rank must announce (or not announce) its next batch alike: the count exchange is a collective."""
+    Every rank must announce (or not announce) its next batch alike: the count exchange is a collective.
+    after: an event of the step's stream recorded at the head of the step — the side stream waits for THAT, while the host
+    enqueues these ~15 launches after the step's own catch-up (the host is less than a step ahead of the GPU here: what it
+    enqueues first starts first; kernel trace of round 5: the step's stream sat idle for 0.13 ms behind them)."""
     side = m._ws.get("route_stream")
     if side is None:
         # HIGH priority: HIP serves each stream priority from its own pool of hardware queues; a normal-priority stream is put
@@ -346,7 +349,10 @@ def _route_ahead(m, next_ids, C):
     if side is None:
         plan = _route(m, next_ids, C, tag, ahead=True, exchange=second)
     else:
-        side.wait_stream(torch.cuda.current_stream())
+        if after is not None:
+            side.wait_event(after)
+        else:
+            side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             plan = _route(m, next_ids, C, tag, ahead=True, exchange=second)
     m._routed = {"ids": next_ids, "version": next_ids._version, "plan": plan, "C": C, "tag": tag, "stream": side, "second": second}
@@ -371,6 +377,25 @@ def _own_ahead(m):
             r["stream"].wait_event(r["gate"])
         with torch.cuda.stream(r["stream"]):
             _owners_side(m, plan, True, ahead=True)
+            _by_gap_ahead_shard(m, plan, m.step)          # (called after this step's apply: m.step is the next step's already)
+
+
+def _by_gap_ahead_shard(m, plan, step_next):
+    """The staleness order of the NEXT batch's owner-side rows (engine._rows_by_gap), right behind the owners' sort on the side
+    stream — it reads the rows' stamps before (or while) this step's apply writes this batch's: a row of both batches is filed
+    under the gap it had before; the order only decides which rows share a wave (engine._presort).  step_next: the value of
+    m.step at the head of the next step."""
+    book = plan.get("book")
+    if book is None or not m.adam_rows or not getattr(m, "BYGAP_AHEAD", False) or not hasattr(m, "_rows_by_gap"):
+        return
+    nr = plan["roff"][-1]
+    if nr < m.GAP_SORT_MIN:
+        return
+    cap = max(2 * plan["slot"].numel(), nr)
+    m._buf("uniq_by_gap_own" + plan["tag"], (cap,), torch.int32)                       # (capacity: no growth between collectives)
+    m._bytes("gap_ws_own" + plan["tag"], m.k.query("mi_sort_unique_workspace_bytes", cap))
+    plan["by_gap"] = m._rows_by_gap(book[1], book[3], nr, step_next, "_own" + plan["tag"], side=True)
+    plan["by_gap_step"] = step_next
 
 
 def _ahead_in_order(m, stage):
@@ -393,6 +418,9 @@ def _ahead_in_order(m, stage):
             plan["pending"] = _comm(m).start_counts(plan.pop("counts"), plan["C"])
     elif "pending" in plan or "uoff" in plan:
         _owners_side(m, _finish_plan(m, plan), True, ahead=True, sort_stream=r["stream"])
+        if r["stream"] is not None:
+            with torch.cuda.stream(r["stream"]):
+                _by_gap_ahead_shard(m, plan, m.step + 1)
 
 
 def _take_route(m, ids, C):
@@ -434,8 +462,11 @@ def _sharded_step(m, ids, labels, x_num, train, next_ids=None):
         m._split_weights_ahead()            # the MLP's weight planes, on a side stream beside the routing
     # (an evaluation between two train steps plans into the first buffer set: a plan made ahead is dropped first)
     plan = _finish_plan(m, _take_route(m, ids, C if train else -1))
-    if train and next_ids is not None and next_ids.shape == ids.shape and not getattr(m, "_capturing", False):
-        _route_ahead(m, next_ids, C)        # (RowShard(route_ahead=False): its local half only)
+    announce = train and next_ids is not None and next_ids.shape == ids.shape and not getattr(m, "_capturing", False)
+    head_ev = None
+    if announce and m.device.type == "cuda":
+        head_ev = torch.cuda.Event()
+        head_ev.record()                    # (the previous step's work on this stream is done: the next batch's routing may start)
     slot, sorted_entry, seg = plan["slot"], plan["sorted_entry"], plan["seg"]
     uoff, roff, umid, rmid, sc0, rc0 = plan["uoff"], plan["roff"], plan["umid"], plan["rmid"], plan["sc0"], plan["rc0"]
     U, nr = uoff[-1], roff[-1]
@@ -446,7 +477,10 @@ def _sharded_step(m, ids, labels, x_num, train, next_ids=None):
     _owners_side(m, plan, train)
     recv_ids, book = plan["recv_ids"], plan["book"]
     if book is not None and m.adam_rows and m.step > 0:
-        m._catchup(book[1], book[3], nr, defer=True)
+        # (the staleness order of the owner's rows was made a step ahead when the batch was announced: _by_gap_ahead_shard)
+        m._catchup(book[1], book[3], nr, defer=True, by_gap=plan.get("by_gap") if plan.get("by_gap_step") == m.step else None)
+    if announce:
+        _route_ahead(m, next_ids, C, after=head_ev)        # (RowShard(route_ahead=False): its local work only)
 
     # Buffers whose size follows the batch's content (U distinct requests <= n entries; nr requests received: ~n for ids
     # spread over the ranks) are allocated at their CAPACITY the first time — n rows, and 2 n on the owner's side — so that

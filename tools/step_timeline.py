@@ -2,12 +2,14 @@
 """One train step of a rocprofv3 --kernel-trace (+ --memory-copy-trace) CSV as a timeline: every kernel / copy between the
 end of one `sparse_apply_k` and the end of the next, with its start relative to the step's start, its duration, the
 queue it ran on and the idle time of the whole GPU before it.
-usage: step_timeline.py <kernel_trace.csv> [<memory_copy_trace.csv>] [--step K]   (K: which step, counted from the
-middle of the trace; default 0 — the timed region of bench.py, before its instrumented pass)"""
+usage: step_timeline.py <kernel_trace.csv> [<memory_copy_trace.csv>] [--step K] [--mark NAME]   (K: which step, counted
+from the middle of the trace; default 0 — the timed region of bench.py, before its instrumented pass; NAME: the kernel whose
+end closes a step, default sparse_apply_k — the row-sharded step launches that one twice: --mark dense_apply_k)"""
 import csv, sys
 
 args = [a for i, a in enumerate(sys.argv[1:], 1) if not a.startswith("--") and not sys.argv[i - 1].startswith("--")]
 k = int(sys.argv[sys.argv.index("--step") + 1]) if "--step" in sys.argv else 0
+mark = sys.argv[sys.argv.index("--mark") + 1] if "--mark" in sys.argv else "sparse_apply_k"
 ev = []
 for r in csv.DictReader(open(args[0])):
     name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")
@@ -16,7 +18,7 @@ if len(args) > 1:
     for r in csv.DictReader(open(args[1])):
         ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "COPY " + r.get("Direction", ""), "copy"))
 ev.sort()
-marks = [i for i, e in enumerate(ev) if e[2].startswith("sparse_apply_k")]
+marks = [i for i, e in enumerate(ev) if e[2].startswith(mark)]
 m0 = marks[len(marks) // 2 + k]
 m1 = marks[len(marks) // 2 + k + 1]
 t0 = ev[m0][1]
