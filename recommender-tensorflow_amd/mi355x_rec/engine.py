@@ -1061,7 +1061,7 @@ class DeepFM:
             # call must not move the stamps the wide call still has to read: it runs second.
             assert not defer
             parts = [(None, l_sched, 4), (t_sched, None, 0)]          # (4 = MI_CATCHUP_KEEP_STAMPS)
-        elif (defer and t_sched is not None and l_sched is not None and self.device.type == "cuda"
+        elif (defer and t_sched is not None and l_sched is not None and self.shard is None and self.device.type == "cuda"
               and self._wide_on_side_stream(n_max // max(self.F, 1)) and self.LIN_SIDE):
             # deferred: neither call writes a stamp or touches the other's state — the wide part's 16-byte records
             # (scattered, latency-bound: 0.08 ms) are replayed on the stream that will run the wide part's forward,
@@ -1086,10 +1086,6 @@ class DeepFM:
                     call()
             else:
                 call()
-        if side is not None and self.shard is not None:
-            # (the row-sharded step: the owners' gather reads the wide weights next — joined here, behind the row kernel the
-            # wide kernel ran beside; the single-GPU step joins in _head, after the wide forward on the same stream)
-            torch.cuda.current_stream().wait_stream(side)
 
     def _side_stream(self):
         side = self._ws.get("side_stream")

@@ -377,25 +377,6 @@ def _own_ahead(m):
             r["stream"].wait_event(r["gate"])
         with torch.cuda.stream(r["stream"]):
             _owners_side(m, plan, True, ahead=True)
-            _by_gap_ahead_shard(m, plan, m.step)          # (called after this step's apply: m.step is the next step's already)
-
-
-def _by_gap_ahead_shard(m, plan, step_next):
-    """The staleness order of the NEXT batch's owner-side rows (engine._rows_by_gap), right behind the owners' sort on the side
-    stream — it reads the rows' stamps before (or while) this step's apply writes this batch's: a row of both batches is filed
-    under the gap it had before; the order only decides which rows share a wave (engine._presort).  step_next: the value of
-    m.step at the head of the next step."""
-    book = plan.get("book")
-    if book is None or not m.adam_rows or not getattr(m, "BYGAP_AHEAD", False) or not hasattr(m, "_rows_by_gap"):
-        return
-    nr = plan["roff"][-1]
-    if nr < m.GAP_SORT_MIN:
-        return
-    cap = max(2 * plan["slot"].numel(), nr)
-    m._buf("uniq_by_gap_own" + plan["tag"], (cap,), torch.int32)                       # (capacity: no growth between collectives)
-    m._bytes("gap_ws_own" + plan["tag"], m.k.query("mi_sort_unique_workspace_bytes", cap))
-    plan["by_gap"] = m._rows_by_gap(book[1], book[3], nr, step_next, "_own" + plan["tag"], side=True)
-    plan["by_gap_step"] = step_next
 
 
 def _ahead_in_order(m, stage):
@@ -418,9 +399,6 @@ def _ahead_in_order(m, stage):
             plan["pending"] = _comm(m).start_counts(plan.pop("counts"), plan["C"])
     elif "pending" in plan or "uoff" in plan:
         _owners_side(m, _finish_plan(m, plan), True, ahead=True, sort_stream=r["stream"])
-        if r["stream"] is not None:
-            with torch.cuda.stream(r["stream"]):
-                _by_gap_ahead_shard(m, plan, m.step + 1)
 
 
 def _take_route(m, ids, C):
@@ -477,8 +455,10 @@ def _sharded_step(m, ids, labels, x_num, train, next_ids=None):
     _owners_side(m, plan, train)
     recv_ids, book = plan["recv_ids"], plan["book"]
     if book is not None and m.adam_rows and m.step > 0:
-        # (the staleness order of the owner's rows was made a step ahead when the batch was announced: _by_gap_ahead_shard)
-        m._catchup(book[1], book[3], nr, defer=True, by_gap=plan.get("by_gap") if plan.get("by_gap_step") == m.step else None)
+        # (the staleness order is made here, on the step's stream, and the wide records are replayed by the same call: made a
+        # step ahead / on a side stream beside the row kernel, as in the single-GPU step, each costs the one-rank step 0.05 ms —
+        # same-box A/B, tools/shard_opt_ab.sh: whatever runs beside the catch-up stretches it by as much)
+        m._catchup(book[1], book[3], nr, defer=True)
     if announce:
         _route_ahead(m, next_ids, C, after=head_ev)        # (RowShard(route_ahead=False): its local work only)
 
