@@ -239,7 +239,7 @@ class Estimator:
         n_log = 0
         done = 0
         loss = None
-        for features, labels in self._grouped(input_fn()):
+        for features, labels in self._with_lookahead(self._grouped(input_fn())):
             self._first_call(features, labels, ModeKeys.TRAIN)
             if max_steps is not None and self.global_step >= max_steps:
                 break
@@ -271,6 +271,35 @@ class Estimator:
             if on_checkpoint:
                 on_checkpoint()
         return self
+
+    LOOKAHEAD_MIN_BATCH = 4096    # from this batch size on the train loop holds the NEXT batch too (see _with_lookahead)
+
+    def _with_lookahead(self, it):
+        """The training batches of `it`, unchanged — but from LOOKAHEAD_MIN_BATCH examples on (one GPU) the loop reads one batch
+        ahead and leaves the next batch in params["_lookahead"]: run_batch then transforms its ids and copies them to the device
+        while the GPU still runs the previous step, and announces them to the engine (train_step(next_ids=...)), whose sort of
+        the next batch then runs beside this step's catch-up instead of at the head of the next step — what a prefetching
+        input pipeline gives the reference (tf.data, ml_100k.py:42-61).  Results are those of the plain loop, bit for bit
+        (tests/test_trainers.py).  Row-sharded training keeps the plain loop: every rank would have to announce alike."""
+        it = iter(it)
+        cur = next(it, None)
+        if cur is None:
+            return
+        try:
+            B = len(cur[1])
+        except TypeError:
+            B = 0
+        if B < self.LOOKAHEAD_MIN_BATCH or self._shard is not None or not isinstance(cur[0], dict):
+            self.params.pop("_lookahead", None)
+            yield cur
+            yield from it
+            return
+        while cur is not None:
+            nxt = next(it, None)
+            self.params["_lookahead"] = None if nxt is None else {"features": nxt[0], "labels": nxt[1]}
+            yield cur
+            cur = nxt
+        self.params.pop("_lookahead", None)
 
     GROUP_ROWS = 2048         # small batches: this many examples' id transforms in one call (see _grouped)
 

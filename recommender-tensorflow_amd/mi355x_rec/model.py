@@ -71,12 +71,17 @@ def run_batch(features, labels, mode, params, make_engine):
         ids, y = g["ids"][lo:hi], g["y"][lo:hi]
         x = g["x"][lo:hi] if g["x"] is not None else None
     else:
-        ids_np, x_np = plan.transform(features)
-        ids = torch.from_numpy(ids_np).to(dev)
-        x = torch.from_numpy(x_np).to(dev) if x_np is not None else None
-        y = None
-        if labels is not None:
-            y = torch.from_numpy(np.ascontiguousarray(np.asarray(labels).reshape(-1)).astype(np.uint8)).to(dev)
+        def stage(f, l):
+            ids_np, x_np = plan.transform(f)
+            y_ = None
+            if l is not None:
+                y_ = torch.from_numpy(np.ascontiguousarray(np.asarray(l).reshape(-1)).astype(np.uint8)).to(dev)
+            return (torch.from_numpy(ids_np).to(dev), torch.from_numpy(x_np).to(dev) if x_np is not None else None, y_)
+        staged = store.pop("staged", None)          # this batch, transformed and copied a step ago (Estimator._with_lookahead)
+        if staged is not None and staged[0] is features and mode == ModeKeys.TRAIN:
+            ids, x, y = staged[1]
+        else:
+            ids, x, y = stage(features, labels)
 
     # multi-GPU: a rank's loss is its SHARE of the global-batch mean (already divided by the global batch); times
     # world = the mean over its own examples — what is logged, and, with every rank evaluating the same batches,
@@ -93,7 +98,15 @@ def run_batch(features, labels, mode, params, make_engine):
         if graph and eng.device.type == "cuda" and hasattr(eng, "graph_ok") and eng.graph_ok():
             loss, logits = eng.graph_train_step(ids, y, x)
         else:
-            loss, logits = eng.train_step(ids, y, x)
+            # the next batch, if the train loop holds it (Estimator._with_lookahead: large batches, one GPU): transformed and
+            # copied now — the GPU still runs the previous step — and announced to the engine
+            la, nxt_ids = params.get("_lookahead"), None
+            if la is not None and ahead is None and eng.shard is None:
+                nxt = stage(la["features"], la["labels"])
+                store["staged"] = (la["features"], nxt)
+                if nxt[0].shape == ids.shape:
+                    nxt_ids = nxt[0]
+            loss, logits = eng.train_step(ids, y, x, next_ids=nxt_ids) if nxt_ids is not None else eng.train_step(ids, y, x)
         return EstimatorSpec(mode, predictions=None, loss=rescale(loss), train_op=eng.step)
     if mode == ModeKeys.EVAL:
         loss, logits = eng.loss(ids, y, x)

@@ -181,6 +181,38 @@ def test_grouped_id_transforms_leave_the_training_unchanged(device, data, monkey
     assert all(np.array_equal(ka, kb) and np.array_equal(ba, bb) for (ka, ba), (kb, bb) in zip(a["mlp"], b["mlp"]))
 
 
+@pytest.mark.gpu
+def test_lookahead_of_large_batches_leaves_the_training_unchanged(data, monkeypatch):
+    """Estimator.train holds the NEXT batch from 4,096 examples on: its ids are transformed and copied a step early and
+    announced to the engine (whose sort of them then runs beside this step's catch-up).  Batches, their order, the loss of
+    every step and the trained variables are those of the plain loop, bit for bit; the engine really took the sorts made
+    ahead."""
+    from mi355x_rec.estimator import Estimator
+    from mi355x_rec.engine import DeepFM
+    fixed = lambda path, mode="train", batch_size=32, seed=None: ml_100k.get_input_fn(path, mode, batch_size=batch_size, seed=5)
+    monkeypatch.setattr(_cli, "get_input_fn", fixed)
+    taken = []
+    orig = DeepFM._take_presorted
+    monkeypatch.setattr(DeepFM, "_take_presorted", lambda self, ids: (lambda ps: (taken.append(ps is not None), ps)[1])(orig(self, ids)))
+    finals = []
+    for min_batch in (4096, 1 << 30):
+        monkeypatch.setattr(Estimator, "LOOKAHEAD_MIN_BATCH", min_batch)
+        taken.clear()
+        job = str(data / ("job_la%d" % min_batch))
+        argv = ["--synthetic", "40960", "--job-dir", job, "--train-steps", "12", "--batch-size", "4096", "--device", "cuda",
+                "--hidden-units", "32", "16", "--dropout", "0.1", "--embedding-size", "32"]
+        opt = ("exclude_linear", "exclude_mf", "exclude_dnn", "hidden_units", "dropout")
+        est = deep_fm.train_and_evaluate(_cli.make_parser("deep_fm", opt).parse_args(argv))
+        assert est.global_step == 12
+        finals.append((est._engine().export_numpy(), sum(taken)))
+    (a, hits_a), (b, hits_b) = finals
+    assert hits_a >= 8 and hits_b == 0, (hits_a, hits_b)
+    for x, y in zip(a["emb"] + a["lin_w"], b["emb"] + b["lin_w"]):
+        assert np.array_equal(x, y)
+    for (ka, ba), (kb, bb) in zip(a["mlp"], b["mlp"]):
+        assert np.array_equal(ka, kb) and np.array_equal(ba, bb)
+
+
 def test_warm_start_from_tf_named_variables(device, data, capsys):
     """--warm-start-from: a dump of TensorFlow-named variables (the reference's checkpoint scopes) seeds a
     fresh job; evaluating before any further step reproduces the donor's metrics."""
