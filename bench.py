@@ -134,6 +134,28 @@ def _run_rank_set(n, extra, label, timeout_s):
     return rc, line
 
 
+def merge_mode_lines(line1, line2, rc2):
+    """The record of a parent-mode run: the faster of the two sets' lines, both modes' numbers in config.communicator_modes;
+    the second set's failure (no line) named there.  Legs only the first set ran (cpu_baseline, other_distribution) are
+    carried over when the second set's line wins."""
+    d1 = json.loads(line1)
+    modes = {"one_communicator": {"value": d1["value"], "ms_per_step": d1["ms_per_step"]}}
+    best = d1
+    if line2:
+        d2 = json.loads(line2)
+        modes["route_ahead_second_communicator"] = {"value": d2["value"], "ms_per_step": d2["ms_per_step"]}
+        if d2["value"] > d1["value"]:
+            for k_ in ("cpu_baseline", "other_distribution"):
+                if k_ in d1 and k_ not in d2:
+                    d2[k_] = d1[k_]
+            best = d2
+    else:
+        modes["route_ahead_second_communicator"] = {"failed": "exit status %d, no line (a collective timeout ends the ranks non-zero)" % rc2}
+    best["config"]["communicator_modes"] = modes
+    best["config"]["communicator_mode_of_value"] = "one_communicator" if best is d1 else "route_ahead_second_communicator"
+    return best
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` without a launcher.  This process has not touched the GPU and never will:
       1. the CPU baseline, timed HERE before any rank exists (the ranks' host threads then do not compete with it), handed to
@@ -163,21 +185,7 @@ def spawn_ranks(args):
     if not line1:
         raise SystemExit(rc1 or 1)
     rc2, line2 = _run_rank_set(n, extra + ["--route-ahead", "1", "--no-second-dist", "--no-cpu-baseline"], "set 2 (routing ahead on a second communicator)", budget)
-    d1 = json.loads(line1)
-    modes = {"one_communicator": {"value": d1["value"], "ms_per_step": d1["ms_per_step"]}}
-    best = d1
-    if line2:
-        d2 = json.loads(line2)
-        modes["route_ahead_second_communicator"] = {"value": d2["value"], "ms_per_step": d2["ms_per_step"]}
-        if d2["value"] > d1["value"]:
-            for k_ in ("cpu_baseline", "other_distribution"):
-                if k_ in d1 and k_ not in d2:
-                    d2[k_] = d1[k_]
-            best = d2
-    else:
-        modes["route_ahead_second_communicator"] = {"failed": "exit status %d, no line (a collective timeout ends the ranks non-zero)" % rc2}
-    best["config"]["communicator_modes"] = modes
-    best["config"]["communicator_mode_of_value"] = "one_communicator" if best is d1 else "route_ahead_second_communicator"
+    best = merge_mode_lines(line1, line2, rc2)
     print(json.dumps(best))
     raise SystemExit(0)
 
