@@ -58,3 +58,39 @@ def test_default_flags_match_the_driver_contract():
     assert inspect.signature(DeepFM.__init__).parameters["catchup"].default == a.catchup
     opt = ("exclude_linear", "exclude_mf", "exclude_dnn", "hidden_units", "dropout")
     assert _cli.make_parser("deep_fm", opt).parse_args([]).catchup == a.catchup
+
+
+def test_every_tool_parses():
+    """tools/*.py run on the GPU box only: at least they must be Python"""
+    import ast
+    import glob
+    for p in sorted(glob.glob(os.path.join(ROOT, "tools", "*.py"))) + [os.path.join(ROOT, "bench.py"), os.path.join(ROOT, "__graft_entry__.py")]:
+        ast.parse(open(p).read(), p)
+
+
+def test_lookahead_loop_yields_the_same_batches_in_the_same_order():
+    """Estimator._with_lookahead: large batches are read one ahead — every batch still comes out once, in order, and
+    params['_lookahead'] names the batch that follows (None behind the last); small batches and row-sharded runs pass through."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "recommender-tensorflow_amd"))
+    import numpy as np
+    from mi355x_rec.estimator import Estimator
+
+    class E(Estimator):
+        def __init__(self):
+            self.params, self._shard = {}, None
+    for B, expect_lookahead in ((4096, True), (32, False)):
+        e = E()
+        batches = [({"user_id": np.full(B, i)}, np.full(B, i % 2)) for i in range(5)]
+        seen, ahead = [], []
+        for f, l in e._with_lookahead(iter(batches)):
+            seen.append(int(f["user_id"][0]))
+            la = e.params.get("_lookahead")
+            ahead.append(None if la is None else int(la["features"]["user_id"][0]))
+        assert seen == [0, 1, 2, 3, 4]
+        assert ahead == ([1, 2, 3, 4, None] if expect_lookahead else [None] * 5)
+        assert "_lookahead" not in e.params
+    e = E()
+    e._shard = object()
+    assert [int(f["user_id"][0]) for f, _ in e._with_lookahead(iter(batches))] == [0, 1, 2, 3, 4] and "_lookahead" not in e.params
+    assert list(E()._with_lookahead(iter([]))) == []
