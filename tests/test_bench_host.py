@@ -78,7 +78,7 @@ def test_lookahead_loop_yields_the_same_batches_in_the_same_order():
 
     class E(Estimator):
         def __init__(self):
-            self.params, self._shard = {}, None
+            self.params = {}
     for B, expect_lookahead in ((4096, True), (32, False)):
         e = E()
         batches = [({"user_id": np.full(B, i)}, np.full(B, i % 2)) for i in range(5)]
@@ -91,6 +91,6 @@ def test_lookahead_loop_yields_the_same_batches_in_the_same_order():
         assert ahead == ([1, 2, 3, 4, None] if expect_lookahead else [None] * 5)
         assert "_lookahead" not in e.params
     e = E()
-    e._shard = object()
+    e.params["_shard"] = object()                        # (a row-sharded run: Estimator._shard)
     assert [int(f["user_id"][0]) for f, _ in e._with_lookahead(iter(batches))] == [0, 1, 2, 3, 4] and "_lookahead" not in e.params
     assert list(E()._with_lookahead(iter([]))) == []
