@@ -52,7 +52,7 @@ enum mi_status {
 };
 
 /* ---- library ---------------------------------------------------------------------------- */
-int32_t mi_abi_version(void);       /* bumps when a signature changes (currently 22) */
+int32_t mi_abi_version(void);       /* bumps when a signature changes (currently 21) */
 const char* mi_last_error(void);    /* thread-local, never NULL */
 const char* mi_build_info(void);    /* "gfx950 hipcc <ver>" */
 
@@ -249,7 +249,6 @@ int32_t mi_sort_unique_rows_slots(const int32_t* rows, int64_t n, int64_t num_ro
  * rows), seg_start, num_uniq.  Every field's ids are sorted on their own, so the radix passes cover the bits of
  * max_vocab, not of the whole table.  B a multiple of 4096, F <= 64 (anything else: the two-entry form).
  * workspace: mi_sort_unique_fields_workspace_bytes(B, F), 256-byte aligned.
- * slot_of_entry (ABI 22; may be NULL): [B*F], the segment u of every entry b * F + f — what mi_wide_stage's records are found by.
  * beside (round 5, ABI 21): how the work is cut into launches — same results either way.  0: the stream has the GPU to itself
  * (a step that was not told its next batch sorts at its head): ONE launch per radix pass and one for the compaction, the
  * tiles of a field exchanging their digit counts inside the launch (5 launches, 130 us at config 3 against 145).  1: the
@@ -259,7 +258,7 @@ int32_t mi_sort_unique_rows_slots(const int32_t* rows, int64_t n, int64_t num_ro
 size_t mi_sort_unique_fields_workspace_bytes(int64_t B, int32_t F);
 int32_t mi_sort_unique_fields(const int32_t* ids, const int64_t* field_off, int64_t B, int32_t F, int64_t max_vocab,
                               int32_t* sorted_entry, int32_t* uniq_rows, int32_t* seg_start, int32_t* num_uniq,
-                              int32_t* slot_of_entry, void* workspace, size_t workspace_bytes, int32_t beside, mi_stream_t stream);
+                              void* workspace, size_t workspace_bytes, int32_t beside, mi_stream_t stream);
 
 /* Routing helpers of the row-sharded multi-GPU path (row r lives on rank r % world as local row
  * r / world; the reference's own multi-worker mode is TF's parameter-server placement of whole
@@ -346,8 +345,7 @@ int32_t mi_sparse_apply_fused(float* table, float* t_slot0, float* t_slot1, floa
                               const int32_t* seg_start, const int32_t* sorted_entry, const int32_t* num_uniq,
                               int64_t n_max, const float* d_concat, int64_t ld_dconcat, const float* sumv,
                               const float* d_logit_fm, const float* d_logit_lin, int32_t F, int32_t E,
-                              int32_t step, const mi_opt_hparams* hp, int32_t lin_stride, int64_t table_stride,
-                              const float* wide_stage, mi_stream_t stream);
+                              int32_t step, const mi_opt_hparams* hp, int32_t lin_stride, int64_t table_stride, mi_stream_t stream);
 
 /* TF-1.12 AdamOptimizer._apply_sparse decays m and v of EVERY row and moves EVERY row each step
  * (SURVEY Appendix A.6).  Instead of sweeping the table, rows carry last_step[r] and are brought
@@ -410,21 +408,6 @@ int32_t mi_sparse_catchup(float* table, float* t_m, float* t_v, float* lin_w, fl
                           int64_t n_max, int32_t E, int32_t step_to, const float* lr_table,
                           float beta1, float beta2, float epsilon, int32_t flags, int32_t lin_stride,
                           int64_t table_stride, mi_stream_t stream);
-
-/* The wide part of a single-GPU Adam train step, STAGED (round 5, ABI 22; reference: the wide weights' share of the same
- * _apply_sparse, and linear_model's lookups deep_fm.py:39).  The wide part's state is one 16-byte record per row; read at
- * random it costs a 128-byte line per touch, and a step touched it five times (~1.2 GB for 26 MB of state).  mi_wide_stage is
- * mi_sparse_catchup(table = NULL, MI_CATCHUP_DEFER_SLOTS) for the batch's distinct rows uniq_rows[0 .. *num_uniq) — which must be
- * the SORTED-unique list of the batch's sort, position u = segment u — writing the replayed record to stage[u] = {w, m, v,
- * stamp bits} (m, v, stamp as in memory: the apply decays and moves them) instead of back to the row.  The step's wide forward
- * then reads stage through the sort's entry -> segment map (mi_linear_from_stage: lin[b] = sum_f stage[slot[b, f]].w, the
- * values and the order of mi_embed_fm_linear_fwd(table = NULL)), and mi_sparse_apply_fused(wide_stage = stage) reads the
- * records from it and writes the rows' records as always.  Results are bit for bit those of the unstaged sequence.
- * flags: MI_CATCHUP_BOUNDED or 0. */
-int32_t mi_wide_stage(float* lin_w, float* l_m, float* l_v, const int32_t* last_step, const int32_t* uniq_rows,
-                      const int32_t* num_uniq, int64_t n_max, int32_t step_to, const float* lr_table, float beta1, float beta2,
-                      float epsilon, int32_t flags, int32_t lin_stride, float* stage, mi_stream_t stream);
-int32_t mi_linear_from_stage(const float* stage, const int32_t* slot_of_entry, int64_t B, int32_t F, float* lin, mi_stream_t stream);
 
 /* ---- (a6) the [hidden_units] MLP: fp32 GEMMs on the matrix cores with fused epilogues -----------
  * replaces tf.layers.dense / tf.layers.dropout (deep_fm.py:98-108).  Row-major everywhere.

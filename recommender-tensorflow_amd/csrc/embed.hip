@@ -307,18 +307,6 @@ __global__ __launch_bounds__(kBlock) void linear_only_fwd_k(const float* __restr
   lin[b] = acc;
 }
 
-// the wide part from the batch's staged records (mi_wide_stage) through the entry -> segment map of the batch's sort:
-// lin[b] = sum_f stage[slot[b, f]].w in field order — the same values in the same order as linear_only_fwd_k, 6.8 MB of slots
-// and 16-byte reads in a 26 MB array instead of a 128-byte line per entry
-__global__ __launch_bounds__(kBlock) void linear_from_stage_k(const float4* __restrict__ stage, const int32_t* __restrict__ slot,
-                                                              int64_t B, int F, float* __restrict__ lin) {
-  const int64_t b = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
-  if (b >= B) return;
-  float acc = 0.f;
-  for (int f = 0; f < F; ++f) acc += stage[slot[b * F + f]].x;
-  lin[b] = acc;
-}
-
 __global__ __launch_bounds__(kBlock) void linear_only_bwd_k(const float* __restrict__ dll,
                                                             const int32_t* __restrict__ pos, int64_t n,
                                                             int F, float* __restrict__ d_lin) {
@@ -633,17 +621,6 @@ int32_t mi_embed_fm_linear_bwd(const float* d_concat, int64_t ld_dconcat, const 
                            d_concat, ld_dconcat, concat, ld_concat, rows, sumv, d_logit_fm,
                            d_lin ? d_logit_lin : nullptr, pos, B, F, E, d_rows, d_lin)));
   MI_CHECK_LAUNCH("embed_fm_linear_bwd");
-  return MI_OK;
-}
-
-int32_t mi_linear_from_stage(const float* stage, const int32_t* slot_of_entry, int64_t B, int32_t F, float* lin, mi_stream_t stream) {
-  MI_REQUIRE(B >= 0 && F > 0, "linear_from_stage: B=%lld F=%d", (long long)B, F);
-  if (B == 0) return MI_OK;
-  MI_REQUIRE(stage && slot_of_entry && lin && mi::aligned16(stage), "linear_from_stage: null / unaligned buffer");
-  const int64_t blocks = mi::ceil_div(B, kBlock);
-  MI_REQUIRE(blocks <= INT32_MAX, "linear_from_stage: grid too large");
-  linear_from_stage_k<<<dim3((unsigned)blocks), dim3(kBlock), 0, mi::as_stream(stream)>>>(reinterpret_cast<const float4*>(stage), slot_of_entry, B, F, lin);
-  MI_CHECK_LAUNCH("linear_from_stage");
   return MI_OK;
 }
 

@@ -173,7 +173,7 @@ int32_t mi_set_step_state(const mi_step_state_t* device_state) {
   return MI_OK;
 }
 
-int32_t mi_abi_version(void) { return 22; }
+int32_t mi_abi_version(void) { return 21; }
 
 const char* mi_last_error(void) { return mi::g_err; }
 

@@ -141,10 +141,6 @@ struct ApplyArgs {
   // as ONE record [row gradient | weight gradient | pad] per request, d_lin = d_rows + E — the packed exchange of the
   // row-sharded step), and the same for out_rows / out_lin of the STORE form
   int64_t gs, gls, os, ols;
-  // wide_stage (mi_wide_stage): the wide part's records of the batch's distinct rows, one float4 {w, slot0, slot1, stamp bits}
-  // per position u of the sorted-unique list — read here (coalesced, 16 bytes per lane group) instead of the row's own
-  // record (a 128-byte line per row); the record is still WRITTEN to lin_w / l0 / l1 / last_step.  NULL: the rows' records.
-  const float4* cs;
 };
 
 // sum of the gradients of entries sorted_entry[k_beg..k_end) of one row, in that order
@@ -193,7 +189,7 @@ __device__ __forceinline__ void seg_accumulate(const ApplyArgs& a, const FusedGr
 // latencies) instead of starting after them — the kernel is bound by bytes in flight per wave (its time scales with
 // occupancy), not by issue.
 struct RowState { float4 s0, s1; float lw, ls0, ls1; int stamp; };
-__device__ __forceinline__ RowState load_row_state(const ApplyArgs& a, const Hp& h, int64_t r, int l, bool lane_on, int64_t u) {
+__device__ __forceinline__ RowState load_row_state(const ApplyArgs& a, const Hp& h, int64_t r, int l, bool lane_on) {
   RowState q;
   q.s0 = q.s1 = make_float4(0.f, 0.f, 0.f, 0.f);
   q.lw = q.ls0 = q.ls1 = 0.f;
@@ -202,12 +198,6 @@ __device__ __forceinline__ RowState load_row_state(const ApplyArgs& a, const Hp&
     const int64_t o = r * a.ts + 4 * l;
     if (a.t0) q.s0 = ld4_nt(a.t0 + o);
     if (a.t1) q.s1 = ld4_nt(a.t1 + o);
-  }
-  if (a.cs) {                                      // the staged copy of the row's wide record (every lane: the stamp)
-    const float4 c = a.cs[u];
-    q.stamp = __float_as_int(c.w);
-    if (l == 0) { q.lw = c.x; q.ls0 = c.y; q.ls1 = c.z; }
-    return q;
   }
   if (h.kind == MI_OPT_ADAM && a.last_step) q.stamp = a.last_step[r * a.ls];
   if (l == 0 && a.lin_w) {
@@ -274,7 +264,7 @@ __global__ __launch_bounds__(kBlock) void sparse_apply_k(ApplyArgs a, Hp h, cons
   float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
   if (a.table && lane_on) w = ld4(a.table + r * a.ts + 4 * l);
   RowState q;
-  if constexpr (!STORE) q = load_row_state(a, h, r, l, lane_on, u);
+  if constexpr (!STORE) q = load_row_state(a, h, r, l, lane_on);
   seg_accumulate<FUSED>(a, fg, s_beg, s_end, l, lane_on, w, g, gl);
   if constexpr (STORE) store_row(a, u, l, lane_on, g, gl);
   else apply_row(a, h, r, l, lane_on, w, g, gl, q);
@@ -340,7 +330,7 @@ __global__ __launch_bounds__(kBlock) void sparse_apply_long_k(ApplyArgs a, Hp h,
           gl += part_l[q];
         }
         if constexpr (STORE) store_row(a, uu, l, lane_on, g, gl);
-        else apply_row(a, h, r, l, lane_on, w, g, gl, load_row_state(a, h, r, l, lane_on, uu));
+        else apply_row(a, h, r, l, lane_on, w, g, gl, load_row_state(a, h, r, l, lane_on));
       }
       __syncthreads();
     }
@@ -453,16 +443,11 @@ __device__ __forceinline__ float bounded_step(float w, float u, float s0, float 
 // The wide part: one thread per row (1/E of the work).  Its own kernel, run BEFORE the row kernel (it
 // reads the stamps the row kernel writes), so that lane 0 of a row's lane group does not drag a fifth
 // chain through a second loop of the same length.
-// STAGE (mi_wide_stage; the replay of a train step: slots deferred): the caught-up record goes to cs[u] = {w, m, v, stamp} —
-// m, v and the stamp as they are in memory, which the apply of the same step decays and moves itself — and NOT back to
-// the row: the wide forward and the apply of this step read cs (16 contiguous bytes per row instead of a 128-byte line each),
-// and the apply writes the row's record anyway.
-template <bool STAGE>
 __global__ __launch_bounds__(kBlock) void catchup_lin_k(
     float* __restrict__ lin_w, float* __restrict__ lm, float* __restrict__ lv, const int32_t* __restrict__ last_step,
     const int32_t* __restrict__ uniq_rows, const int32_t* __restrict__ num_uniq, int64_t n_max, int step_to,
     const float* __restrict__ lr_table, float b1, float b2, float eps, bool defer_slots, int st,
-    const mi_step_state_t* __restrict__ ss, bool bounded, float4* __restrict__ cs) {
+    const mi_step_state_t* __restrict__ ss, bool bounded) {
   if (ss) step_to = ss->step - 1;
   const int64_t u = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
   const int64_t count = uniq_rows ? static_cast<int64_t>(*num_uniq) : n_max;
@@ -471,16 +456,7 @@ __global__ __launch_bounds__(kBlock) void catchup_lin_k(
   const int ls = on ? last_step[r] : step_to;
   const bool work = on && ls > 0 && ls < step_to;
   float w = 0.f, m = 0.f, v = 0.f;
-  if (STAGE ? on : work) { w = lin_w[r]; m = lm[r]; v = lv[r]; }
-  const float m_mem = m, v_mem = v;
-  auto finish = [&]() {
-    if constexpr (STAGE) {
-      if (on) cs[u] = make_float4(w, m_mem, v_mem, __int_as_float(ls));
-    } else if (work) {
-      lin_w[r] = w;
-      if (!defer_slots) { lm[r] = m; lv[r] = v; }
-    }
-  };
+  if (work) { w = lin_w[r]; m = lm[r]; v = lv[r]; }
   if (bounded) {
     if (work) {
       const RhoSplit rho = rho_split(b2);
@@ -493,8 +469,9 @@ __global__ __launch_bounds__(kBlock) void catchup_lin_k(
       }
       if (!defer_slots)
         for (int s = ls + 1; s <= step_to; ++s) v = v * b2;
+      lin_w[r] = w;
+      if (!defer_slots) { lm[r] = m; lv[r] = v; }
     }
-    finish();
     return;
   }
   const bool ok = !work || (catchup_params_in_range(step_to - ls, lr_table[step_to], eps, b1, b2) && catchup_in_range(m, v));
@@ -507,7 +484,10 @@ __global__ __launch_bounds__(kBlock) void catchup_lin_k(
   } else if (work) {
     replay(w, m, v, ls + 1, step_to, lr_table, b1, b2, eps);
   }
-  finish();
+  if (work) {
+    lin_w[r] = w;
+    if (!defer_slots) { lm[r] = m; lv[r] = v; }
+  }
 }
 
 template <int LPR>
@@ -916,11 +896,8 @@ int32_t mi_sparse_apply_fused(float* table, float* t_slot0, float* t_slot1, floa
                               const int32_t* seg_start, const int32_t* sorted_entry, const int32_t* num_uniq,
                               int64_t n_max, const float* d_concat, int64_t ld_dconcat, const float* sumv,
                               const float* d_logit_fm, const float* d_logit_lin, int32_t F, int32_t E,
-                              int32_t step, const mi_opt_hparams* hp, int32_t lin_stride, int64_t table_stride,
-                              const float* wide_stage, mi_stream_t stream) {
+                              int32_t step, const mi_opt_hparams* hp, int32_t lin_stride, int64_t table_stride, mi_stream_t stream) {
   if (int32_t rc = check_hp("sparse_apply_fused", hp)) return rc;
-  MI_REQUIRE(!wide_stage || (lin_w && last_step && hp->kind == MI_OPT_ADAM && mi::aligned16(wide_stage)),
-             "sparse_apply_fused: wide_stage belongs to an Adam step with a wide part (mi_wide_stage), 16-byte aligned");
   if (!table) table_stride = 0;
   MI_REQUIRE(table_stride == 0 || (table_stride >= E && (table_stride & 3) == 0), "%s: table_stride=%lld (0 = E, else >= E and a multiple of 4)", "sparse_apply_fused", (long long)table_stride);
   const int64_t ts = table_stride ? table_stride : E;
@@ -950,7 +927,6 @@ int32_t mi_sparse_apply_fused(float* table, float* t_slot0, float* t_slot1, floa
   ApplyArgs a{table, t_slot0, t_slot1, lin_w, l_slot0, l_slot1, last_step, uniq_rows, seg_start, sorted_entry,
               num_uniq, nullptr, nullptr, E, step};
   a.ls = lin_stride; a.ts = ts;
-  a.cs = reinterpret_cast<const float4*>(wide_stage);
   a.st = mi::step_state();
   MI_DISPATCH_LPR(lpr, (sparse_apply_k<L, true><<<dim3((unsigned)blocks), dim3(kBlock), 0, mi::as_stream(stream)>>>(a, h, fg)));
   MI_CHECK_LAUNCH("sparse_apply_fused");
@@ -1055,9 +1031,9 @@ int32_t mi_sparse_catchup(float* table, float* t_m, float* t_v, float* lin_w, fl
   MI_REQUIRE(!uniq_rows || num_uniq, "sparse_catchup: uniq_rows without num_uniq");
   const bool defer = defer_slots != 0 && uniq_rows != nullptr;
   if (lin_w) {
-    catchup_lin_k<false><<<dim3((unsigned)mi::ceil_div(n_max, kBlock)), dim3(kBlock), 0, mi::as_stream(stream)>>>(
+    catchup_lin_k<<<dim3((unsigned)mi::ceil_div(n_max, kBlock)), dim3(kBlock), 0, mi::as_stream(stream)>>>(
         lin_w, l_m, l_v, last_step, uniq_rows, num_uniq, n_max, step_to, lr_table, beta1, beta2, epsilon, defer, lin_stride, mi::step_state(),
-        bounded, nullptr);
+        bounded);
     MI_CHECK_LAUNCH("sparse_catchup(wide part)");
   }
   // the wide part alone (two Adams, or its replay on a stream of its own): the row kernel would only write the stamps —
@@ -1089,21 +1065,6 @@ int32_t mi_sparse_catchup(float* table, float* t_m, float* t_v, float* lin_w, fl
                              epsilon, defer, lin_stride, mi::step_state(), keep_stamps, ts)));
   }
   MI_CHECK_LAUNCH("sparse_catchup");
-  return MI_OK;
-}
-
-int32_t mi_wide_stage(float* lin_w, float* l_m, float* l_v, const int32_t* last_step, const int32_t* uniq_rows,
-                      const int32_t* num_uniq, int64_t n_max, int32_t step_to, const float* lr_table, float beta1, float beta2,
-                      float epsilon, int32_t flags, int32_t lin_stride, float* stage, mi_stream_t stream) {
-  MI_REQUIRE(n_max >= 0 && step_to >= 0 && lin_stride >= 1, "wide_stage: n_max=%lld step_to=%d", (long long)n_max, step_to);
-  MI_REQUIRE((flags & ~MI_CATCHUP_BOUNDED) == 0, "wide_stage: flags=%d (MI_CATCHUP_BOUNDED or 0: the slots are always deferred here)", flags);
-  if (n_max == 0) return MI_OK;
-  MI_REQUIRE(lin_w && l_m && l_v && last_step && uniq_rows && num_uniq && lr_table && stage && mi::aligned16(stage), "wide_stage: null / unaligned buffer");
-  const bool bounded = (flags & MI_CATCHUP_BOUNDED) != 0 && epsilon >= 1e-30f && beta2 > 0.f && beta2 <= 1.f;
-  catchup_lin_k<true><<<dim3((unsigned)mi::ceil_div(n_max, kBlock)), dim3(kBlock), 0, mi::as_stream(stream)>>>(
-      lin_w, l_m, l_v, last_step, uniq_rows, num_uniq, n_max, step_to, lr_table, beta1, beta2, epsilon, true, lin_stride, mi::step_state(),
-      bounded, reinterpret_cast<float4*>(stage));
-  MI_CHECK_LAUNCH("wide_stage");
   return MI_OK;
 }
 

@@ -481,8 +481,7 @@ __global__ __launch_bounds__(kBlock) void compact_fused_k(const int32_t* __restr
                                                           int32_t* __restrict__ hcf, int32_t* __restrict__ err,
                                                           int32_t* __restrict__ sorted_entry, int32_t* __restrict__ uniq_rows,
                                                           int32_t* __restrict__ seg_start, int32_t* __restrict__ num_uniq,
-                                                          int64_t seg_len, const int64_t* __restrict__ field_off,
-                                                          int32_t* __restrict__ slot_of_entry) {
+                                                          int64_t seg_len, const int64_t* __restrict__ field_off) {
   __shared__ int32_t red[4];
   __shared__ int32_t wc[4];
   const int t = threadIdx.x, w = t >> 6, lane = t & 63;
@@ -529,13 +528,12 @@ __global__ __launch_bounds__(kBlock) void compact_fused_k(const int32_t* __restr
     __syncthreads();                       // previous round's wc consumed
     if (lane == 0) wc[w] = __popcll(hb);
     __syncthreads();
-    int idx = run + __popcll(hb & lt_mask);
-    for (int ww = 0; ww < w; ++ww) idx += wc[ww];
     if (head) {
+      int idx = run + __popcll(hb & lt_mask);
+      for (int ww = 0; ww < w; ++ww) idx += wc[ww];
       uniq_rows[idx] = seg_len > 0 ? static_cast<int32_t>(field_off[i / seg_len] + key) : key;   // (local id -> global row)
       seg_start[idx] = static_cast<int32_t>(i);
     }
-    if (slot_of_entry && valid) slot_of_entry[vals[i]] = head ? idx : idx - 1;      // (the entry's segment: see compact_k)
     run += wc[0] + wc[1] + wc[2] + wc[3];
   }
   if (blockIdx.x == gridDim.x - 1 && t == 0) {
@@ -751,7 +749,7 @@ size_t mi_sort_unique_fields_workspace_bytes(int64_t B, int32_t F) {
 
 int32_t mi_sort_unique_fields(const int32_t* ids, const int64_t* field_off, int64_t B, int32_t F, int64_t max_vocab,
                               int32_t* sorted_entry, int32_t* uniq_rows, int32_t* seg_start, int32_t* num_uniq,
-                              int32_t* slot_of_entry, void* workspace, size_t workspace_bytes, int32_t beside, mi_stream_t stream) {
+                              void* workspace, size_t workspace_bytes, int32_t beside, mi_stream_t stream) {
   const int64_t n = B * F;
   MI_REQUIRE(B > 0 && F > 0 && F <= kFieldsMax && B % kTile == 0 && n < (int64_t)INT32_MAX - kTile,
              "sort_unique_fields: B=%lld (a multiple of %d) F=%d (<= %d)", (long long)B, kTile, F, kFieldsMax);
@@ -808,8 +806,7 @@ int32_t mi_sort_unique_fields(const int32_t* ids, const int64_t* field_off, int6
       kin = kout;
       vin = vout;
     }
-    compact_fused_k<<<dim3(ntiles), dim3(kBlock), 0, st>>>(kin, vin, n, hcf, err, sorted_entry, uniq_rows, seg_start, num_uniq, B, field_off,
-                                                           slot_of_entry);
+    compact_fused_k<<<dim3(ntiles), dim3(kBlock), 0, st>>>(kin, vin, n, hcf, err, sorted_entry, uniq_rows, seg_start, num_uniq, B, field_off);
     MI_CHECK_LAUNCH("sort_unique_fields(compact)");
     return MI_OK;
   }
@@ -837,8 +834,7 @@ int32_t mi_sort_unique_fields(const int32_t* ids, const int64_t* field_off, int6
   MI_CHECK_LAUNCH("sort_unique_fields(heads)");
   scan_small_k<<<dim3(1), dim3(1024), 0, st>>>(heads, ntiles, total);
   MI_CHECK_LAUNCH("sort_unique_fields(scan heads)");
-  compact_k<<<dim3(ntiles), dim3(kBlock), 0, st>>>(kin, vin, n, heads, total, sorted_entry, uniq_rows, seg_start, num_uniq, B, field_off,
-                                                   slot_of_entry);
+  compact_k<<<dim3(ntiles), dim3(kBlock), 0, st>>>(kin, vin, n, heads, total, sorted_entry, uniq_rows, seg_start, num_uniq, B, field_off);
   MI_CHECK_LAUNCH("sort_unique_fields(compact)");
   return MI_OK;
 }

@@ -16,7 +16,7 @@ import torch  # noqa: F401  (loads the HIP runtime this library must share)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmi355x_rec.so")
 
-ABI_VERSION = 22
+ABI_VERSION = 21
 
 
 class MiError(RuntimeError):
@@ -85,7 +85,7 @@ SIGNATURES = {
                                     _p, _p, _sz, _p]),
     "mi_sort_unique_workspace_bytes": (_sz, [_i64]),
     "mi_sort_unique_fields_workspace_bytes": (_sz, [_i64, _i32]),
-    "mi_sort_unique_fields": (_i32, [_p, _p, _i64, _i32, _i64, _p, _p, _p, _p, _p, _p, _sz, _i32, _p]),
+    "mi_sort_unique_fields": (_i32, [_p, _p, _i64, _i32, _i64, _p, _p, _p, _p, _p, _sz, _i32, _p]),
     "mi_sort_unique_rows": (_i32, [_p, _i64, _i64, _p, _p, _p, _p, _p, _sz, _p]),
     "mi_sort_unique_rows_slots": (_i32, [_p, _i64, _i64, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "mi_global_rows": (_i32, [_p, _p, _i64, _i32, _p, _p]),
@@ -98,9 +98,7 @@ SIGNATURES = {
     "mi_sparse_apply": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _p, _i32, _i32,
                                C.POINTER(OptHparams), _i32, _i64, _i64, _p]),
     "mi_sparse_apply_fused": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _i64, _p, _p, _p, _i32,
-                                     _i32, _i32, C.POINTER(OptHparams), _i32, _i64, _p, _p]),
-    "mi_wide_stage": (_i32, [_p, _p, _p, _p, _p, _p, _i64, _i32, _p, _f32, _f32, _f32, _i32, _i32, _p, _p]),
-    "mi_linear_from_stage": (_i32, [_p, _p, _i64, _i32, _p, _p]),
+                                     _i32, _i32, C.POINTER(OptHparams), _i32, _i64, _p]),
     "mi_dense_fwd_gathered": (_i32, [_p, _p, _p, _i32, _i32, _p, _p, _p, _i64, _i64, _i32, _i32, _f32, _u64, _amax, _i64, _p]),
     "mi_dense_bwd_weight_gathered": (_i32, [_p, _p, _p, _i32, _i32, _p, _i64, _p, _p, _i64, _i32, _p, _sz, _amax, _i64, _p]),
     "mi_selftest_sqrt": (_i32, [_u32, _i64, _p, _p]),

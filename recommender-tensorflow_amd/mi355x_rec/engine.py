@@ -717,7 +717,7 @@ class DeepFM:
         self.k.timers = v
 
     # ------------------------------------------------------------------ forward
-    def _forward(self, ids, x_num, train, src=None, pieces=None, stage=None):
+    def _forward(self, ids, x_num, train, src=None, pieces=None):
         """ids [B,F] int32; returns the logit components and caches activations for the backward.
         src = (table, lin_w, field_off, ids) overrides where rows are read from (sharded path: the
         rows received from their owners, addressed by slot).
@@ -777,11 +777,8 @@ class DeepFM:
             side = self._side_stream()
             side.wait_stream(torch.cuda.current_stream())        # (w_ids; the wide part's own catch-up is on this stream already)
             with torch.cuda.stream(side):
-                if stage is not None:        # (the staged wide part: this step's caught-up records, through the sort's entry -> segment map)
-                    k.tagged("mi_linear_from_stage", "/wide")(stage[0], stage[1], B, F, lin)
-                else:
-                    k.tagged("mi_embed_fm_linear_fwd", "/wide")(None, lin_w, w_off, w_ids, B, Fw, self.E, None, 0, None,
-                                                                None, lin, None, ls, 0)
+                k.tagged("mi_embed_fm_linear_fwd", "/wide")(None, lin_w, w_off, w_ids, B, Fw, self.E, None, 0, None,
+                                                            None, lin, None, ls, 0)
             c["lin_join"] = side
         elif pl_gather:
             x0p = self._planes("x0p", B, ld)
@@ -1032,7 +1029,6 @@ class DeepFM:
     WGRAD_BATCH = True        # the planes weight gradients of a backward pass as one batch after the data gradients (_backward_dense)
     TOP_FUSED = True          # ... and the last hidden layer with them, in its GEMM's epilogue (_head: mi_hidden_logits_head_fused)
     TOP_FUSED_MIN_BATCH = 4096
-    WIDE_STAGE = True         # the wide part's records of a batch staged once per step (mi_wide_stage; _wide_stage_ok)
     GRAPH_SHAPES_MAX = 4      # captured steps kept at a time, one per batch shape (graph_train_step)
     SIDE_PRIORITY = 0         # -1: side streams are created with high priority.  HIP serves every stream priority from its own pool
                               # of hardware queues, so a high-priority stream can never share a queue with the step's (normal-priority)
@@ -1041,13 +1037,11 @@ class DeepFM:
     def _new_side_stream(self, priority=None):
         return torch.cuda.Stream(device=self.device, priority=self.SIDE_PRIORITY if priority is None else priority)
 
-    def _catchup(self, uniq, num_uniq, n_max, defer=False, by_gap=None, stage=None):
+    def _catchup(self, uniq, num_uniq, n_max, defer=False, by_gap=None):
         """defer: the rows are about to be applied in this same step by ONE mi_sparse_apply call, which
         then decays m and v itself from the old stamps — the catch-up moves w only (a third less HBM
         traffic).  Not with a separate linear optimizer (two apply calls would see each other's stamps).
-        by_gap: the rows already in staleness order (made ahead by _presort).
-        stage: a [n_max, 4] buffer — the wide part's replay goes there (mi_wide_stage, in sorted-unique order) instead of back
-        to the rows; returns True if it did (the step's wide forward and apply then read the stage: _wide_stage_ok)."""
+        by_gap: the rows already in staleness order (made ahead by _presort)."""
         t_adam = self.opt.name == "Adam" and self.table is not None
         l_adam = (self.lin_opt or self.opt).name == "Adam" and self.lin_w is not None
         if not (t_adam or l_adam) or n_max == 0:
@@ -1056,7 +1050,6 @@ class DeepFM:
         for sc in (self.sched, self.lin_sched):
             if sc is not None:
                 sc.lr_t(self.step)  # make sure the table covers step
-        uniq_sorted = uniq
         if uniq is not None and n_max >= self.GAP_SORT_MIN:
             uniq = by_gap if by_gap is not None else self._rows_by_gap(uniq, num_uniq, n_max, self.step)
         flags = (1 if defer else 0) | (2 if self.catchup == "bounded" else 0)
@@ -1078,16 +1071,8 @@ class DeepFM:
             side.wait_stream(torch.cuda.current_stream())
         else:
             parts = [(t_sched, l_sched, 0)]
-        staged = False
         for i, (ts, lsch, extra) in enumerate(parts):
             s = (ts or lsch).spec
-            if side is not None and i == 0 and stage is not None:
-                # the wide part, staged: the same replay, written to stage[u] (u = position in the SORTED list)
-                with torch.cuda.stream(side):
-                    self.k.mi_wide_stage(self.lin_w, self.l_s0, self.l_s1, self.last_step, uniq_sorted, num_uniq, n_max, self.step,
-                                         lsch.table, s.beta1, s.beta2, s.epsilon, flags & 2, self.ls, stage)
-                staged = True
-                continue
             # (the wide part's own call is timed under its own key: bench.py prices the row kernel and the wide kernel apart)
             entry = self.k.tagged("mi_sparse_catchup", "/wide") if (ts is None and hasattr(self.k, "tagged")) else self.k.mi_sparse_catchup
             call = lambda entry=entry: entry(
@@ -1101,22 +1086,12 @@ class DeepFM:
                     call()
             else:
                 call()
-        return staged
 
     def _side_stream(self):
         side = self._ws.get("side_stream")
         if side is None:
             side = self._ws["side_stream"] = self._new_side_stream()
         return side
-
-    def _wide_stage_ok(self, B):
-        """the wide part of a single-GPU Adam step runs STAGED (include/mi355x_rec.h: mi_wide_stage): its records are read
-        once per step into a compact array in sorted-unique order, which the wide forward (through the sort's entry -> segment
-        map) and the fused apply read instead of a 128-byte line per row and touch.  Where the wide part has its own stream and
-        the per-field sort runs (which makes the map), one Adam for tables and wide part, all columns wide."""
-        return (self.WIDE_STAGE and self.shard is None and self._wide_on_side_stream(B) and self.LIN_SIDE and self.wide_idx is None
-                and self.lin_opt is None and self.opt.name == "Adam" and self.last_step is not None and self.ls == 4
-                and B % 4096 == 0 and self.F <= 64 and hasattr(self.k, "mi_wide_stage"))
 
     def _wide_on_side_stream(self, B):
         """the wide part's forward of a B-example single-GPU batch runs as its own kernel on the side stream (_forward)"""
@@ -1155,10 +1130,8 @@ class DeepFM:
             seg, num_uniq = self._buf(tag + "_seg", (n + 1,), i32), self._buf(tag + "_nu", (1,), i32)
             ws = self._bytes("sortf_ws", k.query("mi_sort_unique_fields_workspace_bytes", B, self.F))
             sort = k.tagged("mi_sort_unique_fields", "/next batch, side stream") if (side and hasattr(k, "tagged")) else k.mi_sort_unique_fields
-            # (the entry -> segment map, for the staged wide part: self._ws[tag + "_slot"])
-            slot = self._buf(tag + "_slot", (n,), i32) if self._wide_stage_ok(B) else None
             # (beside: on a side stream next to the catch-up the many-short-launches form, alone on the step's stream the fused one)
-            sort(ids, self.field_off, B, self.F, self.max_vocab, sorted_entry, uniq, seg, num_uniq, slot, ws, ws.numel(), 1 if side else 0)
+            sort(ids, self.field_off, B, self.F, self.max_vocab, sorted_entry, uniq, seg, num_uniq, ws, ws.numel(), 1 if side else 0)
             return sorted_entry, uniq, seg, num_uniq
         rows = self._buf("rows", (n,), torch.int32)
         k.mi_global_rows(ids, self.field_off, B, self.F, rows)
@@ -1264,22 +1237,18 @@ class DeepFM:
         sorted_entry, uniq, seg, num_uniq = ps["sorted"] if ps is not None else self._sort_batch(ids, tag)
         self._announce(ids, next_ids, x_num, tag)       # the next batch's sort, beside the catch-up (see _presort)
         # (2) TF Adam moved these rows on every step they sat out: replay that now
-        stage = None
         if self.adam_rows and self.step > 0:
             by_gap = ps["by_gap"] if (ps is not None and ps.get("by_gap_step") == self.step) else None
-            slot = self._ws.get(tag + "_slot") if self._wide_stage_ok(B) else None
-            stage = self._buf("wide_stage", (n, 4)) if slot is not None else None
-            if not self._catchup(uniq, num_uniq, n, defer=True, by_gap=by_gap, stage=stage):
-                stage = None
+            self._catchup(uniq, num_uniq, n, defer=True, by_gap=by_gap)
         # (3) forward + head
-        c = self._forward(ids, x_num, True, stage=None if stage is None else (stage, slot[:n]))
+        c = self._forward(ids, x_num, True)
         logits, loss, dlogit = self._head(c, labels, True)
         self._by_gap_ahead()
         # (4) backward through the MLP (+ numeric embeddings)
         d_concat = self._backward_dense(c, dlogit)
         # (5) sparse apply on the unique rows; the per-entry row gradients (deep_fm.py:54,81-87,39
         #     backward) are rebuilt inside the kernel from d_concat / sumv / dlogit
-        self._apply(uniq, seg, sorted_entry, num_uniq, n, None, None, fused=(d_concat, c["sumv"], dlogit), wide_stage=stage)
+        self._apply(uniq, seg, sorted_entry, num_uniq, n, None, None, fused=(d_concat, c["sumv"], dlogit))
         return loss, logits
 
     def _entry_grads(self, c, d_concat, dlogit, pos, d_rows=None, d_lin=None):
@@ -1423,7 +1392,7 @@ class DeepFM:
                                    self.d_grad[self.lin_num_off:] if self.use_linear else None, ws, ws.numel())
         return d_concat
 
-    def _apply(self, uniq, seg, sorted_entry, num_uniq, n_max, d_rows, d_lin, fused=None, d_stride=0, wide_stage=None):
+    def _apply(self, uniq, seg, sorted_entry, num_uniq, n_max, d_rows, d_lin, fused=None, d_stride=0):
         """apply_gradients: dense Apply*, sparse apply on the unique rows, step += 1.
         fused = (d_concat, sumv, dlogit): single-GPU form, entry gradients rebuilt in the kernel.
         d_stride: d_rows / d_lin are views of ONE record buffer, d_stride floats per entry (the packed exchange); 0: two arrays."""
@@ -1460,8 +1429,7 @@ class DeepFM:
                                             d_concat if tb is not None else None, self.D,
                                             sumv if (tb is not None and self.use_mf) else None,
                                             dlogit if (tb is not None and self.use_mf) else None,
-                                            dlogit if lw is not None else None, self.F, self.E, step, h, self.ls, self.ts,
-                                            wide_stage if lw is not None else None)
+                                            dlogit if lw is not None else None, self.F, self.E, step, h, self.ls, self.ts)
                 else:
                     k.mi_sparse_apply(*slots, self.last_step, uniq, seg, sorted_entry, num_uniq, n_max,
                                       d_rows if tb is not None else None, d_lin if lw is not None else None, self.E,

@@ -327,7 +327,7 @@ class NumpyKernels:
         self.mi_dense_bwd_weight(X, F * E, dY, lddy, dW, db, M, N, F * E, ws, wsb)
 
     def mi_sparse_apply_fused(self, table, t0, t1, lin_w, l0, l1, last_step, uniq, seg, sorted_entry, num_uniq,
-                              n_max, d_concat, ldd, sumv, dlf, dll, F, E, step, hp, ls=1, ts=0, wide_stage=None):
+                              n_max, d_concat, ldd, sumv, dlf, dll, F, E, step, hp, ls=1, ts=0):
         n = int(_np(seg)[int(_np(num_uniq)[0])])
         e = np.arange(n)
         b, f = e // F, e % F

@@ -438,7 +438,7 @@ def test_sparse_apply_fused_equals_bwd_then_apply_bitwise(lib, name):
         if fused:
             _chk(lib.mi_sparse_apply_fused(_p(T), _p(t0), _p(t1), _p(L), _p(l0), _p(l1), None, _p(uq), _p(sg), _p(se),
                                            _p(nu), n, _p(d_dc), F * E, _p(d_sv), _p(d_dl), _p(d_dl), F, E, 1,
-                                           C.byref(h), 1, 0, None, _st()))
+                                           C.byref(h), 1, 0, _st()))
         else:
             d_rows = torch.empty(n, E, device="cuda"); d_lin = torch.empty(n, device="cuda")
             _chk(lib.mi_embed_fm_linear_bwd(_p(d_dc), F * E, _p(d_cc), F * E, None, _p(d_sv), _p(d_dl), _p(d_dl), None, B, F,
@@ -918,9 +918,8 @@ def test_sort_unique_fields_equals_global_rows_then_sort(lib, B, F, vocab, besid
         return (torch.empty(n, dtype=torch.int32, device="cuda"), torch.empty(n, dtype=torch.int32, device="cuda"),
                 torch.empty(n + 1, dtype=torch.int32, device="cuda"), torch.empty(1, dtype=torch.int32, device="cuda"))
     se, uq, sg, nu = outs()
-    sl = torch.full((n,), -1, dtype=torch.int32, device="cuda")                   # the entry -> segment map (ABI 22)
     ws = torch.empty(lib.mi_sort_unique_fields_workspace_bytes(B, F) + 256, dtype=torch.uint8, device="cuda")
-    _chk(lib.mi_sort_unique_fields(_p(d_ids), _p(d_off), B, F, max(vs), _p(se), _p(uq), _p(sg), _p(nu), _p(sl), _p(ws), ws.numel(), beside, _st()))
+    _chk(lib.mi_sort_unique_fields(_p(d_ids), _p(d_off), B, F, max(vs), _p(se), _p(uq), _p(sg), _p(nu), _p(ws), ws.numel(), beside, _st()))
     rows = torch.empty(n, dtype=torch.int32, device="cuda")
     _chk(lib.mi_global_rows(_p(d_ids), _p(d_off), B, F, _p(rows), _st()))
     se2, uq2, sg2, nu2 = outs()
@@ -930,10 +929,7 @@ def test_sort_unique_fields_equals_global_rows_then_sort(lib, B, F, vocab, besid
     assert int(nu.item()) == U
     assert torch.equal(se, se2)
     assert torch.equal(uq[:U], uq2[:U]) and torch.equal(sg[:U + 1], sg2[:U + 1])
-    # slot_of_entry[e] = the segment of entry e: the row of that segment is the entry's row
-    rows_h = (ids.astype(np.int64) + off[None, :]).reshape(-1)
-    assert np.array_equal(uq.cpu().numpy()[sl.cpu().numpy()], rows_h)
-    assert lib.mi_sort_unique_fields(_p(d_ids), _p(d_off), B - 1, F, max(vs), _p(se), _p(uq), _p(sg), _p(nu), _p(sl), _p(ws), ws.numel(), beside, _st()) != 0
+    assert lib.mi_sort_unique_fields(_p(d_ids), _p(d_off), B - 1, F, max(vs), _p(se), _p(uq), _p(sg), _p(nu), _p(ws), ws.numel(), beside, _st()) != 0
 
 
 def test_colsum_and_layer_stats(lib):

@@ -510,41 +510,6 @@ def test_layer_summaries_after_a_replay_know_what_the_captured_step_kept_on_the_
     assert "dnn/hiddenlayer_1" in m.layer_summaries()
 
 
-@pytest.mark.parametrize("catchup", ["exact", "bounded"])
-def test_staged_wide_part_is_bitwise_the_unstaged_sequence(catchup, monkeypatch):
-    """Round 5 (mi_wide_stage): the wide part's records of a batch are replayed into a compact array once per step; the wide
-    forward reads it through the sort's entry -> segment map and the fused apply reads its records from it.  Same values, same
-    order of every sum: losses, logits and every variable bit for bit those of the unstaged step — uniform and heavily
-    duplicated ids (segments of thousands of entries: the long-segment apply), with and without an announced next batch."""
-    from mi355x_rec.engine import DeepFM, OptimizerSpec
-    vocab, E, hidden, B = [3000, 50, 20000, 7, 900], 32, [64, 32], 8192
-    rng = np.random.default_rng(3)
-    batches = [(dev(np.stack([rng.integers(0, v, B) for v in vocab], 1).astype(np.int32)), dev((rng.random(B) < 0.3).astype(np.uint8)))
-               for _ in range(7)]
-    runs = {}
-    for staged in (True, False):
-        monkeypatch.setattr(DeepFM, "WIDE_STAGE", staged)
-        m = _engine(vocab, E, hidden, dropout=0.1, seed=5, optimizer=OptimizerSpec("Adam", 0.001), catchup=catchup)
-        g = torch.Generator(device="cuda"); g.manual_seed(3)
-        m.init_variables(g, lin_scale=1e-2)
-        assert m._wide_stage_ok(B) == staged
-        calls = []
-        orig = m.k.mi_wide_stage
-        m.k.__dict__["mi_wide_stage"] = lambda *a: (calls.append(1), orig(*a))[1]
-        out = []
-        for i, (ids, y) in enumerate(batches):
-            nxt = batches[i + 1][0] if (i + 1 < len(batches) and i % 3 != 2) else None      # announced, announced, not, ...
-            loss, logits = m.train_step(ids, y, next_ids=nxt)
-            out.append((loss.clone(), logits.clone()))
-        m.finalize_rows()
-        assert (len(calls) == len(batches) - 1) == staged, len(calls)          # every step but the first (nothing to replay yet)
-        runs[staged] = (out, {k: getattr(m, k).clone() for k in ("t_rec", "lin_state", "dense", "d_s0", "d_s1")})
-    for (la, ga), (lb, gb) in zip(runs[True][0], runs[False][0]):
-        assert torch.equal(la, lb) and torch.equal(ga, gb)
-    for k in runs[True][1]:
-        assert torch.equal(runs[True][1][k], runs[False][1][k]), k
-
-
 @pytest.mark.parametrize("kind", ["deepfm-numeric-embeddings", "wide-and-deep-raw-numeric"])
 def test_graph_train_step_with_numeric_columns_replays_the_eager_step_bitwise(kind):
     """Round 4: numeric columns inside the captured step (a third input copy) — DeepFM's numeric embeddings

@@ -45,7 +45,7 @@ if what in ("fields", "both"):
         n = B * F
         se, uq, sg, nu = torch.empty(n, **i32), torch.empty(n, **i32), torch.empty(n + 1, **i32), torch.empty(1, **i32)
         ws = torch.empty(int(lib.mi_sort_unique_fields_workspace_bytes(B, F)) + 256, dtype=torch.uint8, device="cuda")
-        f = lambda: lib.mi_sort_unique_fields(ids.data_ptr(), off.data_ptr(), B, F, V, se.data_ptr(), uq.data_ptr(), sg.data_ptr(), nu.data_ptr(), None, ws.data_ptr(), ws.numel(), int(os.environ.get("BESIDE", "0")), st())
+        f = lambda: lib.mi_sort_unique_fields(ids.data_ptr(), off.data_ptr(), B, F, V, se.data_ptr(), uq.data_ptr(), sg.data_ptr(), nu.data_ptr(), ws.data_ptr(), ws.numel(), int(os.environ.get("BESIDE", "0")), st())
         rc = f(); torch.cuda.synchronize()
         print("fields B=%6d F=%2d V=%8d %s: rc=%d unique=%d  %.1f us  (MI_SORT_FUSED=%s MI_SORT_BITS=%s)" % (
             B, F, V, "zipf   " if zipf else "uniform", rc, int(nu.item()), timeit(f), os.environ.get("MI_SORT_FUSED", "-"), os.environ.get("MI_SORT_BITS", "-")))

@@ -29,8 +29,8 @@ for B, F, V in ((65536, 26, 1_000_000), (8192, 64, 3_000_000), (4096, 5, 100)):
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):
                     dst.copy_(src); src.copy_(dst)
-            rc = lib.mi_sort_unique_fields(ids.data_ptr(), off.data_ptr(), B, F, V, a[0].data_ptr(), a[1].data_ptr(), a[2].data_ptr(), a[3].data_ptr(), None, wsA.data_ptr(), wsA.numel(), 0, st())
-            rc |= lib.mi_sort_unique_fields(ids.data_ptr(), off.data_ptr(), B, F, V, b[0].data_ptr(), b[1].data_ptr(), b[2].data_ptr(), b[3].data_ptr(), None, wsB.data_ptr(), wsB.numel(), 1, st())
+            rc = lib.mi_sort_unique_fields(ids.data_ptr(), off.data_ptr(), B, F, V, a[0].data_ptr(), a[1].data_ptr(), a[2].data_ptr(), a[3].data_ptr(), wsA.data_ptr(), wsA.numel(), 0, st())
+            rc |= lib.mi_sort_unique_fields(ids.data_ptr(), off.data_ptr(), B, F, V, b[0].data_ptr(), b[1].data_ptr(), b[2].data_ptr(), b[3].data_ptr(), wsB.data_ptr(), wsB.numel(), 1, st())
             U = int(b[3].item())
             ok = rc == 0 and int(a[3].item()) == U and torch.equal(a[0], b[0]) and torch.equal(a[1][:U], b[1][:U]) and torch.equal(a[2][:U + 1], b[2][:U + 1])
             bad += 0 if ok else 1
