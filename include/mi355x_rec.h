@@ -360,14 +360,15 @@ int32_t mi_sparse_apply_fused(float* table, float* t_slot0, float* t_slot1, floa
  * of this kernel's HBM traffic; every row passed here must be applied in the same step.
  * MI_CATCHUP_BOUNDED: the replay with a stated error bound instead of TF's bits (the parity bar is 1e-5 on the
  * logits, not bit equality): m_j and lr_t[s] * m_j are still the reference's chain, bit for bit; sqrt(v_j) is taken as
- * sqrtf(v_0) * beta2^(j/2) (a per-row scalar chain with a two-float multiplier) and the division as v_rcp_f32 (1 ulp),
+ * sqrtf(v_0) * beta2^(j/2) (a per-row scalar chain with a two-float multiplier) and the division as a reciprocal good to
+ * 1 ulp (v_rcp_f32 for the wide part; for the rows one carried from step to step and corrected against each denominator),
  * w is rounded once per step like the reference's.  Every replayed update is within a few 2^-24 (relative) of the
  * reference's, i.e. ~1e-10 |w|.  Enforced against the literal sweep after 150-200 replayed steps, for EVERY variable:
  * |w - w_sweep| <= 3 ulp(w) + 2e-6 * sum_j |t_j| (t_j: the replayed updates) — and in distribution >= 95 % of the variables
  * bit-identical, >= 98 % within 1e-7 relative (measured 96.7 % / 98.7 %; a 1-ulp difference alone is up to 1.19e-7, so
  * "1e-7 for every variable" is NOT claimed): tests/test_hip_kernels.py::test_bounded_catchup_stays_within_its_bound_of_the_sweep.  m, v and the
- * stamps are written exactly as in the exact mode.  4 VALU operations + 1 transcendental per element and step instead
- * of 16 + 2, and no range conditions.  Needs epsilon >= 1e-30 (otherwise the exact form runs).
+ * stamps are written exactly as in the exact mode.  7 packed VALU operations per element and step (no transcendental)
+ * instead of 16 + 2, and no range conditions.  Needs epsilon >= 1e-30 (otherwise the exact form runs).
  * MI_CATCHUP_KEEP_STAMPS: the rows' stamps are left as they are (m, v ARE written) — for a model whose tables and wide part
  * follow two different Adam optimizers (two lr_t tables: two calls; the first must not move the stamps the second reads). */
 enum mi_catchup_flags { MI_CATCHUP_DEFER_SLOTS = 1, MI_CATCHUP_BOUNDED = 2, MI_CATCHUP_KEEP_STAMPS = 4 };

@@ -415,11 +415,12 @@ __device__ __forceinline__ bool catchup_params_in_range(int steps, float lr_last
 //   sqrt(v_j)  ~  s0 * rho_j            s0 = v_sqrt_f32(v_0) (1 ulp, once per element), rho_j ~ beta2^(j/2): a per-ROW
 //                                       scalar chain rho_j = rho_{j-1} * (rho_hi + rho_lo), rho_hi + rho_lo = sqrt(beta2) to
 //                                       2^-48 (no systematic drift; rounding noise <= sqrt(j) * 2^-24 rms)
-//   w_j = fma(-u_j, rcp(fma(s0, rho_j, eps)), w_{j-1})     v_rcp_f32: 1 ulp; ONE rounding of w per step, like the reference
+//   w_j = fma(-u_j, r_j, w_{j-1}), r_j ~ 1 / fma(s0, rho_j, eps)    a reciprocal to <= 1 ulp (the wide part: v_rcp_f32; the rows: carried
+//                                       from step to step and corrected against each d_j, see the row kernel); ONE rounding of w per step, like the reference
 // Per element and step: 4 packed-able VALU operations + 1 transcendental instead of 16 + 2; no range conditions at all
 // (v = 0, denormal m, any gap: the same loop), so no wave ever falls back to a slow generic loop.
 // Error against the reference's literal fp32 sweep, per replayed step j of a row: the update t_j = u_j / (sqrt(v_j) + eps)
-// is reproduced to |t~_j / t_j - 1| <= (2 [v_rcp_f32: 1 ulp] + 2 [s0] + 1 [fma] + 2j [rho chain, worst case; ~sqrt(j)/2
+// is reproduced to |t~_j / t_j - 1| <= (2 [the reciprocal: <= 1 ulp] + 2 [s0] + 1 [fma] + 2j [rho chain, worst case; ~sqrt(j)/2
 // rms] + 3 [the reference's own sqrt, add and divide roundings] + j/2 [its v chain]) * 2^-24; the updates decay like
 // 0.9^j, so the sum over a replay is off by <~ 1e-6 of its FIRST update in the worst case and ~1e-7 of it typically —
 // of an update that is itself ~1e-3 |w|.  On top of that comes the rare step in which the difference moves RN(w - t)
@@ -639,18 +640,40 @@ __global__ __launch_bounds__(kBlock) void sparse_catchup_bounded_k(
           w.z = bounded_step(w.z, lr * m.z, s0.z, rj, eps); w.w = bounded_step(w.w, lr * m.w, s0.w, rj, eps);
         }
         // (two-element vectors: hipcc then packs the fma of the denominators too; two steps per trip of the loop)
+        // The reciprocal is CARRIED from step to step instead of taken anew (round 5): v_rcp_f32 is a transcendental
+        // instruction (half rate on gfx950, one element each: tools/probe/valu_cost_probe.hip) — four of them per lane and
+        // step next to ~13 packed / scalar ones.  Consecutive denominators differ by at most 1 - sqrt(beta2) (5e-4) relatively, d_j / d_{j-1} in [sqrt(beta2), 1], so with
+        // e = 1 - d_j r_{j-1} (one fma: the exact residual, rounded once) the second-order step r_j = r_{j-1} (1 + e + e^2)
+        // lands within e^3 <= 1.3e-10 of 1 / d_j plus ONE rounding (0.5 ulp — tighter than v_rcp_f32's 1 ulp), and since
+        // every step corrects against its own d_j nothing accumulates.  Three packed full-rate fmas per two elements in place
+        // of two v_rcp_f32: 35 instead of 29 + 8 transcendental instructions per two steps.  Measured (same box, alternating,
+        // profiles/r05_catchup_reciprocal.md): rows sorted by staleness 0.441 against 0.444 ms alone and the step 2.685
+        // against 2.69 ms — the kernel waits for rows, not for the VALU — rows NOT sorted 0.63 against 0.66 ms.
         typedef float f32x2 __attribute__((ext_vector_type(2)));
         const f32x2 sa = {s0.x, s0.y}, sb = {s0.z, s0.w};
+        const f32x2 ev = {eps, eps}, one = {1.f, 1.f};
+        f32x2 ra, rb;                                           // 1 / (s0 rho_j + eps) of the step before the loop's first
+        {
+          const f32x2 rv = {rj, rj};
+          const f32x2 da = __builtin_elementwise_fma(sa, rv, ev), db = __builtin_elementwise_fma(sb, rv, ev);
+          ra.x = __builtin_amdgcn_rcpf(da.x); ra.y = __builtin_amdgcn_rcpf(da.y);
+          rb.x = __builtin_amdgcn_rcpf(db.x); rb.y = __builtin_amdgcn_rcpf(db.y);
+        }
+        f32x2 ma = {m.x, m.y}, mb = {m.z, m.w}, wa = {w.x, w.y}, wb = {w.z, w.w};
 #pragma unroll 2
         for (; s <= step_to; ++s) {
           const float lr = lr_s[s - base];
           rj = fmaf(rj, rho.lo, rj * rho.hi);
-          m.x = m.x * b1; m.y = m.y * b1; m.z = m.z * b1; m.w = m.w * b1;
-          const f32x2 rv = {rj, rj}, ev = {eps, eps};
+          ma = ma * b1; mb = mb * b1;
+          const f32x2 rv = {rj, rj};
           const f32x2 da = __builtin_elementwise_fma(sa, rv, ev), db = __builtin_elementwise_fma(sb, rv, ev);
-          w.x = fmaf(-(lr * m.x), __builtin_amdgcn_rcpf(da.x), w.x); w.y = fmaf(-(lr * m.y), __builtin_amdgcn_rcpf(da.y), w.y);
-          w.z = fmaf(-(lr * m.z), __builtin_amdgcn_rcpf(db.x), w.z); w.w = fmaf(-(lr * m.w), __builtin_amdgcn_rcpf(db.y), w.w);
+          const f32x2 ea = __builtin_elementwise_fma(-da, ra, one), eb = __builtin_elementwise_fma(-db, rb, one);
+          const f32x2 pa = __builtin_elementwise_fma(ea, ea, ea), pb = __builtin_elementwise_fma(eb, eb, eb);
+          ra = __builtin_elementwise_fma(ra, pa, ra); rb = __builtin_elementwise_fma(rb, pb, rb);
+          const f32x2 ua = lr * ma, ub = lr * mb;
+          wa = __builtin_elementwise_fma(-ua, ra, wa); wb = __builtin_elementwise_fma(-ub, rb, wb);
         }
+        m = make_float4(ma.x, ma.y, mb.x, mb.y); w = make_float4(wa.x, wa.y, wb.x, wb.y);
         const int64_t o = cur.r * ts + 4 * l;
         st4(table + o, w);
         if (!defer_slots) {

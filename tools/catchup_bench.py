@@ -15,6 +15,8 @@ from mi355x_rec import _lib  # noqa: E402
 
 
 def main():
+    if os.environ.get("MI_TUNING_LIB"):          # the tools' build (make -C csrc tuning): reads MI_CATCHUP_RCP / _DEPTH / _BLOCKS
+        _lib.LIB_PATH = os.path.join(ROOT, "tools", "probe", "libmi355x_rec_tuning.so")
     lib = _lib.load()
     dev = "cuda"
     R, E, U, step_to = 26_000_000, 64, 1_650_000, 400
