@@ -733,7 +733,7 @@ def main():
             wide_apart = "mi_sparse_catchup/wide" in km
             # w, m, v read + w written (deferred slots); + the 16-byte wide record read and written when ONE call does both
             c_bytes = Us * (16 * E + (0 if wide_apart else 32))
-            cyc = 236.0 if mode_catchup == "exact" else 83.0
+            cyc = 236.0 if mode_catchup == "exact" else 73.0
             issue_ms = sparse_stats["element_steps"] / 256.0 * cyc / 1024.0 / 2.1e9 * 1e3
             roof_catchup = {"kernel": "sparse_catchup_%s: lazy replay of TF Adam's dense-equivalent update on the rows "
                                       "about to be read (w only: the apply decays m, v)" % ("bounded_k" if mode_catchup == "bounded" else "k"),
@@ -756,7 +756,8 @@ def main():
                                             "issue_bound_ms": issue_ms, "frac_of_issue_bound": issue_ms / c_ms,
                                             "note": "instruction issue of the replay loop alone (ISA count x the gfx950 prices measured by "
                                                     "tools/probe/valu_cost_probe.hip); exact: 38 packed + 8 transcendental + 3; bounded: "
-                                                    "14 packed + 4 transcendental + 3 per 4 elements and step"},
+                                                    "14 packed + 2 single + 1.5 per 4 elements and step (no transcendental: the reciprocal is carried from step to step; "
+                                                    "the launch does not follow this bound — the kernel waits for rows, profiles/r05_catchup_reciprocal.md)"},
                             "traffic": tr("sparse_catchup_k") if mode_catchup == "exact" else tr("sparse_catchup_bounded_k"),
                             "traffic_note": "PMC bytes per launch of the row kernel (profiles/traffic.json)"}
         out = {
