@@ -252,13 +252,18 @@ __global__ __launch_bounds__(kBlock) void head_count_k(const int32_t* __restrict
   if (threadIdx.x == 0) tile_heads[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
-// exclusive scan of `count` int32 values by ONE block (count = number of tiles: small)
-__global__ __launch_bounds__(1024) void scan_small_k(int32_t* __restrict__ data, int64_t count,
-                                                     int32_t* __restrict__ total_out) {
-  __shared__ int32_t wsum[16];
+// exclusive scan of `count` int32 values by ONE block (count = number of tiles: small).  256 threads, not 1,024: a
+// 16-wave workgroup needs four free wave slots on every SIMD of ONE CU at the same moment, and beside the sparse apply or
+// the resident catch-up workgroups it waited for that for 0.17 ms on average (0.5 ms at worst: rocprofv3 trace of the
+// row-sharded step, profiles/r05_sharded_one_rank.md) — for 5 us of work.
+constexpr int kScanSmallBlock = 256;
+__global__ __launch_bounds__(kScanSmallBlock) void scan_small_k(int32_t* __restrict__ data, int64_t count,
+                                                                int32_t* __restrict__ total_out) {
+  constexpr int NW = kScanSmallBlock / 64;
+  __shared__ int32_t wsum[NW];
   const int t = threadIdx.x, w = t >> 6, lane = t & 63;
   int carry = 0;
-  for (int64_t c0 = 0; c0 < count; c0 += 1024) {
+  for (int64_t c0 = 0; c0 < count; c0 += kScanSmallBlock) {
     const int64_t i = c0 + t;
     const int v = (i < count) ? data[i] : 0;
     const int incl = wave_incl_scan(v, lane);
@@ -266,7 +271,8 @@ __global__ __launch_bounds__(1024) void scan_small_k(int32_t* __restrict__ data,
     if (lane == 63) wsum[w] = incl;
     __syncthreads();
     int pre = carry, tot = 0;
-    for (int ww = 0; ww < 16; ++ww) {
+#pragma unroll
+    for (int ww = 0; ww < NW; ++ww) {
       if (ww < w) pre += wsum[ww];
       tot += wsum[ww];
     }
@@ -689,7 +695,7 @@ static int32_t sort_unique_rows_impl(const int32_t* rows, int64_t n, int64_t num
   if (perm_only) return MI_OK;
   head_count_k<<<dim3(ntiles), dim3(kBlock), 0, st>>>(kin, n, heads);
   MI_CHECK_LAUNCH("sort_unique_rows(heads)");
-  scan_small_k<<<dim3(1), dim3(1024), 0, st>>>(heads, ntiles, total);
+  scan_small_k<<<dim3(1), dim3(kScanSmallBlock), 0, st>>>(heads, ntiles, total);
   MI_CHECK_LAUNCH("sort_unique_rows(scan heads)");
   compact_k<<<dim3(ntiles), dim3(kBlock), 0, st>>>(kin, vin, n, heads, total, sorted_entry, uniq_rows, seg_start, num_uniq, 0, nullptr,
                                                    slot_of_entry);
@@ -832,7 +838,7 @@ int32_t mi_sort_unique_fields(const int32_t* ids, const int64_t* field_off, int6
   }
   head_count_k<<<dim3(ntiles), dim3(kBlock), 0, st>>>(kin, n, heads, B);
   MI_CHECK_LAUNCH("sort_unique_fields(heads)");
-  scan_small_k<<<dim3(1), dim3(1024), 0, st>>>(heads, ntiles, total);
+  scan_small_k<<<dim3(1), dim3(kScanSmallBlock), 0, st>>>(heads, ntiles, total);
   MI_CHECK_LAUNCH("sort_unique_fields(scan heads)");
   compact_k<<<dim3(ntiles), dim3(kBlock), 0, st>>>(kin, vin, n, heads, total, sorted_entry, uniq_rows, seg_start, num_uniq, B, field_off);
   MI_CHECK_LAUNCH("sort_unique_fields(compact)");
