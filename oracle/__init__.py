@@ -16,6 +16,9 @@ pinned on reference-held data.  What pins it instead:
 * FarmHash Fingerprint64 known answers recalled from TensorFlow's own
   ``string_to_hash_bucket`` tests / docs (``tests/test_fingerprint.py``), cross-checked between
   two independent restatements (this package's pure Python and the C in ``csrc/host_ids.cpp``);
+* independent implementations of the same mathematics (``tests/test_oracle_vs_torch.py``): the graph written again in
+  plain torch ops and differentiated by autograd (every gradient to 1e-10), ``torch.optim`` Adam / Adagrad / SGD beside
+  the dense rules, scikit-learn's metrics beside the streaming ones — the calculus and the update algebra, not TF's bits;
 * mathematical identities the reference's formulas must satisfy (FM == sum of pairwise dot
   products, stable sigmoid-CE == naive form, finite-difference gradients in fp64, Adam step-1
   closed form, sync-DP == big batch);
