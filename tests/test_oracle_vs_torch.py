@@ -158,3 +158,27 @@ def test_streaming_metrics_against_scikit_learn():
     assert abs(r["recall"] - sk.recall_score(y, cls)) < 1e-12
     assert abs(r["average_loss"] - sk.log_loss(y, p)) < 1e-6
     assert abs(r["auc_precision_recall"] - sk.average_precision_score(y, p)) < 2e-2   # (different interpolations of the PR curve)
+
+
+@pytest.mark.parametrize("momentum", [0.0, 0.9])
+def test_rmsprop_equals_torch_optim_where_the_two_definitions_coincide(momentum):
+    """TF: ms += (g^2 - ms)(1 - decay), ms starting at 1; mom = momentum * mom + lr * g / sqrt(ms + eps); var -= mom.
+    torch: eps OUTSIDE the root, lr applied to the buffer, square_avg starting at 0.  With eps = 0 and torch's state seeded with
+    ones the two are the same recursion (mom_tf = lr * buf_torch)."""
+    rng = np.random.default_rng(8)
+    w0 = rng.standard_normal((5, 4))
+    hp = OO.Hyper("RMSProp", lr=0.01, decay=0.9, momentum=momentum, epsilon=0.0)
+    w = w0.copy()
+    s0, s1 = OO.slot_init(hp, w)
+    wt = torch.tensor(w0.copy(), requires_grad=True)
+    opt = torch.optim.RMSprop([wt], lr=0.01, alpha=0.9, eps=0.0, momentum=momentum)
+    opt.state[wt]["step"] = torch.tensor(0.0)
+    opt.state[wt]["square_avg"] = torch.ones_like(wt)
+    if momentum > 0:
+        opt.state[wt]["momentum_buffer"] = torch.zeros_like(wt)
+    for t in range(10):
+        g = rng.standard_normal((5, 4))
+        OO.dense_apply(hp, w, s0, s1, g)
+        wt.grad = torch.tensor(g)
+        opt.step()
+        assert np.allclose(w, wt.detach().numpy(), rtol=1e-11, atol=1e-14), t
