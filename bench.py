@@ -83,7 +83,7 @@ def parse():
     ap.add_argument("--chunks", type=int, default=None, help="pipeline depth of the row-sharded step (default: parallel.py's)")
     ap.add_argument("--chunk-compute", type=int, choices=[0, 1], default=None,
                     help="row-sharded step: 1 = every chunk runs its own forward / backward, 0 = only the exchanges and the embedding-side "
-                         "kernels are chunked (default: parallel.RowShard's — 0 from 8 ranks on)")
+                         "kernels are chunked (default: parallel.RowShard's — 1 since the rehearsal of profiles/r05_sim_ranks.md)")
     ap.add_argument("--no-presort", action="store_true",
                     help="do not announce the next batch's ids to train_step (its sort then runs at the head of the next step "
                          "instead of on a side stream beside this step's catch-up)")
@@ -397,14 +397,15 @@ def main():
     # the node: a finite timeout on the group, and RCCL's watchdog told to tear the process down when it fires
     os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
     tmo = datetime.timedelta(seconds=args.collective_timeout)
+    from mi355x_rec.parallel import rccl_options
     if world == 1 and args.force_shard:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(args.backend, init_method="tcp://127.0.0.1:%d" % (29600 + os.getpid() % 300), rank=0,
-                                world_size=1, timeout=tmo, **({"device_id": device} if args.backend == "nccl" else {}))
+                                world_size=1, timeout=tmo, **(dict(device_id=device, **rccl_options()) if args.backend == "nccl" else {}))
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=device, timeout=tmo)
+            dist.init_process_group("nccl", device_id=device, timeout=tmo, **rccl_options())    # (RCCL's stream: the high-priority pool of hardware queues, where the engine keeps nothing)
         else:
             dist.init_process_group("gloo", timeout=tmo)
 

@@ -178,6 +178,65 @@ class AdamSchedule:
         return float(self.host[step])
 
 
+
+_SIDE_STREAMS = {}        # (device index, priority) -> the side streams found so far, in the order engines ask for them
+_SPIN = {}                # device index -> spin cycles for ~0.2 ms
+
+
+def _streams_overlap(a, b, cyc):
+    """Do kernels enqueued on streams a and b run side by side?  A long spin on a, a short one on b: on ONE hardware queue the
+    short one ends after the long one."""
+    e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    torch.cuda.synchronize()
+    with torch.cuda.stream(a):
+        e0.record()
+        torch.cuda._sleep(cyc)
+        e1.record()
+    with torch.cuda.stream(b):
+        torch.cuda._sleep(max(cyc // 8, 1))
+        e2.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e2) < 0.6 * e0.elapsed_time(e1)
+
+
+def _tested_side_stream(device, prio, k):
+    key = (device.index if device.index is not None else torch.cuda.current_device(), prio)
+    found = _SIDE_STREAMS.setdefault(key, [])
+    if k < len(found):
+        return found[k]
+    if not hasattr(torch.cuda, "_sleep") or torch.cuda.is_current_stream_capturing():
+        found.append(torch.cuda.Stream(device=device, priority=prio))
+        return found[-1]
+    cyc = _SPIN.get(key[0])
+    if cyc is None:
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda._sleep(1000)                                 # (the first launch of the spin kernel is not timed)
+        torch.cuda.synchronize()
+        a.record(); torch.cuda._sleep(1_000_000); b.record(); torch.cuda.synchronize()
+        cyc = _SPIN[key[0]] = max(int(1_000_000 * 0.2 / max(a.elapsed_time(b), 1e-3)), 1000)
+    main = torch.cuda.current_stream(device)
+    others = [s for (d, _), ss in _SIDE_STREAMS.items() if d == key[0] for s in ss]
+    seen, fallback = set(), None
+    while len(found) <= k:
+        pick = None
+        for _ in range(32):                                     # once around the pool
+            s = torch.cuda.Stream(device=device, priority=prio)
+            if s.cuda_stream in seen or any(s.cuda_stream == o.cuda_stream for o in others + [main]):
+                continue
+            seen.add(s.cuda_stream)
+            if not _streams_overlap(main, s, cyc):
+                continue
+            if fallback is None:
+                fallback = s                                    # beside the step's stream at least
+            if all(_streams_overlap(o, s, cyc) for o in others):
+                pick = s
+                break
+        pick = pick or fallback or torch.cuda.Stream(device=device, priority=prio)
+        found.append(pick)
+        others.append(pick)
+        fallback = None
+    return found[k]
+
 class DeepFM:
     """model_fn-shaped model (reference trainers/deep_fm.py:11-125).
 
@@ -1035,7 +1094,18 @@ class DeepFM:
                               # stream; normal-priority streams share 4 queues by reference count and may (parallel._side_stream)
 
     def _new_side_stream(self, priority=None):
-        return torch.cuda.Stream(device=self.device, priority=self.SIDE_PRIORITY if priority is None else priority)
+        """A stream whose kernels really run BESIDE the step's stream and beside the side streams handed out before it.
+        torch.cuda.Stream() deals the streams of a pool of 32 per priority in turn and HIP spreads them over a few hardware
+        queues (4 per priority by default); two streams on one queue run one after the other.  Which pool stream the engine
+        gets depends on how many the process took before (the user's own streams; torch's ProcessGroupNCCL takes its
+        stream from the same pool) — tools/stream_alias_probe.py, one GPU: with 3 streams taken before, the single-GPU step
+        2.74 -> 2.92 ms; with 4, the row-sharded step 4.41 -> 8.26 ms.  So a candidate is TESTED (a long and a short spin
+        kernel, three events: do they overlap?) against the current stream and the earlier side streams, and the next
+        pool stream is tried if it does not.  The k-th side stream is found once per process, device and priority."""
+        prio = self.SIDE_PRIORITY if priority is None else priority
+        n = self.__dict__.setdefault("_n_side", {})
+        k = n[prio] = n.get(prio, -1) + 1                       # (this engine's k-th side stream of that priority)
+        return _tested_side_stream(self.device, prio, k)
 
     def _catchup(self, uniq, num_uniq, n_max, defer=False, by_gap=None):
         """defer: the rows are about to be applied in this same step by ONE mi_sparse_apply call, which

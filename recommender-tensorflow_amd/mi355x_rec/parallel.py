@@ -31,8 +31,20 @@ import torch
 import torch.distributed as dist
 
 
+def rccl_options():
+    """Keyword arguments for dist.init_process_group / dist.new_group with the "nccl" (RCCL) backend: RCCL's stream from torch's
+    HIGH-priority pool.  HIP serves each stream priority from its own pool of hardware queues, and every stream of the engine
+    is a normal-priority one tested to run beside the step's stream (engine._new_side_stream) — the collectives' stream, which
+    torch takes from its pool wherever the pool's cursor happens to stand, then cannot land on a hardware queue the step
+    uses (two streams on one queue run one after the other: tools/stream_alias_probe.py, profiles/r05_stream_aliasing.md)."""
+    try:
+        return {"pg_options": dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)}
+    except Exception:                                   # (a build without the NCCL backend: gloo runs need no options)
+        return {}
+
+
 class RowShard:
-    def __init__(self, rank, world, group=None, chunks=None, chunk_compute=None, route_ahead=None, packed=False):
+    def __init__(self, rank, world, group=None, chunks=None, chunk_compute=None, route_ahead=None, packed=False, sim_links=None):
         """chunks: pipeline depth of a train step (None: chosen from the batch and world size, see _n_chunks).
         route_ahead: True (default) — an announced next batch is routed during this step, on a side stream and a SECOND
         RCCL communicator (see Comm / _route_ahead); False — the whole step runs on ONE communicator: no second
@@ -44,17 +56,20 @@ class RowShard:
         side stream; its count exchange and id exchange on THIS communicator and the step's stream, in program order
         (after this step's row exchanges / before its dense all-reduce); the owners' sort behind that on the side
         stream (_ahead_in_order).  The next step then starts with the catch-up, and no host wait drains the queue.
-        chunk_compute: True — every chunk runs its own forward / backward (the exchanges of one chunk travel under the
-        whole compute of its neighbours; the MLP's GEMMs shrink to a chunk's examples); False — only the exchanges and
-        the embedding-side kernels are chunked, the MLP runs once on the whole batch (the row exchange travels under the
-        owners' gathers and the requester's embedding kernels, the gradient exchange under the input layer's weight
-        gradient); None: False from 8 ranks on (7 links per rank: the exchanges are short against the step), True below
-        (exchange-bound: as much compute as possible beside the links)."""
+        chunk_compute: True (the default) — every chunk runs its own forward / backward: the exchanges of one chunk travel
+        under the whole compute of its neighbours, the MLP's GEMMs shrink to a chunk's examples; False — only the exchanges
+        and the embedding-side kernels are chunked, the MLP runs once on the whole batch (the row exchange can then hide under
+        the owners' gathers only, the gradient exchange under the weight gradients).  Rounds 3-5 defaulted to False from 8
+        ranks on, by arithmetic ("7 links per rank: the exchanges are short against the step").  The rehearsal with modelled
+        link time says otherwise (tools/sim_ranks.py, profiles/r05_sim_ranks.md: real kernels of one rank's share of an 8-rank
+        job, 45 / 60 GB/s per link): 2 chunks with their own MLP pass 4.63 / 4.34 ms per step against 5.38 / 4.79 ms with one
+        pass — half of the ~2.2 ms of link time hidden instead of a fifth.
+        sim_links: see below (tools/sim_ranks.py only)."""
         if not (0 <= rank < world):
             raise ValueError("rank %d not in [0, %d)" % (rank, world))
         self.rank, self.world, self.group = int(rank), int(world), group
         self.chunks = chunks
-        self.chunk_compute = (self.world < 8) if chunk_compute is None else bool(chunk_compute)
+        self.chunk_compute = True if chunk_compute is None else bool(chunk_compute)
         self.route_ahead = True if route_ahead is None else bool(route_ahead)
         # packed: rows and wide weights (and their gradients) travel as one record of E + 4 floats per request — one
         # collective per chunk and direction instead of two (_sharded_step).  OFF by default: measured with one rank
@@ -62,6 +77,12 @@ class RowShard:
         # a third cache line per row — gather_rows +0.04, the planes gather +0.05, the segment sum +0.05, the sparse apply
         # +0.13 ms per step — more than two small RCCL launches per chunk can give back.
         self.packed = bool(packed)
+        # sim_links (tools/sim_ranks.py ONLY, a one-rank group): {"world": N, "gbs": aggregate GB/s per direction, "latency_us": per
+        # collective} — every exchange of the step is followed, on a stream of its own (as RCCL's is), by a spin kernel as long as
+        # the N-rank exchange of the same requests would keep the links busy: (N - 1) / N of the bytes at `gbs` + the latency.  The
+        # step's dependency structure and its real kernels against MODELLED link time: a rehearsal of the overlap, not a
+        # measurement of xGMI.  chunk_compute's default then follows the simulated world.
+        self.sim_links = dict(sim_links) if sim_links else None
         self.comm = None
 
     def local_rows(self, R):
@@ -82,7 +103,7 @@ class Comm:
         # same order.)
         # (RowShard(route_ahead=False): no second communicator exists at all)
         ranks = dist.get_process_group_ranks(group if group is not None else dist.group.WORLD)
-        self.ahead_group = dist.new_group(ranks=ranks) if second else None
+        self.ahead_group = dist.new_group(ranks=ranks, **(rccl_options() if self.direct else {})) if second else None
         self._pinned = {}                # (C, parity) -> pinned host buffer of the count tables, allocated once
         self._pin_turn = 0
         if self.direct and torch.cuda.is_available():
@@ -205,18 +226,57 @@ def _wait(handles):
             h.wait()
 
 
+class _SimHandle:
+    def __init__(self, ev):
+        self.ev = ev
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self.ev)
+
+
+def _sim_exchange(m, nbytes, collectives=1):
+    """RowShard.sim_links: a spin kernel on the simulated communicator's stream, behind everything the current stream has
+    enqueued (RCCL's stream waits for the caller's at the call) and behind the simulated exchanges before it (one
+    communicator: its collectives run in issue order); returns a handle like an asynchronous collective's."""
+    sim = m.shard.sim_links
+    if sim is None or m.device.type != "cuda":
+        return None
+    ls = m._ws.get("sim_link_stream")
+    if ls is None:
+        ls = m._ws["sim_link_stream"] = m._new_side_stream(priority=int(sim.get("priority", -1)))
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        a.record(); torch.cuda._sleep(20_000_000); b.record(); torch.cuda.synchronize()
+        m._ws["sim_cycles_per_us"] = 20_000_000 / (a.elapsed_time(b) * 1e3)
+    N = int(sim["world"])
+    us = collectives * float(sim.get("latency_us", 40.0)) + nbytes * (N - 1) / N / (float(sim["gbs"]) * 1e3)
+    m._ws["sim_link_us"] = m._ws.get("sim_link_us", 0.0) + us
+    ls.wait_stream(torch.cuda.current_stream())
+    trace = m._ws.get("sim_trace")                              # (tools/sim_ranks.py --trace: events around every modelled exchange)
+    with torch.cuda.stream(ls):
+        if trace is not None:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+        torch.cuda._sleep(int(us * m._ws["sim_cycles_per_us"]))
+        ev = torch.cuda.Event(enable_timing=trace is not None)
+        ev.record()
+        if trace is not None:
+            trace.append((e0, ev, us, nbytes))
+    return _SimHandle(ev)
+
+
 def _n_chunks(m, B, train):
     if not train:
         return 1
     c = m.shard.chunks
     if c is None:
-        # A chunk is the M of every MLP GEMM: below 32768 examples their grids no longer cover the 256 CUs (128-row
-        # tiles; measured with one rank, bench.py --force-shard, B = 65536: 5.2 / 5.9 / 7.0 ms per step with 1 / 2 / 4
-        # chunks — GEMMs 1.5 / 1.8 / 2.6 ms).  What a chunk buys is exchange time hidden under compute, (1 - 1/C) of it;
-        # xGMI is point to point, so a rank's 7/8 x 436 MB per direction share 7 links at 8 ranks but 218 MB share ONE
-        # link at 2: small worlds are exchange-bound and take the smaller chunks.  (Estimated, not measured: no
-        # multi-GPU box in this pool.)
-        size = 16384 if m.shard.world <= 4 else 32768
+        # A chunk is the M of every MLP GEMM: below 32768 examples their grids no longer cover the 256 CUs (128-row tiles;
+        # one rank, B = 65536: GEMMs 1.5 / 1.8 / 2.6 ms with 1 / 2 / 4 chunks).  What a chunk buys is exchange time hidden
+        # under compute.  Rounds 3-5 took 16,384-example chunks up to 4 ranks ("small worlds are exchange-bound") by
+        # arithmetic; with modelled link time (tools/sim_ranks.py, profiles/r05_sim_ranks.md) 2 chunks of 32,768 beat 4 of
+        # 16,384 at 2, 4 AND 8 ranks (45 GB/s per link: 12.3 / 7.0 / 4.6 against 12.7 / 7.4 / 4.9 ms): what the smaller
+        # chunks hide more, their GEMMs lose.
+        size = 32768
         c = min(4, B // size) if B >= 2 * size else (2 if 2048 <= B < 16384 else 1)
     c = max(1, min(int(c), B))
     while B % c:
@@ -255,6 +315,8 @@ def _route(m, ids, C, tag="", ahead=False, exchange=True):
     plan = {"slot": slot, "send_rows": send_rows, "sorted_entry": sorted_entry, "seg": seg, "C": C, "tag": tag}
     if exchange:
         plan["pending"] = comm.start_counts(counts, C, ahead=ahead)
+        if m.shard.sim_links and comm.world == 1:
+            _wait([_sim_exchange(m, 0)])
     else:
         plan["counts"] = counts
     return plan
@@ -273,6 +335,8 @@ def _finish_plan(m, plan):
     me, C = m.shard.rank, plan["C"]
     if "pending" not in plan:            # (the local half was made ahead on one communicator: the count exchange starts here, in program order)
         plan["pending"] = _comm(m).start_counts(plan.pop("counts"), C)
+        if m.shard.sim_links and _comm(m).world == 1:
+            _wait([_sim_exchange(m, 0)])
     send_counts, recv_counts = _comm(m).finish_counts(plan.pop("pending"))
     uoff, roff = [0], [0]
     for c in range(C):
@@ -308,6 +372,8 @@ def _owners_side(m, plan, train, ahead=False, sort_stream=None):
         comm.all_to_all(recv_ids[roff[c]:rmid[c]], send_rows[uoff[c]:umid[c]], plan["rc0"][c], plan["sc0"][c], ahead=ahead)
         if plan["n_self"][c]:
             recv_ids[rmid[c]:roff[c + 1]].copy_(send_rows[umid[c]:uoff[c + 1]])
+    if m.shard.sim_links and comm.world == 1:                   # (tools/sim_ranks.py: the id exchanges, blocking collectives)
+        _wait([_sim_exchange(m, nr * 4, C)])
     plan["recv_ids"] = recv_ids
     plan["book"] = None
     if train and nr > 0:        # (sorted_entry, uniq, seg, num_uniq)
@@ -335,13 +401,13 @@ def _route_ahead(m, next_ids, C, after=None):
     enqueues first starts first; kernel trace of round 5: the step's stream sat idle for 0.13 ms behind them)."""
     side = m._ws.get("route_stream")
     if side is None:
-        # HIGH priority: HIP serves each stream priority from its own pool of hardware queues; a normal-priority stream is put
-        # on the least-referenced of 4 queues and can land on the one the step's stream uses — with one communicator it did
-        # (rocprofv3 kernel trace: the owners' sort on the step's queue, between the weight gradients and the apply: serial,
-        # +0.2 ms per step).  The kernels themselves get no scheduling advantage from it (measured: profiles/r04_ab_layout_and_fold.md).
-        # (with the second communicator the normal-priority stream of rounds 3-4 stays: there the high-priority one costs the
-        # one-rank step 0.1 ms — 3.74 against 3.62 ms, same box — presumably next to RCCL's own high-priority stream)
-        prio = 0 if m.shard.route_ahead else -1
+        # A NORMAL-priority stream that has been TESTED to run beside the step's stream and the engine's other side streams
+        # (engine._new_side_stream).  History: a plain normal-priority pool stream had landed on the step's hardware queue
+        # with one communicator (rocprofv3 kernel trace of round 5: the owners' sort serial between the weight gradients and
+        # the apply, +0.2 ms per step), so the one-communicator mode used a HIGH-priority stream (its own pool of hardware
+        # queues) — which, with 4 pool streams taken earlier in the process, doubled the step (tools/stream_alias_probe.py:
+        # 4.4 -> 8.2 ms; profiles/r05_stream_aliasing.md).  The tested stream is flat over 0-6 streams taken before.
+        prio = 0
         side = m._ws["route_stream"] = (m._new_side_stream(priority=prio) if hasattr(m, "_new_side_stream") else
                                         torch.cuda.Stream(device=m.device, priority=prio)) if m.device.type == "cuda" else None
     tag = "_b" if getattr(m, "_route_tag", "") == "" else ""      # the buffer set this step's plan does NOT live in
@@ -397,6 +463,8 @@ def _ahead_in_order(m, stage):
             if r["stream"] is not None:
                 torch.cuda.current_stream().wait_stream(r["stream"])
             plan["pending"] = _comm(m).start_counts(plan.pop("counts"), plan["C"])
+            if m.shard.sim_links and _comm(m).world == 1:
+                _wait([_sim_exchange(m, 0)])
     elif "pending" in plan or "uoff" in plan:
         _owners_side(m, _finish_plan(m, plan), True, ahead=True, sort_stream=r["stream"])
 
@@ -474,6 +542,7 @@ def _sharded_step(m, ids, labels, x_num, train, next_ids=None):
     # kernels take the record stride (include/mi355x_rec.h: out_stride / table_stride / rows_stride / grad_stride); the
     # *_rows / *_lin names below are then strided views of the record buffers.
     packed = bool(m.use_emb and m.use_linear and m.shard.packed)
+    sim = m.shard.sim_links if (comm.world == 1 and m.device.type == "cuda") else None       # (tools/sim_ranks.py)
     EP = E + 4
     xs = EP if packed else 0                                     # the exchange buffers' record stride as the entries take it
 
@@ -507,6 +576,9 @@ def _sharded_step(m, ids, labels, x_num, train, next_ids=None):
             if m.use_linear:
                 hs.append(comm.all_to_all(got_lin[ulo:um], own_lin[lo:mid], sc0[c], rc0[c], True))
         gather(recv_ids[mid:hi], hi - mid, got_rows[um:uhi] if m.use_emb else None, got_lin[um:uhi] if m.use_linear else None)
+        if sim is not None:
+            hs.append(_sim_exchange(m, (hi - lo) * 4 * ((E if m.use_emb else 0) + (1 if m.use_linear else 0)),
+                                    1 if (packed or not (m.use_emb and m.use_linear)) else 2))
         return hs
 
     # gradients: one row (record) per distinct request, in send order; the owner's side receives them in request order
@@ -541,6 +613,9 @@ def _sharded_step(m, ids, labels, x_num, train, next_ids=None):
                 grad_h.append(comm.all_to_all(r_rows[lo:mid], d_rows[ulo:um], rc0[c], sc0[c], True))
             if m.use_linear:
                 grad_h.append(comm.all_to_all(r_lin[lo:mid], d_lin[ulo:um], rc0[c], sc0[c], True))
+        if sim is not None:
+            grad_h.append(_sim_exchange(m, (uhi - ulo) * 4 * ((E if m.use_emb else 0) + (1 if m.use_linear else 0)),
+                                        1 if (packed or not (m.use_emb and m.use_linear)) else 2))
 
     def backward(cc, dlogit, chunks, b0):
         """MLP backward of the examples b0..; the gradients of `chunks` leave as soon as the input layer's data gradient
@@ -607,6 +682,8 @@ def _sharded_step(m, ids, labels, x_num, train, next_ids=None):
         m.d_grad.copy_(acc)
     _ahead_in_order(m, "owners")
     comm.all_reduce(m.d_grad)                                   # dense gradients: SUM over ranks
+    if sim is not None:                                         # (a ring all-reduce moves 2 (N - 1) / N of the buffer per rank)
+        _wait([_sim_exchange(m, 2 * m.d_grad.numel() * 4)])
     _wait(grad_h)
     r = getattr(m, "_routed", None)
     if r is not None and r["stream"] is not None:

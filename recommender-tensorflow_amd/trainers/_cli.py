@@ -82,7 +82,8 @@ def init_distributed(args):
     if device.startswith("cuda"):
         device = "cuda:%d" % local
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device(device), timeout=tmo)
+        from mi355x_rec.parallel import rccl_options
+        dist.init_process_group("nccl", device_id=torch.device(device), timeout=tmo, **rccl_options())
     else:
         dist.init_process_group("gloo", timeout=tmo)
     return rank, world, device, RowShard(rank, world, route_ahead=not getattr(args, "single_communicator", False))

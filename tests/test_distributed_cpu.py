@@ -172,7 +172,7 @@ def test_next_batch_routed_ahead_equals_big_batch():
     ([9, 13, 5, 6], 8, [16, 8], 16, 3, "Adagrad", 0.05, 2, (True, False, True), 2,
      dict(numeric="raw", lin_opt=("Ftrl", 0.2), reduction="sum", chunk_compute=False))])
 def test_chunked_exchanges_one_forward_equals_big_batch(cfg):
-    """RowShard(chunk_compute=False) — the default from 8 ranks on: the exchanges and the embedding-side kernels run per
+    """RowShard(chunk_compute=False) — rounds 3-5's default from 8 ranks on (since the rehearsal of profiles/r05_sim_ranks.md an option): the exchanges and the embedding-side kernels run per
     chunk (every chunk's rows served at once, a chunk's embedding kernels behind its own exchange), the MLP once on the
     whole batch, the gradient exchange started from inside the backward (after the input layer's data gradient)."""
     check_against_big_batch(cfg, _run(cfg, 2), 2)
