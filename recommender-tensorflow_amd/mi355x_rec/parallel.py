@@ -234,16 +234,18 @@ class _SimHandle:
         torch.cuda.current_stream().wait_event(self.ev)
 
 
-def _sim_exchange(m, nbytes, collectives=1):
+def _sim_exchange(m, nbytes, collectives=1, ahead=False):
     """RowShard.sim_links: a spin kernel on the simulated communicator's stream, behind everything the current stream has
     enqueued (RCCL's stream waits for the caller's at the call) and behind the simulated exchanges before it (one
     communicator: its collectives run in issue order); returns a handle like an asynchronous collective's."""
     sim = m.shard.sim_links
     if sim is None or m.device.type != "cuda":
         return None
-    ls = m._ws.get("sim_link_stream")
+    key = "sim_link_stream2" if (ahead and m.shard.route_ahead) else "sim_link_stream"      # (a second communicator: its own stream)
+    ls = m._ws.get(key)
     if ls is None:
-        ls = m._ws["sim_link_stream"] = m._new_side_stream(priority=int(sim.get("priority", -1)))
+        ls = m._ws[key] = m._new_side_stream(priority=int(sim.get("priority", -1)))
+    if "sim_cycles_per_us" not in m._ws:
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         a.record(); torch.cuda._sleep(20_000_000); b.record(); torch.cuda.synchronize()
@@ -316,7 +318,7 @@ def _route(m, ids, C, tag="", ahead=False, exchange=True):
     if exchange:
         plan["pending"] = comm.start_counts(counts, C, ahead=ahead)
         if m.shard.sim_links and comm.world == 1:
-            _wait([_sim_exchange(m, 0)])
+            _wait([_sim_exchange(m, 0, ahead=ahead)])
     else:
         plan["counts"] = counts
     return plan
@@ -373,7 +375,7 @@ def _owners_side(m, plan, train, ahead=False, sort_stream=None):
         if plan["n_self"][c]:
             recv_ids[rmid[c]:roff[c + 1]].copy_(send_rows[umid[c]:uoff[c + 1]])
     if m.shard.sim_links and comm.world == 1:                   # (tools/sim_ranks.py: the id exchanges, blocking collectives)
-        _wait([_sim_exchange(m, nr * 4, C)])
+        _wait([_sim_exchange(m, nr * 4, C, ahead=ahead)])
     plan["recv_ids"] = recv_ids
     plan["book"] = None
     if train and nr > 0:        # (sorted_entry, uniq, seg, num_uniq)

@@ -62,6 +62,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--no-single", action="store_true", help="skip the single-GPU reference step")
     ap.add_argument("--link-priority", type=int, default=-1, help="priority of the simulated communicator's stream (bench.py / trainers._cli create the process group with is_high_priority_stream: RCCL's stream then lives in the high-priority pool of hardware queues, where the engine keeps nothing)")
+    ap.add_argument("--route-ahead", type=int, choices=[0, 1], default=0, help="1: the next batch's count / id exchanges on a second communicator (its own modelled stream)")
     ap.add_argument("--trace", action="store_true", help="one step per setting: when each modelled exchange started and how long it took")
     a = ap.parse_args()
     from mi355x_rec.engine import DeepFM, OptimizerSpec
@@ -89,7 +90,7 @@ def main():
     print("|---:|---:|---:|---|---:|---:|---:|---:|", flush=True)
     for N in a.world:
         vocab = V // N
-        sh = RowShard(0, 1, route_ahead=False, sim_links={"world": N, "gbs": a.link_gbs[0] * (N - 1), "latency_us": a.latency_us, "priority": a.link_priority})
+        sh = RowShard(0, 1, route_ahead=bool(a.route_ahead), sim_links={"world": N, "gbs": a.link_gbs[0] * (N - 1), "latency_us": a.latency_us, "priority": a.link_priority})
         m = mk(vocab, sh)
         m.init_variables(gen, lin_scale=1e-3)
         pool = batches(32, vocab, gen, dev)
