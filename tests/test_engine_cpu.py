@@ -172,13 +172,16 @@ def test_tf_named_variables_round_trip():
 
 
 def test_chunk_count_follows_batch_and_world_size():
-    """parallel._n_chunks: a chunk is the M of every MLP GEMM — at least 32768 examples from 8 ranks on (256 CUs x 128-row
-    tiles), 16384 in smaller (exchange-bound) worlds; an explicit RowShard(chunks=...) wins; evaluation never chunks."""
+    """parallel._n_chunks: a chunk is the M of every MLP GEMM — at least 32768 examples (256 CUs x 128-row tiles) at EVERY world
+    size (rounds 3-5 took 16384 up to 4 ranks by arithmetic; with modelled link time 2 chunks of 32768 are ahead at 2, 4 and 8
+    ranks: profiles/r05_sim_ranks.md); an explicit RowShard(chunks=...) wins; evaluation never chunks.  And every chunk runs
+    its own forward / backward unless told otherwise (the same rehearsal: 4.63 against 5.38 ms at 8 ranks)."""
     from types import SimpleNamespace
     from mi355x_rec.parallel import RowShard, _n_chunks
     m = lambda world, chunks=None: SimpleNamespace(shard=RowShard(0, world, chunks=chunks))
     assert _n_chunks(m(8), 65536, True) == 2 and _n_chunks(m(8), 131072, True) == 4 and _n_chunks(m(8), 16384, True) == 1
-    assert _n_chunks(m(2), 65536, True) == 4 and _n_chunks(m(4), 32768, True) == 2 and _n_chunks(m(4), 16384, True) == 1
+    assert _n_chunks(m(2), 65536, True) == 2 and _n_chunks(m(4), 65536, True) == 2 and _n_chunks(m(4), 32768, True) == 1 and _n_chunks(m(4), 131072, True) == 4
+    assert RowShard(0, 2).chunk_compute and RowShard(0, 8).chunk_compute and not RowShard(0, 8, chunk_compute=False).chunk_compute
     assert _n_chunks(m(8), 4096, True) == 2 and _n_chunks(m(8), 1000, True) == 1           # small batches: the old rule
     assert _n_chunks(m(8, chunks=4), 65536, True) == 4 and _n_chunks(m(8, chunks=3), 65536, True) == 2   # (a divisor of B)
     assert _n_chunks(m(8), 65536, False) == 1
