@@ -1089,6 +1089,7 @@ class DeepFM:
     TOP_FUSED = True          # ... and the last hidden layer with them, in its GEMM's epilogue (_head: mi_hidden_logits_head_fused)
     TOP_FUSED_MIN_BATCH = 4096
     GRAPH_SHAPES_MAX = 4      # captured steps kept at a time, one per batch shape (graph_train_step)
+    TEST_SIDE_STREAMS = True  # side streams are tested to run beside the step's stream and each other (_new_side_stream)
     SIDE_PRIORITY = 0         # -1: side streams are created with high priority.  HIP serves every stream priority from its own pool
                               # of hardware queues, so a high-priority stream can never share a queue with the step's (normal-priority)
                               # stream; normal-priority streams share 4 queues by reference count and may (parallel._side_stream)
@@ -1103,6 +1104,8 @@ class DeepFM:
         kernel, three events: do they overlap?) against the current stream and the earlier side streams, and the next
         pool stream is tried if it does not.  The k-th side stream is found once per process, device and priority."""
         prio = self.SIDE_PRIORITY if priority is None else priority
+        if not self.TEST_SIDE_STREAMS:                          # (bench.py --engine-opt TEST_SIDE_STREAMS=0: the next pool stream, as before)
+            return torch.cuda.Stream(device=self.device, priority=prio)
         n = self.__dict__.setdefault("_n_side", {})
         k = n[prio] = n.get(prio, -1) + 1                       # (this engine's k-th side stream of that priority)
         return _tested_side_stream(self.device, prio, k)
