@@ -204,6 +204,11 @@ def _tested_side_stream(device, prio, k):
     found = _SIDE_STREAMS.setdefault(key, [])
     if k < len(found):
         return found[k]
+    with torch.cuda.device(key[0]):                             # (the spin kernels and the synchronisations: on THAT device)
+        return _find_side_stream(device, prio, k, key, found)
+
+
+def _find_side_stream(device, prio, k, key, found):
     if not hasattr(torch.cuda, "_sleep") or torch.cuda.is_current_stream_capturing():
         found.append(torch.cuda.Stream(device=device, priority=prio))
         return found[-1]
