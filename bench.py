@@ -401,11 +401,11 @@ def main():
     if world == 1 and args.force_shard:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(args.backend, init_method="tcp://127.0.0.1:%d" % (29600 + os.getpid() % 300), rank=0,
-                                world_size=1, timeout=tmo, **(dict(device_id=device, **rccl_options()) if args.backend == "nccl" else {}))
+                                world_size=1, timeout=tmo, **(dict(device_id=device, **rccl_options(tmo)) if args.backend == "nccl" else {}))
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=device, timeout=tmo, **rccl_options())    # (RCCL's stream: the high-priority pool of hardware queues, where the engine keeps nothing)
+            dist.init_process_group("nccl", device_id=device, timeout=tmo, **rccl_options(tmo))    # (RCCL's stream: the high-priority pool of hardware queues, where the engine keeps nothing)
         else:
             dist.init_process_group("gloo", timeout=tmo)
 

@@ -31,14 +31,17 @@ import torch
 import torch.distributed as dist
 
 
-def rccl_options():
+def rccl_options(timeout=None):
     """Keyword arguments for dist.init_process_group / dist.new_group with the "nccl" (RCCL) backend: RCCL's stream from torch's
     HIGH-priority pool.  HIP serves each stream priority from its own pool of hardware queues, and every stream of the engine
     is a normal-priority one tested to run beside the step's stream (engine._new_side_stream) — the collectives' stream, which
     torch takes from its pool wherever the pool's cursor happens to stand, then cannot land on a hardware queue the step
     uses (two streams on one queue run one after the other: tools/stream_alias_probe.py, profiles/r05_stream_aliasing.md)."""
     try:
-        return {"pg_options": dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)}
+        opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+        if timeout is not None:
+            opts._timeout = timeout                     # (the group's timeout keyword overrides it anyway; equal values: no warning)
+        return {"pg_options": opts}
     except Exception:                                   # (a build without the NCCL backend: gloo runs need no options)
         return {}
 

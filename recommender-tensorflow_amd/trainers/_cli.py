@@ -83,7 +83,7 @@ def init_distributed(args):
         device = "cuda:%d" % local
         torch.cuda.set_device(local)
         from mi355x_rec.parallel import rccl_options
-        dist.init_process_group("nccl", device_id=torch.device(device), timeout=tmo, **rccl_options())
+        dist.init_process_group("nccl", device_id=torch.device(device), timeout=tmo, **rccl_options(tmo))
     else:
         dist.init_process_group("gloo", timeout=tmo)
     return rank, world, device, RowShard(rank, world, route_ahead=not getattr(args, "single_communicator", False))
