@@ -54,7 +54,8 @@ def _worker(rank, world, port, cfg, out_q, device="cpu", backend="gloo"):
         lin_opt = OptimizerSpec(*extra["lin_opt"]) if "lin_opt" in extra else None
         m = DeepFM(vocab, n_numeric=nn, embedding_size=E, hidden_units=hidden, use_linear=flags[0], use_mf=flags[1],
                    use_dnn=flags[2], optimizer=OptimizerSpec(opt_name, lr), device=device, shard=RowShard(rank, world, chunks=chunks, chunk_compute=extra.get("chunk_compute"),
-                                                                                     route_ahead=extra.get("route_ahead"), packed=extra.get("packed", False)),
+                                                                                     route_ahead=extra.get("route_ahead"), packed=extra.get("packed", False),
+                                                                                     sim_links=extra.get("sim_links")),
                    numeric=extra.get("numeric", "embed"), linear_optimizer=lin_opt, reduction=extra.get("reduction", "mean"),
                    _kernels=kernels, **_subsets(extra))
         m.load_oracle_params(p)

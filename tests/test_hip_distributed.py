@@ -59,3 +59,14 @@ def test_single_rank_rccl_path(chunks, chunk_compute, route_ahead):
     cfg = ([50, 30, 20, 40], 16, [32, 16], 96, 0, "Adam", 0.001, 3, (True, True, True), chunks,
            dict(chunk_compute=chunk_compute, announce=True, route_ahead=route_ahead))
     check_against_big_batch(cfg, _run(cfg, 1, device="cuda", backend="nccl"), 1, tol=3.0)
+
+
+@pytest.mark.parametrize("chunks,chunk_compute", [(1, True), (2, True), (2, False)])
+def test_modelled_link_time_changes_no_number(chunks, chunk_compute):
+    """RowShard(sim_links=...) — tools/sim_ranks.py's rehearsal of an N-rank job on one GPU: a spin kernel on a stream of its
+    own behind every exchange (row and gradient all-to-alls, id and count exchanges, the dense all-reduce).  It may only cost
+    time: the step's results equal the oracle's big-batch step like the plain one-rank RCCL path's."""
+    cfg = ([50, 30, 20, 40], 16, [32, 16], 96, 0, "Adam", 0.001, 3, (True, True, True), chunks,
+           dict(chunk_compute=chunk_compute, announce=True, route_ahead=False,
+                sim_links={"world": 8, "gbs": 7 * 45.0, "latency_us": 40.0}))
+    check_against_big_batch(cfg, _run(cfg, 1, device="cuda", backend="nccl"), 1, tol=3.0)
