@@ -627,9 +627,11 @@ __global__ __launch_bounds__(kBlock) void sparse_catchup_bounded_k(
     if (ls > 0 && ls < step_to) {
       if (lane_on) {
         float4 w = cur.w, m = cur.m;
-        // (v_sqrt_f32: 1 ulp; a v too small for it is also far too small to matter next to eps)
-        const float4 s0 = make_float4(__builtin_amdgcn_sqrtf(cur.v.x), __builtin_amdgcn_sqrtf(cur.v.y),
-                                      __builtin_amdgcn_sqrtf(cur.v.z), __builtin_amdgcn_sqrtf(cur.v.w));
+        // (v_sqrt_f32: 1 ulp; a v too small for it is also far too small to matter next to eps.  An overflowed v = inf keeps a
+        // FINITE root: the sweep's update is u / inf = 0, and so is u * r with r ~ 1 / FLT_MAX — but the carried reciprocal's
+        // residual 1 - inf * 0 would be NaN)
+        const float4 s0 = make_float4(fminf(__builtin_amdgcn_sqrtf(cur.v.x), 3.4028234e38f), fminf(__builtin_amdgcn_sqrtf(cur.v.y), 3.4028234e38f),
+                                      fminf(__builtin_amdgcn_sqrtf(cur.v.z), 3.4028234e38f), fminf(__builtin_amdgcn_sqrtf(cur.v.w), 3.4028234e38f));
         float rj = 1.f;
         int s = ls + 1;
         for (; s < base && s <= step_to; ++s) {                 // steps older than the LDS window (rare)
