@@ -84,7 +84,7 @@ class RowShard:
         # collective} — every exchange of the step is followed, on a stream of its own (as RCCL's is), by a spin kernel as long as
         # the N-rank exchange of the same requests would keep the links busy: (N - 1) / N of the bytes at `gbs` + the latency.  The
         # step's dependency structure and its real kernels against MODELLED link time: a rehearsal of the overlap, not a
-        # measurement of xGMI.  chunk_compute's default then follows the simulated world.
+        # measurement of xGMI.
         self.sim_links = dict(sim_links) if sim_links else None
         self.comm = None
 
